@@ -1,0 +1,354 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (williamedwards/autompc).
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/gen_golden.py
+
+The reference is imported unmodified from /root/reference with four absent
+third-party packages stubbed (ConfigSpace, smac, pysindy, gpytorch) and
+scipy.linalg.pinv2 aliased.  None of the stubbed packages is on
+the MPPI / iLQR / MLP / QuadCost path.  Only DATA is written: ``*.npz`` files
+with inputs (or the seeds that regenerate them) and the reference's outputs.
+
+MLP weights are not stored: they are regenerated from ``oracle.mlp.random_params
+(seed)`` (numpy PCG64) on both sides and loaded into the reference's torch net
+with ``load_state_dict``; a weight checksum is stored to detect RNG drift.
+MPPI noise comes from the legacy global ``np.random.seed`` stream, exactly as
+the reference draws it.
+"""
+import contextlib
+import io
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def install_reference():
+    import scipy.linalg
+    names = ["ConfigSpace", "ConfigSpace.hyperparameters", "ConfigSpace.conditions",
+             "ConfigSpace.forbidden", "smac", "smac.scenario", "smac.scenario.scenario",
+             "smac.facade", "smac.facade.smac_hpo_facade", "pysindy", "pysindy.differentiation",
+             "gpytorch", "gpytorch.models", "gpytorch.variational", "gpytorch.mlls",
+             "gpytorch.distributions", "gpytorch.kernels", "gpytorch.means", "gpytorch.likelihoods"]
+    for n in names:
+        sys.modules[n] = MagicMock()
+    sys.modules["pysindy.differentiation"].base.BaseDifferentiation = type("BaseDifferentiation", (), {})
+    sys.modules["pysindy"].differentiation = sys.modules["pysindy.differentiation"]
+    for cls in ("ExactGP", "ApproximateGP"):
+        t = type(cls, (), {})
+        setattr(sys.modules["gpytorch"].models, cls, t)
+        setattr(sys.modules["gpytorch.models"], cls, t)
+    if not hasattr(scipy.linalg, "pinv2"):
+        scipy.linalg.pinv2 = scipy.linalg.pinv
+    sys.path.insert(0, "/root/reference")
+
+
+install_reference()
+with contextlib.redirect_stdout(io.StringIO()):
+    import autompc as ampc                                   # noqa: E402
+    from autompc.control.mppi import MPPI                    # noqa: E402
+    from autompc.control.ilqr import IterativeLQR            # noqa: E402
+    from autompc.sysid.mlp import MLP                        # noqa: E402
+    from autompc.sysid.model import Model                    # noqa: E402
+    from autompc.costs import QuadCost                       # noqa: E402
+    from autompc.tasks import Task                           # noqa: E402
+    from autompc.utils.simulation import simulate            # noqa: E402
+import torch                                                 # noqa: E402
+
+from oracle import mlp as omlp                               # noqa: E402
+from oracle.analytic import CubicIntegrator                  # noqa: E402
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_system(nx, nu, dt=0.05):
+    return ampc.System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=dt)
+
+
+def normalisers(nx, nu, seed):
+    rng = np.random.default_rng(seed + 7919)
+    return (rng.normal(scale=0.3, size=nx + nu), rng.uniform(0.5, 2.0, size=nx + nu),
+            rng.normal(scale=0.02, size=nx), rng.uniform(0.05, 0.2, size=nx))
+
+
+def ref_mlp(system, hidden, activation, seed, plain_norm=False):
+    """Reference MLP carrying the deterministic numpy weights."""
+    nx, nu = system.obs_dim, system.ctrl_dim
+    p = omlp.random_params(nx, nu, hidden, activation, seed=seed)
+    if not plain_norm:
+        p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"] = normalisers(nx, nu, seed)
+    kw = {"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)}
+    model = quiet(MLP, system, n_hidden_layers=len(hidden), nonlintype=activation,
+                  use_cuda=False, **kw)
+    sd = {}
+    for i in range(len(hidden)):
+        sd["layers.layer%d.weight" % i] = torch.from_numpy(p["weights"][i])
+        sd["layers.layer%d.bias" % i] = torch.from_numpy(p["biases"][i])
+    sd["output_layer.weight"] = torch.from_numpy(p["weights"][-1])
+    sd["output_layer.bias"] = torch.from_numpy(p["biases"][-1])
+    model.net.load_state_dict(sd)
+    model.xu_means, model.xu_std = p["xu_means"], p["xu_std"]
+    model.dy_means, model.dy_std = p["dy_means"], p["dy_std"]
+    return model, p
+
+
+def weight_checksum(p):
+    return np.array([sum(float(np.sum(w)) for w in p["weights"]),
+                     sum(float(np.sum(np.abs(b))) for b in p["biases"]),
+                     float(p["weights"][0][0, 0]), float(p["weights"][-1][-1, -1])])
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote %-40s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+# --------------------------------------------------------------------------- MLP
+MLP_CASES = [
+    # tag, nx, nu, hidden, activation, seed
+    ("p64_relu", 2, 1, [64, 64], "relu", 11),
+    ("p64_tanh", 2, 1, [64, 64], "tanh", 12),
+    ("hc1_relu", 17, 1, [256, 256], "relu", 13),
+    ("hc6_relu", 17, 6, [256, 256], "relu", 14),
+    ("hc6_tanh", 17, 6, [256, 256], "tanh", 15),
+    ("hc6_sigmoid", 17, 6, [256, 256], "sigmoid", 16),
+    ("hc6_selu", 17, 6, [256, 256], "selu", 17),
+    ("cp3_selu", 4, 1, [32, 16, 8], "selu", 18),
+    ("odd1_sigmoid", 4, 2, [100], "sigmoid", 19),
+    ("deep4_tanh", 3, 2, [48, 200, 17, 64], "tanh", 20),
+]
+
+
+def gen_mlp():
+    for tag, nx, nu, hidden, act, seed in MLP_CASES:
+        system = make_system(nx, nu)
+        model, p = ref_mlp(system, hidden, act, seed)
+        rng = np.random.default_rng(seed + 1000)
+        states = rng.normal(size=(32, nx))
+        ctrls = rng.normal(size=(32, nu))
+        pb = model.pred_batch(states, ctrls)
+        db, jx, ju = model.pred_diff_batch(states, ctrls)
+        p0 = model.pred(states[0], ctrls[0])
+        d0, jx0, ju0 = model.pred_diff(states[0], ctrls[0])
+        save("mlp_" + tag, nx=nx, nu=nu, hidden=np.array(hidden), activation=act, seed=seed,
+             wsum=weight_checksum(p), states=states, ctrls=ctrls, pred_batch=pb,
+             diff_pred=db, diff_jx=jx, diff_ju=ju, pred0=p0, diff0_pred=d0, diff0_jx=jx0,
+             diff0_ju=ju0)
+
+
+# -------------------------------------------------------------------------- cost
+def gen_cost():
+    system = make_system(5, 3)
+    rng = np.random.default_rng(5)
+    Q, R, F = rng.normal(size=(5, 5)), rng.normal(size=(3, 3)), rng.normal(size=(5, 5))
+    goal = rng.normal(size=5)
+    cost = QuadCost(system, Q, R, F, goal=goal)
+    obs, ctrl = rng.normal(size=5), rng.normal(size=3)
+    o = cost.eval_obs_cost_hess(obs)
+    c = cost.eval_ctrl_cost_hess(ctrl)
+    t = cost.eval_term_obs_cost_hess(obs)
+    od = cost.eval_obs_cost_diff(obs)
+    td = cost.eval_term_obs_cost_diff(obs)
+    # trajectory score (Cost.__call__)
+    traj = ampc.zeros(system, 7)
+    traj.obs[:] = rng.normal(size=(7, 5))
+    traj.ctrls[:] = rng.normal(size=(7, 3))
+    # the reference's own known answers (tests/test_costs.py:192-205): SumCost of
+    # QuadCost(Q=I,R=I,F=I) + QuadCost(Q=diag(1,5), ...) evaluated at obs [-1, 1]
+    save("cost_quad", Q=Q, R=R, F=F, goal=goal, obs=obs, ctrl=ctrl,
+         obs_cost=cost.eval_obs_cost(obs), ctrl_cost=cost.eval_ctrl_cost(ctrl),
+         term_cost=cost.eval_term_obs_cost(obs),
+         obs_c=o[0], obs_j=o[1], obs_h=o[2], ctrl_c=c[0], ctrl_j=c[1], ctrl_h=c[2],
+         term_c=t[0], term_j=t[1], term_h=t[2], obs_diff_j=od[1], term_diff_c=td[0],
+         term_diff_j=td[1], traj_obs=traj.obs, traj_ctrls=traj.ctrls, traj_cost=cost(traj))
+
+
+# -------------------------------------------------------------------------- MPPI
+MPPI_CASES = [
+    # tag, nx, hidden, act, mlpseed, N, H, sigma, lmda, bounds, costkind, npseed
+    ("c2_pendulum", 2, [64, 64], "relu", 31, 1024, 30, 1.0, 1.0, (-2.0, 2.0), "plain", 0),
+    ("hc_nu1", 17, [256, 256], "relu", 32, 256, 20, 1.0, 1.0, (-1.0, 1.0), "plain", 1),
+    ("clip_asym", 2, [64, 64], "tanh", 33, 200, 12, 1.5, 0.7, (-0.3, 0.5), "plain", 2),
+    ("lowlmda_goal", 4, [32, 32], "tanh", 34, 300, 15, 0.5, 0.1, (-1.5, 1.5), "dense", 3),
+]
+
+
+def make_cost(system, kind, seed):
+    no, nu = system.obs_dim, system.ctrl_dim
+    if kind == "plain":
+        return QuadCost(system, np.eye(no), 0.01 * np.eye(nu), np.eye(no), goal=np.zeros(no))
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(no, no))
+    B = rng.normal(size=(no, no))
+    Q = A @ A.T / no + 0.1 * rng.normal(size=(no, no))      # deliberately non-symmetric
+    F = B @ B.T / no
+    R = np.diag(rng.uniform(0.01, 0.1, size=nu)) + 0.005
+    goal = rng.normal(scale=0.2, size=no)
+    return QuadCost(system, Q, R, F, goal=goal)
+
+
+def gen_mppi():
+    for tag, nx, hidden, act, mseed, N, H, sigma, lmda, bnd, ckind, npseed in MPPI_CASES:
+        system = make_system(nx, 1)
+        model, p = ref_mlp(system, hidden, act, mseed, plain_norm=(ckind == "plain"))
+        task = Task(system)
+        cost = make_cost(system, ckind, mseed)
+        task.set_cost(cost)
+        task.set_ctrl_bound("u0", bnd[0], bnd[1])
+        Q, R, F = cost.get_cost_matrices()
+        np.random.seed(npseed)
+        ctl = quiet(MPPI, system, task, model, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+        out = {"act0": ctl.act_sequence.copy()}
+        obs = np.random.default_rng(npseed + 99).uniform(-0.1, 0.1, size=nx)
+        constate = np.concatenate([obs, np.zeros(1)])
+        n_runs = 4
+        for r in range(n_runs):
+            if r == 3:
+                quiet(ctl.reset)
+                out["act_reset"] = ctl.act_sequence.copy()
+            # capture costs/eps of this solve by wrapping update()
+            cap = {}
+            orig_update = ctl.update
+
+            def spy(costs, eps, cap=cap, orig=orig_update):
+                cap["costs"] = costs.copy()
+                cap["eps"] = eps.copy()
+                return orig(costs, eps)
+            ctl.update = spy
+            u, constate = ctl.run(constate, obs)
+            ctl.update = orig_update
+            out["x0_%d" % r] = obs.copy()
+            out["costs_%d" % r] = cap["costs"]
+            out["eps_sub_%d" % r] = cap["eps"][:, ::16, :].copy()     # (H, N/16, 1) post-clip
+            out["act_%d" % r] = ctl.act_sequence.copy()
+            out["u_%d" % r] = u.copy()
+            out["newstate_%d" % r] = constate.copy()
+            obs = model.pred(obs, u)
+        save("mppi_" + tag, nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed,
+             plain_norm=(ckind == "plain"), wsum=weight_checksum(p), N=N, H=H, sigma=sigma,
+             lmda=lmda, bounds=np.array(bnd), Q=Q, R=R, F=F, goal=cost.get_goal(),
+             np_seed=npseed, n_runs=n_runs, **out)
+
+
+# -------------------------------------------------------------------------- iLQR
+class RefCubic(Model):
+    """The analytic test model wrapped in the reference's Model ABC."""
+
+    def __init__(self, system):
+        super().__init__(system)
+        self.impl = CubicIntegrator(system)
+
+    @property
+    def state_dim(self):
+        return self.impl.state_dim
+
+    def traj_to_state(self, traj):
+        return traj[-1].obs.copy()
+
+    def update_state(self, state, new_ctrl, new_obs):
+        return new_obs.copy()
+
+    def pred(self, state, ctrl):
+        return self.impl.pred(state, ctrl)
+
+    def pred_batch(self, states, ctrls):
+        return self.impl.pred_batch(states, ctrls)
+
+    def pred_diff(self, state, ctrl):
+        return self.impl.pred_diff(state, ctrl)
+
+    def pred_diff_batch(self, states, ctrls):
+        return self.impl.pred_diff_batch(states, ctrls)
+
+
+ILQR_CASES = [
+    # tag, model kind, nx, nu, hidden, act, mseed, H, bounded, costkind, x0scale
+    ("cubic_free", "cubic", 2, 1, None, None, 0, 20, None, "plain", 0.5),
+    ("cubic_bounded", "cubic", 2, 1, None, None, 0, 20, (-0.2, 0.2), "plain", 0.5),
+    ("p64_tanh_free", "mlp", 2, 1, [64, 64], "tanh", 41, 20, None, "plain", 0.3),
+    ("p64_tanh_bounded", "mlp", 2, 1, [64, 64], "tanh", 41, 20, (-0.5, 0.5), "dense", 0.3),
+    ("hc6_relu_free", "mlp", 17, 6, [256, 256], "relu", 42, 50, None, "plain", 0.1),
+    ("p64_tanh_clipped", "mlp", 2, 1, [64, 64], "tanh", 41, 20, (-0.1, 0.15), "plain", 0.3),
+    ("hc6_relu_bounded", "mlp", 17, 6, [256, 256], "relu", 42, 50, (-0.25, 0.25), "plain", 0.1),
+    ("hc6_tanh_free", "mlp", 17, 6, [256, 256], "tanh", 43, 50, None, "dense", 0.1),
+]
+
+
+def gen_ilqr():
+    for tag, kind, nx, nu, hidden, act, mseed, H, bnd, ckind, x0s in ILQR_CASES:
+        system = make_system(nx, nu, dt=0.05)
+        if kind == "cubic":
+            model, p = RefCubic(system), None
+        else:
+            model, p = ref_mlp(system, hidden, act, mseed, plain_norm=(ckind == "plain"))
+        task = Task(system)
+        cost = make_cost(system, ckind, mseed + 500)
+        task.set_cost(cost)
+        if bnd is not None:
+            task.set_ctrl_bounds(np.full(nu, bnd[0]), np.full(nu, bnd[1]))
+        ctl = IterativeLQR(system, task, model, H)
+        x0 = np.random.default_rng(mseed + 77).uniform(-x0s, x0s, size=nx)
+        calls = {"n": 0}
+        orig = model.pred_diff_batch
+
+        def counting(states, ctrls, orig=orig):
+            calls["n"] += 1
+            return orig(states, ctrls)
+        model.pred_diff_batch = counting
+        conv, states, ctrls, Ks, ks = quiet(ctl.compute_ilqr_default, x0, np.zeros((H, nu)),
+                                            silent=True)
+        n_refresh = calls["n"]
+        u, newstate = quiet(ctl.run, np.concatenate([x0, np.zeros(nu)]), x0)
+        model.pred_diff_batch = orig
+        Q, R, F = cost.get_cost_matrices()
+        extra = {} if p is None else {"wsum": weight_checksum(p)}
+        save("ilqr_" + tag, kind=kind, nx=nx, nu=nu, hidden=np.array(hidden or []),
+             activation=act or "", mlp_seed=mseed, plain_norm=(ckind == "plain"), H=H,
+             bounded=bnd is not None, bounds=np.array(bnd if bnd else (0.0, 0.0)), dt=0.05,
+             Q=Q, R=R, F=F, goal=cost.get_goal(), x0=x0, converged=conv, states=states,
+             ctrls=ctrls, Ks=Ks, ks=ks, n_refresh=n_refresh, u=u, newstate=newstate, **extra)
+
+
+# ------------------------------------------------------------------- closed loop
+def gen_closed_loop():
+    # MPPI (nu = 1) on a tanh surrogate, 20 steps; iLQR on the same surrogate.
+    nx, hidden, act, mseed = 3, [48, 48], "tanh", 51
+    system = make_system(nx, 1, dt=0.05)
+    model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+    task = Task(system)
+    cost = make_cost(system, "dense", 600)
+    task.set_cost(cost)
+    task.set_ctrl_bound("u0", -1.0, 1.0)
+    init = np.array([0.2, -0.1, 0.15])
+    np.random.seed(4)
+    ctl = quiet(MPPI, system, task, model, horizon=10, num_path=128, sigma=0.8, lmda=0.5)
+    traj = quiet(simulate, ctl, init, sim_model=model, max_steps=20, silent=True)
+    Q, R, F = cost.get_cost_matrices()
+    common = dict(nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed,
+                  wsum=weight_checksum(p), Q=Q, R=R, F=F, goal=cost.get_goal(), init=init)
+    save("loop_mppi", np_seed=4, N=128, H=10, sigma=0.8, lmda=0.5, bounds=np.array([-1.0, 1.0]),
+         obs=traj.obs, ctrls=traj.ctrls, score=cost(traj), **common)
+    task2 = Task(system)
+    task2.set_cost(cost)
+    ctl2 = IterativeLQR(system, task2, model, 12)
+    traj2 = quiet(simulate, ctl2, init, sim_model=model, max_steps=15, silent=True)
+    save("loop_ilqr", H=12, dt=0.05, obs=traj2.obs, ctrls=traj2.ctrls, score=cost(traj2), **common)
+
+
+if __name__ == "__main__":
+    gen_mlp()
+    gen_cost()
+    gen_mppi()
+    gen_ilqr()
+    gen_closed_loop()

@@ -1,0 +1,45 @@
+"""Shared builders for parity tests: regenerate the exact inputs the golden
+vectors were produced from (tests/golden/gen_golden.py uses the same recipe)."""
+import numpy as np
+
+from autompc_amd import System
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+
+
+def make_system(nx, nu, dt=0.05):
+    return System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=dt)
+
+
+def normalisers(nx, nu, seed):
+    rng = np.random.default_rng(seed + 7919)
+    return (rng.normal(scale=0.3, size=nx + nu), rng.uniform(0.5, 2.0, size=nx + nu),
+            rng.normal(scale=0.02, size=nx), rng.uniform(0.05, 0.2, size=nx))
+
+
+def golden_params(nx, nu, hidden, activation, seed, plain_norm=False):
+    p = omlp.random_params(nx, nu, [int(h) for h in hidden], str(activation), seed=int(seed))
+    if not plain_norm:
+        p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"] = normalisers(nx, nu, int(seed))
+    return p
+
+
+def weight_checksum(p):
+    return np.array([sum(float(np.sum(w)) for w in p["weights"]),
+                     sum(float(np.sum(np.abs(b))) for b in p["biases"]),
+                     float(p["weights"][0][0, 0]), float(p["weights"][-1][-1, -1])])
+
+
+def check_weights(p, g):
+    np.testing.assert_allclose(weight_checksum(p), g["wsum"], rtol=0, atol=1e-12,
+                               err_msg="numpy RNG drifted: golden MLP weights not reproducible")
+
+
+def cost_from_golden(g):
+    return QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"])
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(float(np.max(np.abs(b))), 1e-300)
+    return float(np.max(np.abs(a - b))) / scale
