@@ -9,5 +9,10 @@ from .trajectory import Trajectory, TimeStep, zeros, empty, extend
 from .task import Task
 from .costs import Cost, QuadCost, SumCost, ThresholdCost, BoxThresholdCost
 
-__all__ = ["System", "Trajectory", "TimeStep", "zeros", "empty", "extend", "Task",
+from .sysid import Model, ModelFactory, MLP, MLPFactory
+from .control import Controller, ControllerFactory, MPPI, MPPIFactory
+from .utils import simulate
+
+__all__ = ["Model", "ModelFactory", "MLP", "MLPFactory", "Controller", "ControllerFactory",
+           "MPPI", "MPPIFactory", "simulate", "System", "Trajectory", "TimeStep", "zeros", "empty", "extend", "Task",
            "Cost", "QuadCost", "SumCost", "ThresholdCost", "BoxThresholdCost"]

@@ -1,0 +1,287 @@
+"""ctypes binding of libautompc_hip.so (C ABI: include/autompc_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or no
+MI355X is visible, everything that computes raises ``AmpcError``.
+"""
+import atexit
+import ctypes
+import os
+import weakref
+from ctypes import POINTER, c_char_p, c_double, c_int, c_uint64, c_void_p
+
+import numpy as np
+
+F64, F32 = 0, 1
+ACTIVATIONS = {"relu": 0, "tanh": 1, "sigmoid": 2, "selu": 3}
+TERM_REFERENCE, TERM_PER_PARTICLE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libautompc_hip.so")
+
+
+class AmpcError(RuntimeError):
+    pass
+
+
+_lib = None
+_dp = POINTER(c_double)
+_ip = POINTER(c_int)
+
+# name -> (restype, argtypes); must list every symbol include/autompc_hip.h declares
+SIGNATURES = {
+    "ampc_last_error": (c_char_p, []),
+    "ampc_version": (c_int, []),
+    "ampc_device_count": (c_int, []),
+    "ampc_create": (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "ampc_destroy": (c_int, [c_void_p]),
+    "ampc_synchronize": (c_int, [c_void_p]),
+    "ampc_precision": (c_int, [c_void_p]),
+    "ampc_set_mlp": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(_dp),
+                             POINTER(_dp), _dp, _dp, _dp, _dp]),
+    "ampc_mlp_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
+    "ampc_mlp_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
+    "ampc_set_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]),
+    "ampc_set_ctrl_bounds": (c_int, [c_void_p, _dp, _dp]),
+    "ampc_mppi_plan_create": (c_int, [c_void_p, c_int, _ip, _ip, _dp, _dp, _ip, c_int,
+                                      POINTER(c_void_p)]),
+    "ampc_mppi_plan_destroy": (c_int, [c_void_p]),
+    "ampc_mppi_upload": (c_int, [c_void_p, _dp, _dp, _dp]),
+    "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
+    "ampc_mppi_solve": (c_int, [c_void_p]),
+    "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
+    "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
+    "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
+    "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
+    "ampc_mppi_plan_timing": (c_int, [c_void_p, _dp, _dp, _ip]),
+}
+
+
+def load():
+    """Load the shared library (once) and attach prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmpcError("libautompc_hip.so is not built (%s). Run `python -c 'import "
+                        "__graft_entry__ as g; g.build()'` or `make -C autompc_amd/csrc`."
+                        % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().ampc_last_error()
+        raise AmpcError(msg.decode() if msg else "libautompc_hip error %d" % rc)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+# Device objects must be destroyed before the HIP runtime's own static teardown: close every live
+# plan, then every live handle, from an atexit hook (runs before interpreter/module teardown).
+_live_plans = weakref.WeakSet()
+_live_handles = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    for obj in list(_live_plans) + list(_live_handles):
+        try:
+            obj.close()
+        except Exception:
+            pass
+
+
+class Handle:
+    """One device context: model + cost blocks + bounds on one MI355X / one stream."""
+
+    def __init__(self, device=0, precision="f64", stream=None):
+        lib = load()
+        if lib.ampc_device_count() <= 0:
+            raise AmpcError("no HIP device visible: the MI355X path cannot run here "
+                            "(there is no CPU fallback by design)")
+        self.lib = lib
+        self.precision = {"f64": F64, "f32": F32}[precision]
+        self.precision_name = precision
+        self._h = c_void_p()
+        check(lib.ampc_create(int(device), self.precision, c_void_p(stream) if stream else None,
+                              ctypes.byref(self._h)))
+        self.device = int(device)
+        self.nx = self.nu = None
+        _live_handles.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.ampc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self.lib.ampc_synchronize(self._h))
+
+    # -- model ---------------------------------------------------------------
+    def set_mlp(self, nx, nu, weights, biases, activation, xu_means, xu_std, dy_means, dy_std):
+        n_hidden = len(weights) - 1
+        Ws = [as_f64(w) for w in weights]
+        bs = [as_f64(b) for b in biases]
+        hidden = np.array([w.shape[0] for w in Ws[:-1]], dtype=np.int32)
+        sizes = [nx + nu] + [int(x) for x in hidden] + [nx]
+        for l, w in enumerate(Ws):
+            if w.shape != (sizes[l + 1], sizes[l]) or bs[l].shape != (sizes[l + 1],):
+                raise ValueError("layer %d has shape %r, expected %r" % (l, w.shape,
+                                                                          (sizes[l + 1], sizes[l])))
+        wp = (_dp * len(Ws))(*[dptr(w) for w in Ws])
+        bp = (_dp * len(bs))(*[dptr(b) for b in bs])
+        norm = [as_f64(v) for v in (xu_means, xu_std, dy_means, dy_std)]
+        if norm[0].shape != (nx + nu,) or norm[1].shape != (nx + nu,) \
+                or norm[2].shape != (nx,) or norm[3].shape != (nx,):
+            raise ValueError("normaliser shapes do not match (nx+nu, nx+nu, nx, nx)")
+        check(self.lib.ampc_set_mlp(self._h, nx, nu, n_hidden, iptr(hidden), ACTIVATIONS[activation],
+                                    wp, bp, dptr(norm[0]), dptr(norm[1]), dptr(norm[2]),
+                                    dptr(norm[3])))
+        self.nx, self.nu = nx, nu
+
+    def pred_batch(self, states, ctrls):
+        states, ctrls = as_f64(states), as_f64(ctrls)
+        n = states.shape[0]
+        if states.shape != (n, self.nx) or ctrls.shape != (n, self.nu):
+            raise ValueError("pred_batch: states %r / ctrls %r do not match (n,%d)/(n,%d)"
+                             % (states.shape, ctrls.shape, self.nx, self.nu))
+        out = np.empty((n, self.nx))
+        check(self.lib.ampc_mlp_pred_batch(self._h, dptr(states), dptr(ctrls), dptr(out), n))
+        return out
+
+    def pred_diff_batch(self, states, ctrls):
+        states, ctrls = as_f64(states), as_f64(ctrls)
+        n = states.shape[0]
+        if states.shape != (n, self.nx) or ctrls.shape != (n, self.nu):
+            raise ValueError("pred_diff_batch: bad shapes %r %r" % (states.shape, ctrls.shape))
+        out = np.empty((n, self.nx))
+        jx = np.empty((n, self.nx, self.nx))
+        ju = np.empty((n, self.nx, self.nu))
+        check(self.lib.ampc_mlp_pred_diff_batch(self._h, dptr(states), dptr(ctrls), dptr(out),
+                                                dptr(jx), dptr(ju), n))
+        return out, jx, ju
+
+    # -- cost / bounds ----------------------------------------------------------
+    def set_quad_costs(self, Q, R, F, goal):
+        """Q [C,no,no], R [C,nu,nu], F [C,no,no], goal [C,no] (or a single block without C)."""
+        Q, R, F, goal = as_f64(Q), as_f64(R), as_f64(F), as_f64(goal)
+        if Q.ndim == 2:
+            Q, R, F, goal = Q[None], R[None], F[None], goal[None]
+        C, no = Q.shape[0], Q.shape[1]
+        if Q.shape != (C, no, no) or F.shape != (C, no, no) or R.shape != (C, self.nu, self.nu) \
+                or goal.shape != (C, no):
+            raise ValueError("cost block shapes are inconsistent")
+        check(self.lib.ampc_set_quad_costs(self._h, C, no, dptr(Q), dptr(R), dptr(F), dptr(goal)))
+        self.obs_dim = no
+        self.n_costs = C
+
+    def set_ctrl_bounds(self, lo, hi):
+        lo, hi = as_f64(lo), as_f64(hi)
+        check(self.lib.ampc_set_ctrl_bounds(self._h, dptr(lo), dptr(hi)))
+
+
+class MppiPlan:
+    """Device buffers + launch geometry for a batch of independent MPPI problems."""
+
+    def __init__(self, handle, num_path, horizon, sigma, lmda, cost_index=None,
+                 term_mode=TERM_REFERENCE):
+        self.handle = handle
+        self.lib = handle.lib
+        self.N = np.atleast_1d(np.asarray(num_path, dtype=np.int32)).copy()
+        self.B = self.N.shape[0]
+        self.H = np.broadcast_to(np.asarray(horizon, dtype=np.int32), (self.B,)).copy()
+        self.sigma = np.broadcast_to(as_f64(sigma), (self.B,)).copy()
+        self.lmda = np.broadcast_to(as_f64(lmda), (self.B,)).copy()
+        ci = None if cost_index is None else \
+            np.broadcast_to(np.asarray(cost_index, dtype=np.int32), (self.B,)).copy()
+        self._p = c_void_p()
+        check(self.lib.ampc_mppi_plan_create(handle._h, self.B, iptr(self.N), iptr(self.H),
+                                             dptr(self.sigma), dptr(self.lmda), iptr(ci),
+                                             int(term_mode), ctypes.byref(self._p)))
+        _live_plans.add(self)
+        nu = handle.nu
+        self.sum_hnu = int(np.sum(self.H.astype(np.int64) * nu))
+        self.sum_n = int(np.sum(self.N.astype(np.int64)))
+        self.sum_nhnu = int(np.sum(self.N.astype(np.int64) * self.H * nu))
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            self.lib.ampc_mppi_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _flat(self, a, size, name):
+        if a is None:
+            return None
+        a = as_f64(a).reshape(-1)
+        if a.size != size:
+            raise ValueError("%s has %d elements, expected %d" % (name, a.size, size))
+        return a
+
+    def upload(self, x0=None, act_seq=None, eps=None):
+        x0 = self._flat(x0, self.B * self.handle.nx, "x0")
+        act_seq = self._flat(act_seq, self.sum_hnu, "act_seq")
+        eps = self._flat(eps, self.sum_nhnu, "eps")
+        check(self.lib.ampc_mppi_upload(self._p, dptr(x0), dptr(act_seq), dptr(eps)))
+
+    def generate_eps(self, seed, stream=0):
+        check(self.lib.ampc_mppi_generate_eps(self._p, int(seed), int(stream)))
+
+    def solve(self):
+        check(self.lib.ampc_mppi_solve(self._p))
+
+    def download(self, act_seq=True, u=True, costs=False, eps_out=False):
+        nu = self.handle.nu
+        a = np.empty(self.sum_hnu) if act_seq else None
+        uu = np.empty((self.B, nu)) if u else None
+        c = np.empty(self.sum_n) if costs else None
+        e = np.empty(self.sum_nhnu) if eps_out else None
+        check(self.lib.ampc_mppi_download(self._p, dptr(a), dptr(uu), dptr(c), dptr(e)))
+        return a, uu, c, e
+
+    def set_x0_dev(self, ptr):
+        check(self.lib.ampc_mppi_set_x0_dev(self._p, c_void_p(ptr)))
+
+    def set_timing(self, enable=True):
+        check(self.lib.ampc_mppi_plan_set_timing(self._p, int(bool(enable))))
+
+    def timing(self):
+        r, u, n = c_double(), c_double(), c_int()
+        check(self.lib.ampc_mppi_plan_timing(self._p, ctypes.byref(r), ctypes.byref(u),
+                                             ctypes.byref(n)))
+        return {"rollout_ms": r.value, "update_ms": u.value, "count": n.value}
+
+    def info(self):
+        wg, spw = c_int(), c_int()
+        fl, by = c_double(), c_double()
+        check(self.lib.ampc_mppi_plan_info(self._p, ctypes.byref(wg), ctypes.byref(spw),
+                                           ctypes.byref(fl), ctypes.byref(by)))
+        return {"workgroups": wg.value, "samples_per_wg": spw.value, "flops": fl.value,
+                "bytes": by.value}

@@ -1,0 +1,167 @@
+"""MPPI controller whose solve runs on MI355X (HIP rollout + update kernels).
+
+Drop-in for the reference's ``autompc.control.MPPI`` / ``MPPIFactory`` (reference:
+autompc/control/mppi.py:26-64 factory, :66-181 controller): same keyword
+hyper-parameters (``horizon``, ``num_path``, ``sigma``, ``lmda``, ``seed``,
+``niter``), same ``run`` / ``reset`` / ``traj_to_state`` / ``state_dim``, same
+state (``act_sequence`` in units of ``umax``, random-initialised).
+
+What runs where
+  host   the noise draw, in parity mode: ``np.random.normal(scale=sqrt(sigma),
+         size=(num_path, H, nu))`` from numpy's GLOBAL legacy stream -- the same call,
+         order and shape as mppi.py:21-24,126 (with the trailing 1 generalised to
+         ``nu``: the reference is only correct for ctrl_dim == 1)
+  device everything else: warm-start shift, clipping, batched surrogate rollout, stage /
+         action / terminal costs, softmin weights, sequence update (ampc_mppi_solve)
+
+``noise="device"`` replaces the host draw with an on-device Philox stream
+(statistically equivalent, not bit-identical; no PCIe traffic per solve).
+"""
+import numpy as np
+
+from .. import _lib
+from .controller import Controller, ControllerFactory
+
+
+def _quad_cost_blocks(cost):
+    if not getattr(cost, "is_quad", False):
+        raise TypeError("the HIP MPPI path evaluates quadratic costs in-kernel; got %r"
+                        % type(cost).__name__)
+    Q, R, F = cost.get_cost_matrices()
+    return Q, R, F, np.asarray(cost.get_goal(), dtype=np.float64)
+
+
+class MPPI(Controller):
+    def __init__(self, system, task, model, **kwargs):
+        super().__init__(system, task, model)
+        if not hasattr(model, "stage_into"):
+            raise TypeError("MPPI needs a device-stageable model (autompc_amd.sysid.MLP); "
+                            "there is no CPU fallback")
+        self.kwargs = kwargs
+        self.dim_state, self.dim_ctrl = model.state_dim, system.ctrl_dim
+        self.seed = kwargs.get("seed", 0)
+        self.H = int(kwargs.get("horizon", 20))
+        self.num_path = int(kwargs.get("num_path", 1000))
+        self.num_iter = kwargs.get("niter", 1)      # stored, unused -- as in the reference (:92,105)
+        self.niter = 1
+        self.sigma = kwargs.get("sigma", 1)
+        self.lmda = kwargs.get("lmda", 1.0)
+        self.noise = kwargs.get("noise", "numpy")
+        self.precision = kwargs.get("precision", getattr(model, "precision", "f64"))
+        self.device = kwargs.get("device", getattr(model, "device", 0))
+        self.per_particle_terminal = bool(kwargs.get("per_particle_terminal", False))
+        if self.noise not in ("numpy", "device"):
+            raise ValueError("noise must be 'numpy' (parity) or 'device' (fast)")
+        bounds = task.get_ctrl_bounds()
+        self.umin = bounds[:, 0].copy()
+        self.umax = bounds[:, 1].copy()
+        self.ctrl_scale = self.umax
+        self._scale = np.sqrt(self.sigma)
+        self._handle = None
+        self._plan = None
+        self._init_sequence()
+
+    # -- construction-time state (mppi.py:96-105) ------------------------------------
+    def _init_sequence(self):
+        self._act_host = np.random.normal(scale=self._scale, size=(self.H, self.dim_ctrl))
+        self._act_dirty = True        # host copy is newer than the device copy
+        self.cur_step = 0
+
+    def _device(self):
+        if self._plan is None:
+            h = _lib.Handle(self.device, self.precision)
+            self.model.stage_into(h)
+            Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
+            h.set_quad_costs(Q, R, F, goal)
+            h.set_ctrl_bounds(self.umin, self.umax)
+            term = _lib.TERM_PER_PARTICLE if self.per_particle_terminal else _lib.TERM_REFERENCE
+            self._handle = h
+            self._plan = _lib.MppiPlan(h, [self.num_path], [self.H], [self.sigma], [self.lmda],
+                                       term_mode=term)
+            self._act_dirty = True
+        return self._plan
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        if self._plan is not None and not self._act_dirty:
+            state["_act_host"] = self.act_sequence.copy()
+        state["_handle"] = state["_plan"] = None
+        state["_act_dirty"] = True
+        return state
+
+    @property
+    def act_sequence(self):
+        if self._plan is not None and not self._act_dirty:
+            a, _, _, _ = self._plan.download(act_seq=True, u=False)
+            self._act_host = a.reshape(self.H, self.dim_ctrl)
+        return self._act_host
+
+    @act_sequence.setter
+    def act_sequence(self, value):
+        self._act_host = np.array(value, dtype=np.float64).reshape(self.H, self.dim_ctrl)
+        self._act_dirty = True
+
+    def reset(self):
+        self._init_sequence()
+
+    # -- one control step (mppi.py:154-168) ------------------------------------------
+    def run(self, constate, new_obs, return_details=False):
+        nu = self.system.ctrl_dim
+        x0 = self.model.update_state(constate[:-nu], constate[-nu:], new_obs)
+        plan = self._device()
+        act = self._act_host if self._act_dirty else None
+        if self.noise == "numpy":
+            eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
+            plan.upload(x0=x0, act_seq=act, eps=eps)
+        else:
+            plan.upload(x0=x0, act_seq=act)
+            plan.generate_eps(self.seed, self.cur_step)
+        self._act_dirty = False
+        plan.solve()
+        self.cur_step += 1
+        if return_details:
+            a, u, costs, eps_out = plan.download(costs=True, eps_out=True)
+            self.last_costs = costs
+            self.last_eps = eps_out.reshape(self.H, self.num_path, nu)
+            self._act_host = a.reshape(self.H, nu)
+        else:
+            _, u, _, _ = plan.download(act_seq=False, u=True)
+        ret_action = u[0].copy()
+        return ret_action, np.concatenate([x0, ret_action])
+
+    def traj_to_state(self, traj):
+        return np.concatenate([self.model.traj_to_state(traj), traj[-1].ctrl])
+
+    @property
+    def state_dim(self):
+        return self.model.state_dim + self.system.ctrl_dim
+
+    @staticmethod
+    def is_compatible(system, task, model):
+        return bool(getattr(task.get_cost(), "is_quad", False)) and hasattr(model, "stage_into")
+
+
+class MPPIFactory(ControllerFactory):
+    """Hyper-parameter ranges of the reference's factory (mppi.py:48-64)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.Controller = MPPI
+        self.name = "MPPI"
+
+    def get_configuration_space(self):
+        try:
+            import ConfigSpace as CS
+            import ConfigSpace.hyperparameters as CSH
+        except ImportError as e:
+            raise ImportError("ConfigSpace is required for get_configuration_space()") from e
+        cs = CS.ConfigurationSpace()
+        cs.add_hyperparameter(CSH.UniformIntegerHyperparameter("horizon", lower=5, upper=30,
+                                                               default_value=20))
+        cs.add_hyperparameter(CSH.UniformFloatHyperparameter("sigma", lower=1e-4, upper=2.0,
+                                                             default_value=1.0))
+        cs.add_hyperparameter(CSH.UniformFloatHyperparameter("lmda", lower=0.1, upper=2.0,
+                                                             default_value=1.0))
+        cs.add_hyperparameter(CSH.UniformIntegerHyperparameter("num_path", lower=100, upper=1000,
+                                                               default_value=200))
+        return cs

@@ -1,0 +1,822 @@
+// autompc_hip.cpp -- host side of libautompc_hip.so: handles, weight packing, launches.
+// C ABI declared in include/autompc_hip.h.  Built with hipcc for gfx950 only.
+#include "../../include/autompc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mlp_kernels.hpp"
+#include "mppi_kernels.hpp"
+#include "rng_kernels.hpp"
+
+using namespace ampc;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(const std::string& msg) {
+  g_err = msg;
+  return -1;
+}
+#define HIP_OK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+#define REQUIRE(cond, msg) \
+  do {                     \
+    if (!(cond)) return fail(msg); \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+static constexpr size_t kLdsLimit = 160 * 1024;
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct ampc_handle {
+  int device = 0;
+  int precision = AMPC_F64;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t esz() const { return precision == AMPC_F64 ? 8 : 4; }
+
+  // model (host copy, double) ---------------------------------------------------------------
+  bool has_mlp = false;
+  int nx = 0, nu = 0, n_hidden = 0, act = 0;
+  int hidden[kMaxHidden] = {0, 0, 0, 0};
+  int hpad = 0, nt = 0, k1p = 0, nxp = 0;
+  std::vector<std::vector<double>> W, b;
+  std::vector<double> norm;
+  DevBuf model_buf;   // all packed arrays, contiguous
+  const void* wout_plain = nullptr;  // [nx][hpad] view into model_buf (Jacobian chain)
+  MlpDev<double> md{};
+  MlpDev<float> mf{};
+
+  // cost blocks / bounds ----------------------------------------------------------------------
+  int n_costs = 0, obs_dim = 0, cost_stride = 0;
+  DevBuf cost_buf;
+  bool has_bounds = false;
+  std::vector<double> lo, hi;
+  DevBuf bounds_buf;  // lo/scale, hi/scale, scale
+
+  // scratch for the batched model calls -----------------------------------------------------------
+  DevBuf s_states, s_ctrls, s_out, s_dz, s_jx, s_ju;
+};
+
+template <typename T> static MlpDev<T>& model_of(ampc_handle* h);
+template <> MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }
+template <> MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
+
+template <typename T>
+static hipError_t upload_converted(void* dst, const double* src, size_t n, hipStream_t s) {
+  if (sizeof(T) == 8) return hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, s);
+  std::vector<float> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), n * 4, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);  // tmp goes out of scope
+}
+template <typename T>
+static hipError_t download_converted(double* dst, const void* src, size_t n, hipStream_t s) {
+  if (sizeof(T) == 8) {
+    hipError_t e = hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+  }
+  std::vector<float> tmp(n);
+  hipError_t e = hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
+  return hipSuccess;
+}
+
+extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
+extern "C" int ampc_version(void) { return 100; }
+extern "C" int ampc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle** out) {
+  REQUIRE(out != nullptr, "ampc_create: out is NULL");
+  REQUIRE(precision == AMPC_F64 || precision == AMPC_F32, "ampc_create: bad precision");
+  int n = 0;
+  HIP_OK(hipGetDeviceCount(&n));
+  REQUIRE(device >= 0 && device < n, "ampc_create: no such HIP device");
+  HIP_OK(hipSetDevice(device));
+  ampc_handle* h = new ampc_handle();
+  h->device = device;
+  h->precision = precision;
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete h;
+      return fail(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    h->own_stream = true;
+  }
+  *out = h;
+  return 0;
+}
+
+extern "C" int ampc_destroy(ampc_handle* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->model_buf, &h->cost_buf, &h->bounds_buf, &h->s_states,
+                    &h->s_ctrls,   &h->s_out,      &h->s_dz,     &h->s_jx,       &h->s_ju};
+  for (DevBuf* b : bufs) b->release();
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+extern "C" int ampc_synchronize(ampc_handle* h) {
+  REQUIRE(h, "ampc_synchronize: NULL handle");
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : -1; }
+
+// ---------------------------------------------------------------------------------------------
+// weight packing (host, double) -- layouts documented in mlp_tile.hpp
+// ---------------------------------------------------------------------------------------------
+// B[k][n] supplied by a functor; N-split over 4 waves, NT tiles per wave.
+template <typename F>
+static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, F B) {
+  const int KS = kpad / 4;
+  dst.assign((size_t)kpad * hpad, 0.0);
+  for (int w = 0; w < kWaves; ++w)
+    for (int ks = 0; ks < KS; ++ks)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int nt = 0; nt < NT; ++nt) {
+          const int k = 4 * ks + (lane >> 4);
+          const int n = 16 * (NT * w + nt) + (lane & 15);
+          dst[(((size_t)w * KS + ks) * 64 + lane) * NT + nt] = B(k, n);
+        }
+}
+// K-split over 4 waves, `tiles` 16-column tiles.
+template <typename F>
+static void pack_ksplit(std::vector<double>& dst, int hpad, int tiles, F B) {
+  const int KS = hpad / 4, KSW = KS / kWaves;
+  dst.assign((size_t)hpad * tiles * 16, 0.0);
+  for (int w = 0; w < kWaves; ++w)
+    for (int ksl = 0; ksl < KSW; ++ksl)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int t = 0; t < tiles; ++t) {
+          const int k = 4 * (w * KSW + ksl) + (lane >> 4);
+          const int n = 16 * t + (lane & 15);
+          dst[(((size_t)w * KSW + ksl) * 64 + lane) * tiles + t] = B(k, n);
+        }
+}
+
+template <typename T> static int build_model(ampc_handle* h) {
+  const int L = h->n_hidden, nx = h->nx, nu = h->nu, kin = nx + nu;
+  const int hpad = h->hpad, NT = h->nt, k1p = h->k1p, nxp = h->nxp;
+  auto width_in = [&](int l) { return l == 0 ? kin : h->hidden[l - 1]; };
+  auto width_out = [&](int l) { return l == L ? nx : h->hidden[l]; };
+  std::vector<std::vector<double>> parts;  // in upload order
+  std::vector<size_t> off;
+  auto push = [&](std::vector<double>&& v) {
+    parts.emplace_back(std::move(v));
+  };
+  // forward weights w[0..L]
+  for (int l = 0; l <= L; ++l) {
+    const std::vector<double>& Wl = h->W[l];
+    const int in = width_in(l), out = width_out(l);
+    std::vector<double> pk;
+    auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
+    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, Bt);
+    else pack_ksplit(pk, hpad, nxp / 16, Bt);
+    push(std::move(pk));
+  }
+  // biases b[0..L]
+  for (int l = 0; l <= L; ++l) {
+    std::vector<double> bb(l < L ? hpad : nxp, 0.0);
+    for (int i = 0; i < width_out(l); ++i) bb[i] = h->b[l][i];
+    push(std::move(bb));
+  }
+  // Jacobian-chain weights wj[0..L-1]: B[k][n] = W_l[k][n]  (k = out index, n = in index)
+  const int ni = (kin + 15) / 16;
+  for (int l = 0; l < L; ++l) {
+    const std::vector<double>& Wl = h->W[l];
+    const int in = width_in(l), out = width_out(l);
+    std::vector<double> pk;
+    auto Bn = [&](int k, int n) { return (k < out && n < in) ? Wl[(size_t)k * in + n] : 0.0; };
+    if (l == 0) pack_ksplit(pk, hpad, ni, Bn);
+    else pack_nsplit(pk, hpad, hpad, NT, Bn);
+    push(std::move(pk));
+  }
+  push(std::vector<double>(h->norm));
+  // output weights in plain [nx][hpad]
+  {
+    std::vector<double> wp((size_t)nx * hpad, 0.0);
+    const int in = width_in(L);
+    for (int i = 0; i < nx; ++i)
+      for (int k = 0; k < in; ++k) wp[(size_t)i * hpad + k] = h->W[L][(size_t)i * in + k];
+    push(std::move(wp));
+  }
+  size_t total = 0;
+  for (auto& v : parts) {
+    off.push_back(total);
+    total += (v.size() + 3) / 4 * 4;  // keep every array 16/32-byte aligned
+  }
+  std::vector<double> flat(total, 0.0);
+  for (size_t i = 0; i < parts.size(); ++i)
+    std::memcpy(flat.data() + off[i], parts[i].data(), parts[i].size() * sizeof(double));
+  HIP_OK(h->model_buf.reserve(total * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->model_buf.p, flat.data(), total, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  MlpDev<T>& m = model_of<T>(h);
+  std::memset(&m, 0, sizeof(m));
+  m.nx = nx; m.nu = nu; m.kin = kin; m.k1p = k1p; m.n_hidden = L; m.hpad = hpad; m.nxp = nxp;
+  m.act = h->act;
+  const T* base = (const T*)h->model_buf.p;
+  size_t idx = 0;
+  for (int l = 0; l <= L; ++l) m.w[l] = base + off[idx++];
+  for (int l = 0; l <= L; ++l) m.b[l] = base + off[idx++];
+  for (int l = 0; l < L; ++l) m.wj[l] = base + off[idx++];
+  m.norm = base + off[idx++];
+  h->wout_plain = (const void*)(base + off[idx++]);
+  return 0;
+}
+
+extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
+                            int activation, const double* const* weights,
+                            const double* const* biases, const double* xu_mean,
+                            const double* xu_std, const double* dy_mean, const double* dy_std) {
+  REQUIRE(h, "ampc_set_mlp: NULL handle");
+  REQUIRE(nx >= 1 && nx <= 32, "ampc_set_mlp: state dim must be in 1..32");
+  REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_mlp: ctrl dim must be in 1..16");
+  REQUIRE(n_hidden >= 1 && n_hidden <= kMaxHidden, "ampc_set_mlp: 1..4 hidden layers");
+  REQUIRE(activation >= 0 && activation <= 3, "ampc_set_mlp: unknown activation");
+  REQUIRE(weights && biases && xu_mean && xu_std && dy_mean && dy_std && hidden_sizes,
+          "ampc_set_mlp: NULL argument");
+  HIP_OK(hipSetDevice(h->device));
+  int hmax = 0;
+  for (int l = 0; l < n_hidden; ++l) {
+    REQUIRE(hidden_sizes[l] >= 1 && hidden_sizes[l] <= 256, "ampc_set_mlp: hidden size 1..256");
+    hmax = hidden_sizes[l] > hmax ? hidden_sizes[l] : hmax;
+  }
+  h->nx = nx; h->nu = nu; h->n_hidden = n_hidden; h->act = activation;
+  for (int l = 0; l < kMaxHidden; ++l) h->hidden[l] = l < n_hidden ? hidden_sizes[l] : 0;
+  h->hpad = round_up(hmax, 64);
+  h->nt = h->hpad / 64;
+  h->k1p = round_up(nx + nu, 16);
+  h->nxp = round_up(nx, 16);
+  h->W.assign(n_hidden + 1, {});
+  h->b.assign(n_hidden + 1, {});
+  for (int l = 0; l <= n_hidden; ++l) {
+    const int in = l == 0 ? nx + nu : hidden_sizes[l - 1];
+    const int out = l == n_hidden ? nx : hidden_sizes[l];
+    h->W[l].assign(weights[l], weights[l] + (size_t)in * out);
+    h->b[l].assign(biases[l], biases[l] + out);
+  }
+  const int kin = nx + nu;
+  h->norm.resize(2 * kin + 2 * nx);
+  std::memcpy(h->norm.data(), xu_mean, kin * 8);
+  std::memcpy(h->norm.data() + kin, xu_std, kin * 8);
+  std::memcpy(h->norm.data() + 2 * kin, dy_mean, nx * 8);
+  std::memcpy(h->norm.data() + 2 * kin + nx, dy_std, nx * 8);
+  int rc = h->precision == AMPC_F64 ? build_model<double>(h) : build_model<float>(h);
+  if (rc) return rc;
+  h->has_mlp = true;
+  return 0;
+}
+
+extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                                   const double* R, const double* F, const double* goal) {
+  REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
+  REQUIRE(h->has_mlp, "ampc_set_quad_costs: set the model first");
+  REQUIRE(n_costs >= 1, "ampc_set_quad_costs: n_costs < 1");
+  REQUIRE(obs_dim >= 1 && obs_dim <= h->nx, "ampc_set_quad_costs: obs_dim must be <= state dim");
+  HIP_OK(hipSetDevice(h->device));
+  const int no = obs_dim, nu = h->nu;
+  const int stride = round_up(2 * no * no + nu * nu + no, 4);
+  std::vector<double> flat((size_t)n_costs * stride, 0.0);
+  for (int c = 0; c < n_costs; ++c) {
+    double* d = flat.data() + (size_t)c * stride;
+    std::memcpy(d, Q + (size_t)c * no * no, no * no * 8);
+    std::memcpy(d + no * no, R + (size_t)c * nu * nu, nu * nu * 8);
+    std::memcpy(d + no * no + nu * nu, F + (size_t)c * no * no, no * no * 8);
+    std::memcpy(d + 2 * no * no + nu * nu, goal + (size_t)c * no, no * 8);
+  }
+  HIP_OK(h->cost_buf.reserve(flat.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->n_costs = n_costs;
+  h->obs_dim = obs_dim;
+  h->cost_stride = stride;
+  return 0;
+}
+
+extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
+  REQUIRE(h && lo && hi, "ampc_set_ctrl_bounds: NULL argument");
+  REQUIRE(h->has_mlp, "ampc_set_ctrl_bounds: set the model first");
+  HIP_OK(hipSetDevice(h->device));
+  const int nu = h->nu;
+  h->lo.assign(lo, lo + nu);
+  h->hi.assign(hi, hi + nu);
+  // MPPI works in units of umax (ctrl_scale = umax, mppi.py:100-102): store lo/scale, hi/scale, scale.
+  std::vector<double> flat(3 * nu);
+  for (int j = 0; j < nu; ++j) {
+    flat[j] = lo[j] / hi[j];
+    flat[nu + j] = hi[j] / hi[j];
+    flat[2 * nu + j] = hi[j];
+  }
+  HIP_OK(h->bounds_buf.reserve(flat.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->has_bounds = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch on (NT, MT)
+// ---------------------------------------------------------------------------------------------
+template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define AMPC_DISPATCH_NT_MT(NTV, MTV, ...)                                 \
+  do {                                                                       \
+    const int key_ = (NTV) * 10 + (MTV);                                     \
+    switch (key_) {                                                          \
+      case 11: { constexpr int NT = 1, MT = 1; __VA_ARGS__; } break;                \
+      case 12: { constexpr int NT = 1, MT = 2; __VA_ARGS__; } break;                \
+      case 14: { constexpr int NT = 1, MT = 4; __VA_ARGS__; } break;                \
+      case 21: { constexpr int NT = 2, MT = 1; __VA_ARGS__; } break;                \
+      case 22: { constexpr int NT = 2, MT = 2; __VA_ARGS__; } break;                \
+      case 24: { constexpr int NT = 2, MT = 4; __VA_ARGS__; } break;                \
+      case 31: { constexpr int NT = 3, MT = 1; __VA_ARGS__; } break;                \
+      case 32: { constexpr int NT = 3, MT = 2; __VA_ARGS__; } break;                \
+      case 34: { constexpr int NT = 3, MT = 4; __VA_ARGS__; } break;                \
+      case 41: { constexpr int NT = 4, MT = 1; __VA_ARGS__; } break;                \
+      case 42: { constexpr int NT = 4, MT = 2; __VA_ARGS__; } break;                \
+      case 44: { constexpr int NT = 4, MT = 4; __VA_ARGS__; } break;                \
+      default: return fail("internal: unsupported (NT, MT) combination");    \
+    }                                                                        \
+  } while (0)
+
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
+// Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
+template <typename T>
+static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_rows,
+                     size_t extra_elems) {
+  const int forced = env_int("AMPC_MT", 0);
+  int best = 1;
+  for (int mt : {1, 2, 4}) {
+    TileLds L = make_tile_lds(m, 16 * mt);
+    const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
+    if (bytes > kLdsLimit) break;
+    if (forced == mt) return mt;
+    if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
+  }
+  (void)h;
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Model.pred_batch / pred_diff_batch
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                     double* jx, double* ju, int n) {
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nx = h->nx, nu = h->nu;
+  const bool deriv = jx != nullptr;
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const int mt = choose_mt<T>(h, m, n, 0);
+  const int M = 16 * mt;
+  const int tiles = (n + M - 1) / M;
+  const int n_pad = tiles * M;
+  TileLds L = make_tile_lds(m, M);
+  const size_t lds_bytes = (size_t)L.extra * sizeof(T);
+  if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
+  T* dz = (T*)h->s_dz.p;
+  AMPC_DISPATCH_NT_MT(h->nt, mt, {
+    if (deriv) {
+      auto k = mlp_forward_kernel<T, NT, MT, true>;
+      HIP_OK(allow_lds(k, lds_bytes));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(kWG), lds_bytes, h->stream, m, L,
+                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
+                         n_pad);
+    } else {
+      auto k = mlp_forward_kernel<T, NT, MT, false>;
+      HIP_OK(allow_lds(k, lds_bytes));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(kWG), lds_bytes, h->stream, m, L,
+                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
+                         (T*)nullptr, n, n_pad);
+    }
+  });
+  HIP_OK(hipGetLastError());
+  if (deriv) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    const int rows = n * nx;
+    const int jmt = 1;
+    const int JM = 16 * jmt;
+    const int jtiles = (rows + JM - 1) / JM;
+    const int kinp = 16 * ((m.kin + 15) / 16);
+    const size_t jl = (size_t)JM * imax(m.hpad + 2, kWaves * kinp) * sizeof(T);
+    AMPC_DISPATCH_NT_MT(h->nt, jmt, {
+      auto k = mlp_jacobian_kernel<T, NT, MT>;
+      HIP_OK(allow_lds(k, jl));
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(kWG), jl, h->stream, m,
+                         (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
+                         (T*)h->s_ju.p);
+    });
+    HIP_OK(hipGetLastError());
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
+extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                   double* out, int n) {
+  REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
+  REQUIRE(h->has_mlp, "ampc_mlp_pred_batch: no model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                  : pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+}
+
+extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                        double* out, double* jx, double* ju, int n) {
+  REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
+  REQUIRE(h->has_mlp, "ampc_mlp_pred_diff_batch: no model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                  : pred_impl<float>(h, states, ctrls, out, jx, ju, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MPPI plan
+// ---------------------------------------------------------------------------------------------
+struct ampc_mppi_plan {
+  ampc_handle* h = nullptr;
+  int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
+  std::vector<int> N, H, cost_idx, a_off;
+  std::vector<double> sigma, lmda;
+  std::vector<long long> eps_off, epso_off, cost_off;
+  long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
+  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out;
+  int cur = 0;          // act[cur] is the input of the next solve
+  bool costs_final = true;
+  bool solved = false;
+  size_t lds_bytes = 0;
+  TileLds L{};
+  int lds_aseq = 0, lds_cost = 0;
+  // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // 3 per solve: before rollout, after rollout, after update
+  size_t ev_used = 0;
+};
+
+template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
+  ampc_handle* h = p->h;
+  MppiArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.mlp = model_of<T>(h);
+  a.lds = p->L;
+  a.lds_aseq = p->lds_aseq;
+  a.lds_cost = p->lds_cost;
+  a.obs_dim = h->obs_dim;
+  a.cost_stride = h->cost_stride;
+  a.term_mode = p->term_mode;
+  a.max_h = p->max_h;
+  a.costs_par = (const T*)h->cost_buf.p;
+  a.bounds = (const T*)h->bounds_buf.p;
+  a.probs = (const MppiProblem<T>*)p->probs.p;
+  a.tile_prob = (const int*)p->tile_prob.p;
+  a.x0 = (const T*)p->x0.p;
+  a.act_in = (const T*)p->act[p->cur].p;
+  a.act_out = (T*)p->act[p->cur ^ 1].p;
+  a.eps = (const T*)p->eps.p;
+  a.eps_out = (T*)p->eps_out.p;
+  a.costs = (T*)p->costs.p;
+  a.term_last = (T*)p->term_last.p;
+  a.u_out = (T*)p->u_out.p;
+  return a;
+}
+
+template <typename T> static int plan_build(ampc_mppi_plan* p) {
+  ampc_handle* h = p->h;
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nu = h->nu, nx = h->nx;
+  const size_t extra = (size_t)p->max_h * nu + h->cost_stride + 3 * nu + 8;
+  p->mt = choose_mt<T>(h, m, p->sum_n, extra);
+  const int M = 16 * p->mt;
+  p->L = make_tile_lds(m, M);
+  p->lds_aseq = p->L.extra;
+  p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
+  p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);
+  REQUIRE(p->lds_bytes <= kLdsLimit, "mppi plan: model + horizon do not fit the 160 KB LDS");
+  std::vector<MppiProblem<T>> pr(p->B);
+  std::vector<int> tile_prob;
+  int tile = 0;
+  for (int b = 0; b < p->B; ++b) {
+    MppiProblem<T>& q = pr[b];
+    std::memset(&q, 0, sizeof(q));
+    q.N = p->N[b]; q.H = p->H[b]; q.tile0 = tile; q.cost_idx = p->cost_idx[b];
+    q.lam_over_sigma = (T)(p->lmda[b] / p->sigma[b]);
+    q.neg_inv_lambda = (T)(-1.0 / p->lmda[b]);
+    q.sqrt_sigma = (T)std::sqrt(p->sigma[b]);
+    q.eps_off = p->eps_off[b]; q.epso_off = p->epso_off[b]; q.cost_off = p->cost_off[b];
+    q.a_off = p->a_off[b];
+    const int nt = (q.N + M - 1) / M;
+    for (int t = 0; t < nt; ++t) tile_prob.push_back(b);
+    tile += nt;
+  }
+  p->n_tiles = tile;
+  HIP_OK(p->probs.reserve(pr.size() * sizeof(MppiProblem<T>)));
+  HIP_OK(hipMemcpy(p->probs.p, pr.data(), pr.size() * sizeof(MppiProblem<T>), hipMemcpyHostToDevice));
+  HIP_OK(p->tile_prob.reserve(tile_prob.size() * sizeof(int)));
+  HIP_OK(hipMemcpy(p->tile_prob.p, tile_prob.data(), tile_prob.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(p->x0.reserve((size_t)p->B * nx * sizeof(T)));
+  for (int i = 0; i < 2; ++i) {
+    HIP_OK(p->act[i].reserve((size_t)p->sum_hnu * sizeof(T)));
+    HIP_OK(hipMemset(p->act[i].p, 0, (size_t)p->sum_hnu * sizeof(T)));
+  }
+  HIP_OK(p->eps.reserve((size_t)p->sum_nhnu * sizeof(T)));
+  HIP_OK(hipMemset(p->eps.p, 0, (size_t)p->sum_nhnu * sizeof(T)));
+  HIP_OK(p->eps_out.reserve((size_t)p->sum_nhnu * sizeof(T)));
+  HIP_OK(p->costs.reserve((size_t)p->sum_n * sizeof(T)));
+  HIP_OK(p->term_last.reserve((size_t)p->B * sizeof(T)));
+  HIP_OK(p->u_out.reserve((size_t)p->B * nu * sizeof(T)));
+  HIP_OK(hipMemset(p->x0.p, 0, (size_t)p->B * nx * sizeof(T)));
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
+                                     const int* horizon, const double* sigma, const double* lmda,
+                                     const int* cost_index, int term_mode, ampc_mppi_plan** out) {
+  REQUIRE(h && num_path && horizon && sigma && lmda && out, "ampc_mppi_plan_create: NULL argument");
+  REQUIRE(h->has_mlp && h->n_costs > 0 && h->has_bounds,
+          "ampc_mppi_plan_create: model, cost and control bounds must be set first");
+  REQUIRE(B >= 1, "ampc_mppi_plan_create: B < 1");
+  REQUIRE(term_mode == 0 || term_mode == 1, "ampc_mppi_plan_create: bad term_mode");
+  for (int j = 0; j < h->nu; ++j)
+    REQUIRE(std::isfinite(h->lo[j]) && std::isfinite(h->hi[j]) && h->hi[j] != 0.0,
+            "MPPI requires finite, non-zero upper control bounds (ctrl_scale = umax)");
+  HIP_OK(hipSetDevice(h->device));
+  ampc_mppi_plan* p = new ampc_mppi_plan();
+  p->h = h; p->B = B; p->term_mode = term_mode;
+  const int nu = h->nu;
+  for (int b = 0; b < B; ++b) {
+    if (!(num_path[b] >= 1 && horizon[b] >= 2 && sigma[b] > 0 && lmda[b] > 0) ||
+        (cost_index && (cost_index[b] < 0 || cost_index[b] >= h->n_costs))) {
+      delete p;
+      return fail("ampc_mppi_plan_create: need num_path>=1, horizon>=2, sigma>0, lmda>0, valid cost_index");
+    }
+    p->N.push_back(num_path[b]); p->H.push_back(horizon[b]);
+    p->sigma.push_back(sigma[b]); p->lmda.push_back(lmda[b]);
+    p->cost_idx.push_back(cost_index ? cost_index[b] : 0);
+    p->a_off.push_back((int)p->sum_hnu);
+    p->eps_off.push_back(p->sum_nhnu); p->epso_off.push_back(p->sum_nhnu);
+    p->cost_off.push_back(p->sum_n);
+    p->sum_n += num_path[b];
+    p->sum_hnu += (long long)horizon[b] * nu;
+    p->sum_nhnu += (long long)num_path[b] * horizon[b] * nu;
+    p->max_h = horizon[b] > p->max_h ? horizon[b] : p->max_h;
+  }
+  int rc = h->precision == AMPC_F64 ? plan_build<double>(p) : plan_build<float>(p);
+  if (rc) {
+    ampc_mppi_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->h->device);
+  (void)hipStreamSynchronize(p->h->stream);
+  DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
+                    &p->eps_out, &p->costs, &p->term_last, &p->u_out};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  delete p;
+  return 0;
+}
+
+template <typename T>
+static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq,
+                            const double* eps) {
+  ampc_handle* h = p->h;
+  if (x0) HIP_OK(upload_converted<T>(p->x0.p, x0, (size_t)p->B * h->nx, h->stream));
+  if (act_seq) HIP_OK(upload_converted<T>(p->act[p->cur].p, act_seq, (size_t)p->sum_hnu, h->stream));
+  if (eps) HIP_OK(upload_converted<T>(p->eps.p, eps, (size_t)p->sum_nhnu, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
+                                const double* eps) {
+  REQUIRE(p, "ampc_mppi_upload: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64 ? mppi_upload_impl<double>(p, x0, act_seq, eps)
+                                     : mppi_upload_impl<float>(p, x0, act_seq, eps);
+}
+
+template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
+  ampc_handle* h = p->h;
+  const int nu = h->nu;
+  for (int b = 0; b < p->B; ++b) {
+    const long long count = (long long)p->N[b] * p->H[b] * nu;
+    const long long pairs = (count + 1) / 2;
+    const int blocks = (int)((pairs + 255) / 256);
+    hipLaunchKernelGGL(philox_normal_kernel<T>, dim3(blocks), dim3(256), 0, h->stream,
+                       (T*)p->eps.p + p->eps_off[b], count, (T)std::sqrt(p->sigma[b]), seed,
+                       stream * 65536ull + (uint64_t)b);
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
+  REQUIRE(p, "ampc_mppi_generate_eps: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64 ? mppi_generate_impl<double>(p, seed, stream)
+                                     : mppi_generate_impl<float>(p, seed, stream);
+}
+
+template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
+  ampc_handle* h = p->h;
+  MppiArgs<T> a = make_args<T>(p);
+  hipEvent_t* e = nullptr;
+  if (p->timing) {
+    if (p->ev_used + 3 > p->ev.size()) {
+      for (int i = 0; i < 3; ++i) {
+        hipEvent_t x;
+        HIP_OK(hipEventCreate(&x));
+        p->ev.push_back(x);
+      }
+    }
+    e = &p->ev[p->ev_used];
+    p->ev_used += 3;
+    HIP_OK(hipEventRecord(e[0], h->stream));
+  }
+  AMPC_DISPATCH_NT_MT(h->nt, p->mt, {
+    auto k = mppi_rollout_kernel<T, NT, MT>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(kWG), p->lds_bytes, h->stream, a);
+  });
+  if (e) HIP_OK(hipEventRecord(e[1], h->stream));
+  hipLaunchKernelGGL(mppi_update_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a);
+  if (e) HIP_OK(hipEventRecord(e[2], h->stream));
+  HIP_OK(hipGetLastError());
+  p->cur ^= 1;
+  p->costs_final = false;
+  p->solved = true;
+  return 0;
+}
+
+extern "C" int ampc_mppi_solve(ampc_mppi_plan* p) {
+  REQUIRE(p, "ampc_mppi_solve: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64 ? mppi_solve_impl<double>(p) : mppi_solve_impl<float>(p);
+}
+
+template <typename T>
+static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
+                              double* eps_out) {
+  ampc_handle* h = p->h;
+  if (costs && !p->costs_final && p->term_mode == 0) {
+    MppiArgs<T> a = make_args<T>(p);
+    int maxn = 0;
+    for (int n : p->N) maxn = n > maxn ? n : maxn;
+    hipLaunchKernelGGL(mppi_finalize_costs_kernel<T>, dim3((maxn + 255) / 256, p->B), dim3(256), 0,
+                       h->stream, a);
+    HIP_OK(hipGetLastError());
+    p->costs_final = true;
+  }
+  if (act_seq) HIP_OK(download_converted<T>(act_seq, p->act[p->cur].p, (size_t)p->sum_hnu, h->stream));
+  if (u) HIP_OK(download_converted<T>(u, p->u_out.p, (size_t)p->B * h->nu, h->stream));
+  if (costs) HIP_OK(download_converted<T>(costs, p->costs.p, (size_t)p->sum_n, h->stream));
+  if (eps_out) HIP_OK(download_converted<T>(eps_out, p->eps_out.p, (size_t)p->sum_nhnu, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
+                                  double* eps_out) {
+  REQUIRE(p, "ampc_mppi_download: NULL plan");
+  REQUIRE(p->solved || (!u && !costs && !eps_out), "ampc_mppi_download: nothing solved yet");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64 ? mppi_download_impl<double>(p, act_seq, u, costs, eps_out)
+                                     : mppi_download_impl<float>(p, act_seq, u, costs, eps_out);
+}
+
+extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {
+  REQUIRE(p && x0_dev, "ampc_mppi_set_x0_dev: NULL argument");
+  HIP_OK(hipSetDevice(p->h->device));
+  HIP_OK(hipMemcpyAsync(p->x0.p, x0_dev, (size_t)p->B * p->h->nx * p->h->esz(),
+                        hipMemcpyDeviceToDevice, p->h->stream));
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples_per_wg,
+                                   double* flops, double* bytes) {
+  REQUIRE(p, "ampc_mppi_plan_info: NULL plan");
+  const ampc_handle* h = p->h;
+  if (n_workgroups) *n_workgroups = p->n_tiles;
+  if (samples_per_wg) *samples_per_wg = 16 * p->mt;
+  // Algorithmic work: per sample-step 2*sum(in*out) MLP flops plus the quadratic
+  // stage cost; bytes = noise in + clipped noise out + costs + weights once.
+  double macs = 0;
+  for (int l = 0; l <= h->n_hidden; ++l) {
+    const int in = l == 0 ? h->nx + h->nu : h->hidden[l - 1];
+    const int out = l == h->n_hidden ? h->nx : h->hidden[l];
+    macs += (double)in * out;
+  }
+  const int no = h->obs_dim, nu = h->nu;
+  const double fcost = 2.0 * (no * no + no) + 2.0 * nu * nu + 2.0 * nu;
+  double f = 0, by = 0;
+  for (int b = 0; b < p->B; ++b) {
+    f += (double)p->N[b] * p->H[b] * (2.0 * macs + fcost);
+    by += 2.0 * h->esz() * (double)p->N[b] * p->H[b] * nu + (double)h->esz() * p->N[b];
+  }
+  by += (double)h->esz() * (macs + 0);
+  if (flops) *flops = f;
+  if (bytes) *bytes = by;
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable) {
+  REQUIRE(p, "ampc_mppi_plan_set_timing: NULL plan");
+  p->timing = enable != 0;
+  p->ev_used = 0;
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms,
+                                     int* count) {
+  REQUIRE(p, "ampc_mppi_plan_timing: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  double r = 0, u = 0;
+  const size_t n = p->ev_used / 3;
+  for (size_t i = 0; i < n; ++i) {
+    float a = 0, b = 0;
+    HIP_OK(hipEventElapsedTime(&a, p->ev[3 * i], p->ev[3 * i + 1]));
+    HIP_OK(hipEventElapsedTime(&b, p->ev[3 * i + 1], p->ev[3 * i + 2]));
+    r += a;
+    u += b;
+  }
+  if (rollout_ms) *rollout_ms = n ? r / n : 0.0;
+  if (update_ms) *update_ms = n ? u / n : 0.0;
+  if (count) *count = (int)n;
+  p->ev_used = 0;
+  return 0;
+}

@@ -1,0 +1,187 @@
+// mlp_kernels.hpp -- batched MLP dynamics step and its analytic Jacobian (gfx950).
+//
+// pred_batch      (reference: autompc/sysid/mlp.py:229-236)   -> mlp_forward_kernel
+// pred_diff_batch (reference: autompc/sysid/mlp.py:281-305)   -> mlp_forward_kernel<DERIV> +
+//                                                                mlp_jacobian_kernel
+// The reference obtains d(net)/d(input) by running autograd over an nx-fold repeated batch.
+// Here it is the chain  J_net = W_out D_L W_L ... D_1 W_1  evaluated left to right on MFMA, with
+// the rows (sample s, output i) of all samples flattened into one tall matrix so the 16-row
+// MFMA tiles carry no padding: G_L[(s,i)][k] = W_out[i][k] d_L[s][k], then per layer
+// G_{l-1} = (G_l W_l) * d_{l-1}[s], finally J_net = G_1 W_1 and
+// J = J_net * dy_std[i] / xu_std[c] + [c == i].
+#pragma once
+#include "mlp_tile.hpp"
+
+namespace ampc {
+
+template <typename T, int NT, int MT, bool DERIV>
+__global__ __launch_bounds__(kWG) void mlp_forward_kernel(const MlpDev<T> mlp, const TileLds L,
+                                                          const T* __restrict__ states,
+                                                          const T* __restrict__ ctrls,
+                                                          T* __restrict__ out, T* __restrict__ dz,
+                                                          int n, int n_pad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int M = 16 * MT;
+  const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
+  const int first = blockIdx.x * M;
+  T* xs = lds + L.xs;
+  T* xin = lds + L.xin;
+  tile_load_constants(mlp, L, lds);
+  for (int i = tid; i < M * L.xin_stride; i += kWG) xin[i] = T(0);
+  __syncthreads();
+  const T* xmean = lds + L.norm;
+  const T* xstd = xmean + mlp.kin;
+  const T* dmean = xstd + mlp.kin;
+  const T* dstd = dmean + nx;
+  for (int i = tid; i < M * nx; i += kWG) {
+    const int row = i / nx, col = i - row * nx;
+    const T v = (first + row < n) ? states[(size_t)(first + row) * nx + col] : T(0);
+    xs[i] = v;
+    xin[row * L.xin_stride + col] = (v - xmean[col]) / xstd[col];
+  }
+  for (int i = tid; i < M * nu; i += kWG) {
+    const int row = i / nu, col = i - row * nu;
+    const T v = (first + row < n) ? ctrls[(size_t)(first + row) * nu + col] : T(0);
+    xin[row * L.xin_stride + nx + col] = (v - xmean[nx + col]) / xstd[nx + col];
+  }
+  __syncthreads();
+  // dz layout: [layer][n_pad][hpad]; this tile's rows start at first
+  tile_network<T, NT, MT, DERIV>(mlp, L, lds, DERIV ? dz + (size_t)first * mlp.hpad : nullptr,
+                                 n_pad * mlp.hpad);
+  for (int i = tid; i < M * nx; i += kWG) {
+    const int row = i / nx, col = i - row * nx;
+    if (first + row < n) {
+      const T y = tile_output<T, MT>(mlp, L, lds, row, col);
+      out[(size_t)(first + row) * nx + col] = xs[i] + (y * dstd[col] + dmean[col]);
+    }
+  }
+}
+
+// K-split small-N layer used by the Jacobian's last stage: acc[mt][n] over this wave's k range.
+template <typename T, int MT, int NMAX>
+__device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as, int ksw,
+                                           const T* __restrict__ wl, int n_tiles,
+                                           typename Acc<T>::type (&acc)[MT][NMAX]) {
+#pragma unroll 2
+  for (int ks = 0; ks < ksw; ++ks) {
+    T a[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt * 16 * as + 4 * ks];
+#pragma unroll
+    for (int nn = 0; nn < NMAX; ++nn)
+      if (nn < n_tiles) {
+        const T b = wl[(size_t)ks * 64 * n_tiles + nn];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][nn] = mfma16(a[mt], b, acc[mt][nn]);
+      }
+  }
+}
+
+struct JacLds {
+  int g;        // [M][hpad+2]  (reused for last-stage partials [4][M][kinp])
+  int g_stride;
+};
+
+// rows = n * nx flattened (s, i); tile = 16*MT rows.
+// wout_plain: [nx][hpad] (zero padded); dz: [layer][n_pad][hpad] from mlp_forward_kernel<DERIV>.
+// jx[n][nx][nx], ju[n][nx][nu].
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
+                                                           const T* __restrict__ wout_plain,
+                                                           const T* __restrict__ dz, int n,
+                                                           int n_pad, T* __restrict__ jx,
+                                                           T* __restrict__ ju) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* G = reinterpret_cast<T*>(smem_raw);
+  using acc_t = typename Acc<T>::type;
+  constexpr int M = 16 * MT;
+  constexpr int NIMAX = 4;  // kin <= 64
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int nx = mlp.nx, nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
+  const int gs = hpad + 2;
+  const int rows_total = n * nx;
+  const int first = blockIdx.x * M;
+  const size_t lstride = (size_t)n_pad * hpad;
+
+  // G_L[(s,i)][k] = W_out[i][k] * d_L[s][k]
+  for (int e = tid; e < M * hpad; e += kWG) {
+    const int row = e / hpad, k = e - row * hpad;
+    const int gr = first + row;
+    T v = T(0);
+    if (gr < rows_total) {
+      const int s = gr / nx, i = gr - s * nx;
+      v = wout_plain[i * hpad + k] * dz[(size_t)(Lh - 1) * lstride + (size_t)s * hpad + k];
+    }
+    G[row * gs + k] = v;
+  }
+  __syncthreads();
+
+  const int ks_h = hpad / 4;
+  for (int l = Lh - 1; l >= 1; --l) {  // hidden->hidden layer l (torch index), uses wj[l]
+    acc_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
+    layer_mma_static<T, NT, MT, 16 * NT, 8>(G, gs, mlp.wj[l] + (size_t)w * ks_h * 64 * NT, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = 16 * (NT * w + nt) + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + acc_row<T>(q, r);
+          const int gr = first + row;
+          T d = T(0);
+          if (gr < rows_total) d = dz[(size_t)(l - 1) * lstride + (size_t)(gr / nx) * hpad + col];
+          G[row * gs + col] = acc[mt][nt][r] * d;
+        }
+      }
+    __syncthreads();
+  }
+
+  // last stage: J_net = G_1 W_1  (K = hpad split over waves, N = kin padded to 16*ni)
+  const int ni = (mlp.kin + 15) / 16;
+  const int kinp = 16 * ni;
+  const int ksw = ks_h / kWaves;
+  acc_t oacc[MT][NIMAX];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nn = 0; nn < NIMAX; ++nn) oacc[mt][nn] = acc_t{0, 0, 0, 0};
+  ksplit_mma<T, MT, NIMAX>(G + i16 * gs + q + 4 * w * ksw, gs, ksw,
+                           mlp.wj[0] + ((size_t)w * ksw * 64 + lane) * ni, ni, oacc);
+  __syncthreads();
+  T* part = G + w * M * kinp;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nn = 0; nn < NIMAX; ++nn)
+      if (nn < ni) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          part[(16 * mt + acc_row<T>(q, r)) * kinp + 16 * nn + i16] = oacc[mt][nn][r];
+      }
+  __syncthreads();
+  const T* xstd = mlp.norm + mlp.kin;
+  const T* dstd = mlp.norm + 2 * mlp.kin + nx;
+  for (int e = tid; e < M * mlp.kin; e += kWG) {
+    const int row = e / mlp.kin, c = e - row * mlp.kin;
+    const int gr = first + row;
+    if (gr >= rows_total) continue;
+    const int s = gr / nx, i = gr - s * nx;
+    T v = T(0);
+#pragma unroll
+    for (int ww = 0; ww < kWaves; ++ww) v += G[ww * M * kinp + row * kinp + c];
+    v = v / xstd[c] * dstd[i];
+    if (c < nx) jx[((size_t)s * nx + i) * nx + c] = v + (c == i ? T(1) : T(0));
+    else ju[((size_t)s * nx + i) * nu + (c - nx)] = v;
+  }
+}
+
+}  // namespace ampc

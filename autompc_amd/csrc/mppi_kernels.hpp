@@ -1,0 +1,280 @@
+// mppi_kernels.hpp -- MPPI solve on gfx950: persistent rollout kernel + softmin update kernel.
+//
+// What one solve computes (reference: autompc/control/mppi.py:110-152):
+//   a      <- shift(a)                                   a[t] = a_old[min(t+1, H-1)]
+//   for t: A = clip(eps_t + a_t, lo, hi); eps_t <- A - a_t; u = A * umax
+//          c  += (x-g)'Q(x-g) + u'Ru ;  ca += (lmda/sigma) * sum_j A_j eps_tj ;  x <- f(x, u)
+//   c += terminal (last particle's, or per particle) + ca
+//   w = softmax(-(c - min c)/lmda) ;  a += sum_n w_n eps[:, n, :]
+//
+// Kernel 1 (rollout): one workgroup owns M = 16*MT samples of one problem for ALL H time steps
+// (the time loop is serial, parallelism is over samples / problems).  State, running costs and
+// activations never leave the CU; per step the only HBM traffic is the sample's noise row in and
+// the clipped noise out.  MLP weights stream from L2 in MFMA-fragment order (mlp_tile.hpp).
+// Kernel 2 (update): one workgroup per (problem, time step): wave-shuffle min / sum reductions
+// for the softmin weights, then the weighted noise sum for that step.
+#pragma once
+#include "mlp_tile.hpp"
+
+namespace ampc {
+
+template <typename T> struct MppiProblem {
+  int N, H;            // samples, horizon
+  int tile0;           // first rollout workgroup of this problem
+  int cost_idx;        // cost block
+  T lam_over_sigma;    // lmda / sigma   (mppi.py:143)
+  T neg_inv_lambda;    // -1 / lmda      (mppi.py:115)
+  T sqrt_sigma;        // noise std      (mppi.py:18)
+  long long eps_off;   // into eps      [N][H][nu]
+  long long epso_off;  // into eps_out  [H][N][nu]
+  long long cost_off;  // into costs    [N]
+  int a_off;           // into act_seq  [H][nu]
+  int pad_;
+};
+
+template <typename T> struct MppiArgs {
+  MlpDev<T> mlp;
+  TileLds lds;
+  int lds_aseq, lds_cost;       // extra LDS regions: shifted act sequence, cost block + bounds
+  int obs_dim, cost_stride;     // cost block = Q[no*no] R[nu*nu] F[no*no] goal[no]
+  int term_mode, max_h;
+  const T* costs_par;           // [n_costs][cost_stride]
+  const T* bounds;              // lo[nu] hi[nu] scale[nu]   (lo, hi already divided by scale)
+  const MppiProblem<T>* probs;
+  const int* tile_prob;         // [n_tiles] -> problem
+  const T* x0;                  // [B][nx]
+  const T* act_in;              // [sum H*nu]
+  T* act_out;                   // [sum H*nu]
+  const T* eps;                 // noise in
+  T* eps_out;                   // clipped noise out
+  T* costs;                     // per-sample cost (terminal scalar of reference mode NOT included)
+  T* term_last;                 // [B] terminal cost of the last particle (reference mode)
+  T* u_out;                     // [B][nu] first action * scale (written by the update kernel)
+};
+
+template <typename T, int NT, int MT>
+__global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int M = 16 * MT;
+  constexpr int TPS = kWG / M;  // threads cooperating on one sample (16 / 8 / 4), same wave
+  const MlpDev<T>& mlp = args.mlp;
+  const TileLds& L = args.lds;
+  const int tid = threadIdx.x;
+  const int nx = mlp.nx, nu = mlp.nu, no = args.obs_dim;
+
+  const int p = args.tile_prob[blockIdx.x];
+  const MppiProblem<T> pr = args.probs[p];
+  const int first = (blockIdx.x - pr.tile0) * M;
+  const int H = pr.H, N = pr.N;
+
+  T* aseq = lds + args.lds_aseq;              // [H][nu] shifted warm start
+  T* cpar = lds + args.lds_cost;              // Q R F goal | lo hi scale
+  const T* Qm = cpar;
+  const T* Rm = Qm + no * no;
+  const T* Fm = Rm + nu * nu;
+  const T* goal = Fm + no * no;
+  const T* blo = cpar + args.cost_stride;
+  const T* bhi = blo + nu;
+  const T* bsc = bhi + nu;
+  T* xs = lds + L.xs;
+  T* us = lds + L.us;
+  T* xin = lds + L.xin;
+  const T* xmean = lds + L.norm;
+  const T* xstd = xmean + mlp.kin;
+  const T* dmean = xstd + mlp.kin;
+  const T* dstd = dmean + nx;
+
+  // ---- prologue: constants, shifted sequence, initial state ------------------------------
+  tile_load_constants(mlp, L, lds);
+  for (int i = tid; i < args.cost_stride; i += kWG)
+    cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
+  for (int i = tid; i < 3 * nu; i += kWG) cpar[args.cost_stride + i] = args.bounds[i];
+  for (int i = tid; i < H * nu; i += kWG) {
+    const int t = i / nu, j = i - t * nu;
+    const int ts = (t + 1 < H) ? t + 1 : H - 1;  // a[:-1] = a[1:]; a[-1] = a[-2]
+    aseq[i] = args.act_in[pr.a_off + ts * nu + j];
+  }
+  for (int i = tid; i < M * nx; i += kWG) xs[i] = args.x0[p * nx + (i % nx)];
+  for (int i = tid; i < M * L.xin_stride; i += kWG) xin[i] = T(0);
+
+  const int m = tid / TPS, r = tid % TPS;   // sample-in-tile, helper index
+  const int n = first + m;
+  const bool valid = n < N;
+  const T* eps_row = args.eps + pr.eps_off + (size_t)(valid ? n : 0) * H * nu;
+  T* epso = args.eps_out + pr.epso_off;
+
+  T c_part = T(0), ca_part = T(0);
+  T e_next[MT];
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int j = r + e * TPS;
+    e_next[e] = (valid && j < nu) ? eps_row[j] : T(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < H; ++t) {
+    // ---- P1: actions, clipped noise out, normalised network input --------------------------
+#pragma unroll
+    for (int e = 0; e < MT; ++e) {
+      const int j = r + e * TPS;
+      if (j < nu) {
+        const T a = aseq[t * nu + j];
+        T A = e_next[e] + a;
+        A = A < blo[j] ? blo[j] : A;
+        A = A > bhi[j] ? bhi[j] : A;
+        const T ec = A - a;
+        const T u = A * bsc[j];
+        if (valid) epso[((size_t)t * N + n) * nu + j] = ec;
+        ca_part += A * ec;
+        us[m * nu + j] = u;
+        xin[m * L.xin_stride + nx + j] = (u - xmean[nx + j]) / xstd[nx + j];
+        if (t + 1 < H) e_next[e] = valid ? eps_row[(t + 1) * nu + j] : T(0);
+      }
+    }
+    for (int i = r; i < nx; i += TPS)
+      xin[m * L.xin_stride + i] = (xs[m * nx + i] - xmean[i]) / xstd[i];
+    __syncthreads();
+
+    // ---- P2: stage cost (partial per thread: rows r, r+TPS, ...) ----------------------------
+    {
+      const T* x = xs + m * nx;
+      for (int i = r; i < no; i += TPS) {
+        T s = T(0);
+        for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (x[j] - goal[j]);
+        c_part += (x[i] - goal[i]) * s;
+      }
+      const T* u = us + m * nu;
+      for (int i = r; i < nu; i += TPS) {
+        T s = T(0);
+        for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * u[j];
+        c_part += u[i] * s;
+      }
+    }
+
+    // ---- dynamics: x <- x + dy_mean + dy_std * net(xin) -------------------------------------
+    tile_network<T, NT, MT>(mlp, L, lds);
+    for (int i = tid; i < M * nx; i += kWG) {
+      const int row = i / nx, col = i - row * nx;
+      const T y = tile_output<T, MT>(mlp, L, lds, row, col);
+      xs[i] = xs[i] + (y * dstd[col] + dmean[col]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------
+  T term = T(0);
+  {
+    const T* x = xs + m * nx;
+    for (int i = r; i < no; i += TPS) {
+      T s = T(0);
+      for (int j = 0; j < no; ++j) s += Fm[i * no + j] * (x[j] - goal[j]);
+      term += (x[i] - goal[i]) * s;
+    }
+  }
+  T c = c_part + pr.lam_over_sigma * ca_part;
+  if (args.term_mode == 1) c += term;
+#pragma unroll
+  for (int off = TPS / 2; off > 0; off >>= 1) {
+    c += __shfl_xor(c, off);
+    term += __shfl_xor(term, off);
+  }
+  if (r == 0 && valid) {
+    args.costs[pr.cost_off + n] = c;
+    if (n == N - 1) args.term_last[p] = term;
+  }
+}
+
+// ---- block-wide reductions built on wave shuffles ---------------------------------------------
+template <typename T> __device__ __forceinline__ T wave_min(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { T o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch) {
+  v = wave_min(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T o = scratch[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) o = scratch[w] < o ? scratch[w] : o;
+  return o;
+}
+template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T o = scratch[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) o += scratch[w];
+  return o;
+}
+
+constexpr int kMaxNu = 16;
+
+// grid = (max_h, B).  Block (t, p) recomputes the softmin normaliser (N reads, L2 resident) and
+// produces act_out[p][t][:].  Block t == 0 also finalises the costs (adds the reference-mode
+// terminal scalar) and writes the control to apply.
+template <typename T>
+__global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args) {
+  __shared__ T scratch[kWaves];
+  __shared__ T red[kWaves][kMaxNu];
+  const int p = blockIdx.y, t = blockIdx.x;
+  const MppiProblem<T> pr = args.probs[p];
+  if (t >= pr.H) return;
+  const int N = pr.N, nu = args.mlp.nu, tid = threadIdx.x;
+  const T* c = args.costs + pr.cost_off;
+
+  T vmin = c[0];
+  for (int n = tid; n < N; n += kWG) vmin = c[n] < vmin ? c[n] : vmin;
+  vmin = block_min(vmin, scratch);
+  T ssum = T(0);
+  for (int n = tid; n < N; n += kWG) ssum += exp(pr.neg_inv_lambda * (c[n] - vmin));
+  ssum = block_sum(ssum, scratch);
+
+  T acc[kMaxNu];
+#pragma unroll
+  for (int j = 0; j < kMaxNu; ++j) acc[j] = T(0);
+  const T* e = args.eps_out + pr.epso_off + (size_t)t * N * nu;
+  for (int n = tid; n < N; n += kWG) {
+    const T wgt = exp(pr.neg_inv_lambda * (c[n] - vmin)) / ssum;
+#pragma unroll
+    for (int j = 0; j < kMaxNu; ++j)
+      if (j < nu) acc[j] += wgt * e[(size_t)n * nu + j];
+  }
+#pragma unroll
+  for (int j = 0; j < kMaxNu; ++j)
+    if (j < nu) {
+      const T s = wave_sum(acc[j]);
+      if ((tid & 63) == 0) red[tid >> 6][j] = s;
+    }
+  __syncthreads();
+  if (tid < nu) {
+    const int ts = (t + 1 < pr.H) ? t + 1 : pr.H - 1;
+    T s = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w][tid];
+    const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s;
+    args.act_out[pr.a_off + t * nu + tid] = a_new;
+    if (t == 0) args.u_out[p * nu + tid] = a_new * args.bounds[2 * nu + tid];
+  }
+}
+
+// Adds the reference-mode terminal scalar into the stored per-sample costs (only needed when the
+// caller downloads them; the softmin weights are invariant to a constant shift).
+template <typename T>
+__global__ void mppi_finalize_costs_kernel(const MppiArgs<T> args) {
+  const int p = blockIdx.y;
+  const MppiProblem<T> pr = args.probs[p];
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < pr.N) args.costs[pr.cost_off + n] += args.term_last[p];
+}
+
+}  // namespace ampc

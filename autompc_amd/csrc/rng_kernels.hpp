@@ -1,0 +1,64 @@
+// rng_kernels.hpp -- counter-based normal noise on the device (Philox4x32-10 + Box-Muller).
+//
+// "Fast mode" replacement for the reference's host-side draw
+//   np.random.normal(scale=sqrt(sigma), size=(N, H, nu))     (autompc/control/mppi.py:21-24, :126)
+// The reference uses numpy's legacy global MT19937 stream; that stream is reproduced only by
+// generating the noise on the host with numpy ("parity mode": ampc_mppi_upload).  This kernel is
+// statistically equivalent (same N(0, sigma) marginals, independent across samples/steps/dims)
+// but not bit-identical, and results obtained with it are compared distributionally only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ampc {
+
+struct Philox4 { uint32_t v[4]; };
+
+__host__ __device__ inline uint32_t mulhi32(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+
+// Philox4x32 with 10 rounds (Salmon et al., SC'11): counter c, key k.
+__host__ __device__ inline Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = mulhi32(M0, c.v[0]), lo0 = M0 * c.v[0];
+    const uint32_t hi1 = mulhi32(M1, c.v[2]), lo1 = M1 * c.v[2];
+    Philox4 n;
+    n.v[0] = hi1 ^ c.v[1] ^ k0;
+    n.v[1] = lo1;
+    n.v[2] = hi0 ^ c.v[3] ^ k1;
+    n.v[3] = lo0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+// One Philox block -> two uniforms in (0,1) with 53 (f64) bits -> two standard normals.
+template <typename T>
+__global__ void philox_normal_kernel(T* __restrict__ out, long long count, T scale, uint64_t seed,
+                                     uint64_t stream) {
+  const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e0 = 2 * pair;
+  if (e0 >= count) return;
+  Philox4 c;
+  c.v[0] = (uint32_t)pair;
+  c.v[1] = (uint32_t)((uint64_t)pair >> 32);
+  c.v[2] = (uint32_t)stream;
+  c.v[3] = (uint32_t)(stream >> 32);
+  const Philox4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t a = ((uint64_t)r.v[0] << 32) | r.v[1];
+  const uint64_t b = ((uint64_t)r.v[2] << 32) | r.v[3];
+  const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double s, cth;
+  sincospi(2.0 * u2, &s, &cth);
+  out[e0] = (T)(rad * cth) * scale;
+  if (e0 + 1 < count) out[e0 + 1] = (T)(rad * s) * scale;
+}
+
+}  // namespace ampc

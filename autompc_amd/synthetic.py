@@ -1,0 +1,52 @@
+"""Synthetic workloads of the BASELINE.json shapes (no datasets / checkpoints exist offline).
+
+Weights follow torch.nn.Linear's default initialisation distribution
+(U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases), drawn from a seeded numpy
+generator; normalisers are mean 0 / std 1 on the input and mean 0 / std 0.1 on the output, which
+keeps 30-step rollouts bounded.
+"""
+import numpy as np
+
+from .costs import QuadCost
+from .sysid import MLP
+from .system import System
+from .task import Task
+
+WORKLOADS = {
+    # name: nx, nu, hidden, num_path, horizon, ctrl bound
+    "c2": dict(label="Pendulum, MLP 2x64, MPPI 1024 samples x 30 horizon",
+               nx=2, nu=1, hidden=[64, 64], num_path=1024, horizon=30, bound=2.0),
+    "c3": dict(label="HalfCheetah (17-dim state, 6-dim ctrl), MLP 2x256, MPPI 4096 samples x 30 horizon",
+               nx=17, nu=6, hidden=[256, 256], num_path=4096, horizon=30, bound=1.0),
+}
+
+
+def random_mlp_params(nx, nu, hidden, seed=0, dy_std=0.1):
+    rng = np.random.default_rng(seed)
+    dims = [nx + nu] + list(hidden) + [nx]
+    weights, biases = [], []
+    for fan_in, fan_out in zip(dims[:-1], dims[1:]):
+        bound = 1.0 / np.sqrt(fan_in)
+        weights.append(rng.uniform(-bound, bound, size=(fan_out, fan_in)))
+        biases.append(rng.uniform(-bound, bound, size=(fan_out,)))
+    return dict(weights=weights, biases=biases, xu_means=np.zeros(nx + nu),
+                xu_std=np.ones(nx + nu), dy_means=np.zeros(nx), dy_std=np.full(nx, dy_std))
+
+
+def make_workload(name, precision="f64", device=0, seed=0):
+    """(system, task, model, spec) for a named BASELINE configuration."""
+    spec = WORKLOADS[name]
+    nx, nu = spec["nx"], spec["nu"]
+    system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+    p = random_mlp_params(nx, nu, spec["hidden"], seed=seed)
+    kw = {"hidden_size_%d" % (i + 1): h for i, h in enumerate(spec["hidden"])}
+    model = MLP(system, n_hidden_layers=len(spec["hidden"]), nonlintype="relu",
+                precision=precision, device=device, **kw)
+    model.weights, model.biases = p["weights"], p["biases"]
+    model.xu_means, model.xu_std = p["xu_means"], p["xu_std"]
+    model.dy_means, model.dy_std = p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), goal=np.zeros(nx)))
+    task.set_ctrl_bounds(np.full(nu, -spec["bound"]), np.full(nu, spec["bound"]))
+    task.set_init_obs(np.random.default_rng(seed).uniform(-0.1, 0.1, size=nx))
+    return system, task, model, dict(spec, params=p)

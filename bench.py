@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC solves/sec of the MPPI inner solve on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2] [--precision f64|f32]
+
+One "step" = one complete MPPI solve of the named BASELINE.json configuration (default c3:
+HalfCheetah-shaped MLP 2x256, 4096 samples x 30 horizon): fresh device-resident noise, batched
+surrogate rollout with stage/action/terminal costs, softmin weighting and warm-start update --
+i.e. everything MPPI.run() does between receiving an observation and returning a control
+(reference: autompc/control/mppi.py:120-168).  Inputs are resident in HBM when the timed region
+starts.  For N > 1 every rank (one process per GPU, launched by torch.distributed.run) solves
+its own independent problems -- the tuning use case shards candidate controllers, a single
+solve does not shard -- so scaling is weak and there is no collective on
+the data path; ranks only meet at the barriers that bracket the timed region and at the final
+max-over-ranks reduction of the elapsed time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--noise", default="device", choices=["device", "resident"],
+                    help="device: fresh Philox noise generated on the GPU inside every step; "
+                         "resident: one numpy-drawn noise set uploaded before timing and reused")
+    ap.add_argument("--batch", type=int, default=1, help="independent solves per step per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-solves", type=int, default=0, help="0 = auto (about 10-30 s)")
+    return ap.parse_args()
+
+
+def cpu_baseline(workload, spec, n_solves):
+    """The oracle (numpy restatement of the reference, strict_reference=True: per-step
+    pred_batch + the per-particle Python cost loop of mppi.py:73-78) timed on the host."""
+    from oracle.costs import QuadCostOracle
+    from oracle.mlp import MLPOracle, make_params
+    from oracle.mppi import MPPIOracle
+    from autompc_amd import System
+    nx, nu = spec["nx"], spec["nu"]
+    p = spec["params"]
+    params = make_params(p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"],
+                         p["dy_means"], p["dy_std"])
+    system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+    cost = QuadCostOracle(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+    bnd = np.tile([-spec["bound"], spec["bound"]], (nu, 1))
+    np.random.seed(0)
+    ctl = MPPIOracle(MLPOracle(system, params), cost, bnd, horizon=spec["horizon"],
+                     num_path=spec["num_path"], sigma=1.0, lmda=1.0, strict_reference=True)
+    x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
+    cs = np.concatenate([x0, np.zeros(nu)])
+    u, cs = ctl.run(cs, x0)                      # warm-up (BLAS threads, caches)
+    if n_solves <= 0:
+        t0 = time.perf_counter()
+        u, cs = ctl.run(cs, x0)
+        one = time.perf_counter() - t0
+        n_solves = int(max(2, min(50, round(12.0 / max(one, 1e-3)))))
+    t0 = time.perf_counter()
+    for _ in range(n_solves):
+        u, cs = ctl.run(cs, x0)
+    dt = time.perf_counter() - t0
+    return {"value": n_solves / dt, "unit": "solves/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d consecutive %s solves (oracle, numpy f64 + per-particle Python cost loop, "
+                      "OpenBLAS threads = host cores), %.1f s" % (n_solves, workload, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from autompc_amd import _lib
+    from autompc_amd.synthetic import make_workload
+    system, task, model, spec = make_workload(args.workload, precision=args.precision,
+                                              device=local_rank, seed=0)
+    nx, nu, N, H = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"]
+    stream = torch.cuda.current_stream().cuda_stream
+    h = _lib.Handle(local_rank, args.precision, stream=stream)
+    model.stage_into(h)
+    Q, R, F = task.get_cost().get_cost_matrices()
+    h.set_quad_costs(Q, R, F, task.get_cost().get_goal())
+    bounds = task.get_ctrl_bounds()
+    h.set_ctrl_bounds(bounds[:, 0], bounds[:, 1])
+    B = args.batch
+    plan = _lib.MppiPlan(h, [N] * B, [H] * B, [1.0] * B, [1.0] * B)
+    rng = np.random.default_rng(1000 + rank)
+    x0 = np.tile(task.get_init_obs(), (B, 1)) + rng.uniform(-0.01, 0.01, size=(B, nx))
+    np.random.seed(rank)
+    act0 = np.random.normal(size=(B * H * nu))
+    eps0 = np.random.normal(size=(B * N * H * nu)) if args.noise == "resident" else None
+    plan.upload(x0, act0, eps0)
+    info = plan.info()
+
+    def step(i):
+        if args.noise == "device":
+            plan.generate_eps(rank, i)
+        plan.solve()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    plan.set_timing(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kt = plan.timing()
+    plan.set_timing(False)
+    _, u, _, _ = plan.download(act_seq=False, u=True)
+    if not np.all(np.isfinite(u)):
+        raise RuntimeError("non-finite control returned by the solve")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        solves = world * args.steps * B
+        value = solves / elapsed
+        rollout_s = kt["rollout_ms"] * 1e-3
+        achieved = info["flops"] / rollout_s / 1e12 if rollout_s > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        out = {
+            "metric": "MPC solves/sec (MPPI, n_samples x horizon rollouts + update per solve)",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%s: %s; random-weight relu MLP, QuadCost Q=I R=0.01I F=I, "
+                                   "sigma=1 lmda=1, %d independent solve(s) per step per GPU, "
+                                   "noise=%s" % (args.workload, spec["label"], B, args.noise),
+                       "n_samples": N, "horizon": H, "state_dim": nx, "ctrl_dim": nu,
+                       "hidden": spec["hidden"], "parallelism": "independent solves per GPU (dp%d)" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": None,
+                         "kernel": "mppi_rollout_kernel", "kernel_ms": kt["rollout_ms"],
+                         "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"],
+                         "algorithmic_flops_per_launch": info["flops"],
+                         "algorithmic_bytes_per_launch": info["bytes"],
+                         "workgroups": info["workgroups"], "samples_per_workgroup": info["samples_per_wg"]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.workload, spec, args.cpu_solves)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

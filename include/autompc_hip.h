@@ -1,0 +1,122 @@
+/*
+ * autompc_hip.h -- C ABI of libautompc_hip.so, the MI355X (gfx950) MPC inner-solve library.
+ *
+ * The reference (williamedwards/autompc) is pure Python and has no FFI; its hot path is reached
+ * through two Python ABCs.  Each entry point below states which reference function(s) it
+ * replaces (file:line relative to the reference tree).  The Python classes in autompc_amd/
+ * bind these with ctypes and reproduce the reference's Controller / Model plugin surface.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; ampc_last_error() returns the message
+ *     of the calling thread's last failure.  Nothing throws across this boundary.
+ *   - all host arrays are caller-owned, contiguous, row-major, IEEE float64 ("double").  The
+ *     library converts to its compute precision (AMPC_F64 or AMPC_F32) on the device.
+ *   - a handle is bound to one HIP device and one stream; calls on one handle must be
+ *     serialised by the caller (the reference is single-threaded).  Different handles may be
+ *     used from different threads / processes (one per GPU).
+ *   - "_dev" variants take DEVICE pointers (in the handle's compute precision) and only enqueue
+ *     work on the handle's stream: no host synchronisation, no PCIe traffic.
+ */
+#ifndef AUTOMPC_HIP_H
+#define AUTOMPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ampc_handle ampc_handle;
+typedef struct ampc_mppi_plan ampc_mppi_plan;
+
+enum { AMPC_F64 = 0, AMPC_F32 = 1 };
+enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU = 3 };
+/* MPPI terminal-cost mode: 0 = the reference's behaviour (terminal cost of the LAST particle
+ * added to every particle, mppi.py:79-82,146-148); 1 = per-particle terminal cost. */
+enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
+
+const char* ampc_last_error(void);
+int ampc_version(void);
+int ampc_device_count(void);
+
+/* ---- handle ------------------------------------------------------------------------------ */
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to let the library
+ * create its own. */
+int ampc_create(int device, int precision, void* stream, ampc_handle** out);
+int ampc_destroy(ampc_handle* h);
+int ampc_synchronize(ampc_handle* h);
+int ampc_precision(const ampc_handle* h);
+
+/* ---- model: MLP surrogate dynamics --------------------------------------------------------
+ * Replaces the state held by autompc.sysid.MLP (mlp.py:137-165 net, :308-321 parameters).
+ * weights[l] is torch.nn.Linear layout [out_l][in_l]; l = 0..n_hidden (last = output layer).
+ * x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)          (mlp.py:219-236) */
+int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
+                 int activation, const double* const* weights, const double* const* biases,
+                 const double* xu_mean, const double* xu_std, const double* dy_mean,
+                 const double* dy_std);
+
+/* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */
+int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                        int n);
+/* Model.pred_diff_batch (model.py:155-184, mlp.py:281-305): out[n][nx], jx[n][nx][nx],
+ * ju[n][nx][nu].  Analytic Jacobian chain instead of the reference's autograd. */
+int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                             double* out, double* jx, double* ju, int n);
+
+/* ---- cost / bounds ------------------------------------------------------------------------
+ * Replaces QuadCost (quad_cost.py:7-51) as read through Cost.eval_* (cost.py:66-213).
+ * n_costs blocks (one per tuning candidate), each Q[no][no], R[nu][nu], F[no][no], goal[no]. */
+int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                        const double* R, const double* F, const double* goal);
+/* Task.get_ctrl_bounds (task.py:257-267): lo[nu], hi[nu] (MPPI requires finite bounds,
+ * mppi.py:100-102; iLQR clips only if bounded, ilqr.py:62-64). */
+int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi);
+
+/* ---- MPPI ---------------------------------------------------------------------------------
+ * A plan owns device buffers for a batch of B independent MPPI problems (B = 1 for the plain
+ * Controller.run() path; B = candidates-per-GPU for the tuning evaluator).
+ * Problem p has num_path[p] samples, horizon[p] steps, noise variance sigma[p], temperature
+ * lmda[p] and cost block cost_index[p]  (MPPI.__init__, mppi.py:87-105). */
+int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path, const int* horizon,
+                          const double* sigma, const double* lmda, const int* cost_index,
+                          int term_mode, ampc_mppi_plan** out);
+int ampc_mppi_plan_destroy(ampc_mppi_plan* p);
+/* Host -> device.  Any pointer may be NULL (left unchanged on the device).
+ *   x0      [B][nx]                       model state each solve starts from
+ *   act_seq [sum_p H_p*nu]                warm-start sequences, problem-major, units of umax
+ *   eps     [sum_p N_p*H_p*nu]            noise exactly as numpy draws it: per problem
+ *                                         [N][H][nu] (mppi.py:126 before the transpose)       */
+int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
+                     const double* eps);
+/* Fill the plan's noise buffer on the device: eps ~ N(0, sigma_p) from Philox4x32-10 keyed by
+ * (seed, stream, sample, t, j).  Statistically equivalent to, not bit-identical with, numpy. */
+int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
+/* One MPPI solve per problem, enqueued on the handle's stream (MPPI.do_rollouts + update,
+ * mppi.py:110-152): shift warm start, rollout all samples, softmin weights, update act_seq. */
+int ampc_mppi_solve(ampc_mppi_plan* p);
+/* Device -> host (synchronises).  Any pointer may be NULL.
+ *   act_seq [sum_p H_p*nu]   updated sequences;  u [B][nu] = act_seq[p][0] * umax
+ *   costs   [sum_p N_p]      per-sample costs (mppi.py:150-152)
+ *   eps_out [sum_p H_p*N_p*nu] post-clip noise, per problem [H][N][nu] (as do_rollouts returns) */
+int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
+                       double* eps_out);
+/* Overwrite x0 of every problem from a device buffer [B][nx] in compute precision (closed-loop
+ * evaluator: no host round trip). */
+int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev);
+/* Kernel-level introspection for bench.py: grid size (workgroups) and samples per workgroup of
+ * the rollout launch, algorithmic FLOPs and bytes of one solve. */
+int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples_per_wg,
+                        double* flops, double* bytes);
+
+/* Per-kernel timing for the roofline report: when enabled, every ampc_mppi_solve brackets the
+ * rollout and update launches with HIP events on the handle's stream.  ampc_mppi_plan_timing
+ * synchronises, returns the AVERAGE duration (ms) of each kernel over the solves since the last
+ * call, and resets the counters. */
+int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable);
+int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms, int* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOMPC_HIP_H */

@@ -1,0 +1,191 @@
+"""HIP MPPI solve vs the reference's golden vectors (nu = 1) and the oracle (nu > 1, full
+BASELINE sizes).  Goes through Controller.run() -> ctypes -> C ABI -> HIP kernels."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import check_weights, cost_from_golden, golden_params, make_system, rel_err
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+from oracle.mlp import MLPOracle
+from oracle.mppi import MPPIOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _names():
+    return sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN, "mppi_*.npz")))
+
+
+def _hip_stack(p, nx, nu, Q, R, F, goal, bounds, precision="f64", **mppi_kw):
+    from autompc_amd import MLP, MPPI, QuadCost, Task
+    system = make_system(nx, nu)
+    m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
+            precision=precision,
+            **{"hidden_size_%d" % (i + 1): w.shape[0] for i, w in enumerate(p["weights"][:-1])})
+    m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    task.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
+    return system, m, task
+
+
+@pytest.mark.parametrize("name", _names())
+def test_mppi_matches_reference_golden(name):
+    from autompc_amd import MPPI
+    g = golden(name)
+    nx = int(g["nx"])
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    check_weights(p, g)
+    system, model, task = _hip_stack(p, nx, 1, g["Q"], g["R"], g["F"], g["goal"], g["bounds"])
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPI(system, task, model, horizon=int(g["H"]), num_path=int(g["N"]),
+               sigma=float(g["sigma"]), lmda=float(g["lmda"]))
+    np.testing.assert_array_equal(ctl.act_sequence, g["act0"])
+    obs = np.random.default_rng(int(g["np_seed"]) + 99).uniform(-0.1, 0.1, size=nx)
+    constate = np.concatenate([obs, np.zeros(1)])
+    ref_model = MLPOracle(system, p)
+    for r in range(int(g["n_runs"])):
+        if r == 3:
+            ctl.reset()
+            np.testing.assert_array_equal(ctl.act_sequence, g["act_reset"])
+        u, constate = ctl.run(constate, obs, return_details=True)
+        assert rel_err(ctl.last_costs, g["costs_%d" % r]) < 1e-9
+        assert rel_err(ctl.last_eps[:, ::16, :], g["eps_sub_%d" % r]) < 1e-12
+        assert rel_err(ctl.act_sequence, g["act_%d" % r]) < 1e-8
+        assert rel_err(u, g["u_%d" % r]) < 1e-8
+        assert rel_err(constate, g["newstate_%d" % r]) < 1e-8
+        obs = ref_model.pred(obs, g["u_%d" % r])
+
+
+def _oracle_vs_hip(nx, nu, hidden, act, N, H, sigma, lmda, bounds, precision, tol, seed=0,
+                   per_particle=False, runs=2):
+    from autompc_amd import MPPI
+    p = omlp.random_params(nx, nu, hidden, act, seed=seed + 5)
+    rng = np.random.default_rng(seed)
+    Q = np.diag(rng.uniform(0.5, 2.0, size=nx))
+    R = np.diag(rng.uniform(0.01, 0.1, size=nu))
+    F = np.diag(rng.uniform(0.5, 2.0, size=nx))
+    goal = rng.normal(scale=0.1, size=nx)
+    system, model, task = _hip_stack(p, nx, nu, Q, R, F, goal, bounds, precision)
+    omodel = MLPOracle(system, p)
+    bnd = np.tile(np.array(bounds), (nu, 1))
+    np.random.seed(seed)
+    orc = MPPIOracle(omodel, QuadCostOracle(Q, R, F, goal), bnd, horizon=H, num_path=N, sigma=sigma,
+                     lmda=lmda, per_particle_terminal=per_particle)
+    np.random.seed(seed)
+    ctl = MPPI(system, task, model, horizon=H, num_path=N, sigma=sigma, lmda=lmda,
+               per_particle_terminal=per_particle)
+    obs = rng.uniform(-0.1, 0.1, size=nx)
+    cs_o = cs_h = np.concatenate([obs, np.zeros(nu)])
+    for _ in range(runs):
+        state = np.random.get_state()
+        uo, cs_o = orc.run(cs_o, obs)
+        np.random.set_state(state)
+        uh, cs_h = ctl.run(cs_h, obs, return_details=True)
+        assert rel_err(ctl.last_costs, orc.last_costs) < tol
+        assert rel_err(ctl.last_eps, orc.last_eps) < max(tol, 1e-12)
+        assert rel_err(ctl.act_sequence, orc.act_sequence) < tol * 10
+        assert rel_err(uh, uo) < tol * 10
+        # keep the two in lock-step: only per-solve error is under test here
+        ctl.act_sequence = orc.act_sequence
+        obs = omodel.pred(obs, uo)
+
+
+def test_mppi_multi_ctrl_small_vs_oracle():
+    _oracle_vs_hip(17, 6, [256, 256], "relu", 300, 12, 1.0, 1.0, (-1.0, 1.0), "f64", 1e-9)
+
+
+def test_mppi_multi_ctrl_tanh_per_particle_terminal():
+    _oracle_vs_hip(5, 3, [100, 40], "tanh", 77, 9, 0.6, 0.4, (-0.7, 1.3), "f64", 1e-9, seed=3,
+                   per_particle=True)
+
+
+def test_mppi_halfcheetah_full_size_vs_oracle():
+    # BASELINE config 3: 4096 samples x 30 horizon, 17-dim state, 6 controls, MLP 2x256
+    _oracle_vs_hip(17, 6, [256, 256], "relu", 4096, 30, 1.0, 1.0, (-1.0, 1.0), "f64", 1e-9, runs=1)
+
+
+def test_mppi_pendulum_full_size_vs_oracle():
+    # BASELINE config 2: 1024 x 30, 2-dim state, 1 control, MLP 2x64
+    _oracle_vs_hip(2, 1, [64, 64], "relu", 1024, 30, 1.0, 1.0, (-2.0, 2.0), "f64", 1e-9, runs=2)
+
+
+def test_mppi_f32_fast_mode_within_tolerance():
+    # north_star tolerance: 1e-4 relative on state and cost
+    _oracle_vs_hip(17, 6, [256, 256], "relu", 4096, 30, 1.0, 1.0, (-1.0, 1.0), "f32", 1e-4, runs=1)
+
+
+def test_mppi_heterogeneous_batch_matches_single_solves():
+    """The batch plan (different N, H, sigma, lmda, cost per problem) must give exactly what
+    one-problem plans give: problems are independent."""
+    from autompc_amd import _lib
+    nx, nu = 17, 6
+    p = omlp.random_params(nx, nu, [256, 256], "relu", seed=9)
+    rng = np.random.default_rng(1)
+    B = 5
+    Ns, Hs = [100, 257, 64, 1000, 31], [5, 30, 17, 12, 8]
+    sig, lam = rng.uniform(0.2, 2.0, size=B), rng.uniform(0.1, 2.0, size=B)
+    Q = np.stack([np.diag(rng.uniform(0.1, 3.0, size=nx)) for _ in range(B)])
+    R = np.stack([np.diag(rng.uniform(0.01, 0.2, size=nu)) for _ in range(B)])
+    F = np.stack([np.diag(rng.uniform(0.1, 3.0, size=nx)) for _ in range(B)])
+    goal = rng.normal(scale=0.1, size=(B, nx))
+    h = _lib.Handle(0, "f64")
+    h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
+              p["dy_std"])
+    h.set_quad_costs(Q, R, F, goal)
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    x0 = rng.uniform(-0.1, 0.1, size=(B, nx))
+    acts = [rng.normal(size=(Hs[b], nu)) for b in range(B)]
+    eps = [rng.normal(scale=np.sqrt(sig[b]), size=(Ns[b], Hs[b], nu)) for b in range(B)]
+    plan = _lib.MppiPlan(h, Ns, Hs, sig, lam, cost_index=np.arange(B))
+    plan.upload(x0, np.concatenate([a.ravel() for a in acts]), np.concatenate([e.ravel() for e in eps]))
+    plan.solve()
+    a_all, u_all, c_all, _ = plan.download(costs=True)
+    ao = co = 0
+    system = make_system(nx, nu)
+    for b in range(B):
+        orc = MPPIOracle(MLPOracle(system, p), QuadCostOracle(Q[b], R[b], F[b], goal[b]),
+                         np.tile([-1.0, 1.0], (nu, 1)), horizon=Hs[b], num_path=Ns[b],
+                         sigma=sig[b], lmda=lam[b])
+        orc.act_sequence = acts[b].copy()
+        u, _ = orc.run(np.concatenate([x0[b], np.zeros(nu)]), x0[b], eps_nhu=eps[b])
+        assert rel_err(c_all[co:co + Ns[b]], orc.last_costs) < 1e-9
+        assert rel_err(a_all[ao:ao + Hs[b] * nu].reshape(Hs[b], nu), orc.act_sequence) < 1e-8
+        assert rel_err(u_all[b], u) < 1e-8
+        ao += Hs[b] * nu
+        co += Ns[b]
+
+
+def test_device_noise_is_standard_normal():
+    from autompc_amd import _lib
+    nx, nu = 2, 1
+    p = omlp.random_params(nx, nu, [64, 64], "relu", seed=1)
+    h = _lib.Handle(0, "f64")
+    h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
+              p["dy_std"])
+    h.set_quad_costs(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+    h.set_ctrl_bounds([-1.0], [1.0])
+    # sigma = 0.01 -> std 0.1: with a zero warm start |eps| never reaches the clip at 1 (10 sigma),
+    # so the post-clip noise the solve returns IS the generated noise.
+    plan = _lib.MppiPlan(h, [20000], [30], [0.01], [1.0])
+    plan.upload(np.zeros((1, nx)), np.zeros(30))
+    plan.generate_eps(1234, 0)
+    plan.solve()
+    _, _, _, e = plan.download(eps_out=True)
+    assert abs(e.mean()) < 1e-3 and abs(e.std() - 0.1) < 1e-3
+    k = np.mean(((e - e.mean()) / e.std()) ** 4)
+    assert abs(k - 3.0) < 0.05
+    plan.generate_eps(1234, 1)
+    plan.solve()
+    _, _, _, e2 = plan.download(eps_out=True)
+    assert abs(np.corrcoef(e, e2)[0, 1]) < 0.01
+    plan.generate_eps(1234, 0)
+    plan.solve()
+    _, _, _, e3 = plan.download(eps_out=True)
+    # counter-based: same (seed, stream) -> same noise (up to the (eps + a) - a round trip)
+    np.testing.assert_allclose(e, e3, rtol=0, atol=1e-12)
