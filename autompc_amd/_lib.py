@@ -16,7 +16,7 @@ ACTIVATIONS = {"relu": 0, "tanh": 1, "sigmoid": 2, "selu": 3}
 TERM_REFERENCE, TERM_PER_PARTICLE = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libautompc_hip.so")
+LIB_PATH = os.environ.get("AMPC_LIB") or os.path.join(_HERE, "libautompc_hip.so")
 
 
 class AmpcError(RuntimeError):

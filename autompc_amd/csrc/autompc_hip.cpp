@@ -57,6 +57,12 @@ struct DevBuf {
 
 static constexpr size_t kLdsLimit = 160 * 1024;
 
+static int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------------
@@ -71,7 +77,7 @@ struct ampc_handle {
   bool has_mlp = false;
   int nx = 0, nu = 0, n_hidden = 0, act = 0;
   int hidden[kMaxHidden] = {0, 0, 0, 0};
-  int hpad = 0, nt = 0, k1p = 0, nxp = 0;
+  int hpad = 0, nt = 0, nw = 4, k1p = 0, nxp = 0;  // nw = waves per workgroup (4 or 8)
   std::vector<std::vector<double>> W, b;
   std::vector<double> norm;
   DevBuf model_buf;   // all packed arrays, contiguous
@@ -80,7 +86,7 @@ struct ampc_handle {
   MlpDev<float> mf{};
 
   // cost blocks / bounds ----------------------------------------------------------------------
-  int n_costs = 0, obs_dim = 0, cost_stride = 0;
+  int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0;
   DevBuf cost_buf;
   bool has_bounds = false;
   std::vector<double> lo, hi;
@@ -174,12 +180,12 @@ extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host, double) -- layouts documented in mlp_tile.hpp
 // ---------------------------------------------------------------------------------------------
-// B[k][n] supplied by a functor; N-split over 4 waves, NT tiles per wave.
+// B[k][n] supplied by a functor; N-split over W waves, NT tiles per wave.
 template <typename F>
-static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, F B) {
+static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, int W, F B) {
   const int KS = kpad / 4;
   dst.assign((size_t)kpad * hpad, 0.0);
-  for (int w = 0; w < kWaves; ++w)
+  for (int w = 0; w < W; ++w)
     for (int ks = 0; ks < KS; ++ks)
       for (int lane = 0; lane < 64; ++lane)
         for (int nt = 0; nt < NT; ++nt) {
@@ -188,12 +194,12 @@ static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, F 
           dst[(((size_t)w * KS + ks) * 64 + lane) * NT + nt] = B(k, n);
         }
 }
-// K-split over 4 waves, `tiles` 16-column tiles.
+// K-split over W waves, `tiles` 16-column tiles.
 template <typename F>
-static void pack_ksplit(std::vector<double>& dst, int hpad, int tiles, F B) {
-  const int KS = hpad / 4, KSW = KS / kWaves;
+static void pack_ksplit(std::vector<double>& dst, int hpad, int tiles, int W, F B) {
+  const int KS = hpad / 4, KSW = KS / W;
   dst.assign((size_t)hpad * tiles * 16, 0.0);
-  for (int w = 0; w < kWaves; ++w)
+  for (int w = 0; w < W; ++w)
     for (int ksl = 0; ksl < KSW; ++ksl)
       for (int lane = 0; lane < 64; ++lane)
         for (int t = 0; t < tiles; ++t) {
@@ -205,48 +211,67 @@ static void pack_ksplit(std::vector<double>& dst, int hpad, int tiles, F B) {
 
 template <typename T> static int build_model(ampc_handle* h) {
   const int L = h->n_hidden, nx = h->nx, nu = h->nu, kin = nx + nu;
-  const int hpad = h->hpad, NT = h->nt, k1p = h->k1p, nxp = h->nxp;
+  const int hpad = h->hpad, NT = h->nt, W = h->nw, k1p = h->k1p, nxp = h->nxp;
   auto width_in = [&](int l) { return l == 0 ? kin : h->hidden[l - 1]; };
   auto width_out = [&](int l) { return l == L ? nx : h->hidden[l]; };
+  const double* xmean = h->norm.data();
+  const double* xstd = xmean + kin;
+  const double* dmean = xstd + kin;
+  const double* dstd = dmean + nx;
+  // Fold the affine normalisers into the first / last layer (double precision, see mlp_tile.hpp).
+  std::vector<std::vector<double>> Wf = h->W, bf = h->b;
+  {
+    const int out0 = width_out(0);
+    for (int n = 0; n < out0; ++n) {
+      double shift = 0.0;
+      for (int k = 0; k < kin; ++k) {
+        Wf[0][(size_t)n * kin + k] = h->W[0][(size_t)n * kin + k] / xstd[k];
+        shift += Wf[0][(size_t)n * kin + k] * xmean[k];
+      }
+      bf[0][n] = h->b[0][n] - shift;
+    }
+    const int inL = width_in(L);
+    for (int i = 0; i < nx; ++i) {
+      for (int k = 0; k < inL; ++k) Wf[L][(size_t)i * inL + k] *= dstd[i];
+      bf[L][i] = bf[L][i] * dstd[i] + dmean[i];
+    }
+  }
   std::vector<std::vector<double>> parts;  // in upload order
   std::vector<size_t> off;
-  auto push = [&](std::vector<double>&& v) {
-    parts.emplace_back(std::move(v));
-  };
+  auto push = [&](std::vector<double>&& v) { parts.emplace_back(std::move(v)); };
   // forward weights w[0..L]
   for (int l = 0; l <= L; ++l) {
-    const std::vector<double>& Wl = h->W[l];
+    const std::vector<double>& Wl = Wf[l];
     const int in = width_in(l), out = width_out(l);
     std::vector<double> pk;
     auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
-    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, Bt);
-    else pack_ksplit(pk, hpad, nxp / 16, Bt);
+    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, W, Bt);
+    else pack_ksplit(pk, hpad, nxp / 16, W, Bt);
     push(std::move(pk));
   }
   // biases b[0..L]
   for (int l = 0; l <= L; ++l) {
     std::vector<double> bb(l < L ? hpad : nxp, 0.0);
-    for (int i = 0; i < width_out(l); ++i) bb[i] = h->b[l][i];
+    for (int i = 0; i < width_out(l); ++i) bb[i] = bf[l][i];
     push(std::move(bb));
   }
   // Jacobian-chain weights wj[0..L-1]: B[k][n] = W_l[k][n]  (k = out index, n = in index)
   const int ni = (kin + 15) / 16;
   for (int l = 0; l < L; ++l) {
-    const std::vector<double>& Wl = h->W[l];
+    const std::vector<double>& Wl = Wf[l];
     const int in = width_in(l), out = width_out(l);
     std::vector<double> pk;
     auto Bn = [&](int k, int n) { return (k < out && n < in) ? Wl[(size_t)k * in + n] : 0.0; };
-    if (l == 0) pack_ksplit(pk, hpad, ni, Bn);
-    else pack_nsplit(pk, hpad, hpad, NT, Bn);
+    if (l == 0) pack_ksplit(pk, hpad, ni, W, Bn);
+    else pack_nsplit(pk, hpad, hpad, NT, W, Bn);
     push(std::move(pk));
   }
-  push(std::vector<double>(h->norm));
-  // output weights in plain [nx][hpad]
+  // folded output weights in plain [nx][hpad]
   {
     std::vector<double> wp((size_t)nx * hpad, 0.0);
     const int in = width_in(L);
     for (int i = 0; i < nx; ++i)
-      for (int k = 0; k < in; ++k) wp[(size_t)i * hpad + k] = h->W[L][(size_t)i * in + k];
+      for (int k = 0; k < in; ++k) wp[(size_t)i * hpad + k] = Wf[L][(size_t)i * in + k];
     push(std::move(wp));
   }
   size_t total = 0;
@@ -269,7 +294,6 @@ template <typename T> static int build_model(ampc_handle* h) {
   for (int l = 0; l <= L; ++l) m.w[l] = base + off[idx++];
   for (int l = 0; l <= L; ++l) m.b[l] = base + off[idx++];
   for (int l = 0; l < L; ++l) m.wj[l] = base + off[idx++];
-  m.norm = base + off[idx++];
   h->wout_plain = (const void*)(base + off[idx++]);
   return 0;
 }
@@ -293,8 +317,11 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   }
   h->nx = nx; h->nu = nu; h->n_hidden = n_hidden; h->act = activation;
   for (int l = 0; l < kMaxHidden; ++l) h->hidden[l] = l < n_hidden ? hidden_sizes[l] : 0;
+  // Workgroup shape: 8 waves (two per SIMD) whenever the padded width allows whole 16-column
+  // tiles per wave, else 4 waves.  (W, NT) in {(4,1), (8,1), (4,3), (8,2)} for hpad 64..256.
   h->hpad = round_up(hmax, 64);
-  h->nt = h->hpad / 64;
+  h->nw = (h->hpad % 128 == 0 && env_int("AMPC_WAVES", 8) == 8) ? 8 : 4;
+  h->nt = h->hpad / (16 * h->nw);
   h->k1p = round_up(nx + nu, 16);
   h->nxp = round_up(nx, 16);
   h->W.assign(n_hidden + 1, {});
@@ -341,6 +368,16 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
   h->n_costs = n_costs;
   h->obs_dim = obs_dim;
   h->cost_stride = stride;
+  bool diag = true;
+  for (int c = 0; c < n_costs && diag; ++c) {
+    for (int i = 0; i < no && diag; ++i)
+      for (int j = 0; j < no; ++j)
+        if (i != j && (Q[((size_t)c * no + i) * no + j] != 0.0 || F[((size_t)c * no + i) * no + j] != 0.0)) diag = false;
+    for (int i = 0; i < nu && diag; ++i)
+      for (int j = 0; j < nu; ++j)
+        if (i != j && R[((size_t)c * nu + i) * nu + j] != 0.0) diag = false;
+  }
+  h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
   return 0;
 }
 
@@ -375,30 +412,19 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-#define AMPC_DISPATCH_NT_MT(NTV, MTV, ...)                                 \
+// (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.
+#define AMPC_CASE(WV, NTV, MTV, ...) \
+  case (WV) * 100 + (NTV) * 10 + (MTV): { constexpr int W = WV, NT = NTV, MT = MTV; __VA_ARGS__; } break;
+#define AMPC_DISPATCH(WV, NTV, MTV, ...)                                     \
   do {                                                                       \
-    const int key_ = (NTV) * 10 + (MTV);                                     \
-    switch (key_) {                                                          \
-      case 11: { constexpr int NT = 1, MT = 1; __VA_ARGS__; } break;                \
-      case 12: { constexpr int NT = 1, MT = 2; __VA_ARGS__; } break;                \
-      case 14: { constexpr int NT = 1, MT = 4; __VA_ARGS__; } break;                \
-      case 21: { constexpr int NT = 2, MT = 1; __VA_ARGS__; } break;                \
-      case 22: { constexpr int NT = 2, MT = 2; __VA_ARGS__; } break;                \
-      case 24: { constexpr int NT = 2, MT = 4; __VA_ARGS__; } break;                \
-      case 31: { constexpr int NT = 3, MT = 1; __VA_ARGS__; } break;                \
-      case 32: { constexpr int NT = 3, MT = 2; __VA_ARGS__; } break;                \
-      case 34: { constexpr int NT = 3, MT = 4; __VA_ARGS__; } break;                \
-      case 41: { constexpr int NT = 4, MT = 1; __VA_ARGS__; } break;                \
-      case 42: { constexpr int NT = 4, MT = 2; __VA_ARGS__; } break;                \
-      case 44: { constexpr int NT = 4, MT = 4; __VA_ARGS__; } break;                \
-      default: return fail("internal: unsupported (NT, MT) combination");    \
+    switch ((WV) * 100 + (NTV) * 10 + (MTV)) {                               \
+      AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
+      AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
+      AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
+      AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
+      default: return fail("internal: unsupported (W, NT, MT) combination");  \
     }                                                                        \
   } while (0)
-
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v ? std::atoi(v) : dflt;
-}
 
 // Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
 template <typename T>
@@ -407,13 +433,12 @@ static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_r
   const int forced = env_int("AMPC_MT", 0);
   int best = 1;
   for (int mt : {1, 2, 4}) {
-    TileLds L = make_tile_lds(m, 16 * mt);
+    TileLds L = make_tile_lds(m, 16 * mt, h->nw);
     const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
     if (bytes > kLdsLimit) break;
     if (forced == mt) return mt;
     if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
   }
-  (void)h;
   return best;
 }
 
@@ -435,21 +460,21 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
   const int M = 16 * mt;
   const int tiles = (n + M - 1) / M;
   const int n_pad = tiles * M;
-  TileLds L = make_tile_lds(m, M);
+  TileLds L = make_tile_lds(m, M, h->nw);
   const size_t lds_bytes = (size_t)L.extra * sizeof(T);
   if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
   T* dz = (T*)h->s_dz.p;
-  AMPC_DISPATCH_NT_MT(h->nt, mt, {
+  AMPC_DISPATCH(h->nw, h->nt, mt, {
     if (deriv) {
-      auto k = mlp_forward_kernel<T, NT, MT, true>;
+      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
       HIP_OK(allow_lds(k, lds_bytes));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(kWG), lds_bytes, h->stream, m, L,
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
                          n_pad);
     } else {
-      auto k = mlp_forward_kernel<T, NT, MT, false>;
+      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
       HIP_OK(allow_lds(k, lds_bytes));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(kWG), lds_bytes, h->stream, m, L,
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
                          (T*)nullptr, n, n_pad);
     }
@@ -463,11 +488,11 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
     const int JM = 16 * jmt;
     const int jtiles = (rows + JM - 1) / JM;
     const int kinp = 16 * ((m.kin + 15) / 16);
-    const size_t jl = (size_t)JM * imax(m.hpad + 2, kWaves * kinp) * sizeof(T);
-    AMPC_DISPATCH_NT_MT(h->nt, jmt, {
-      auto k = mlp_jacobian_kernel<T, NT, MT>;
+    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, jmt, {
+      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
       HIP_OK(allow_lds(k, jl));
-      hipLaunchKernelGGL(k, dim3(jtiles), dim3(kWG), jl, h->stream, m,
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m,
                          (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
                          (T*)h->s_ju.p);
     });
@@ -534,6 +559,7 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.cost_stride = h->cost_stride;
   a.term_mode = p->term_mode;
   a.max_h = p->max_h;
+  a.cost_diag = h->cost_diag;
   a.costs_par = (const T*)h->cost_buf.p;
   a.bounds = (const T*)h->bounds_buf.p;
   a.probs = (const MppiProblem<T>*)p->probs.p;
@@ -556,7 +582,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   const size_t extra = (size_t)p->max_h * nu + h->cost_stride + 3 * nu + 8;
   p->mt = choose_mt<T>(h, m, p->sum_n, extra);
   const int M = 16 * p->mt;
-  p->L = make_tile_lds(m, M);
+  p->L = make_tile_lds(m, M, h->nw);
   p->lds_aseq = p->L.extra;
   p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
   p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);
@@ -707,10 +733,10 @@ template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
     p->ev_used += 3;
     HIP_OK(hipEventRecord(e[0], h->stream));
   }
-  AMPC_DISPATCH_NT_MT(h->nt, p->mt, {
-    auto k = mppi_rollout_kernel<T, NT, MT>;
+  AMPC_DISPATCH(h->nw, h->nt, p->mt, {
+    auto k = mppi_rollout_kernel<T, NT, MT, W>;
     HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(kWG), p->lds_bytes, h->stream, a);
+    hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
   });
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
   hipLaunchKernelGGL(mppi_update_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a);

@@ -4,67 +4,58 @@
 // pred_diff_batch (reference: autompc/sysid/mlp.py:281-305)   -> mlp_forward_kernel<DERIV> +
 //                                                                mlp_jacobian_kernel
 // The reference obtains d(net)/d(input) by running autograd over an nx-fold repeated batch.
-// Here it is the chain  J_net = W_out D_L W_L ... D_1 W_1  evaluated left to right on MFMA, with
-// the rows (sample s, output i) of all samples flattened into one tall matrix so the 16-row
-// MFMA tiles carry no padding: G_L[(s,i)][k] = W_out[i][k] d_L[s][k], then per layer
-// G_{l-1} = (G_l W_l) * d_{l-1}[s], finally J_net = G_1 W_1 and
-// J = J_net * dy_std[i] / xu_std[c] + [c == i].
+// Here it is the chain  J = W_out' D_L W_L ... D_1 W_1' (+ I on the state block) on the folded
+// weights (mlp_tile.hpp), evaluated left to right on MFMA with the rows (sample s, output i) of
+// all samples flattened into one tall matrix so the 16-row MFMA tiles carry no padding:
+// G_L[(s,i)][k] = W_out'[i][k] d_L[s][k], then per layer G_{l-1} = (G_l W_l) * d_{l-1}[s],
+// finally J = G_1 W_1' + [c == i].
 #pragma once
 #include "mlp_tile.hpp"
 
 namespace ampc {
 
-template <typename T, int NT, int MT, bool DERIV>
-__global__ __launch_bounds__(kWG) void mlp_forward_kernel(const MlpDev<T> mlp, const TileLds L,
-                                                          const T* __restrict__ states,
-                                                          const T* __restrict__ ctrls,
-                                                          T* __restrict__ out, T* __restrict__ dz,
-                                                          int n, int n_pad) {
+template <typename T, int NT, int MT, int W, bool DERIV>
+__global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp, const TileLds L,
+                                                             const T* __restrict__ states,
+                                                             const T* __restrict__ ctrls,
+                                                             T* __restrict__ out,
+                                                             T* __restrict__ dz, int n, int n_pad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  constexpr int M = 16 * MT;
+  using Net = TileNet<T, NT, MT, W, DERIV>;
+  constexpr int M = 16 * MT, NTHR = 64 * W;
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   const int first = blockIdx.x * M;
-  T* xs = lds + L.xs;
-  T* xin = lds + L.xin;
-  tile_load_constants(mlp, L, lds);
-  for (int i = tid; i < M * L.xin_stride; i += kWG) xin[i] = T(0);
+  T* xu = lds + L.xu;
+  Net net;
+  net.prefetch0(mlp);
+  tile_load_constants<T, W>(mlp, L, lds, M);
   __syncthreads();
-  const T* xmean = lds + L.norm;
-  const T* xstd = xmean + mlp.kin;
-  const T* dmean = xstd + mlp.kin;
-  const T* dstd = dmean + nx;
-  for (int i = tid; i < M * nx; i += kWG) {
+  for (int i = tid; i < M * nx; i += NTHR) {
     const int row = i / nx, col = i - row * nx;
-    const T v = (first + row < n) ? states[(size_t)(first + row) * nx + col] : T(0);
-    xs[i] = v;
-    xin[row * L.xin_stride + col] = (v - xmean[col]) / xstd[col];
+    xu[row * L.xu_stride + col] = (first + row < n) ? states[(size_t)(first + row) * nx + col] : T(0);
   }
-  for (int i = tid; i < M * nu; i += kWG) {
+  for (int i = tid; i < M * nu; i += NTHR) {
     const int row = i / nu, col = i - row * nu;
-    const T v = (first + row < n) ? ctrls[(size_t)(first + row) * nu + col] : T(0);
-    xin[row * L.xin_stride + nx + col] = (v - xmean[nx + col]) / xstd[nx + col];
+    xu[row * L.xu_stride + nx + col] = (first + row < n) ? ctrls[(size_t)(first + row) * nu + col] : T(0);
   }
   __syncthreads();
-  // dz layout: [layer][n_pad][hpad]; this tile's rows start at first
-  tile_network<T, NT, MT, DERIV>(mlp, L, lds, DERIV ? dz + (size_t)first * mlp.hpad : nullptr,
-                                 n_pad * mlp.hpad);
-  for (int i = tid; i < M * nx; i += kWG) {
+  // dz layout: [layer][n_pad][hpad]; this tile's rows start at `first`
+  net.run(mlp, L, lds, DERIV ? dz + (size_t)first * mlp.hpad : nullptr, (size_t)n_pad * mlp.hpad);
+  for (int i = tid; i < M * nx; i += NTHR) {
     const int row = i / nx, col = i - row * nx;
-    if (first + row < n) {
-      const T y = tile_output<T, MT>(mlp, L, lds, row, col);
-      out[(size_t)(first + row) * nx + col] = xs[i] + (y * dstd[col] + dmean[col]);
-    }
+    if (first + row < n)
+      out[(size_t)(first + row) * nx + col] = xu[row * L.xu_stride + col] + Net::output(mlp, L, lds, row, col);
   }
 }
 
-// K-split small-N layer used by the Jacobian's last stage: acc[mt][n] over this wave's k range.
-template <typename T, int MT, int NMAX>
-__device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as, int ksw,
+// K-split small-N stage used by the Jacobian's last product: acc[mt][n] over this wave's k range.
+template <typename T, int MT, int KSW, int NMAX>
+__device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
                                            const T* __restrict__ wl, int n_tiles,
                                            typename Acc<T>::type (&acc)[MT][NMAX]) {
-#pragma unroll 2
-  for (int ks = 0; ks < ksw; ++ks) {
+#pragma unroll
+  for (int ks = 0; ks < KSW; ++ks) {
     T a[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt * 16 * as + 4 * ks];
@@ -78,25 +69,22 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as, i
   }
 }
 
-struct JacLds {
-  int g;        // [M][hpad+2]  (reused for last-stage partials [4][M][kinp])
-  int g_stride;
-};
-
 // rows = n * nx flattened (s, i); tile = 16*MT rows.
-// wout_plain: [nx][hpad] (zero padded); dz: [layer][n_pad][hpad] from mlp_forward_kernel<DERIV>.
-// jx[n][nx][nx], ju[n][nx][nu].
-template <typename T, int NT, int MT>
-__global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
-                                                           const T* __restrict__ wout_plain,
-                                                           const T* __restrict__ dz, int n,
-                                                           int n_pad, T* __restrict__ jx,
-                                                           T* __restrict__ ju) {
+// wout_plain: folded output weights [nx][hpad] (zero padded); dz: [layer][n_pad][hpad] from
+// mlp_forward_kernel<DERIV>.  jx[n][nx][nx], ju[n][nx][nu].
+template <typename T, int NT, int MT, int W>
+__global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> mlp,
+                                                              const T* __restrict__ wout_plain,
+                                                              const T* __restrict__ dz, int n,
+                                                              int n_pad, T* __restrict__ jx,
+                                                              T* __restrict__ ju) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* G = reinterpret_cast<T*>(smem_raw);
   using acc_t = typename Acc<T>::type;
-  constexpr int M = 16 * MT;
-  constexpr int NIMAX = 4;  // kin <= 64
+  using Net = TileNet<T, NT, MT, W, false>;
+  constexpr int M = 16 * MT, NTHR = 64 * W;
+  constexpr int NIMAX = 3;  // kin <= 48
+  constexpr int KSH = Net::KSH, KSW = Net::KSW, GH = Net::GH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
@@ -106,8 +94,8 @@ __global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
   const int first = blockIdx.x * M;
   const size_t lstride = (size_t)n_pad * hpad;
 
-  // G_L[(s,i)][k] = W_out[i][k] * d_L[s][k]
-  for (int e = tid; e < M * hpad; e += kWG) {
+  // G_L[(s,i)][k] = W_out'[i][k] * d_L[s][k]
+  for (int e = tid; e < M * hpad; e += NTHR) {
     const int row = e / hpad, k = e - row * hpad;
     const int gr = first + row;
     T v = T(0);
@@ -119,14 +107,16 @@ __global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
   }
   __syncthreads();
 
-  const int ks_h = hpad / 4;
   for (int l = Lh - 1; l >= 1; --l) {  // hidden->hidden layer l (torch index), uses wj[l]
     acc_t acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-    layer_mma_static<T, NT, MT, 16 * NT, 8>(G, gs, mlp.wj[l] + (size_t)w * ks_h * 64 * NT, lane, acc);
+    const T* wl = mlp.wj[l] + ((size_t)w * KSH * 64 + lane) * NT;
+    T first_group[GH][NT];
+    load_group<T, NT, GH>(wl, 0, first_group);
+    layer_mma_static<T, NT, MT, KSH, GH>(G, gs, wl, lane, first_group, acc);
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -145,17 +135,16 @@ __global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
     __syncthreads();
   }
 
-  // last stage: J_net = G_1 W_1  (K = hpad split over waves, N = kin padded to 16*ni)
+  // last product: J_net = G_1 W_1'  (K = hpad split over waves, N = kin padded to 16*ni)
   const int ni = (mlp.kin + 15) / 16;
   const int kinp = 16 * ni;
-  const int ksw = ks_h / kWaves;
   acc_t oacc[MT][NIMAX];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nn = 0; nn < NIMAX; ++nn) oacc[mt][nn] = acc_t{0, 0, 0, 0};
-  ksplit_mma<T, MT, NIMAX>(G + i16 * gs + q + 4 * w * ksw, gs, ksw,
-                           mlp.wj[0] + ((size_t)w * ksw * 64 + lane) * ni, ni, oacc);
+  ksplit_mma<T, MT, KSW, NIMAX>(G + i16 * gs + q + 4 * w * KSW, gs,
+                                mlp.wj[0] + ((size_t)w * KSW * 64 + lane) * ni, ni, oacc);
   __syncthreads();
   T* part = G + w * M * kinp;
 #pragma unroll
@@ -168,17 +157,14 @@ __global__ __launch_bounds__(kWG) void mlp_jacobian_kernel(const MlpDev<T> mlp,
           part[(16 * mt + acc_row<T>(q, r)) * kinp + 16 * nn + i16] = oacc[mt][nn][r];
       }
   __syncthreads();
-  const T* xstd = mlp.norm + mlp.kin;
-  const T* dstd = mlp.norm + 2 * mlp.kin + nx;
-  for (int e = tid; e < M * mlp.kin; e += kWG) {
+  for (int e = tid; e < M * mlp.kin; e += NTHR) {
     const int row = e / mlp.kin, c = e - row * mlp.kin;
     const int gr = first + row;
     if (gr >= rows_total) continue;
     const int s = gr / nx, i = gr - s * nx;
     T v = T(0);
 #pragma unroll
-    for (int ww = 0; ww < kWaves; ++ww) v += G[ww * M * kinp + row * kinp + c];
-    v = v / xstd[c] * dstd[i];
+    for (int ww = 0; ww < W; ++ww) v += G[ww * M * kinp + row * kinp + c];
     if (c < nx) jx[((size_t)s * nx + i) * nx + c] = v + (c == i ? T(1) : T(0));
     else ju[((size_t)s * nx + i) * nu + (c - nx)] = v;
   }

@@ -1,29 +1,34 @@
 // mlp_tile.hpp -- fused MLP dynamics step on one workgroup-resident tile of samples (gfx950).
 //
-// One workgroup = 256 threads = 4 wave64, one wave per SIMD.  A tile is M = 16*MT samples.
-// Hidden width is padded to HPAD = 64*NT so each wave owns NT 16-column MFMA tiles of every
-// hidden layer (N-split); the small output layer is K-split across the four waves and reduced
-// through LDS.  Arithmetic is exact f64 (v_mfma_f64_16x16x4_f64) or exact f32
-// (v_mfma_f32_16x16x4_f32) -- both are k-ordered fma chains, no reduced-precision inputs.
+// A workgroup is W wave64 (W = 8: two waves per SIMD, or W = 4 for narrow nets).  A tile is
+// M = 16*MT samples.  Hidden width is padded to HPAD = 16*NT*W so each wave owns NT 16-column
+// MFMA tiles of every hidden layer (N-split); the small output layer is K-split across the W
+// waves and reduced through LDS.  Arithmetic is exact f64 (v_mfma_f64_16x16x4_f64) or exact f32
+// (v_mfma_f32_16x16x4_f32): k-ordered fma chains, no reduced-precision inputs.
 //
-// Operand sources:
+// Operand sources
 //   A (activations)  LDS, row-major [M][K+2]: the +2 pad makes the 16-row x 2-column access of
 //                    each 32-lane half conflict-free for ds_read_b64 (f64) / ds_read_b32 (f32).
-//   B (weights)      global memory, pre-packed on the host in exact fragment order so every wave
-//                    reads one contiguous, fully coalesced run per k-step; weights are re-read
-//                    every time step but stay L2-resident (<= 640 KB per model).
+//   B (weights)      global memory, pre-packed on the host in exact fragment order, so each wave
+//                    reads one contiguous, fully coalesced run per k-step.  Weights are re-read
+//                    every time step but stay L2-resident (<= 640 KB per model).  Fragments are
+//                    double-buffered in registers in groups of G k-steps, and the FIRST group of
+//                    every layer is requested before the barrier that precedes that layer, so
+//                    the L2 round trip overlaps the previous layer's epilogue.
 //
-// What the math is (reference: autompc/sysid/mlp.py:20-30, :55-59, :229-236):
-//   xin = ([x,u] - xu_mean) / xu_std ; h = act(W h + b) per hidden layer ; y = W_out h + b_out
-//   x' = x + (y * dy_std + dy_mean)
+// The math (reference: autompc/sysid/mlp.py:20-30, :55-59, :229-236):
+//   x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)
+// The affine normalisers are folded into the first and last layer on the host (double
+// precision): W1' = W1 diag(1/xu_std), b1' = b1 - W1' xu_mean, W3' = diag(dy_std) W3,
+// b3' = dy_std*b3 + dy_mean, so the kernel computes x' = x + net'([x,u]) with no per-step
+// normalisation work; the Jacobian chain on the folded weights is already the scaled Jacobian.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ampc {
 
-constexpr int kWG = 256;      // threads per workgroup
-constexpr int kWaves = 4;     // waves per workgroup
-constexpr int kMaxHidden = 4; // hidden layers supported (reference config space: 1..4)
+constexpr int kMaxHidden = 4;  // hidden layers supported (reference config space: 1..4)
+constexpr int kMaxWaves = 8;
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -32,11 +37,22 @@ template <typename T> struct Acc;
 template <> struct Acc<double> { using type = d4; };
 template <> struct Acc<float> { using type = f4; };
 
+// AMPC_X_* macros are timing experiments only (tools/variants.sh); never defined in the product.
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
+#ifdef AMPC_X_NOMFMA
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
+#ifdef AMPC_X_NOMFMA
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 // Row of accumulator register r held by lane-quad q (= lane >> 4); column is lane & 15.
 //   f64 16x16x4: row = q + 4 r      f32 16x16x4: row = 4 q + r
@@ -76,54 +92,48 @@ template <typename T> struct MlpDev {
   int nx, nu, kin;      // state dim, ctrl dim, nx+nu
   int k1p;              // kin zero-padded to 16, 32 or 48 (first-layer MFMA K)
   int n_hidden;         // hidden layers
-  int hpad;             // 64*NT
+  int hpad;             // 16*NT*W
   int nxp;              // nx rounded up to a multiple of 16
   int act;              // activation kind
   const T* w[kMaxHidden + 1];   // packed fragments, layer 0..n_hidden (last = output layer)
-  const T* b[kMaxHidden + 1];   // padded biases
+  const T* b[kMaxHidden + 1];   // padded biases (normalisers folded in)
   const T* wj[kMaxHidden + 1];  // packed fragments for the Jacobian chain (transposed use)
-  const T* norm;                // xu_mean[kin] xu_std[kin] dy_mean[nx] dy_std[nx]
 };
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
 struct TileLds {
-  int act;      // [M][hpad+2]  (also reused for the output-layer partials [4][M][nxp])
-  int xin;      // [M][k1p+2]
-  int xs;       // [M][nx]   current state
-  int us;       // [M][nu]   current scaled control
-  int norm;     // xu_mean, xu_std, dy_mean, dy_std
+  int act;      // [M][hpad+2]  (also reused for the output-layer partials [W][M][nxp])
+  int xu;       // [M][k1p+2]   raw state | control | zero pad: the first layer's A operand
   int bias;     // n_hidden*hpad + nxp
   int extra;    // kernel-specific region starts here
-  int act_stride, xin_stride;
+  int act_stride, xu_stride;
 };
 
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 template <typename T>
-__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M) {
+__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W) {
   TileLds L;
   int o = 0;
   L.act_stride = m.hpad + 2;
-  L.xin_stride = m.k1p + 2;
-  L.act = o; o += M * imax(L.act_stride, kWaves * m.nxp);
-  L.xin = o; o += M * L.xin_stride;
-  L.xs = o; o += M * m.nx;
-  L.us = o; o += M * m.nu;
-  L.norm = o; o += 2 * m.kin + 2 * m.nx;
+  L.xu_stride = m.k1p + 2;
+  L.act = o; o += M * imax(L.act_stride, W * m.nxp);
+  L.xu = o; o += M * L.xu_stride;
   L.bias = o; o += m.n_hidden * m.hpad + m.nxp;
   L.extra = round_up(o, 4);
   return L;
 }
 
-// Stage normalisers and biases into LDS (call once per kernel, then __syncthreads()).
-template <typename T>
-__device__ __forceinline__ void tile_load_constants(const MlpDev<T>& m, const TileLds& L, T* lds) {
+// Stage biases into LDS and zero the first-layer operand (call once, then __syncthreads()).
+template <typename T, int W>
+__device__ __forceinline__ void tile_load_constants(const MlpDev<T>& m, const TileLds& L, T* lds,
+                                                    int M) {
   const int tid = threadIdx.x;
-  for (int i = tid; i < 2 * m.kin + 2 * m.nx; i += kWG) lds[L.norm + i] = m.norm[i];
   for (int l = 0; l < m.n_hidden; ++l)
-    for (int i = tid; i < m.hpad; i += kWG) lds[L.bias + l * m.hpad + i] = m.b[l][i];
-  for (int i = tid; i < m.nxp; i += kWG) lds[L.bias + m.n_hidden * m.hpad + i] = m.b[m.n_hidden][i];
+    for (int i = tid; i < m.hpad; i += 64 * W) lds[L.bias + l * m.hpad + i] = m.b[l][i];
+  for (int i = tid; i < m.nxp; i += 64 * W) lds[L.bias + m.n_hidden * m.hpad + i] = m.b[m.n_hidden][i];
+  for (int i = tid; i < M * L.xu_stride; i += 64 * W) lds[L.xu + i] = T(0);
 }
 
 // ---- weight fragment loads -------------------------------------------------------------------
@@ -132,6 +142,11 @@ template <typename T, int N> using vec_t = T __attribute__((ext_vector_type(N)))
 
 template <typename T, int NT>
 __device__ __forceinline__ void load_frag(const T* __restrict__ p, T (&b)[NT]) {
+#ifdef AMPC_X_NOLOAD
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) b[nt] = T((threadIdx.x + nt) & 7) * T(1e-3);
+  return;
+#endif
   if constexpr (NT == 4) {
     const vec_t<T, 4> v = *reinterpret_cast<const vec_t<T, 4>*>(p);
     b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
@@ -144,28 +159,34 @@ __device__ __forceinline__ void load_frag(const T* __restrict__ p, T (&b)[NT]) {
   }
 }
 
-// One N-split layer with compile-time k extent KS (hidden layers, K = HPAD): fully unrolled,
-// weight fragments double-buffered in groups of G k-steps so the L2 fetch of group g+1 is in
-// flight while group g's MFMAs issue.
+// Fetch group `g` (G k-steps) of a wave's N-split fragment stream.  wl = layer base + this
+// wave's slice + lane*NT.
+template <typename T, int NT, int G>
+__device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&b)[G][NT]) {
+#pragma unroll
+  for (int kk = 0; kk < G; ++kk) load_frag<T, NT>(wl + (size_t)(g * G + kk) * 64 * NT, b[kk]);
+}
+
+// One N-split layer with compile-time k extent KS: acc[mt][nt] += A[16mt.., :] * Wpacked.
+// Fully unrolled; group 0 arrives pre-loaded in `first`, later groups are double-buffered so the
+// fetch of group g+1 is in flight while group g's MFMAs issue.
 template <typename T, int NT, int MT, int KS, int G>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
-                                                 const T* __restrict__ wp, int lane,
+                                                 const T* __restrict__ wl, int lane,
+                                                 const T (&first)[G][NT],
                                                  typename Acc<T>::type (&acc)[MT][NT]) {
   static_assert(KS % G == 0, "group size must divide the k extent");
   constexpr int NG = KS / G;
   const int i = lane & 15, q = lane >> 4;
   const T* arow = A + i * a_stride + q;
-  const T* wl = wp + lane * NT;
   T b[2][G][NT];
 #pragma unroll
-  for (int kk = 0; kk < G; ++kk) load_frag<T, NT>(wl + kk * 64 * NT, b[0][kk]);
+  for (int kk = 0; kk < G; ++kk)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[0][kk][nt] = first[kk][nt];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) {
-#pragma unroll
-      for (int kk = 0; kk < G; ++kk)
-        load_frag<T, NT>(wl + ((g + 1) * G + kk) * 64 * NT, b[(g + 1) & 1][kk]);
-    }
+    if (g + 1 < NG) load_group<T, NT, G>(wl, g + 1, b[(g + 1) & 1]);
 #pragma unroll
     for (int kk = 0; kk < G; ++kk) {
       const int ks = g * G + kk;
@@ -180,119 +201,166 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
   }
 }
 
-// Full network on the tile.  On entry lds[L.xin] holds the normalised inputs [M][k1p] (columns
-// kin..k1p-1 zero) and every thread has passed a barrier after writing them.  On exit
-// lds[L.act + (w*M + row)*nxp + col] holds wave w's partial of the output layer (bias NOT added)
-// and a barrier has been passed, i.e. y[row][col] = bias + sum_w partial.
-// If DERIV, act'(z) of hidden layer l is also written to dz[l][row*hpad + col] (global scratch).
-template <typename T, int NT, int MT, bool DERIV = false>
-__device__ __forceinline__ void tile_network(const MlpDev<T>& m, const TileLds& L, T* lds,
-                                             T* __restrict__ dz = nullptr, int dz_layer_stride = 0) {
+// ---- the fused network on one tile -------------------------------------------------------------
+template <typename T, int NT, int MT, int W, bool DERIV = false>
+struct TileNet {
   using acc_t = typename Acc<T>::type;
-  constexpr int M = 16 * MT;
-  const int lane = threadIdx.x & 63;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15, q = lane >> 4;
-  T* act = lds + L.act;
-  const int as = L.act_stride;
-  const int ks_h = m.hpad / 4;
+  static constexpr int M = 16 * MT;
+  static constexpr int HP = 16 * NT * W;      // padded hidden width
+  static constexpr int KSH = HP / 4;          // k-steps of a hidden->hidden layer
+  static constexpr int KSW = KSH / W;         // output-layer k-steps per wave (= 4*NT)
+  static constexpr int G0 = 4;                // first-layer group (k1p/4 is 4, 8 or 12)
+  static constexpr int GH = 8;                // hidden-layer group
+  static constexpr int NOMAX = 2;             // nx <= 32
 
-  for (int l = 0; l < m.n_hidden; ++l) {
-    acc_t acc[MT][NT];
+  T pf0[G0][NT];  // first group of layer 0, requested ahead of time (see prefetch0)
+
+  __device__ __forceinline__ static const T* slice0(const MlpDev<T>& m, int w, int lane) {
+    return m.w[0] + ((size_t)w * (m.k1p / 4) * 64 + lane) * NT;
+  }
+  __device__ __forceinline__ static const T* slice_h(const MlpDev<T>& m, int l, int w, int lane) {
+    return m.w[l] + ((size_t)w * KSH * 64 + lane) * NT;
+  }
+
+  // Request the first weight group of layer 0.  Call before the barrier/phase that precedes
+  // run(); the loads complete while other work proceeds.
+  __device__ __forceinline__ void prefetch0(const MlpDev<T>& m) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    load_group<T, NT, G0>(slice0(m, w, lane), 0, pf0);
+  }
+
+  // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, pf0 has been requested and every
+  // thread has passed a barrier after the last write to lds[L.xu].  On exit
+  // lds[L.act + (w*M + row)*nxp + col] holds wave w's partial of the output layer (bias NOT
+  // added), pf0 has been re-requested for the next call, and a barrier has been passed.
+  // If DERIV, act'(z) of hidden layer l is written to dz[l*dz_layer_stride + row*hpad + col].
+  __device__ __forceinline__ void run(const MlpDev<T>& m, const TileLds& L, T* lds,
+                                      T* __restrict__ dz = nullptr, size_t dz_layer_stride = 0) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    T* act = lds + L.act;
+    const int as = L.act_stride;
+    const int no = m.nxp / 16;
+    T pfh[GH][NT];        // first group of the next hidden layer
+    T pfo[KSW][NOMAX];    // all output-layer fragments of this wave
+
+    auto prefetch_next = [&](int l_next) {
+      if (l_next < m.n_hidden) {
+        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfh);
+      } else {
+        if (no == 1) {
+          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+          for (int ks = 0; ks < KSW; ++ks) { pfo[ks][0] = wl[ks * 64]; pfo[ks][1] = T(0); }
+        } else {
+          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-    if (l == 0) {
-      // first layer: K = k1p is 16, 32 or 48 (kin zero-padded) -> three fully unrolled variants
-      const T* w0 = m.w[0] + (size_t)w * (m.k1p / 4) * 64 * NT;
-      if (m.k1p == 16) layer_mma_static<T, NT, MT, 4, 4>(lds + L.xin, L.xin_stride, w0, lane, acc);
-      else if (m.k1p == 32) layer_mma_static<T, NT, MT, 8, 8>(lds + L.xin, L.xin_stride, w0, lane, acc);
-      else layer_mma_static<T, NT, MT, 12, 4>(lds + L.xin, L.xin_stride, w0, lane, acc);
-    } else {
-      layer_mma_static<T, NT, MT, 16 * NT, 8>(act, as, m.w[l] + (size_t)w * ks_h * 64 * NT, lane, acc);
-      __syncthreads();  // every wave finished reading act before it is overwritten
-    }
-    const T* bias = lds + L.bias + l * m.hpad;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = 16 * (NT * w + nt) + i;
-        const T bc = bias[col];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + acc_row<T>(q, r);
-          const T z = acc[mt][nt][r] + bc;
-          act[row * as + col] = act_apply<T>(m.act, z);
-          if (DERIV) dz[(size_t)l * dz_layer_stride + row * m.hpad + col] = act_deriv<T>(m.act, z);
+          for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, pfo[ks]);
         }
       }
+    };
+    auto epilogue = [&](int l, acc_t (&acc)[MT][NT]) {
+      const T* bias = lds + L.bias + l * m.hpad;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = 16 * (NT * w + nt) + i;
+          const T bc = bias[col];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + acc_row<T>(q, r);
+            const T z = acc[mt][nt][r] + bc;
+            act[row * as + col] = act_apply<T>(m.act, z);
+            if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(m.act, z);
+          }
+        }
+    };
+
+    // ---- layer 0: K = k1p (16 / 32 / 48), A = [x | u] ----------------------------------------
+    {
+      acc_t acc[MT][NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
+      const T* wl = slice0(m, w, lane);
+      const T* A = lds + L.xu;
+      if (m.k1p == 16) layer_mma_static<T, NT, MT, 4, G0>(A, L.xu_stride, wl, lane, pf0, acc);
+      else if (m.k1p == 32) layer_mma_static<T, NT, MT, 8, G0>(A, L.xu_stride, wl, lane, pf0, acc);
+      else layer_mma_static<T, NT, MT, 12, G0>(A, L.xu_stride, wl, lane, pf0, acc);
+      prefetch_next(1);
+      epilogue(0, acc);
+    }
+    __syncthreads();
+
+    // ---- hidden -> hidden layers ---------------------------------------------------------------
+    for (int l = 1; l < m.n_hidden; ++l) {
+      acc_t acc[MT][NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
+      layer_mma_static<T, NT, MT, KSH, GH>(act, as, slice_h(m, l, w, lane), lane, pfh, acc);
+      prefetch_next(l + 1);
+      __syncthreads();  // every wave finished reading act before it is overwritten
+      epilogue(l, acc);
+      __syncthreads();
+    }
+
+    // ---- output layer: K-split, wave w owns k-steps [w*KSW, (w+1)*KSW) -----------------------
+    acc_t oacc[MT][NOMAX];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
+    {
+      const T* arow = act + i * as + q + 4 * w * KSW;
+      if (no == 1) {
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], pfo[ks][0], oacc[mt][0]);
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const T a = arow[mt * 16 * as + 4 * ks];
+            oacc[mt][0] = mfma16(a, pfo[ks][0], oacc[mt][0]);
+            oacc[mt][1] = mfma16(a, pfo[ks][1], oacc[mt][1]);
+          }
+      }
+    }
+    prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
+    __syncthreads();  // act fully consumed; reuse it for the partials
+    T* part = act + w * M * m.nxp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int n = 0; n < NOMAX; ++n)
+        if (n < no) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * mt + acc_row<T>(q, r);
+            part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
+          }
+        }
     __syncthreads();
   }
 
-  // output layer: K-split, wave w owns k-steps [w*KSW, (w+1)*KSW)
-  constexpr int NOMAX = 2;  // nx <= 32
-  constexpr int KSW = 4 * NT;
-  const int no = m.nxp / 16;
-  acc_t oacc[MT][NOMAX];
+  // y[row][col] (folded output: already the state increment) from the partials left by run().
+  __device__ __forceinline__ static T output(const MlpDev<T>& m, const TileLds& L, const T* lds,
+                                             int row, int col) {
+    const T* p = lds + L.act + row * m.nxp + col;
+    T y = lds[L.bias + m.n_hidden * m.hpad + col];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
-  {
-    const T* arow = act + i * as + q + 4 * w * KSW;
-    if (no == 1) {
-      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
-      T b[KSW];
-#pragma unroll
-      for (int ks = 0; ks < KSW; ++ks) b[ks] = wl[ks * 64];
-#pragma unroll
-      for (int ks = 0; ks < KSW; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], b[ks], oacc[mt][0]);
-    } else {
-      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
-      T b[KSW][2];
-#pragma unroll
-      for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, b[ks]);
-#pragma unroll
-      for (int ks = 0; ks < KSW; ++ks)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const T a = arow[mt * 16 * as + 4 * ks];
-          oacc[mt][0] = mfma16(a, b[ks][0], oacc[mt][0]);
-          oacc[mt][1] = mfma16(a, b[ks][1], oacc[mt][1]);
-        }
-    }
+    for (int w = 0; w < W; ++w) y += p[w * M * m.nxp];
+    return y;
   }
-  __syncthreads();  // act fully consumed; reuse it for the partials
-  T* part = act + w * M * m.nxp;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int n = 0; n < NOMAX; ++n)
-      if (n < no) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * mt + acc_row<T>(q, r);
-          part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
-        }
-      }
-  __syncthreads();
-}
-
-// y[row][col] from the partials left by tile_network.
-template <typename T, int MT>
-__device__ __forceinline__ T tile_output(const MlpDev<T>& m, const TileLds& L, const T* lds, int row,
-                                         int col) {
-  constexpr int M = 16 * MT;
-  const T* p = lds + L.act + row * m.nxp + col;
-  T y = lds[L.bias + m.n_hidden * m.hpad + col];
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) y += p[w * M * m.nxp];
-  return y;
-}
+};
 
 }  // namespace ampc

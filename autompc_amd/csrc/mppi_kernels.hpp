@@ -38,6 +38,7 @@ template <typename T> struct MppiArgs {
   int lds_aseq, lds_cost;       // extra LDS regions: shifted act sequence, cost block + bounds
   int obs_dim, cost_stride;     // cost block = Q[no*no] R[nu*nu] F[no*no] goal[no]
   int term_mode, max_h;
+  int cost_diag;                // 1: every Q, R, F is diagonal -> O(n) stage cost
   const T* costs_par;           // [n_costs][cost_stride]
   const T* bounds;              // lo[nu] hi[nu] scale[nu]   (lo, hi already divided by scale)
   const MppiProblem<T>* probs;
@@ -52,21 +53,48 @@ template <typename T> struct MppiArgs {
   T* u_out;                     // [B][nu] first action * scale (written by the update kernel)
 };
 
-template <typename T, int NT, int MT>
-__global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> args) {
+// x' M x for the rows this thread owns (rows r, r+TPS, ...); d[j] = v[j] - g[j].
+template <typename T>
+__device__ __forceinline__ T quad_rows(const T* __restrict__ Mx, const T* __restrict__ v,
+                                       const T* __restrict__ g, int n, int r, int tps, bool diag) {
+  T acc = T(0);
+  if (diag) {
+    for (int i = r; i < n; i += tps) {
+      const T d = v[i] - (g ? g[i] : T(0));
+      acc += Mx[i * n + i] * d * d;
+    }
+  } else {
+    for (int i = r; i < n; i += tps) {
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += Mx[i * n + j] * (v[j] - (g ? g[j] : T(0)));
+      acc += (v[i] - (g ? g[i] : T(0))) * s;
+    }
+  }
+  return acc;
+}
+
+template <typename T, int NT, int MT, int W>
+__global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  constexpr int M = 16 * MT;
-  constexpr int TPS = kWG / M;  // threads cooperating on one sample (16 / 8 / 4), same wave
+  using Net = TileNet<T, NT, MT, W>;
+  constexpr int M = 16 * MT, NTHR = 64 * W;
+  constexpr int TPS = NTHR / M;                 // threads per sample (32..4), all in one wave
+  constexpr int EPT = (16 + TPS - 1) / TPS;     // noise elements per thread (nu <= 16)
   const MlpDev<T>& mlp = args.mlp;
   const TileLds& L = args.lds;
   const int tid = threadIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, no = args.obs_dim;
+  const int xs_ = L.xu_stride;
+  const bool diag = args.cost_diag != 0;
 
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
   const int first = (blockIdx.x - pr.tile0) * M;
   const int H = pr.H, N = pr.N;
+
+  Net net;
+  net.prefetch0(mlp);
 
   T* aseq = lds + args.lds_aseq;              // [H][nu] shifted warm start
   T* cpar = lds + args.lds_cost;              // Q R F goal | lo hi scale
@@ -77,26 +105,18 @@ __global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> arg
   const T* blo = cpar + args.cost_stride;
   const T* bhi = blo + nu;
   const T* bsc = bhi + nu;
-  T* xs = lds + L.xs;
-  T* us = lds + L.us;
-  T* xin = lds + L.xin;
-  const T* xmean = lds + L.norm;
-  const T* xstd = xmean + mlp.kin;
-  const T* dmean = xstd + mlp.kin;
-  const T* dstd = dmean + nx;
+  T* xu = lds + L.xu;
 
   // ---- prologue: constants, shifted sequence, initial state ------------------------------
-  tile_load_constants(mlp, L, lds);
-  for (int i = tid; i < args.cost_stride; i += kWG)
+  tile_load_constants<T, W>(mlp, L, lds, M);
+  for (int i = tid; i < args.cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
-  for (int i = tid; i < 3 * nu; i += kWG) cpar[args.cost_stride + i] = args.bounds[i];
-  for (int i = tid; i < H * nu; i += kWG) {
+  for (int i = tid; i < 3 * nu; i += NTHR) cpar[args.cost_stride + i] = args.bounds[i];
+  for (int i = tid; i < H * nu; i += NTHR) {
     const int t = i / nu, j = i - t * nu;
     const int ts = (t + 1 < H) ? t + 1 : H - 1;  // a[:-1] = a[1:]; a[-1] = a[-2]
     aseq[i] = args.act_in[pr.a_off + ts * nu + j];
   }
-  for (int i = tid; i < M * nx; i += kWG) xs[i] = args.x0[p * nx + (i % nx)];
-  for (int i = tid; i < M * L.xin_stride; i += kWG) xin[i] = T(0);
 
   const int m = tid / TPS, r = tid % TPS;   // sample-in-tile, helper index
   const int n = first + m;
@@ -105,18 +125,22 @@ __global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> arg
   T* epso = args.eps_out + pr.epso_off;
 
   T c_part = T(0), ca_part = T(0);
-  T e_next[MT];
+  T e_next[EPT];
 #pragma unroll
-  for (int e = 0; e < MT; ++e) {
+  for (int e = 0; e < EPT; ++e) {
     const int j = r + e * TPS;
     e_next[e] = (valid && j < nu) ? eps_row[j] : T(0);
   }
   __syncthreads();
+  for (int i = tid; i < M * nx; i += NTHR) {
+    const int row = i / nx, col = i - row * nx;
+    xu[row * xs_ + col] = args.x0[p * nx + col];
+  }
 
-  for (int t = 0; t < H; ++t) {
-    // ---- P1: actions, clipped noise out, normalised network input --------------------------
+  // actions of step t: A = clip(eps + a), eps <- A - a, u = A * scale  (mppi.py:134-139)
+  auto actions = [&](int t) {
 #pragma unroll
-    for (int e = 0; e < MT; ++e) {
+    for (int e = 0; e < EPT; ++e) {
       const int j = r + e * TPS;
       if (j < nu) {
         const T a = aseq[t * nu + j];
@@ -124,54 +148,34 @@ __global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> arg
         A = A < blo[j] ? blo[j] : A;
         A = A > bhi[j] ? bhi[j] : A;
         const T ec = A - a;
-        const T u = A * bsc[j];
         if (valid) epso[((size_t)t * N + n) * nu + j] = ec;
         ca_part += A * ec;
-        us[m * nu + j] = u;
-        xin[m * L.xin_stride + nx + j] = (u - xmean[nx + j]) / xstd[nx + j];
+        xu[m * xs_ + nx + j] = A * bsc[j];
         if (t + 1 < H) e_next[e] = valid ? eps_row[(t + 1) * nu + j] : T(0);
       }
     }
-    for (int i = r; i < nx; i += TPS)
-      xin[m * L.xin_stride + i] = (xs[m * nx + i] - xmean[i]) / xstd[i];
-    __syncthreads();
+  };
+  actions(0);
+  __syncthreads();
 
-    // ---- P2: stage cost (partial per thread: rows r, r+TPS, ...) ----------------------------
-    {
-      const T* x = xs + m * nx;
-      for (int i = r; i < no; i += TPS) {
-        T s = T(0);
-        for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (x[j] - goal[j]);
-        c_part += (x[i] - goal[i]) * s;
-      }
-      const T* u = us + m * nu;
-      for (int i = r; i < nu; i += TPS) {
-        T s = T(0);
-        for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * u[j];
-        c_part += u[i] * s;
-      }
-    }
-
-    // ---- dynamics: x <- x + dy_mean + dy_std * net(xin) -------------------------------------
-    tile_network<T, NT, MT>(mlp, L, lds);
-    for (int i = tid; i < M * nx; i += kWG) {
+  for (int t = 0; t < H; ++t) {
+    // ---- stage cost of (x_t, u_t): partial per thread, reduced once after the loop ------------
+#ifndef AMPC_X_NOCOST
+    c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, diag);
+    c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, diag);
+#endif
+    // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
+    net.run(mlp, L, lds);
+    for (int i = tid; i < M * nx; i += NTHR) {
       const int row = i / nx, col = i - row * nx;
-      const T y = tile_output<T, MT>(mlp, L, lds, row, col);
-      xs[i] = xs[i] + (y * dstd[col] + dmean[col]);
+      xu[row * xs_ + col] += Net::output(mlp, L, lds, row, col);
     }
+    if (t + 1 < H) actions(t + 1);
     __syncthreads();
   }
 
   // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------
-  T term = T(0);
-  {
-    const T* x = xs + m * nx;
-    for (int i = r; i < no; i += TPS) {
-      T s = T(0);
-      for (int j = 0; j < no; ++j) s += Fm[i * no + j] * (x[j] - goal[j]);
-      term += (x[i] - goal[i]) * s;
-    }
-  }
+  T term = quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, diag);
   T c = c_part + pr.lam_over_sigma * ca_part;
   if (args.term_mode == 1) c += term;
 #pragma unroll
@@ -184,6 +188,9 @@ __global__ __launch_bounds__(kWG) void mppi_rollout_kernel(const MppiArgs<T> arg
     if (n == N - 1) args.term_last[p] = term;
   }
 }
+
+constexpr int kWG = 256;      // threads of the update / finalize kernels
+constexpr int kWaves = 4;
 
 // ---- block-wide reductions built on wave shuffles ---------------------------------------------
 template <typename T> __device__ __forceinline__ T wave_min(T v) {
