@@ -846,3 +846,12 @@ extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, doub
   p->ev_used = 0;
   return 0;
 }
+
+#ifdef AMPC_X_PHASETIME
+// experiment only: read back the phase marks of the rollout kernel (tools/phasetime.py)
+extern "C" int ampc_x_phase_marks(long long* out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
+  return 0;
+}
+#endif

@@ -25,6 +25,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace ampc {
 
 constexpr int kMaxHidden = 4;  // hidden layers supported (reference config space: 1..4)
@@ -108,6 +110,17 @@ struct TileLds {
   int extra;    // kernel-specific region starts here
   int act_stride, xu_stride;
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope
+// release fence that hipcc lowers to s_waitcnt vmcnt(0): it would drain the weight prefetches
+// this kernel deliberately keeps in flight across phase boundaries.  Every cross-wave hand-off in
+// the tile goes through LDS, so waiting for this wave's LDS operations (lgkmcnt) is sufficient;
+// the asm memory clobbers keep the compiler from moving LDS accesses across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
@@ -201,6 +214,17 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
   }
 }
 
+#ifdef AMPC_X_PHASETIME
+__device__ long long g_phase_marks[64];
+#define AMPC_MARK(idx)                                                              \
+  do {                                                                              \
+    if (blockIdx.x == 7 && threadIdx.x == 0 && g_phase_marks[63] == 1)              \
+      g_phase_marks[idx] = (long long)__builtin_amdgcn_s_memtime();                 \
+  } while (0)
+#else
+#define AMPC_MARK(idx) do { } while (0)
+#endif
+
 // ---- the fused network on one tile -------------------------------------------------------------
 template <typename T, int NT, int MT, int W, bool DERIV = false>
 struct TileNet {
@@ -243,25 +267,36 @@ struct TileNet {
     T* act = lds + L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
-    T pfh[GH][NT];        // first group of the next hidden layer
-    T pfo[KSW][NOMAX];    // all output-layer fragments of this wave
+    // Prefetch buffer for whatever comes next: the first group of the next hidden layer
+    // ([GH][NT]) or all of this wave's output-layer fragments ([KSW][2]); both are 8*NT values.
+    T pfn[GH][NT];
+    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");
 
     auto prefetch_next = [&](int l_next) {
       if (l_next < m.n_hidden) {
-        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfh);
+        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
       } else {
+        T* flat = &pfn[0][0];
         if (no == 1) {
           const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
-          for (int ks = 0; ks < KSW; ++ks) { pfo[ks][0] = wl[ks * 64]; pfo[ks][1] = T(0); }
+          for (int ks = 0; ks < KSW; ++ks) { flat[2 * ks] = wl[ks * 64]; flat[2 * ks + 1] = T(0); }
         } else {
           const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
-          for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, pfo[ks]);
+          for (int ks = 0; ks < KSW; ++ks) {
+            T two[2];
+            load_frag<T, 2>(wl + ks * 128, two);
+            flat[2 * ks] = two[0];
+            flat[2 * ks + 1] = two[1];
+          }
         }
       }
     };
-    auto epilogue = [&](int l, acc_t (&acc)[MT][NT]) {
+    // bias + activation + store of one layer's accumulators (activation kind hoisted out of
+    // the element loops: one uniform branch per layer instead of one per element)
+    auto epilogue_k = [&](int l, acc_t (&acc)[MT][NT], auto kind_tag) {
+      constexpr int KIND = decltype(kind_tag)::value;
       const T* bias = lds + L.bias + l * m.hpad;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -273,10 +308,18 @@ struct TileNet {
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + acc_row<T>(q, r);
             const T z = acc[mt][nt][r] + bc;
-            act[row * as + col] = act_apply<T>(m.act, z);
-            if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(m.act, z);
+            act[row * as + col] = act_apply<T>(KIND, z);
+            if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(KIND, z);
           }
         }
+    };
+    auto epilogue = [&](int l, acc_t (&acc)[MT][NT]) {
+      switch (m.act) {
+        case 0: epilogue_k(l, acc, std::integral_constant<int, 0>{}); break;
+        case 1: epilogue_k(l, acc, std::integral_constant<int, 1>{}); break;
+        case 2: epilogue_k(l, acc, std::integral_constant<int, 2>{}); break;
+        default: epilogue_k(l, acc, std::integral_constant<int, 3>{}); break;
+      }
     };
 
     // ---- layer 0: K = k1p (16 / 32 / 48), A = [x | u] ----------------------------------------
@@ -291,10 +334,12 @@ struct TileNet {
       if (m.k1p == 16) layer_mma_static<T, NT, MT, 4, G0>(A, L.xu_stride, wl, lane, pf0, acc);
       else if (m.k1p == 32) layer_mma_static<T, NT, MT, 8, G0>(A, L.xu_stride, wl, lane, pf0, acc);
       else layer_mma_static<T, NT, MT, 12, G0>(A, L.xu_stride, wl, lane, pf0, acc);
+      AMPC_MARK(2);
       prefetch_next(1);
       epilogue(0, acc);
     }
-    __syncthreads();
+    lds_barrier();
+    AMPC_MARK(3);
 
     // ---- hidden -> hidden layers ---------------------------------------------------------------
     for (int l = 1; l < m.n_hidden; ++l) {
@@ -303,11 +348,14 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-      layer_mma_static<T, NT, MT, KSH, GH>(act, as, slice_h(m, l, w, lane), lane, pfh, acc);
+      layer_mma_static<T, NT, MT, KSH, GH>(act, as, slice_h(m, l, w, lane), lane, pfn, acc);
+      AMPC_MARK(4);
       prefetch_next(l + 1);
-      __syncthreads();  // every wave finished reading act before it is overwritten
+      lds_barrier();  // every wave finished reading act before it is overwritten
+      AMPC_MARK(5);
       epilogue(l, acc);
-      __syncthreads();
+      lds_barrier();
+      AMPC_MARK(6);
     }
 
     // ---- output layer: K-split, wave w owns k-steps [w*KSW, (w+1)*KSW) -----------------------
@@ -317,26 +365,29 @@ struct TileNet {
 #pragma unroll
       for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
     {
+      const T* pfo = &pfn[0][0];
       const T* arow = act + i * as + q + 4 * w * KSW;
       if (no == 1) {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], pfo[ks][0], oacc[mt][0]);
+            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], pfo[2 * ks], oacc[mt][0]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const T a = arow[mt * 16 * as + 4 * ks];
-            oacc[mt][0] = mfma16(a, pfo[ks][0], oacc[mt][0]);
-            oacc[mt][1] = mfma16(a, pfo[ks][1], oacc[mt][1]);
+            oacc[mt][0] = mfma16(a, pfo[2 * ks], oacc[mt][0]);
+            oacc[mt][1] = mfma16(a, pfo[2 * ks + 1], oacc[mt][1]);
           }
       }
     }
+    AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
-    __syncthreads();  // act fully consumed; reuse it for the partials
+    lds_barrier();  // act fully consumed; reuse it for the partials
+    AMPC_MARK(8);
     T* part = act + w * M * m.nxp;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -349,7 +400,8 @@ struct TileNet {
             part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
           }
         }
-    __syncthreads();
+    lds_barrier();
+    AMPC_MARK(9);
   }
 
   // y[row][col] (folded output: already the state increment) from the partials left by run().

@@ -159,11 +159,16 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   __syncthreads();
 
   for (int t = 0; t < H; ++t) {
+#ifdef AMPC_X_PHASETIME
+    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == 5) ? 1 : 0;
+#endif
+    AMPC_MARK(0);
     // ---- stage cost of (x_t, u_t): partial per thread, reduced once after the loop ------------
 #ifndef AMPC_X_NOCOST
     c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, diag);
     c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, diag);
 #endif
+    AMPC_MARK(1);
     // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
     net.run(mlp, L, lds);
     for (int i = tid; i < M * nx; i += NTHR) {
@@ -171,7 +176,9 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
       xu[row * xs_ + col] += Net::output(mlp, L, lds, row, col);
     }
     if (t + 1 < H) actions(t + 1);
-    __syncthreads();
+    AMPC_MARK(10);
+    lds_barrier();
+    AMPC_MARK(11);
   }
 
   // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------

@@ -10,5 +10,6 @@ build nomfma -DAMPC_X_NOMFMA
 build noload -DAMPC_X_NOLOAD
 build nocost -DAMPC_X_NOCOST
 build nomfma_noload -DAMPC_X_NOMFMA -DAMPC_X_NOLOAD
+build phasetime -DAMPC_X_PHASETIME
 wait
 ls -la variants
