@@ -427,13 +427,21 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
   } while (0)
 
 // Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
+// LDS map for a tile: separate partials region when it fits the 160 KB, else aliased onto `act`.
+template <typename T>
+static TileLds tile_lds_for(const ampc_handle* h, const MlpDev<T>& m, int M, size_t extra_elems) {
+  TileLds L = make_tile_lds(m, M, h->nw, true);
+  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, false);
+  return L;
+}
+
 template <typename T>
 static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_rows,
                      size_t extra_elems) {
   const int forced = env_int("AMPC_MT", 0);
   int best = 1;
   for (int mt : {1, 2, 4}) {
-    TileLds L = make_tile_lds(m, 16 * mt, h->nw);
+    TileLds L = tile_lds_for<T>(h, m, 16 * mt, extra_elems);
     const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
     if (bytes > kLdsLimit) break;
     if (forced == mt) return mt;
@@ -460,7 +468,7 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
   const int M = 16 * mt;
   const int tiles = (n + M - 1) / M;
   const int n_pad = tiles * M;
-  TileLds L = make_tile_lds(m, M, h->nw);
+  TileLds L = tile_lds_for<T>(h, m, M, 0);
   const size_t lds_bytes = (size_t)L.extra * sizeof(T);
   if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
   T* dz = (T*)h->s_dz.p;
@@ -582,7 +590,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   const size_t extra = (size_t)p->max_h * nu + h->cost_stride + 3 * nu + 8;
   p->mt = choose_mt<T>(h, m, p->sum_n, extra);
   const int M = 16 * p->mt;
-  p->L = make_tile_lds(m, M, h->nw);
+  p->L = tile_lds_for<T>(h, m, M, extra);
   p->lds_aseq = p->L.extra;
   p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
   p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);

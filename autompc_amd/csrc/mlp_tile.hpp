@@ -104,7 +104,9 @@ template <typename T> struct MlpDev {
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
 struct TileLds {
-  int act;      // [M][hpad+2]  (also reused for the output-layer partials [W][M][nxp])
+  int act;      // [M][hpad+2]
+  int part;     // [W][M][nxp] output-layer partials; aliases `act` when LDS is tight
+  int part_alias;
   int xu;       // [M][k1p+2]   raw state | control | zero pad: the first layer's A operand
   int bias;     // n_hidden*hpad + nxp
   int extra;    // kernel-specific region starts here
@@ -126,12 +128,18 @@ __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 template <typename T>
-__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W) {
+__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true) {
   TileLds L;
   int o = 0;
   L.act_stride = m.hpad + 2;
   L.xu_stride = m.k1p + 2;
-  L.act = o; o += M * imax(L.act_stride, W * m.nxp);
+  L.part_alias = separate_partials ? 0 : 1;
+  if (separate_partials) {
+    L.act = o; o += M * L.act_stride;
+    L.part = o; o += W * M * m.nxp;
+  } else {
+    L.act = o; L.part = o; o += M * imax(L.act_stride, W * m.nxp);
+  }
   L.xu = o; o += M * L.xu_stride;
   L.bias = o; o += m.n_hidden * m.hpad + m.nxp;
   L.extra = round_up(o, 4);
@@ -256,7 +264,7 @@ struct TileNet {
 
   // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, pf0 has been requested and every
   // thread has passed a barrier after the last write to lds[L.xu].  On exit
-  // lds[L.act + (w*M + row)*nxp + col] holds wave w's partial of the output layer (bias NOT
+  // lds[L.part + (w*M + row)*nxp + col] holds wave w's partial of the output layer (bias NOT
   // added), pf0 has been re-requested for the next call, and a barrier has been passed.
   // If DERIV, act'(z) of hidden layer l is written to dz[l*dz_layer_stride + row*hpad + col].
   __device__ __forceinline__ void run(const MlpDev<T>& m, const TileLds& L, T* lds,
@@ -386,9 +394,9 @@ struct TileNet {
     }
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
-    lds_barrier();  // act fully consumed; reuse it for the partials
+    if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
-    T* part = act + w * M * m.nxp;
+    T* part = lds + L.part + w * M * m.nxp;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -407,7 +415,7 @@ struct TileNet {
   // y[row][col] (folded output: already the state increment) from the partials left by run().
   __device__ __forceinline__ static T output(const MlpDev<T>& m, const TileLds& L, const T* lds,
                                              int row, int col) {
-    const T* p = lds + L.act + row * m.nxp + col;
+    const T* p = lds + L.part + row * m.nxp + col;
     T y = lds[L.bias + m.n_hidden * m.hpad + col];
 #pragma unroll
     for (int w = 0; w < W; ++w) y += p[w * M * m.nxp];

@@ -150,13 +150,18 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
         const T ec = A - a;
         if (valid) epso[((size_t)t * N + n) * nu + j] = ec;
         ca_part += A * ec;
-        xu[m * xs_ + nx + j] = A * bsc[j];
+        const T u = A * bsc[j];
+        xu[m * xs_ + nx + j] = u;
+        if (diag) c_part += Rm[j * nu + j] * u * u;   // diagonal R: the term is thread-local
         if (t + 1 < H) e_next[e] = valid ? eps_row[(t + 1) * nu + j] : T(0);
       }
     }
   };
   actions(0);
   __syncthreads();
+  // Diagonal costs are accumulated where the values are produced (actions / state update), so
+  // the time loop has no separate cost phase; the stage cost of x_0 is added here.
+  if (diag) c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, true);
 
   for (int t = 0; t < H; ++t) {
 #ifdef AMPC_X_PHASETIME
@@ -165,15 +170,21 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     AMPC_MARK(0);
     // ---- stage cost of (x_t, u_t): partial per thread, reduced once after the loop ------------
 #ifndef AMPC_X_NOCOST
-    c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, diag);
-    c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, diag);
+    if (!diag) {
+      c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false);
+      c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false);
+    }
 #endif
     AMPC_MARK(1);
     // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
     net.run(mlp, L, lds);
-    for (int i = tid; i < M * nx; i += NTHR) {
-      const int row = i / nx, col = i - row * nx;
-      xu[row * xs_ + col] += Net::output(mlp, L, lds, row, col);
+    for (int i = r; i < nx; i += TPS) {
+      const T xn = xu[m * xs_ + i] + Net::output(mlp, L, lds, m, i);
+      xu[m * xs_ + i] = xn;
+      if (diag && i < no && t + 1 < H) {       // stage cost of x_{t+1} (x_H only pays the terminal cost)
+        const T d = xn - goal[i];
+        c_part += Qm[i * no + i] * d * d;
+      }
     }
     if (t + 1 < H) actions(t + 1);
     AMPC_MARK(10);
