@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
   const int nx = mlp.nx, nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
-  const int gs = hpad + 2;
+  const int gs = hpad + (sizeof(T) == 8 ? 1 : 2);  // same padding rule as TileLds::act_stride
   const int rows_total = n * nx;
   const int first = blockIdx.x * M;
   const size_t lstride = (size_t)n_pad * hpad;

@@ -7,8 +7,8 @@
 // (v_mfma_f32_16x16x4_f32): k-ordered fma chains, no reduced-precision inputs.
 //
 // Operand sources
-//   A (activations)  LDS, row-major [M][K+2]: the +2 pad makes the 16-row x 2-column access of
-//                    each 32-lane half conflict-free for ds_read_b64 (f64) / ds_read_b32 (f32).
+//   A (activations)  LDS, row-major [M][K+pad]: pad = 2 (f32) / 1 (f64) keeps the 16-row fragment
+//                    reads (ds_read2_b32 / ds_read2_b64) free of bank conflicts.
 //   B (weights)      global memory, pre-packed on the host in exact fragment order, so each wave
 //                    reads one contiguous, fully coalesced run per k-step.  Weights are re-read
 //                    every time step but stay L2-resident (<= 640 KB per model).  Fragments are
@@ -131,8 +131,13 @@ template <typename T>
 __host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true) {
   TileLds L;
   int o = 0;
-  L.act_stride = m.hpad + 2;
-  L.xu_stride = m.k1p + 2;
+  // Row padding for conflict-free A-fragment reads (16 rows x consecutive k per access):
+  //   f32  ds_read(2)_b32 banks = dword mod 32 over 32-lane halves  -> stride = 2 (mod 4)
+  //   f64  hipcc pairs k-steps into ds_read2_b64 (16-lane groups, banks = dword mod 32)
+  //        -> odd stride in 8-byte units (measured: SQ_LDS_BANK_CONFLICT 40% -> ~0 of LDS cycles)
+  const int pad = sizeof(T) == 8 ? 1 : 2;
+  L.act_stride = m.hpad + pad;
+  L.xu_stride = m.k1p + pad;
   L.part_alias = separate_partials ? 0 : 1;
   if (separate_partials) {
     L.act = o; o += M * L.act_stride;

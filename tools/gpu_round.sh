@@ -1,18 +1,33 @@
 #!/bin/bash
-# One GPU-box session: parity tests, smoke, bench, rocprof summary.  Run via gpurun from repo root.
+# One GPU-box session for the record: parity tests, smoke, bench, rocprofv3 summaries.
+# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r01
 set -u
-mkdir -p gpurun_out
+TAG=${1:-r01}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/pytest_gpu.log
-timeout 300 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
-timeout 600 python bench.py --steps 200 --warmup 20 > gpurun_out/bench_f64.json 2> gpurun_out/bench_f64.err
-timeout 300 python bench.py --steps 200 --warmup 20 --precision f32 --no-cpu-baseline > gpurun_out/bench_f32.json 2> gpurun_out/bench_f32.err
-timeout 300 python bench.py --steps 200 --warmup 20 --workload c2 --no-cpu-baseline > gpurun_out/bench_c2_f64.json 2> gpurun_out/bench_c2.err
-for mt in 1 2; do
-  AMPC_MT=$mt timeout 300 python bench.py --steps 100 --warmup 10 --batch 8 --no-cpu-baseline > gpurun_out/bench_b8_mt$mt.json 2>> gpurun_out/bench_b8.err
-done
-cd /tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_c3 -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_c3.log 2>&1
 cd $GRAFT_REPO_ROOT
-find gpurun_out/prof_c3 -name "*kernel_stats*" | head -3
-cat gpurun_out/pytest_gpu.log gpurun_out/smoke.log | tail -20
-head -c 2500 gpurun_out/bench_f64.json; echo; tail -3 gpurun_out/bench_f64.err
+timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu.log
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1
+timeout 900 python bench.py > $OUT/bench_c3_f64.json 2> $OUT/bench_c3_f64.err
+timeout 300 python bench.py --precision f32 --no-cpu-baseline > $OUT/bench_c3_f32.json 2> $OUT/bench_c3_f32.err
+timeout 300 python bench.py --workload c2 > $OUT/bench_c2_f64.json 2> $OUT/bench_c2_f64.err
+timeout 300 python bench.py --batch 8 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c3_f64_batch8.json 2> $OUT/bench_c3_f64_batch8.err
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- $BENCH > $OUT/prof_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_pmc_sq -- $BENCH > $OUT/prof_pmc_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_pmc_fetch -- $BENCH > $OUT/prof_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_pmc_write -- $BENCH > $OUT/prof_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_LDS --output-format csv -d $OUT/prof_pmc_lds -- $BENCH > $OUT/prof_pmc_lds.log 2>&1
+cd $GRAFT_REPO_ROOT
+find $OUT -name "*.csv" | head -30
+cat $OUT/pytest_gpu.log | tail -3; cat $OUT/smoke.log | tail -1
+python - <<PY
+import json,glob
+for f in sorted(glob.glob("$OUT/bench_*.json")):
+    try:
+        d=json.load(open(f)); r=d["roofline"]
+        print("%-28s value=%8.1f ms/step=%.3f kernel_ms=%.3f TF=%.1f frac=%.3f cpu=%s" % (f.split("/")[-1], d["value"], d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"], d.get("cpu_baseline",{}).get("value")))
+    except Exception as e: print(f, "failed", e)
+PY
