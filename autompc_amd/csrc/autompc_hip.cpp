@@ -322,7 +322,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   h->hpad = round_up(hmax, 64);
   h->nw = (h->hpad % 128 == 0 && env_int("AMPC_WAVES", 8) == 8) ? 8 : 4;
   h->nt = h->hpad / (16 * h->nw);
-  h->k1p = round_up(nx + nu, 16);
+  h->k1p = round_up(nx + nu, 8);
   h->nxp = round_up(nx, 16);
   h->W.assign(n_hidden + 1, {});
   h->b.assign(n_hidden + 1, {});
@@ -421,6 +421,8 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
       AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
       AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
       AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
+      AMPC_CASE(4, 2, 1, __VA_ARGS__) AMPC_CASE(4, 2, 2, __VA_ARGS__) AMPC_CASE(4, 2, 4, __VA_ARGS__) \
+      AMPC_CASE(4, 4, 1, __VA_ARGS__) AMPC_CASE(4, 4, 2, __VA_ARGS__) AMPC_CASE(4, 4, 4, __VA_ARGS__) \
       AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
       default: return fail("internal: unsupported (W, NT, MT) combination");  \
     }                                                                        \

@@ -92,7 +92,7 @@ template <typename T> __device__ __forceinline__ T act_deriv(int kind, T z) {
 // ---- device-side model descriptor ------------------------------------------------------------
 template <typename T> struct MlpDev {
   int nx, nu, kin;      // state dim, ctrl dim, nx+nu
-  int k1p;              // kin zero-padded to 16, 32 or 48 (first-layer MFMA K)
+  int k1p;              // kin zero-padded to a multiple of 8, <= 48 (first-layer MFMA K)
   int n_hidden;         // hidden layers
   int hpad;             // 16*NT*W
   int nxp;              // nx rounded up to a multiple of 16
@@ -246,7 +246,7 @@ struct TileNet {
   static constexpr int HP = 16 * NT * W;      // padded hidden width
   static constexpr int KSH = HP / 4;          // k-steps of a hidden->hidden layer
   static constexpr int KSW = KSH / W;         // output-layer k-steps per wave (= 4*NT)
-  static constexpr int G0 = 4;                // first-layer group (k1p/4 is 4, 8 or 12)
+  static constexpr int G0 = 2;                // first-layer group (k1p/4 is 2, 4, .. 12)
   static constexpr int GH = 8;                // hidden-layer group
   static constexpr int NOMAX = 2;             // nx <= 32
 
@@ -335,7 +335,7 @@ struct TileNet {
       }
     };
 
-    // ---- layer 0: K = k1p (16 / 32 / 48), A = [x | u] ----------------------------------------
+    // ---- layer 0: K = k1p (8, 16, .. 48), A = [x | u] ----------------------------------------
     {
       acc_t acc[MT][NT];
 #pragma unroll
@@ -344,9 +344,14 @@ struct TileNet {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
       const T* wl = slice0(m, w, lane);
       const T* A = lds + L.xu;
-      if (m.k1p == 16) layer_mma_static<T, NT, MT, 4, G0>(A, L.xu_stride, wl, lane, pf0, acc);
-      else if (m.k1p == 32) layer_mma_static<T, NT, MT, 8, G0>(A, L.xu_stride, wl, lane, pf0, acc);
-      else layer_mma_static<T, NT, MT, 12, G0>(A, L.xu_stride, wl, lane, pf0, acc);
+      switch (m.k1p) {   // one fully unrolled variant per padded input width
+        case 8: layer_mma_static<T, NT, MT, 2, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+        case 16: layer_mma_static<T, NT, MT, 4, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+        case 24: layer_mma_static<T, NT, MT, 6, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+        case 32: layer_mma_static<T, NT, MT, 8, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+        case 40: layer_mma_static<T, NT, MT, 10, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+        default: layer_mma_static<T, NT, MT, 12, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+      }
       AMPC_MARK(2);
       prefetch_next(1);
       epilogue(0, acc);
