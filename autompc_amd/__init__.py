@@ -10,9 +10,10 @@ from .task import Task
 from .costs import Cost, QuadCost, SumCost, ThresholdCost, BoxThresholdCost
 
 from .sysid import Model, ModelFactory, MLP, MLPFactory
-from .control import Controller, ControllerFactory, MPPI, MPPIFactory
+from .control import (Controller, ControllerFactory, MPPI, MPPIFactory, IterativeLQR,
+                      IterativeLQRFactory)
 from .utils import simulate
 
 __all__ = ["Model", "ModelFactory", "MLP", "MLPFactory", "Controller", "ControllerFactory",
-           "MPPI", "MPPIFactory", "simulate", "System", "Trajectory", "TimeStep", "zeros", "empty", "extend", "Task",
+           "MPPI", "MPPIFactory", "IterativeLQR", "IterativeLQRFactory", "simulate", "System", "Trajectory", "TimeStep", "zeros", "empty", "extend", "Task",
            "Cost", "QuadCost", "SumCost", "ThresholdCost", "BoxThresholdCost"]

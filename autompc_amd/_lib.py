@@ -53,6 +53,10 @@ SIGNATURES = {
     "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_timing": (c_int, [c_void_p, _dp, _dp, _ip]),
+    "ampc_ilqr_plan_create": (c_int, [c_void_p, c_int, c_int, c_double, _ip, c_int,
+                                      POINTER(c_void_p)]),
+    "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
+    "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
 }
 
 
@@ -123,10 +127,15 @@ class Handle:
                               ctypes.byref(self._h)))
         self.device = int(device)
         self.nx = self.nu = None
+        self._plans = weakref.WeakSet()      # plans hold raw pointers into this handle
         _live_handles.add(self)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            # garbage collection may finalise a handle before the plans built on it: destroy
+            # those first, they dereference the handle
+            for plan in list(getattr(self, "_plans", ())):
+                plan.close()
             self.lib.ampc_destroy(self._h)
             self._h = None
 
@@ -221,6 +230,7 @@ class MppiPlan:
                                              dptr(self.sigma), dptr(self.lmda), iptr(ci),
                                              int(term_mode), ctypes.byref(self._p)))
         _live_plans.add(self)
+        handle._plans.add(self)
         nu = handle.nu
         self.sum_hnu = int(np.sum(self.H.astype(np.int64) * nu))
         self.sum_n = int(np.sum(self.N.astype(np.int64)))
@@ -285,3 +295,44 @@ class MppiPlan:
                                            ctypes.byref(fl), ctypes.byref(by)))
         return {"workgroups": wg.value, "samples_per_wg": spw.value, "flops": fl.value,
                 "bytes": by.value}
+
+
+class IlqrPlan:
+    """Device buffers for a batch of B independent iLQR problems of horizon H."""
+
+    def __init__(self, handle, B, horizon, dt, cost_index=None, clip_to_bounds=False):
+        self.handle = handle
+        self.lib = handle.lib
+        self.B, self.H = int(B), int(horizon)
+        ci = None if cost_index is None else \
+            np.broadcast_to(np.asarray(cost_index, dtype=np.int32), (self.B,)).copy()
+        self._p = c_void_p()
+        check(self.lib.ampc_ilqr_plan_create(handle._h, self.B, self.H, float(dt), iptr(ci),
+                                             int(bool(clip_to_bounds)), ctypes.byref(self._p)))
+        _live_plans.add(self)
+        handle._plans.add(self)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p:
+            self.lib.ampc_ilqr_plan_destroy(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, x0, uguess, max_iter=50):
+        nx, nu, B, H = self.handle.nx, self.handle.nu, self.B, self.H
+        x0 = as_f64(x0).reshape(B, nx)
+        uguess = as_f64(uguess).reshape(B, H, nu)
+        out = {"states": np.empty((B, H + 1, nx)), "ctrls": np.empty((B, H, nu)),
+               "Ks": np.empty((B, H, nu, nx)), "ks": np.empty((B, H, nu)),
+               "converged": np.zeros(B, dtype=np.int32), "iters": np.zeros(B, dtype=np.int32),
+               "status": np.zeros(B, dtype=np.int32), "objective": np.empty(B)}
+        check(self.lib.ampc_ilqr_solve(self._p, dptr(x0), dptr(uguess), int(max_iter),
+                                       dptr(out["states"]), dptr(out["ctrls"]), dptr(out["Ks"]),
+                                       dptr(out["ks"]), iptr(out["converged"]), iptr(out["iters"]),
+                                       iptr(out["status"]), dptr(out["objective"])))
+        return out

@@ -1,4 +1,6 @@
 from .controller import Controller, ControllerFactory
 from .mppi import MPPI, MPPIFactory
+from .ilqr import IterativeLQR, IterativeLQRFactory
 
-__all__ = ["Controller", "ControllerFactory", "MPPI", "MPPIFactory"]
+__all__ = ["Controller", "ControllerFactory", "MPPI", "MPPIFactory", "IterativeLQR",
+           "IterativeLQRFactory"]

@@ -1,0 +1,139 @@
+"""Iterative LQR controller whose solve runs on MI355X.
+
+Drop-in for the reference's ``autompc.control.IterativeLQR`` / ``IterativeLQRFactory``
+(reference: autompc/control/ilqr.py:16-41 factory, :43-295 controller): same constructor
+(``horizon``, ``reuse_feedback``, ``ubounds``, ``mode``, ``verbose``), same
+``compute_ilqr_default`` return tuple ``(converged, states, ctrls, Ks, ks)``, same ``run`` (full
+re-solve from a zero guess every control step, ``u = u0 + K0 (x - x0)``).
+
+Everything numerical happens in ``ampc_ilqr_solve`` (csrc/ilqr_kernels.hpp): rollout of the
+guess, backward Riccati sweeps with an unregularised partial-pivot LU, the 10-step-size batched
+line search through the MFMA MLP tile, acceptance logic, and the analytic Jacobian refresh.
+A singular ``Quu`` surfaces as ``numpy.linalg.LinAlgError`` exactly where the reference's
+``np.linalg.solve`` would raise it (the tuner catches that, pipeline_tuner.py:236-239).
+
+Deviations, on purpose: ``mode='barrier'|'auglag'`` raise NotImplementedError at construction
+(the reference binds them to methods that do not exist, ilqr.py:71-74); ``state_dim`` returns
+``model.state_dim + ctrl_dim`` (the reference's property references an undefined name,
+ilqr.py:84-87).
+"""
+import numpy as np
+
+from .. import _lib
+from .controller import Controller, ControllerFactory
+from .mppi import _quad_cost_blocks
+
+
+class IterativeLQR(Controller):
+    def __init__(self, system, task, model, horizon, reuse_feedback=-1, ubounds=None, mode=None,
+                 verbose=False, precision=None, device=None):
+        super().__init__(system, task, model)
+        if not hasattr(model, "stage_into"):
+            raise TypeError("IterativeLQR needs a device-stageable model (autompc_amd.sysid.MLP); "
+                            "there is no CPU fallback")
+        self.horizon = int(horizon)
+        self.dt = system.dt
+        if reuse_feedback is None or reuse_feedback <= 0:
+            self.reuse_feedback = 0
+        else:
+            self.reuse_feedback = min(int(reuse_feedback), self.horizon)
+        if ubounds is None and task.are_ctrl_bounded():
+            b = task.get_ctrl_bounds()
+            self.ubounds = (b[:, 0], b[:, 1])
+        else:
+            self.ubounds = ubounds
+        if mode is not None:
+            if mode in ("barrier", "auglag"):
+                raise NotImplementedError("mode=%r is not implemented (nor in the reference)" % mode)
+            raise Exception("mode has to be None/barrier/auglag")
+        self.mode = mode
+        self.verbose = verbose
+        self.precision = precision or getattr(model, "precision", "f64")
+        self.device = device if device is not None else getattr(model, "device", 0)
+        self.compute_ilqr = self.compute_ilqr_default
+        self._handle = self._plan = None
+        self.reset()
+
+    def reset(self):
+        self._need_recompute = True
+        self._step_count = 0
+        self._states = None
+        self._guess = None
+
+    def _device(self):
+        if self._plan is None:
+            h = _lib.Handle(self.device, self.precision)
+            self.model.stage_into(h)
+            Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
+            h.set_quad_costs(Q, R, F, goal)
+            bounded = self.ubounds is not None
+            if bounded:
+                h.set_ctrl_bounds(np.asarray(self.ubounds[0], dtype=float),
+                                  np.asarray(self.ubounds[1], dtype=float))
+            self._handle = h
+            self._plan = _lib.IlqrPlan(h, 1, self.horizon, self.dt, clip_to_bounds=bounded)
+        return self._plan
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handle"] = state["_plan"] = None
+        return state
+
+    def compute_ilqr_default(self, state, uguess, u_threshold=1e-3, max_iter=50, ls_max_iter=10,
+                             ls_discount=0.2, ls_cost_threshold=0.3, silent=False):
+        if (u_threshold, ls_max_iter, ls_discount, ls_cost_threshold) != (1e-3, 10, 0.2, 0.3):
+            raise NotImplementedError("the HIP solve is built for the reference's constants")
+        out = self._device().solve(np.asarray(state)[None, :], np.asarray(uguess)[None], max_iter)
+        if out["status"][0] == 1:
+            raise np.linalg.LinAlgError("Singular matrix")
+        self.last_iters = int(out["iters"][0])
+        self.last_objective = float(out["objective"][0])
+        return (bool(out["converged"][0]), out["states"][0], out["ctrls"][0], out["Ks"][0],
+                out["ks"][0])
+
+    def run(self, constate, new_obs, silent=True):
+        nu = self.system.ctrl_dim
+        state = self.model.update_state(constate[:-nu], constate[-nu:], new_obs)
+        if self._need_recompute:
+            converged, states, ctrls, Ks, ks = self.compute_ilqr(
+                state, np.zeros((self.horizon, nu)), silent=silent)
+            self._states, self._ctrls, self._gain, self._ks = states, ctrls, Ks, ks
+            self._need_recompute = False
+            self._step_count = 0
+        if self._step_count == self.reuse_feedback:
+            self._need_recompute = True
+        i = self._step_count
+        u = self._ctrls[i] + self._gain[i] @ (state - self._states[i])
+        self._step_count += 1
+        return u, np.concatenate([state, u])
+
+    def traj_to_state(self, traj):
+        return self.model.traj_to_state(traj)
+
+    @property
+    def state_dim(self):
+        return self.model.state_dim + self.system.ctrl_dim
+
+    @staticmethod
+    def is_compatible(system, task, model):
+        return bool(getattr(task.get_cost(), "is_quad", False)) and hasattr(model, "stage_into")
+
+
+class IterativeLQRFactory(ControllerFactory):
+    """horizon in [5, 25], default 20 (ilqr.py:36-41)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.Controller = IterativeLQR
+        self.name = "IterativeLQR"
+
+    def get_configuration_space(self):
+        try:
+            from ConfigSpace import ConfigurationSpace
+            from ConfigSpace.hyperparameters import UniformIntegerHyperparameter
+        except ImportError as e:
+            raise ImportError("ConfigSpace is required for get_configuration_space()") from e
+        cs = ConfigurationSpace()
+        cs.add_hyperparameter(UniformIntegerHyperparameter(name="horizon", lower=5, upper=25,
+                                                           default_value=20))
+        return cs

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "mlp_kernels.hpp"
+#include "ilqr_kernels.hpp"
 #include "mppi_kernels.hpp"
 #include "rng_kernels.hpp"
 
@@ -72,6 +73,11 @@ struct ampc_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   size_t esz() const { return precision == AMPC_F64 ? 8 : 4; }
+  // Plans hold raw pointers to their handle.  Language bindings with garbage collection may
+  // destroy a handle before the plans built on it, so the handle is reference counted: it is
+  // actually freed when ampc_destroy has been called AND the last plan is gone.
+  int refs = 0;
+  bool dead = false;
 
   // model (host copy, double) ---------------------------------------------------------------
   bool has_mlp = false;
@@ -90,7 +96,8 @@ struct ampc_handle {
   DevBuf cost_buf;
   bool has_bounds = false;
   std::vector<double> lo, hi;
-  DevBuf bounds_buf;  // lo/scale, hi/scale, scale
+  DevBuf bounds_buf;  // lo/scale, hi/scale, scale   (MPPI units)
+  DevBuf ubounds_buf; // lo, hi                     (iLQR clips in physical units)
 
   // scratch for the batched model calls -----------------------------------------------------------
   DevBuf s_states, s_ctrls, s_out, s_dz, s_jx, s_ju;
@@ -157,16 +164,30 @@ extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle*
   return 0;
 }
 
+static void handle_free(ampc_handle* h);
+
 extern "C" int ampc_destroy(ampc_handle* h) {
   if (!h) return 0;
+  if (h->refs > 0) {
+    h->dead = true;
+    return 0;
+  }
+  handle_free(h);
+  return 0;
+}
+
+static void handle_release(ampc_handle* h) {
+  if (--h->refs == 0 && h->dead) handle_free(h);
+}
+
+static void handle_free(ampc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->model_buf, &h->cost_buf, &h->bounds_buf, &h->s_states,
+  DevBuf* bufs[] = {&h->model_buf, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
                     &h->s_ctrls,   &h->s_out,      &h->s_dz,     &h->s_jx,       &h->s_ju};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
-  return 0;
 }
 
 extern "C" int ampc_synchronize(ampc_handle* h) {
@@ -398,6 +419,11 @@ extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const doub
   HIP_OK(h->bounds_buf.reserve(flat.size() * h->esz()));
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
   else HIP_OK(upload_converted<float>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
+  std::vector<double> raw(2 * nu);
+  for (int j = 0; j < nu; ++j) { raw[j] = lo[j]; raw[nu + j] = hi[j]; }
+  HIP_OK(h->ubounds_buf.reserve(raw.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->ubounds_buf.p, raw.data(), raw.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->ubounds_buf.p, raw.data(), raw.size(), h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   h->has_bounds = true;
   return 0;
@@ -474,19 +500,20 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
   const size_t lds_bytes = (size_t)L.extra * sizeof(T);
   if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
   T* dz = (T*)h->s_dz.p;
+  const RowMap rm{n, 0, 0, nullptr};
   AMPC_DISPATCH(h->nw, h->nt, mt, {
     if (deriv) {
       auto k = mlp_forward_kernel<T, NT, MT, W, true>;
       HIP_OK(allow_lds(k, lds_bytes));
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
-                         n_pad);
+                         n_pad, rm);
     } else {
       auto k = mlp_forward_kernel<T, NT, MT, W, false>;
       HIP_OK(allow_lds(k, lds_bytes));
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
-                         (T*)nullptr, n, n_pad);
+                         (T*)nullptr, n, n_pad, rm);
     }
   });
   HIP_OK(hipGetLastError());
@@ -504,7 +531,7 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
       HIP_OK(allow_lds(k, jl));
       hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m,
                          (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
-                         (T*)h->s_ju.p);
+                         (T*)h->s_ju.p, rm);
     });
     HIP_OK(hipGetLastError());
     HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
@@ -647,10 +674,12 @@ extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
   HIP_OK(hipSetDevice(h->device));
   ampc_mppi_plan* p = new ampc_mppi_plan();
   p->h = h; p->B = B; p->term_mode = term_mode;
+  h->refs++;
   const int nu = h->nu;
   for (int b = 0; b < B; ++b) {
     if (!(num_path[b] >= 1 && horizon[b] >= 2 && sigma[b] > 0 && lmda[b] > 0) ||
         (cost_index && (cost_index[b] < 0 || cost_index[b] >= h->n_costs))) {
+      h->refs--;
       delete p;
       return fail("ampc_mppi_plan_create: need num_path>=1, horizon>=2, sigma>0, lmda>0, valid cost_index");
     }
@@ -682,7 +711,9 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  ampc_handle* h = p->h;
   delete p;
+  handle_release(h);
   return 0;
 }
 
@@ -865,3 +896,207 @@ extern "C" int ampc_x_phase_marks(long long* out) {
   return 0;
 }
 #endif
+
+// ---------------------------------------------------------------------------------------------
+// iLQR plan
+// ---------------------------------------------------------------------------------------------
+struct ampc_ilqr_plan {
+  ampc_handle* h = nullptr;
+  int B = 0, H = 0, ls_n = 10, bounded = 0;
+  double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
+  std::vector<int> cost_idx;
+  DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz;
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
+  TileLds L{};
+  int lds_work = 0;
+  size_t lds_bytes = 0;
+  int last_iterations = 0;
+};
+
+template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {
+  ampc_handle* h = p->h;
+  IlqrArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.mlp = model_of<T>(h);
+  a.lds = p->L;
+  a.lds_work = p->lds_work;
+  a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
+  a.ls_n = p->ls_n; a.mode = mode;
+  a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
+  for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
+  a.costs_par = (const T*)h->cost_buf.p;
+  a.cost_idx = (const int*)p->d_cost_idx.p;
+  a.ubounds = (const T*)h->ubounds_buf.p;
+  a.states = (T*)p->states.p; a.ctrls = (T*)p->ctrls.p;
+  a.jx = (const T*)p->jx.p; a.ju = (const T*)p->ju.p;
+  a.Ks = (T*)p->Ks.p; a.ks = (T*)p->ks.p;
+  a.ls_states = (T*)p->ls_states.p; a.ls_ctrls = (T*)p->ls_ctrls.p;
+  a.obj = (T*)p->obj.p;
+  int* f = (int*)p->flags.p;
+  a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
+  a.refresh = f + 4 * p->B;
+  return a;
+}
+
+template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
+  ampc_handle* h = p->h;
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
+  const IlqrWork wk = make_ilqr_work(nx, nu, h->cost_stride);
+  p->L = tile_lds_for<T>(h, m, 16, (size_t)wk.total + 8);
+  p->lds_work = p->L.extra;
+  p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
+  REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
+  const size_t e = sizeof(T);
+  HIP_OK(p->d_cost_idx.reserve(B * sizeof(int)));
+  HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), B * sizeof(int), hipMemcpyHostToDevice));
+  HIP_OK(p->states.reserve((size_t)B * (H + 1) * nx * e));
+  HIP_OK(p->ctrls.reserve((size_t)B * H * nu * e));
+  HIP_OK(p->jx.reserve((size_t)B * H * nx * nx * e));
+  HIP_OK(p->ju.reserve((size_t)B * H * nx * nu * e));
+  HIP_OK(p->Ks.reserve((size_t)B * H * nu * nx * e));
+  HIP_OK(p->ks.reserve((size_t)B * H * nu * e));
+  HIP_OK(hipMemset(p->Ks.p, 0, (size_t)B * H * nu * nx * e));
+  HIP_OK(hipMemset(p->ks.p, 0, (size_t)B * H * nu * e));
+  HIP_OK(p->ls_states.reserve((size_t)B * p->ls_n * (H + 1) * nx * e));
+  HIP_OK(p->ls_ctrls.reserve((size_t)B * p->ls_n * H * nu * e));
+  HIP_OK(p->obj.reserve((size_t)B * e));
+  HIP_OK(p->flags.reserve((size_t)5 * B * sizeof(int)));
+  HIP_OK(hipMemset(p->flags.p, 0, (size_t)5 * B * sizeof(int)));
+  const int rows = B * H;
+  const int n_pad = round_up(rows, 64);
+  HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
+  return 0;
+}
+
+extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt,
+                                     const int* cost_index, int clip_to_bounds,
+                                     ampc_ilqr_plan** out) {
+  REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
+  REQUIRE(h->has_mlp && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
+  REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
+  REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
+  HIP_OK(hipSetDevice(h->device));
+  ampc_ilqr_plan* p = new ampc_ilqr_plan();
+  h->refs++;
+  p->h = h; p->B = B; p->H = horizon; p->dt = dt; p->bounded = clip_to_bounds ? 1 : 0;
+  for (int b = 0; b < B; ++b) {
+    const int ci = cost_index ? cost_index[b] : 0;
+    if (ci < 0 || ci >= h->n_costs) { h->refs--; delete p; return fail("ampc_ilqr_plan_create: bad cost_index"); }
+    p->cost_idx.push_back(ci);
+  }
+  int rc = h->precision == AMPC_F64 ? ilqr_plan_build<double>(p) : ilqr_plan_build<float>(p);
+  if (rc) { ampc_ilqr_plan_destroy(p); return rc; }
+  *out = p;
+  return 0;
+}
+
+extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->h->device);
+  (void)hipStreamSynchronize(p->h->stream);
+  DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
+                    &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz};
+  for (DevBuf* b : bufs) b->release();
+  ampc_handle* h = p->h;
+  delete p;
+  handle_release(h);
+  return 0;
+}
+
+// Jacobians of every (problem, t) row of the nominal trajectories whose problem asked for it.
+template <typename T> static int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
+  ampc_handle* h = p->h;
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
+  const int n_pad = round_up(rows, 64);
+  const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
+  {
+    const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
+    TileLds L = tile_lds_for<T>(h, m, M, 0);
+    const size_t lb = (size_t)L.extra * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, mt, {
+      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+      HIP_OK(allow_lds(k, lb));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
+                         (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
+    });
+  }
+  {
+    const int jrows = rows * nx, JM = 16, jtiles = (jrows + JM - 1) / JM;
+    const int kinp = 16 * ((m.kin + 15) / 16);
+    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, 1, {
+      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+      HIP_OK(allow_lds(k, jl));
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
+                         (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
+    });
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <typename T> static int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
+  ampc_handle* h = p->h;
+  IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  AMPC_DISPATCH(h->nw, h->nt, 1, {
+    auto k = ilqr_iter_kernel<T, NT, W>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
+  });
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* uguess, int max_iter,
+                           double* states, double* ctrls, double* Ks, double* ks, int* converged,
+                           int* iters, int* status, double* objective) {
+  ampc_handle* h = p->h;
+  const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
+  // states[:, 0, :] = x0 ; ctrls = uguess
+  std::vector<double> st((size_t)B * (H + 1) * nx, 0.0);
+  for (int b = 0; b < B; ++b) std::memcpy(&st[(size_t)b * (H + 1) * nx], x0 + (size_t)b * nx, nx * 8);
+  HIP_OK(upload_converted<T>(p->states.p, st.data(), st.size(), h->stream));
+  HIP_OK(upload_converted<T>(p->ctrls.p, uguess, (size_t)B * H * nu, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (int rc = ilqr_launch_iter<T>(p, 0)) return rc;        // rollout of the guess + objective
+  if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
+  std::vector<int> flags(5 * B);
+  int it = 0;
+  for (; it < max_iter; ++it) {
+    if (int rc = ilqr_launch_iter<T>(p, 1)) return rc;      // backward sweep + line search + accept
+    if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
+    if ((it & 3) == 3 || it + 1 == max_iter) {              // poll the active flags every 4 iterations
+      HIP_OK(hipMemcpyAsync(flags.data(), p->flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_OK(hipStreamSynchronize(h->stream));
+      bool any = false;
+      for (int b = 0; b < B; ++b) any |= flags[B + b] != 0;
+      if (!any) { ++it; break; }
+    }
+  }
+  p->last_iterations = it;
+  HIP_OK(hipMemcpyAsync(flags.data(), p->flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (converged) std::memcpy(converged, flags.data(), B * sizeof(int));
+  if (iters) std::memcpy(iters, flags.data() + 2 * B, B * sizeof(int));
+  if (status) std::memcpy(status, flags.data() + 3 * B, B * sizeof(int));
+  if (states) HIP_OK(download_converted<T>(states, p->states.p, (size_t)B * (H + 1) * nx, h->stream));
+  if (ctrls) HIP_OK(download_converted<T>(ctrls, p->ctrls.p, (size_t)B * H * nu, h->stream));
+  if (Ks) HIP_OK(download_converted<T>(Ks, p->Ks.p, (size_t)B * H * nu * nx, h->stream));
+  if (ks) HIP_OK(download_converted<T>(ks, p->ks.p, (size_t)B * H * nu, h->stream));
+  if (objective) HIP_OK(download_converted<T>(objective, p->obj.p, (size_t)B, h->stream));
+  return 0;
+}
+
+extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess,
+                               int max_iter, double* states, double* ctrls, double* Ks, double* ks,
+                               int* converged, int* iters, int* status, double* objective) {
+  REQUIRE(p && x0 && uguess, "ampc_ilqr_solve: NULL argument");
+  REQUIRE(max_iter >= 0, "ampc_ilqr_solve: max_iter < 0");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? ilqr_solve_impl<double>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective)
+             : ilqr_solve_impl<float>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective);
+}

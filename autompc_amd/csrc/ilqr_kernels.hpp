@@ -1,0 +1,401 @@
+// ilqr_kernels.hpp -- iLQR on gfx950: one workgroup per problem, batched over problems.
+//
+// What one solve computes (reference: autompc/control/ilqr.py:100-265):
+//   rollout the guess, obj = dt*sum(stage) + terminal
+//   repeat <= max_iter:
+//     backward Riccati sweep t = H-1..0:  Qt = Ct + J'VJ, qt = ct + J'v,
+//         K = -solve(Quu, Qux), k = -solve(Quu, qu)   (unregularised, partial-pivot LU)
+//         V <- Qxx + Qxu K + K'Qux + K'Quu K ;  v <- qx + Qxu k + K'(qu + Quu k)
+//     forward: all ls_n step sizes alpha_j = discount^j rolled out together
+//         u = alpha k_i + ubar_i + K_i (x - xbar_i), clipped when bounded
+//     accept the first alpha with (obj-new)/(-(alpha lin + alpha^2 quad/2)) > 0.3, else best-so-far;
+//     refresh Jacobians of the accepted trajectory; stop on ||du|| < 1e-3 or line-search failure
+//
+// Decomposition.  ilqr_iter_kernel (this file) does the backward sweep, the batched line-search
+// rollout (the MLP tile of mlp_tile.hpp, rows = step sizes) and the acceptance logic for one
+// problem per workgroup, entirely from LDS.  Between iterations the host launches
+// mlp_forward_kernel<DERIV> + mlp_jacobian_kernel over all (problem, t) rows at once -- the
+// Jacobian refresh is the only phase with H-fold parallelism, so it gets the whole chip.
+// Problems that have converged / failed keep their workgroup slot but exit immediately.
+//
+// Kept reference quirks: terminal gradient / Hessian ignore the goal (cost.py:195,208-211); when
+// the line search neither succeeds nor trips the failure test the LAST candidate evaluated
+// becomes the nominal trajectory and the Jacobians stay stale (ilqr.py:208-255).
+#pragma once
+#include "mlp_tile.hpp"
+
+namespace ampc {
+
+constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows of one MFMA tile
+
+template <typename T> struct IlqrArgs {
+  MlpDev<T> mlp;
+  TileLds lds;
+  int lds_work;                  // start of the Riccati / line-search scratch (elements)
+  int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
+  T dt, u_threshold, ls_cost_threshold;
+  T alphas[kIlqrMaxLs];          // step sizes discount**j, computed on the host like the reference
+  const T* costs_par;            // [n_costs][cost_stride]: Q R F goal
+  const int* cost_idx;           // [B]
+  const T* ubounds;              // lo[nu] hi[nu]
+  T* states;                     // [B][H+1][nx]  nominal trajectory
+  T* ctrls;                      // [B][H][nu]
+  const T* jx;                   // [B*H][nx][nx]
+  const T* ju;                   // [B*H][nx][nu]
+  T* Ks;                         // [B][H][nu][nx]
+  T* ks;                         // [B][H][nu]
+  T* ls_states;                  // [B][ls_n][H+1][nx]
+  T* ls_ctrls;                   // [B][ls_n][H][nu]
+  T* obj;                        // [B]
+  int* converged;                // [B]
+  int* active;                   // [B]
+  int* iters;                    // [B]
+  int* status;                   // [B] 0 ok, 1 singular Quu, 2 no line-search candidate
+  int* refresh;                  // [B] Jacobians must be recomputed for this problem
+};
+
+// Scratch map inside the work region (offsets in elements of T), nx/nu/n known at run time.
+struct IlqrWork {
+  int V, v, J, VJ, Qt, qt, K, k, Wk, wq, lu, rhs, xbar, ubar, cpar, lo, hi, scal, lsobj, piv, total;
+};
+__host__ __device__ inline IlqrWork make_ilqr_work(int nx, int nu, int cost_stride) {
+  const int n = nx + nu;
+  IlqrWork w;
+  int o = 0;
+  w.V = o; o += nx * nx;
+  w.v = o; o += nx;
+  w.J = o; o += nx * n;
+  w.VJ = o; o += nx * n;
+  w.Qt = o; o += n * n;
+  w.qt = o; o += n;
+  w.K = o; o += nu * nx;
+  w.k = o; o += nu;
+  w.Wk = o; o += nu * nx;
+  w.wq = o; o += nu;
+  w.lu = o; o += nu * nu;
+  w.rhs = o; o += nu * (nx + 1);
+  w.xbar = o; o += nx;
+  w.ubar = o; o += nu;
+  w.cpar = o; o += cost_stride;
+  w.lo = o; o += nu;
+  w.hi = o; o += nu;
+  w.scal = o; o += 16;
+  w.lsobj = o; o += kIlqrMaxLs;
+  w.piv = o; o += (nu + 1) / 2 + 8;   // int pivots stored in this slot
+  w.total = o;
+  return w;
+}
+
+template <typename T> __device__ __forceinline__ T block_sum_any(T v, T* scratch, int nwaves) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T o = T(0);
+  for (int w = 0; w < nwaves; ++w) o += scratch[w];
+  __syncthreads();
+  return o;
+}
+
+template <typename T, int NT, int W>
+__global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  using Net = TileNet<T, NT, 1, W>;
+  constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
+  const MlpDev<T>& mlp = args.mlp;
+  const TileLds& L = args.lds;
+  const int tid = threadIdx.x, p = blockIdx.x;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = args.obs_dim, H = args.H;
+  const int xs_ = L.xu_stride;
+  const IlqrWork wk = make_ilqr_work(nx, nu, args.cost_stride);
+  T* Wr = lds + args.lds_work;
+  T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
+  T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
+  T* Wk = Wr + wk.Wk; T* wq = Wr + wk.wq; T* lu = Wr + wk.lu; T* rhs = Wr + wk.rhs;
+  T* xbar = Wr + wk.xbar; T* ubar = Wr + wk.ubar; T* cpar = Wr + wk.cpar;
+  T* blo = Wr + wk.lo; T* bhi = Wr + wk.hi; T* scal = Wr + wk.scal; T* lsobj = Wr + wk.lsobj;
+  int* piv = reinterpret_cast<int*>(Wr + wk.piv);
+  const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
+  const T* goal = Fm + no * no;
+  T* xu = lds + L.xu;
+
+  if (args.mode == 1 && args.active[p] == 0) {
+    if (tid == 0) args.refresh[p] = 0;
+    return;
+  }
+
+  Net net;
+  net.prefetch0(mlp);
+  tile_load_constants<T, W>(mlp, L, lds, M);
+  for (int i = tid; i < args.cost_stride; i += NTHR)
+    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * args.cost_stride + i];
+  for (int i = tid; i < nu; i += NTHR) {
+    blo[i] = args.bounded ? args.ubounds[i] : T(0);
+    bhi[i] = args.bounded ? args.ubounds[nu + i] : T(0);
+  }
+  __syncthreads();
+
+  T* st = args.states + (size_t)p * (H + 1) * nx;
+  T* ct = args.ctrls + (size_t)p * H * nu;
+  T* Kg = args.Ks + (size_t)p * H * nu * nx;
+  T* kg = args.ks + (size_t)p * H * nu;
+  T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
+
+  // =========================== backward Riccati sweep (ilqr.py:159-187) ========================
+  if (args.mode == 1) {
+    const T dt = args.dt;
+    for (int idx = tid; idx < nx * nx; idx += NTHR) {
+      const int a = idx / nx, b = idx - a * nx;
+      V[idx] = (a < no && b < no) ? Fm[a * no + b] + Fm[b * no + a] : T(0);
+    }
+    for (int a = tid; a < nx; a += NTHR) {
+      T s = T(0);
+      if (a < no)
+        for (int b = 0; b < no; ++b) s += (Fm[a * no + b] + Fm[b * no + a]) * st[(size_t)H * nx + b];
+      v[a] = s;     // NOTE: no goal subtraction -- the reference's terminal gradient quirk
+    }
+    if (tid == 0) scal[8] = T(0);
+    __syncthreads();
+    for (int t = H - 1; t >= 0; --t) {
+      const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
+      const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
+      for (int idx = tid; idx < nx * n; idx += NTHR) {
+        const int a = idx / n, c = idx - a * n;
+        Jm[idx] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
+      }
+      for (int a = tid; a < nx; a += NTHR) xbar[a] = st[(size_t)t * nx + a];
+      for (int j = tid; j < nu; j += NTHR) ubar[j] = ct[(size_t)t * nu + j];
+      __syncthreads();
+      for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
+        const int a = idx / n, c = idx - a * n;
+        T s = T(0);
+        for (int b = 0; b < nx; ++b) s += V[a * nx + b] * Jm[b * n + c];
+        VJ[idx] = s;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
+        const int c = idx / n, d = idx - c * n;
+        T s = T(0);
+        for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * VJ[a * n + d];
+        T cc = T(0);
+        if (c < no && d < no) cc = (Qm[c * no + d] + Qm[d * no + c]) * dt;
+        else if (c >= nx && d >= nx) cc = (Rm[(c - nx) * nu + (d - nx)] + Rm[(d - nx) * nu + (c - nx)]) * dt;
+        Qt[idx] = cc + s;
+      }
+      for (int c = tid; c < n; c += NTHR) {                  // qt = ct + J' v
+        T s = T(0);
+        for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * v[a];
+        T cc = T(0);
+        if (c < no) {
+          for (int b = 0; b < no; ++b) cc += (Qm[c * no + b] + Qm[b * no + c]) * (xbar[b] - goal[b]);
+        } else if (c >= nx) {
+          const int cj = c - nx;
+          for (int j = 0; j < nu; ++j) cc += (Rm[cj * nu + j] + Rm[j * nu + cj]) * ubar[j];
+        }
+        qt[c] = cc * dt + s;
+      }
+      __syncthreads();
+      // ---- LU of Quu with partial pivoting (what numpy.linalg.solve / LAPACK gesv does) -------
+      if (tid == 0) {
+        for (int i = 0; i < nu; ++i)
+          for (int j = 0; j < nu; ++j) lu[i * nu + j] = Qt[(nx + i) * n + nx + j];
+        int sing = 0;
+        for (int c = 0; c < nu; ++c) {
+          int pr = c;
+          T best = fabs(lu[c * nu + c]);
+          for (int i = c + 1; i < nu; ++i) {
+            const T a = fabs(lu[i * nu + c]);
+            if (a > best) { best = a; pr = i; }
+          }
+          piv[c] = pr;
+          if (pr != c)
+            for (int j = 0; j < nu; ++j) { const T tmp = lu[c * nu + j]; lu[c * nu + j] = lu[pr * nu + j]; lu[pr * nu + j] = tmp; }
+          const T d = lu[c * nu + c];
+          if (d == T(0)) { sing = 1; continue; }
+          for (int i = c + 1; i < nu; ++i) {
+            const T f = lu[i * nu + c] / d;
+            lu[i * nu + c] = f;
+            for (int j = c + 1; j < nu; ++j) lu[i * nu + j] -= f * lu[c * nu + j];
+          }
+        }
+        if (sing) { args.status[p] = 1; scal[8] = T(1); }
+      }
+      __syncthreads();
+      // ---- solve for the nx+1 right-hand sides: columns of Qux, then qu -----------------------
+      for (int c = tid; c <= nx; c += NTHR) {
+        T* y = rhs + c * nu;
+        for (int i = 0; i < nu; ++i) y[i] = c < nx ? Qt[(nx + i) * n + c] : qt[nx + i];
+        for (int i = 0; i < nu; ++i) { const int pr = piv[i]; if (pr != i) { const T tmp = y[i]; y[i] = y[pr]; y[pr] = tmp; } }
+        for (int i = 1; i < nu; ++i) { T s = y[i]; for (int j = 0; j < i; ++j) s -= lu[i * nu + j] * y[j]; y[i] = s; }
+        for (int i = nu - 1; i >= 0; --i) { T s = y[i]; for (int j = i + 1; j < nu; ++j) s -= lu[i * nu + j] * y[j]; y[i] = s / lu[i * nu + i]; }
+        for (int i = 0; i < nu; ++i) {
+          if (c < nx) Km[i * nx + c] = -y[i];
+          else kv[i] = -y[i];
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
+        const int i = idx / nx, b = idx - i * nx;
+        T s = T(0);
+        for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * Km[j * nx + b];
+        Wk[idx] = s;
+        Kg[(size_t)t * nu * nx + idx] = Km[idx];
+      }
+      for (int i = tid; i < nu; i += NTHR) {                 // wq = qu + Quu k ; store k
+        T s = qt[nx + i];
+        for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
+        wq[i] = s;
+        kg[(size_t)t * nu + i] = kv[i];
+      }
+      if (tid == 0) {
+        T l = T(0), qd = T(0);
+        for (int i = 0; i < nu; ++i) {
+          l += qt[nx + i] * kv[i];
+          T s = T(0);
+          for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
+          qd += kv[i] * s;
+          ksn2 += kv[i] * kv[i];
+        }
+        lin += l;
+        quad += qd;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
+        const int a = idx / nx, b = idx - a * nx;
+        T s = Qt[a * n + b];
+        for (int j = 0; j < nu; ++j)
+          s += Qt[a * n + nx + j] * Km[j * nx + b] + Km[j * nx + a] * Qt[(nx + j) * n + b] +
+               Km[j * nx + a] * Wk[j * nx + b];
+        V[idx] = s;
+      }
+      for (int a = tid; a < nx; a += NTHR) {                 // v <- qx + Qxu k + K'(qu + Quu k)
+        T s = qt[a];
+        for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
+        v[a] = s;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) { scal[0] = lin; scal[1] = quad; scal[2] = sqrt(ksn2); }
+    __syncthreads();
+    if (scal[8] != T(0)) {          // singular Quu: the reference raises LinAlgError here
+      if (tid == 0) { args.active[p] = 0; args.refresh[p] = 0; }
+      return;
+    }
+  }
+
+  // =========================== forward rollout(s) (ilqr.py:141-149, 196-205) ===================
+  const int rows = args.mode == 0 ? 1 : args.ls_n;
+  const int m = tid / TPS, r = tid % TPS;        // row-in-tile, helper index (same wave)
+  T obj_part = T(0);
+  const T alpha = args.alphas[m];
+  for (int i = tid; i < M * nx; i += NTHR) {
+    const int row = i / nx, col = i - row * nx;
+    xu[row * xs_ + col] = st[col];
+  }
+  __syncthreads();
+  T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
+  T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
+  for (int t = 0; t < H; ++t) {
+    if (args.mode == 1) {
+      for (int idx = tid; idx < nu * nx; idx += NTHR) Km[idx] = Kg[(size_t)t * nu * nx + idx];
+      for (int j = tid; j < nu; j += NTHR) { kv[j] = kg[(size_t)t * nu + j]; ubar[j] = ct[(size_t)t * nu + j]; }
+      for (int a = tid; a < nx; a += NTHR) xbar[a] = st[(size_t)t * nx + a];
+      __syncthreads();
+    }
+    // controls for this step
+    for (int a = r; a < nu; a += TPS) {
+      T u;
+      if (args.mode == 0) {
+        u = ct[(size_t)t * nu + a];
+      } else {
+        T fb = T(0);
+        for (int b = 0; b < nx; ++b) fb += Km[a * nx + b] * (xu[m * xs_ + b] - xbar[b]);
+        u = alpha * kv[a] + ubar[a] + fb;
+        if (args.bounded) { u = u < blo[a] ? blo[a] : u; u = u > bhi[a] ? bhi[a] : u; }
+        if (m < rows) lsc[((size_t)m * H + t) * nu + a] = u;
+      }
+      xu[m * xs_ + nx + a] = u;
+    }
+    if (args.mode == 1 && m < rows)
+      for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
+    __syncthreads();
+    // objective: dt * (stage costs)
+    obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false) +
+                           quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false));
+    net.run(mlp, L, lds);
+    for (int a = r; a < nx; a += TPS) {
+      const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
+      xu[m * xs_ + a] = xn;
+      if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+    }
+    __syncthreads();
+  }
+  if (args.mode == 1 && m < rows)
+    for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
+  obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, false);
+#pragma unroll
+  for (int off = TPS / 2; off > 0; off >>= 1) obj_part += __shfl_xor(obj_part, off);
+  if (r == 0) lsobj[m] = obj_part;
+  __syncthreads();
+
+  if (args.mode == 0) {
+    if (tid == 0) {
+      args.obj[p] = lsobj[0];
+      args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
+      args.refresh[p] = 1;
+    }
+    return;
+  }
+
+  // =========================== acceptance (ilqr.py:207-261) ====================================
+  if (tid == 0) {
+    const T obj = args.obj[p];
+    const T lin_ = scal[0], quad_ = scal[1], ksn = scal[2];
+    T best_obj = INFINITY;
+    int best = -1, last = 0;
+    for (int j = 0; j < rows; ++j) {
+      last = j;
+      const T a = args.alphas[j];
+      const T new_obj = lsobj[j];
+      const T expect = a * lin_ + a * a * quad_ / T(2);
+      const T ratio = (obj - new_obj) / (-expect);
+      if (ratio > args.ls_cost_threshold) { best_obj = new_obj; best = j; break; }
+      if (new_obj < best_obj) { best_obj = new_obj; best = j; }
+      if (ksn < args.u_threshold) break;
+    }
+    const bool success = (best_obj < obj) || (ksn < args.u_threshold);
+    int sel = success ? best : last;
+    int fail = 0;
+    if (best < 0) { fail = 1; sel = 0; if (success) args.status[p] = 2; }
+    const T new_obj = lsobj[sel];
+    if (!success && new_obj > obj + T(1e-3)) fail = 1;
+    piv[0] = sel; piv[1] = fail; piv[2] = success ? 1 : 0;
+    scal[3] = new_obj;
+    args.iters[p] += 1;
+  }
+  __syncthreads();
+  const int sel = piv[0], fail = piv[1], success = piv[2];
+  if (fail) {
+    if (tid == 0) { args.active[p] = 0; args.refresh[p] = 0; }
+    return;
+  }
+  // ||new_ctrls - ctrls||, then swap in the selected candidate
+  T du2 = T(0);
+  for (int i = tid; i < H * nu; i += NTHR) {
+    const T d = lsc[(size_t)sel * H * nu + i] - ct[i];
+    du2 += d * d;
+  }
+  du2 = block_sum_any(du2, lsobj, W);
+  for (int i = tid; i < H * nu; i += NTHR) ct[i] = lsc[(size_t)sel * H * nu + i];
+  for (int i = tid; i < (H + 1) * nx; i += NTHR) st[i] = lss[(size_t)sel * (H + 1) * nx + i];
+  if (tid == 0) {
+    const bool conv = sqrt(du2) < args.u_threshold;
+    args.obj[p] = scal[3];
+    args.refresh[p] = success;
+    if (conv) { args.converged[p] = 1; args.active[p] = 0; }
+  }
+}
+
+}  // namespace ampc

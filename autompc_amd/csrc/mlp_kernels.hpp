@@ -14,12 +14,23 @@
 
 namespace ampc {
 
+// Row r of a batched model call lives at states + (r / grp) * s_stride + (r % grp) * nx (and the
+// same with c_stride / nu for controls).  A plain [n][nx] batch is grp = n, strides 0.  iLQR uses
+// grp = H with the [B][H+1][nx] / [B][H][nu] trajectory layout.  mask (optional) is per group:
+// groups with mask[g] == 0 are skipped by the Jacobian kernel (their Jacobians stay untouched).
+struct RowMap {
+  int grp;
+  long long s_stride, c_stride;
+  const int* mask;
+};
+
 template <typename T, int NT, int MT, int W, bool DERIV>
 __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp, const TileLds L,
                                                              const T* __restrict__ states,
                                                              const T* __restrict__ ctrls,
                                                              T* __restrict__ out,
-                                                             T* __restrict__ dz, int n, int n_pad) {
+                                                             T* __restrict__ dz, int n, int n_pad,
+                                                             const RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   using Net = TileNet<T, NT, MT, W, DERIV>;
@@ -33,18 +44,22 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   __syncthreads();
   for (int i = tid; i < M * nx; i += NTHR) {
     const int row = i / nx, col = i - row * nx;
-    xu[row * L.xu_stride + col] = (first + row < n) ? states[(size_t)(first + row) * nx + col] : T(0);
+    const int gr = first + row;
+    xu[row * L.xu_stride + col] =
+        (gr < n) ? states[(size_t)(gr / rm.grp) * rm.s_stride + (size_t)(gr % rm.grp) * nx + col] : T(0);
   }
   for (int i = tid; i < M * nu; i += NTHR) {
     const int row = i / nu, col = i - row * nu;
-    xu[row * L.xu_stride + nx + col] = (first + row < n) ? ctrls[(size_t)(first + row) * nu + col] : T(0);
+    const int gr = first + row;
+    xu[row * L.xu_stride + nx + col] =
+        (gr < n) ? ctrls[(size_t)(gr / rm.grp) * rm.c_stride + (size_t)(gr % rm.grp) * nu + col] : T(0);
   }
   __syncthreads();
   // dz layout: [layer][n_pad][hpad]; this tile's rows start at `first`
   net.run(mlp, L, lds, DERIV ? dz + (size_t)first * mlp.hpad : nullptr, (size_t)n_pad * mlp.hpad);
   for (int i = tid; i < M * nx; i += NTHR) {
     const int row = i / nx, col = i - row * nx;
-    if (first + row < n)
+    if (out != nullptr && first + row < n)
       out[(size_t)(first + row) * nx + col] = xu[row * L.xu_stride + col] + Net::output(mlp, L, lds, row, col);
   }
 }
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
                                                               const T* __restrict__ wout_plain,
                                                               const T* __restrict__ dz, int n,
                                                               int n_pad, T* __restrict__ jx,
-                                                              T* __restrict__ ju) {
+                                                              T* __restrict__ ju, const RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* G = reinterpret_cast<T*>(smem_raw);
   using acc_t = typename Acc<T>::type;
@@ -162,6 +177,7 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
     const int gr = first + row;
     if (gr >= rows_total) continue;
     const int s = gr / nx, i = gr - s * nx;
+    if (rm.mask != nullptr && rm.mask[s / rm.grp] == 0) continue;
     T v = T(0);
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) v += G[ww * M * kinp + row * kinp + c];

@@ -433,4 +433,24 @@ struct TileNet {
   }
 };
 
+// x' M x for the rows this thread owns (rows r, r+TPS, ...); d[j] = v[j] - g[j].
+template <typename T>
+__device__ __forceinline__ T quad_rows(const T* __restrict__ Mx, const T* __restrict__ v,
+                                       const T* __restrict__ g, int n, int r, int tps, bool diag) {
+  T acc = T(0);
+  if (diag) {
+    for (int i = r; i < n; i += tps) {
+      const T d = v[i] - (g ? g[i] : T(0));
+      acc += Mx[i * n + i] * d * d;
+    }
+  } else {
+    for (int i = r; i < n; i += tps) {
+      T s = T(0);
+      for (int j = 0; j < n; ++j) s += Mx[i * n + j] * (v[j] - (g ? g[j] : T(0)));
+      acc += (v[i] - (g ? g[i] : T(0))) * s;
+    }
+  }
+  return acc;
+}
+
 }  // namespace ampc

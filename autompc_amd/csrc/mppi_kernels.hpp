@@ -53,26 +53,6 @@ template <typename T> struct MppiArgs {
   T* u_out;                     // [B][nu] first action * scale (written by the update kernel)
 };
 
-// x' M x for the rows this thread owns (rows r, r+TPS, ...); d[j] = v[j] - g[j].
-template <typename T>
-__device__ __forceinline__ T quad_rows(const T* __restrict__ Mx, const T* __restrict__ v,
-                                       const T* __restrict__ g, int n, int r, int tps, bool diag) {
-  T acc = T(0);
-  if (diag) {
-    for (int i = r; i < n; i += tps) {
-      const T d = v[i] - (g ? g[i] : T(0));
-      acc += Mx[i * n + i] * d * d;
-    }
-  } else {
-    for (int i = r; i < n; i += tps) {
-      T s = T(0);
-      for (int j = 0; j < n; ++j) s += Mx[i * n + j] * (v[j] - (g ? g[j] : T(0)));
-      acc += (v[i] - (g ? g[i] : T(0))) * s;
-    }
-  }
-  return acc;
-}
-
 template <typename T, int NT, int MT, int W>
 __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -28,6 +28,7 @@ extern "C" {
 
 typedef struct ampc_handle ampc_handle;
 typedef struct ampc_mppi_plan ampc_mppi_plan;
+typedef struct ampc_ilqr_plan ampc_ilqr_plan;
 
 enum { AMPC_F64 = 0, AMPC_F32 = 1 };
 enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU = 3 };
@@ -115,6 +116,22 @@ int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples
  * call, and resets the counters. */
 int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable);
 int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms, int* count);
+
+/* ---- iLQR ---------------------------------------------------------------------------------
+ * B independent problems of horizon H (IterativeLQR.compute_ilqr_default, ilqr.py:100-265, with
+ * its constants u_threshold 1e-3, ls_max_iter 10, ls_discount 0.2, ls_cost_threshold 0.3).
+ * clip_to_bounds != 0 clips controls to the handle's bounds in the forward pass (ilqr.py:62-64,
+ * 203-204).  Per problem:  x0 [B][nx], uguess [B][H][nu] in;  states [B][H+1][nx],
+ * ctrls [B][H][nu], Ks [B][H][nu][nx], ks [B][H][nu], converged/iters/status [B], objective [B]
+ * out (any output pointer may be NULL).
+ * status: 0 ok; 1 singular Quu (the reference raises numpy.linalg.LinAlgError, ilqr.py:179);
+ *         2 line search produced no candidate. */
+int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt, const int* cost_index,
+                          int clip_to_bounds, ampc_ilqr_plan** out);
+int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
+int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess, int max_iter,
+                    double* states, double* ctrls, double* Ks, double* ks, int* converged,
+                    int* iters, int* status, double* objective);
 
 #ifdef __cplusplus
 }

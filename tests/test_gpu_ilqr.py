@@ -1,0 +1,99 @@
+"""HIP iLQR vs the reference's golden vectors and the oracle (needs MI355X).  Goes through
+IterativeLQR.compute_ilqr_default()/run() -> ctypes -> C ABI -> HIP kernels."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+from helpers import check_weights, golden_params, make_system, rel_err
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+from oracle.ilqr import ILQROracle
+from oracle.mlp import MLPOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _names():
+    out = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "ilqr_*.npz"))):
+        name = os.path.basename(f)[:-4]
+        if "cubic" not in name:          # the analytic test model has no device implementation
+            out.append(name)
+    return out
+
+
+def _hip_ilqr(p, nx, nu, Q, R, F, goal, H, dt, bounds, precision="f64"):
+    from autompc_amd import MLP, IterativeLQR, QuadCost, Task
+    system = make_system(nx, nu, dt=dt)
+    m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
+            precision=precision,
+            **{"hidden_size_%d" % (i + 1): w.shape[0] for i, w in enumerate(p["weights"][:-1])})
+    m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    if bounds is not None:
+        task.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
+    return IterativeLQR(system, task, m, H)
+
+
+@pytest.mark.parametrize("name", _names())
+def test_ilqr_matches_reference_golden(name):
+    g = golden(name)
+    nx, nu, H = int(g["nx"]), int(g["nu"]), int(g["H"])
+    p = golden_params(nx, nu, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    check_weights(p, g)
+    bounds = (g["bounds"][0], g["bounds"][1]) if bool(g["bounded"]) else None
+    ctl = _hip_ilqr(p, nx, nu, g["Q"], g["R"], g["F"], g["goal"], H, float(g["dt"]), bounds)
+    conv, states, ctrls, Ks, ks = ctl.compute_ilqr_default(g["x0"], np.zeros((H, nu)))
+    assert conv == bool(g["converged"])
+    # iLQR amplifies rounding through up to 50 Riccati sweeps and 50 discrete line-search
+    # decisions; the non-converged tanh case is chaotic in its last digits.
+    tol = 1e-6 if conv else 1e-3
+    assert rel_err(states, g["states"]) < tol
+    assert rel_err(ctrls, g["ctrls"]) < tol
+    assert rel_err(Ks, g["Ks"]) < tol * 10
+    assert rel_err(ks, g["ks"]) < tol * 10 or np.max(np.abs(ks - g["ks"])) < 1e-8
+    u, newstate = ctl.run(np.concatenate([g["x0"], np.zeros(nu)]), g["x0"])
+    assert rel_err(u, g["u"]) < tol and rel_err(newstate, g["newstate"]) < tol
+
+
+def test_ilqr_batch_matches_oracle_per_problem():
+    """B problems in one launch == B independent oracle solves (different x0 and cost blocks)."""
+    from autompc_amd import _lib
+    nx, nu, H, B, dt = 17, 6, 20, 6, 0.05
+    p = omlp.random_params(nx, nu, [256, 256], "tanh", seed=21)
+    rng = np.random.default_rng(3)
+    Q = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(B)])
+    R = np.stack([np.diag(rng.uniform(0.05, 0.2, size=nu)) for _ in range(B)])
+    F = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(B)])
+    goal = rng.normal(scale=0.05, size=(B, nx))
+    h = _lib.Handle(0, "f64")
+    h.set_mlp(nx, nu, p["weights"], p["biases"], "tanh", p["xu_means"], p["xu_std"], p["dy_means"],
+              p["dy_std"])
+    h.set_quad_costs(Q, R, F, goal)
+    plan = _lib.IlqrPlan(h, B, H, dt, cost_index=np.arange(B))
+    x0 = rng.uniform(-0.2, 0.2, size=(B, nx))
+    out = plan.solve(x0, np.zeros((B, H, nu)), max_iter=50)
+    system = make_system(nx, nu, dt=dt)
+    for b in range(B):
+        orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q[b], R[b], F[b], goal[b]), dt, H)
+        conv, st, ct, Ks, ks = orc.solve(x0[b], np.zeros((H, nu)))
+        assert bool(out["converged"][b]) == conv and out["status"][b] == 0
+        assert int(out["iters"][b]) == orc.n_iter
+        assert rel_err(out["states"][b], st) < 1e-6 and rel_err(out["ctrls"][b], ct) < 1e-6
+        assert abs(out["objective"][b] - orc.final_obj) < 1e-8 * max(1.0, abs(orc.final_obj))
+
+
+def test_ilqr_singular_quu_raises_linalgerror():
+    """R = 0 and a model that ignores the control make Quu exactly singular: the reference's
+    np.linalg.solve raises LinAlgError there (ilqr.py:179), so must the HIP path."""
+    nx, nu, H = 2, 1, 5
+    p = omlp.random_params(nx, nu, [64, 64], "relu", seed=4)
+    p["weights"][0][:, nx:] = 0.0                 # control has no effect on the dynamics
+    ctl = _hip_ilqr(p, nx, nu, np.eye(nx), np.zeros((nu, nu)), np.eye(nx), np.zeros(nx), H, 0.05, None)
+    with pytest.raises(np.linalg.LinAlgError):
+        ctl.compute_ilqr_default(np.array([0.1, -0.2]), np.zeros((H, nu)))
