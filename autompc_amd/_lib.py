@@ -53,6 +53,7 @@ SIGNATURES = {
     "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_timing": (c_int, [c_void_p, _dp, _dp, _ip]),
+    "ampc_mppi_closed_loop": (c_int, [c_void_p, c_void_p, _dp, c_int, c_uint64, _dp, _dp, _dp]),
     "ampc_ilqr_plan_create": (c_int, [c_void_p, c_int, c_int, c_double, _ip, c_int,
                                       POINTER(c_void_p)]),
     "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
@@ -278,6 +279,19 @@ class MppiPlan:
 
     def set_x0_dev(self, ptr):
         check(self.lib.ampc_mppi_set_x0_dev(self._p, c_void_p(ptr)))
+
+    def closed_loop(self, init_obs, n_steps, seed=0, eps_all=None, surrogate=None):
+        """simulate() for every problem of the plan, device resident.  Returns
+        (traj_obs [B, n_steps+1, nx], traj_ctrls [B, n_steps+1, nu])."""
+        nx, nu = self.handle.nx, self.handle.nu
+        init_obs = self._flat(init_obs, self.B * nx, "init_obs")
+        eps_all = self._flat(eps_all, n_steps * self.sum_nhnu, "eps_all")
+        obs = np.empty((self.B, n_steps + 1, nx))
+        ctl = np.empty((self.B, n_steps + 1, nu))
+        check(self.lib.ampc_mppi_closed_loop(self._p, surrogate._h if surrogate is not None else None,
+                                             dptr(init_obs), int(n_steps), int(seed), dptr(eps_all),
+                                             dptr(obs), dptr(ctl)))
+        return obs, ctl
 
     def set_timing(self, enable=True):
         check(self.lib.ampc_mppi_plan_set_timing(self._p, int(bool(enable))))

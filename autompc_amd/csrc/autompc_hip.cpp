@@ -1100,3 +1100,75 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
              ? ilqr_solve_impl<double>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective)
              : ilqr_solve_impl<float>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Closed loop on a surrogate model, device resident (simulate(), utils/simulation.py:11-64)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* init_obs, int n_steps,
+                            uint64_t seed, const double* eps_all, double* traj_obs,
+                            double* traj_ctrls) {
+  ampc_handle* h = p->h;
+  const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
+  const MlpDev<T>& sm = model_of<T>(sur);
+  DevBuf d_obs, d_ctl, d_next, d_dummy;
+  HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
+  HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
+  HIP_OK(d_next.reserve((size_t)B * nx * sizeof(T)));
+  HIP_OK(hipMemsetAsync(d_ctl.p, 0, (size_t)B * T1 * nu * sizeof(T), h->stream));
+  HIP_OK(upload_converted<T>(p->x0.p, init_obs, (size_t)B * nx, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  // traj_obs[:, 0, :] = init_obs
+  HIP_OK(hipMemcpy2DAsync(d_obs.p, (size_t)T1 * nx * sizeof(T), p->x0.p, (size_t)nx * sizeof(T),
+                          (size_t)nx * sizeof(T), B, hipMemcpyDeviceToDevice, h->stream));
+  const int smt = 1, SM = 16, stiles = (B + SM - 1) / SM;
+  TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
+  const size_t slds = (size_t)SL.extra * sizeof(T);
+  const RowMap rm{B, 0, 0, nullptr};
+  int rc = 0;
+  for (int s = 0; s < n_steps && rc == 0; ++s) {
+    if (eps_all) {
+      rc = mppi_upload_impl<T>(p, nullptr, nullptr, eps_all + (size_t)s * p->sum_nhnu);
+    } else {
+      rc = mppi_generate_impl<T>(p, seed, (uint64_t)s);
+    }
+    if (rc) break;
+    rc = mppi_solve_impl<T>(p);
+    if (rc) break;
+    // x_next = surrogate.pred(x, u)
+    AMPC_DISPATCH(sur->nw, sur->nt, smt, {
+      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+      HIP_OK(allow_lds(k, slds));
+      hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)p->x0.p,
+                         (const T*)p->u_out.p, (T*)d_next.p, (T*)nullptr, B, stiles * SM, rm);
+    });
+    const int n = B * (nx > nu ? nx : nu);
+    hipLaunchKernelGGL(closed_loop_record_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, h->stream,
+                       (const T*)d_next.p, (const T*)p->u_out.p, (T*)p->x0.p, (T*)d_obs.p,
+                       (T*)d_ctl.p, B, nx, nu, T1, s);
+    HIP_OK(hipGetLastError());
+  }
+  if (rc == 0) {
+    if (traj_obs) rc = download_converted<T>(traj_obs, d_obs.p, (size_t)B * T1 * nx, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
+    if (rc == 0 && traj_ctrls) rc = download_converted<T>(traj_ctrls, d_ctl.p, (size_t)B * T1 * nu, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
+  }
+  (void)hipStreamSynchronize(h->stream);
+  d_obs.release(); d_ctl.release(); d_next.release();
+  return rc;
+}
+
+extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
+                                     const double* init_obs, int n_steps, uint64_t seed,
+                                     const double* eps_all, double* traj_obs, double* traj_ctrls) {
+  REQUIRE(p && init_obs, "ampc_mppi_closed_loop: NULL argument");
+  REQUIRE(n_steps >= 1, "ampc_mppi_closed_loop: n_steps < 1");
+  ampc_handle* sur = surrogate ? surrogate : p->h;
+  REQUIRE(sur->has_mlp && sur->nx == p->h->nx && sur->nu == p->h->nu,
+          "ampc_mppi_closed_loop: surrogate model must have the controller model's dimensions");
+  REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
+          "ampc_mppi_closed_loop: surrogate must share the plan's device and precision");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
+             : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls);
+}

@@ -282,4 +282,26 @@ __global__ void mppi_finalize_costs_kernel(const MppiArgs<T> args) {
   if (n < pr.N) args.costs[pr.cost_off + n] += args.term_last[p];
 }
 
+// Closed-loop bookkeeping after one control step of every problem: append the applied control and
+// the surrogate's next observation to the trajectory buffers and make it the next solve's x0.
+//   traj_obs [B][T+1][nx], traj_ctrls [B][T+1][nu] (row T of ctrls stays zero, as simulate()
+//   appends a zero control row, utils/simulation.py:59-61)
+template <typename T>
+__global__ void closed_loop_record_kernel(const T* __restrict__ x_next, const T* __restrict__ u,
+                                          T* __restrict__ x0, T* __restrict__ traj_obs,
+                                          T* __restrict__ traj_ctrls, int B, int nx, int nu, int T1,
+                                          int step) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * nx) {
+    const int p = i / nx, c = i - p * nx;
+    const T v = x_next[i];
+    x0[i] = v;
+    traj_obs[((size_t)p * T1 + step + 1) * nx + c] = v;
+  }
+  if (i < B * nu) {
+    const int p = i / nu, c = i - p * nu;
+    traj_ctrls[((size_t)p * T1 + step) * nu + c] = u[i];
+  }
+}
+
 }  // namespace ampc

@@ -117,6 +117,20 @@ int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples
 int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable);
 int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms, int* count);
 
+/* ---- closed loop on the surrogate (device resident) ---------------------------------------
+ * simulate() (utils/simulation.py:11-64) for the B controllers of a plan, as the tuner's
+ * eval_cfg drives it (pipeline_tuner.py:222-231): n_steps x { MPPI solve from the current
+ * observation; obs <- surrogate.pred(obs, u) } with no host round trip per step.
+ * surrogate: handle holding the simulation model (NULL = the plan's own model); it shares the
+ * plan's device, precision and dimensions; its work is enqueued on the plan's stream.
+ * eps_all: NULL -> device Philox noise keyed by (seed, step); else host noise for every step,
+ *          [n_steps][sum_p N_p*H_p*nu], each step laid out as ampc_mppi_upload expects.
+ * traj_obs [B][n_steps+1][nx], traj_ctrls [B][n_steps+1][nu] (last control row zero, as
+ * simulate() returns them).  Scoring (Cost.__call__, cost.py:27-41) is left to the caller. */
+int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate, const double* init_obs,
+                          int n_steps, uint64_t seed, const double* eps_all, double* traj_obs,
+                          double* traj_ctrls);
+
 /* ---- iLQR ---------------------------------------------------------------------------------
  * B independent problems of horizon H (IterativeLQR.compute_ilqr_default, ilqr.py:100-265, with
  * its constants u_threshold 1e-3, ls_max_iter 10, ls_discount 0.2, ls_cost_threshold 0.3).
