@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
+                    help="c3 (default, headline): HalfCheetah MPPI 4096x30; c2: Pendulum MPPI; "
+                         "c4: HalfCheetah iLQR H=50, --batch problems per step; c5: --batch tuning "
+                         "candidates x 200-step closed loop per step")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--noise", default="device", choices=["device", "resident"],
                     help="device: fresh Philox noise generated on the GPU inside every step; "
@@ -80,6 +83,96 @@ def cpu_baseline(workload, spec, n_solves):
                       "OpenBLAS threads = host cores), %.1f s" % (n_solves, workload, dt)}
 
 
+def secondary_workload(args, rank, local_rank, world):
+    """c4 / c5: the other BASELINE configurations, same timing contract (barrier + sync on both
+    sides, max over ranks), reported with their own unit of work."""
+    import torch
+    import torch.distributed as dist
+    from autompc_amd import _lib
+    from autompc_amd.synthetic import make_workload
+    system, task, model, spec = make_workload("c3", precision=args.precision, device=local_rank)
+    nx, nu = spec["nx"], spec["nu"]
+    B = args.batch if args.batch > 1 else (64 if args.workload == "c5" else 256)
+    extra = {}
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.workload == "c4":
+        h = _lib.Handle(local_rank, args.precision)
+        model.stage_into(h)
+        Q, R, F = task.get_cost().get_cost_matrices()
+        h.set_quad_costs(Q, R, F, task.get_cost().get_goal())
+        plan = _lib.IlqrPlan(h, B, 50, system.dt)
+        rng = np.random.default_rng(rank)
+        x0 = rng.uniform(-0.1, 0.1, size=(B, nx))
+        ug = np.zeros((B, 50, nu))
+        iters = []
+
+        def step(i):
+            out = plan.solve(x0, ug, max_iter=50)
+            iters.append(float(out["iters"].mean()))
+        label = "c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU" % B
+        unit_per_step = B
+        metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
+    else:
+        from autompc_amd.tuning import CandidateEvaluator, random_candidates
+        task.set_num_steps(200)
+        cands = random_candidates(system, B, seed=rank)
+        ev = CandidateEvaluator(system, task, model, precision=args.precision, device=local_rank)
+
+        def step(i):
+            ev.evaluate(cands, n_steps=200, seed=i)
+        label = ("c5: %d tuning candidates (MPPI horizon/sigma/lmda/num_path + QuadCost weights from "
+                 "the reference's config ranges) x 200-step closed loop per step per GPU" % B)
+        unit_per_step = B * 200
+        metric, unit = "MPC solves/sec (MPPI inside the batched closed-loop candidate evaluator)", "solves/s"
+    steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
+    for i in range(warm):
+        step(i)
+    iters.clear() if args.workload == "c4" else None
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        if args.workload == "c4":
+            extra["mean_iterations_per_solve"] = float(np.mean(iters))
+        out = {"metric": metric, "value": world * steps * unit_per_step / elapsed, "unit": unit,
+               "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.precision, "data": "synthetic",
+               "config": {"workload": label, "parallelism": "independent problems per GPU (dp%d)" % world},
+               "roofline": None, **extra}
+        if not args.no_cpu_baseline and world == 1 and args.workload == "c4":
+            from oracle.costs import QuadCostOracle
+            from oracle.ilqr import ILQROracle
+            from oracle.mlp import MLPOracle, make_params
+            p = spec["params"]
+            om = MLPOracle(system, make_params(p["weights"], p["biases"], "relu", p["xu_means"],
+                                               p["xu_std"], p["dy_means"], p["dy_std"]))
+            orc = ILQROracle(om, QuadCostOracle(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx)),
+                             system.dt, 50)
+            t0 = time.perf_counter()
+            n = 0
+            while time.perf_counter() - t0 < 10.0:
+                orc.solve(x0[n % B], np.zeros((50, nu)))
+                n += 1
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n / dt, "unit": "solves/s", "cores": os.cpu_count(),
+                                   "kind": "port", "sample": "%d iLQR solves (oracle, numpy f64), %.1f s" % (n, dt)}
+        print(json.dumps(out))
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -91,6 +184,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.workload in ("c4", "c5"):
+        secondary_workload(args, rank, local_rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from autompc_amd import _lib
     from autompc_amd.synthetic import make_workload

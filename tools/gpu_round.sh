@@ -13,6 +13,8 @@ timeout 900 python bench.py > $OUT/bench_c3_f64.json 2> $OUT/bench_c3_f64.err
 timeout 300 python bench.py --precision f32 --no-cpu-baseline > $OUT/bench_c3_f32.json 2> $OUT/bench_c3_f32.err
 timeout 300 python bench.py --workload c2 > $OUT/bench_c2_f64.json 2> $OUT/bench_c2_f64.err
 timeout 300 python bench.py --batch 8 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c3_f64_batch8.json 2> $OUT/bench_c3_f64_batch8.err
+timeout 600 python bench.py --workload c4 --steps 3 --warmup 1 > $OUT/bench_c4_ilqr_f64.json 2> $OUT/bench_c4.err
+timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_candidates_f64.json 2> $OUT/bench_c5.err
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- $BENCH > $OUT/prof_trace.log 2>&1
@@ -23,11 +25,13 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_V
 cd $GRAFT_REPO_ROOT
 find $OUT -name "*.csv" | head -30
 cat $OUT/pytest_gpu.log | tail -3; cat $OUT/smoke.log | tail -1
+python tools/summarize_profiles.py $OUT > $OUT/pmc_summary.txt 2>&1
+cat $OUT/pmc_summary.txt
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
     try:
-        d=json.load(open(f)); r=d["roofline"]
+        d=json.load(open(f)); r=d["roofline"] or {"kernel_ms":0,"achieved":0,"frac":0}
         print("%-28s value=%8.1f ms/step=%.3f kernel_ms=%.3f TF=%.1f frac=%.3f cpu=%s" % (f.split("/")[-1], d["value"], d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"], d.get("cpu_baseline",{}).get("value")))
     except Exception as e: print(f, "failed", e)
 PY

@@ -1,0 +1,36 @@
+"""Condense the rocprofv3 CSVs of one tools/gpu_round.sh session into a small text summary
+(per-kernel averages of every collected counter + derived MFMA-busy and HBM bytes)."""
+import collections
+import csv
+import glob
+import sys
+
+out = sys.argv[1]
+print("# rocprofv3 summary of `python bench.py --steps 50 --warmup 5` (c3, f64), per launch averages")
+for f in glob.glob(out + "/prof_trace/*/*_kernel_stats.csv"):
+    print("\n## kernel-trace --stats")
+    for row in csv.DictReader(open(f)):
+        print("%-70s calls=%s avg_ns=%.0f pct=%s" % (row["Name"][:70], row["Calls"], float(row["AverageNs"]), row["Percentage"]))
+vals = collections.defaultdict(dict)
+for d in ("prof_pmc_sq", "prof_pmc_fetch", "prof_pmc_write", "prof_pmc_lds"):
+    for f in glob.glob(out + "/" + d + "/*/*_counter_collection.csv"):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            for c, x in v.items():
+                vals[k][c] = sum(x) / len(x)
+print("\n## PMC (separate passes), average per launch")
+for k, v in vals.items():
+    if "rollout" not in k and "update" not in k:
+        continue
+    print(k[:90])
+    for c in sorted(v):
+        print("    %-32s %.4g" % (c, v[c]))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over 256 CUs x 4 SIMDs
+        cyc = v["GRBM_GUI_ACTIVE"] / 8.0
+        print("    -> kernel cycles (per XCD)        %.4g" % cyc)
+        print("    -> MFMA busy fraction             %.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)))
+    if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
+        print("    -> HBM bytes (FETCH+WRITE, KB->B) %.4g" % (1024.0 * (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0))))
