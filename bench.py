@@ -141,7 +141,8 @@ def secondary_workload(args, rank, local_rank, world):
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -180,10 +181,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
+    # Plumbing test hooks (tools/gpu_round.sh): run a 2-rank job on a 1-GPU box by mapping every
+    # rank to one device and using gloo for the barriers.  Never set by the driver.
+    if "AMPC_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["AMPC_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("AMPC_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     if args.workload in ("c4", "c5"):
         secondary_workload(args, rank, local_rank, world)
@@ -239,7 +248,8 @@ def main():
     if not np.all(np.isfinite(u)):
         raise RuntimeError("non-finite control returned by the solve")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
