@@ -224,6 +224,20 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt], b[g & 1][kk][nt], acc[mt][nt]);
     }
+#ifndef AMPC_X_NOSCHED
+    // Issue order for this group: LDS fragment reads run one k-step pair AHEAD of the MFMAs that
+    // consume them, weight loads for the next group are spread between MFMA clusters.
+    //   masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read
+    if (KS >= 8) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+#pragma unroll
+      for (int i = 0; i < G / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+    }
+#endif
   }
 }
 

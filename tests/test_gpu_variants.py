@@ -1,0 +1,121 @@
+"""Every kernel instantiation the dispatcher can pick -- workgroup shapes (W waves, NT tiles per
+wave) and tile heights (MT) -- checked against the oracle.  The defaults only exercise a few of
+them; the overrides AMPC_WAVES / AMPC_MT force the rest (needs MI355X)."""
+import numpy as np
+import pytest
+
+from helpers import make_system, rel_err
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+from oracle.mlp import MLPOracle
+from oracle.mppi import MPPIOracle
+
+pytestmark = pytest.mark.gpu
+
+# hidden sizes -> padded width -> (W, NT) by default:  64->(4,1) 128->(8,1) 192->(4,3) 256->(8,2)
+SHAPES = [([40, 64], None), ([100, 128], None), ([150, 192], None), ([256, 200], None),
+          ([128, 100], "4"), ([256, 256], "4")]          # with AMPC_WAVES=4: (4,2) and (4,4)
+
+
+def _handle(p, nx, nu, act, precision):
+    from autompc_amd import _lib
+    h = _lib.Handle(0, precision)
+    h.set_mlp(nx, nu, p["weights"], p["biases"], act, p["xu_means"], p["xu_std"], p["dy_means"],
+              p["dy_std"])
+    return h
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-10), ("f32", 1e-4)])
+@pytest.mark.parametrize("mt", ["1", "2", "4"])
+@pytest.mark.parametrize("hidden,waves", SHAPES)
+def test_forward_and_jacobian_all_instantiations(monkeypatch, hidden, waves, mt, precision, tol):
+    if mt == "4" and precision == "f64" and max(hidden) > 128:
+        pytest.skip("f64 tile of 64 samples x 256 hidden units exceeds the 160 KB LDS (by design)")
+    monkeypatch.setenv("AMPC_MT", mt)
+    if waves:
+        monkeypatch.setenv("AMPC_WAVES", waves)
+    nx, nu = 11, 3
+    p = omlp.random_params(nx, nu, hidden, "tanh", seed=sum(hidden))
+    rng = np.random.default_rng(1)
+    p["xu_means"], p["xu_std"] = rng.normal(scale=0.2, size=nx + nu), rng.uniform(0.5, 2, size=nx + nu)
+    p["dy_means"], p["dy_std"] = rng.normal(scale=0.05, size=nx), rng.uniform(0.05, 0.3, size=nx)
+    h = _handle(p, nx, nu, "tanh", precision)
+    s, c = rng.normal(size=(150, nx)), rng.normal(size=(150, nu))
+    assert rel_err(h.pred_batch(s, c), omlp.pred_batch(p, s, c)) < tol
+    o, jx, ju = h.pred_diff_batch(s[:40], c[:40])
+    eo, ejx, eju = omlp.pred_diff_batch(p, s[:40], c[:40])
+    assert rel_err(o, eo) < tol and rel_err(jx, ejx) < 10 * tol and rel_err(ju, eju) < 10 * tol
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 1e-4)])
+@pytest.mark.parametrize("mt", ["1", "2", "4"])
+@pytest.mark.parametrize("hidden,waves", SHAPES)
+def test_mppi_solve_all_instantiations(monkeypatch, hidden, waves, mt, precision, tol):
+    if mt == "4" and precision == "f64" and max(hidden) > 128:
+        pytest.skip("f64 tile of 64 samples x 256 hidden units exceeds the 160 KB LDS (by design)")
+    from autompc_amd import _lib
+    monkeypatch.setenv("AMPC_MT", mt)
+    if waves:
+        monkeypatch.setenv("AMPC_WAVES", waves)
+    nx, nu, N, H = 9, 4, 203, 7          # N is not a multiple of any tile height
+    p = omlp.random_params(nx, nu, hidden, "relu", seed=7 + sum(hidden))
+    rng = np.random.default_rng(2)
+    Q, R, F = rng.normal(size=(nx, nx)), np.diag(rng.uniform(0.01, 0.1, size=nu)), np.eye(nx)
+    goal = rng.normal(scale=0.1, size=nx)                 # dense, non-symmetric Q: dense-cost path
+    h = _handle(p, nx, nu, "relu", precision)
+    h.set_quad_costs(Q, R, F, goal)
+    lo, hi = -rng.uniform(0.5, 1.5, size=nu), rng.uniform(0.5, 1.5, size=nu)
+    h.set_ctrl_bounds(lo, hi)
+    plan = _lib.MppiPlan(h, [N], [H], [0.8], [0.6], term_mode=_lib.TERM_PER_PARTICLE)
+    assert plan.info()["samples_per_wg"] == 16 * int(mt)
+    x0 = rng.uniform(-0.1, 0.1, size=nx)
+    act = rng.normal(scale=0.5, size=(H, nu))
+    eps = rng.normal(scale=np.sqrt(0.8), size=(N, H, nu))
+    plan.upload(x0, act, eps)
+    plan.solve()
+    a, u, c, e = plan.download(costs=True, eps_out=True)
+    orc = MPPIOracle(MLPOracle(make_system(nx, nu), p), QuadCostOracle(Q, R, F, goal),
+                     np.stack([lo, hi], axis=1), horizon=H, num_path=N, sigma=0.8, lmda=0.6,
+                     per_particle_terminal=True)
+    orc.act_sequence = act.copy()
+    uo, _ = orc.run(np.concatenate([x0, np.zeros(nu)]), x0, eps_nhu=eps)
+    assert rel_err(c, orc.last_costs) < tol
+    assert rel_err(e.reshape(H, N, nu), orc.last_eps) < max(tol, 1e-12)
+    assert rel_err(a.reshape(H, nu), orc.act_sequence) < 10 * tol and rel_err(u[0], uo) < 10 * tol
+
+
+@pytest.mark.parametrize("nx,nu,H", [(1, 1, 2), (32, 16, 5), (17, 6, 30), (3, 2, 64)])
+def test_mppi_dimension_extremes(nx, nu, H):
+    """Smallest / largest supported state and control widths, shortest horizon, a long one."""
+    from autompc_amd import _lib
+    N = 50
+    p = omlp.random_params(nx, nu, [64, 64], "sigmoid", seed=nx)
+    rng = np.random.default_rng(nx + nu)
+    Q, R, F = np.diag(rng.uniform(0.5, 2, nx)), np.diag(rng.uniform(0.01, 0.1, nu)), np.eye(nx)
+    h = _handle(p, nx, nu, "sigmoid", "f64")
+    h.set_quad_costs(Q, R, F, np.zeros(nx))
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    plan = _lib.MppiPlan(h, [N], [H], [1.0], [1.0])
+    x0, act = rng.uniform(-0.1, 0.1, size=nx), rng.normal(size=(H, nu))
+    eps = rng.normal(size=(N, H, nu))
+    plan.upload(x0, act, eps)
+    plan.solve()
+    a, u, c, _ = plan.download(costs=True)
+    orc = MPPIOracle(MLPOracle(make_system(nx, nu), p), QuadCostOracle(Q, R, F, np.zeros(nx)),
+                     np.tile([-1.0, 1.0], (nu, 1)), horizon=H, num_path=N)
+    orc.act_sequence = act.copy()
+    uo, _ = orc.run(np.concatenate([x0, np.zeros(nu)]), x0, eps_nhu=eps)
+    assert rel_err(c, orc.last_costs) < 1e-9 and rel_err(u[0], uo) < 1e-8
+
+
+def test_unsupported_shapes_fail_loudly():
+    from autompc_amd import _lib
+    p = omlp.random_params(33, 1, [64], "relu", seed=0)
+    h = _lib.Handle(0, "f64")
+    with pytest.raises(_lib.AmpcError):
+        h.set_mlp(33, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
+                  p["dy_std"])
+    p = omlp.random_params(4, 1, [300], "relu", seed=0)
+    with pytest.raises(_lib.AmpcError):
+        h.set_mlp(4, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
+                  p["dy_std"])
