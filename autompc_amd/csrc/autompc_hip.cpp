@@ -780,7 +780,14 @@ template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
     hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
   });
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
-  hipLaunchKernelGGL(mppi_update_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a);
+  {
+    int maxn = 0;
+    for (int n : p->N) maxn = n > maxn ? n : maxn;
+    const size_t ub = ((size_t)(maxn <= kUpdateMaxN ? maxn : 0) + kWaves + kWG) * sizeof(T);
+    auto uk = mppi_update_kernel<T>;
+    HIP_OK(allow_lds(uk, ub));
+    hipLaunchKernelGGL(uk, dim3(p->max_h, p->B), dim3(kWG), ub, h->stream, a);
+  }
   if (e) HIP_OK(hipEventRecord(e[2], h->stream));
   HIP_OK(hipGetLastError());
   p->cur ^= 1;

@@ -224,49 +224,70 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch) {
 
 constexpr int kMaxNu = 16;
 
-// grid = (max_h, B).  Block (t, p) recomputes the softmin normaliser (N reads, L2 resident) and
-// produces act_out[p][t][:].  Block t == 0 also finalises the costs (adds the reference-mode
-// terminal scalar) and writes the control to apply.
+// grid = (max_h, B).  Block (t, p) recomputes the softmin normaliser (N reads, L2 resident),
+// keeps the unnormalised weights S_n = exp(-(c_n - min c)/lmda) in LDS, and produces
+// act_out[p][t][:] = a_shift[t] + (sum_n S_n eps[t][n][:]) / sum_n S_n.  The [N][nu] noise slab of
+// step t is read as one flat, fully coalesced stream: only the first (256/nu)*nu threads take part,
+// so a thread's control index j = tid % nu is fixed and its partial sum is a scalar.
+// Block t == 0 also writes the control to apply.
+constexpr int kUpdateMaxN = 8192;   // weights kept in LDS up to this many samples (64 KB f64)
+
 template <typename T>
 __global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args) {
-  __shared__ T scratch[kWaves];
-  __shared__ T red[kWaves][kMaxNu];
+  extern __shared__ __attribute__((aligned(16))) unsigned char upd_smem[];
+  T* wts = reinterpret_cast<T*>(upd_smem);          // [min(N, kUpdateMaxN)] weights, then scratch
   const int p = blockIdx.y, t = blockIdx.x;
   const MppiProblem<T> pr = args.probs[p];
   if (t >= pr.H) return;
   const int N = pr.N, nu = args.mlp.nu, tid = threadIdx.x;
+  const bool cached = N <= kUpdateMaxN;
+  T* scratch = wts + (cached ? N : 0);              // kWaves reduction slots + kWG partials
+  T* part = scratch + kWaves;
   const T* c = args.costs + pr.cost_off;
 
   T vmin = c[0];
   for (int n = tid; n < N; n += kWG) vmin = c[n] < vmin ? c[n] : vmin;
   vmin = block_min(vmin, scratch);
   T ssum = T(0);
-  for (int n = tid; n < N; n += kWG) ssum += exp(pr.neg_inv_lambda * (c[n] - vmin));
-  ssum = block_sum(ssum, scratch);
-
-  T acc[kMaxNu];
-#pragma unroll
-  for (int j = 0; j < kMaxNu; ++j) acc[j] = T(0);
-  const T* e = args.eps_out + pr.epso_off + (size_t)t * N * nu;
   for (int n = tid; n < N; n += kWG) {
-    const T wgt = exp(pr.neg_inv_lambda * (c[n] - vmin)) / ssum;
-#pragma unroll
-    for (int j = 0; j < kMaxNu; ++j)
-      if (j < nu) acc[j] += wgt * e[(size_t)n * nu + j];
+    const T s = exp(pr.neg_inv_lambda * (c[n] - vmin));
+    if (cached) wts[n] = s;
+    ssum += s;
   }
+  ssum = block_sum(ssum, scratch);   // (barriers inside also publish wts)
+
+  const int active = (kWG / nu) * nu;               // threads with a fixed j = tid % nu
+  const T* e = args.eps_out + pr.epso_off + (size_t)t * N * nu;
+  T acc = T(0);
+  if (tid < active) {
+    const int total = N * nu;
+    int n = tid / nu;
+    const int dn = active / nu;
+    constexpr int U = 8;                               // independent loads in flight per thread
+    int i = tid;
+    for (; i + (U - 1) * active < total; i += U * active, n += U * dn) {
+      T ev[U];
 #pragma unroll
-  for (int j = 0; j < kMaxNu; ++j)
-    if (j < nu) {
-      const T s = wave_sum(acc[j]);
-      if ((tid & 63) == 0) red[tid >> 6][j] = s;
+      for (int k = 0; k < U; ++k) ev[k] = e[i + k * active];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int nn = n + k * dn;
+        const T wgt = cached ? wts[nn] : exp(pr.neg_inv_lambda * (c[nn] - vmin));
+        acc += wgt * ev[k];
+      }
     }
+    for (; i < total; i += active, n += dn) {
+      const T wgt = cached ? wts[n] : exp(pr.neg_inv_lambda * (c[n] - vmin));
+      acc += wgt * e[i];
+    }
+  }
+  part[tid] = tid < active ? acc : T(0);
   __syncthreads();
   if (tid < nu) {
+    T s = T(0);
+    for (int i = tid; i < active; i += nu) s += part[i];
     const int ts = (t + 1 < pr.H) ? t + 1 : pr.H - 1;
-    T s = red[0][tid];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) s += red[w][tid];
-    const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s;
+    const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s / ssum;
     args.act_out[pr.a_off + t * nu + tid] = a_new;
     if (t == 0) args.u_out[p * nu + tid] = a_new * args.bounds[2 * nu + tid];
   }
