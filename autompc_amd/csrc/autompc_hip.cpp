@@ -458,8 +458,10 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
 // LDS map for a tile: separate partials region when it fits the 160 KB, else aliased onto `act`.
 template <typename T>
 static TileLds tile_lds_for(const ampc_handle* h, const MlpDev<T>& m, int M, size_t extra_elems) {
-  TileLds L = make_tile_lds(m, M, h->nw, true);
-  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, false);
+  // richest map first: ping-pong activations + separate partials, then drop one at a time
+  TileLds L = make_tile_lds(m, M, h->nw, true, env_int("AMPC_PINGPONG", 1) != 0);
+  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, true, false);
+  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, false, false);
   return L;
 }
 

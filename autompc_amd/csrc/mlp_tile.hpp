@@ -104,7 +104,8 @@ template <typename T> struct MlpDev {
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
 struct TileLds {
-  int act;      // [M][hpad+2]
+  int act;      // [M][hpad+pad]
+  int act2;     // second activation buffer (ping-pong across layers); == act when LDS is tight
   int part;     // [W][M][nxp] output-layer partials; aliases `act` when LDS is tight
   int part_alias;
   int xu;       // [M][k1p+2]   raw state | control | zero pad: the first layer's A operand
@@ -128,7 +129,8 @@ __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
 template <typename T>
-__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true) {
+__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true,
+                                      bool double_act = true) {
   TileLds L;
   int o = 0;
   // Row padding for conflict-free A-fragment reads (16 rows x consecutive k per access):
@@ -141,9 +143,11 @@ __host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool sep
   L.part_alias = separate_partials ? 0 : 1;
   if (separate_partials) {
     L.act = o; o += M * L.act_stride;
+    L.act2 = L.act;
+    if (double_act && m.n_hidden > 1) { L.act2 = o; o += M * L.act_stride; }
     L.part = o; o += W * M * m.nxp;
   } else {
-    L.act = o; L.part = o; o += M * imax(L.act_stride, W * m.nxp);
+    L.act = o; L.act2 = o; L.part = o; o += M * imax(L.act_stride, W * m.nxp);
   }
   L.xu = o; o += M * L.xu_stride;
   L.bias = o; o += m.n_hidden * m.hpad + m.nxp;
@@ -196,7 +200,7 @@ __device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&
 // One N-split layer with compile-time k extent KS: acc[mt][nt] += A[16mt.., :] * Wpacked.
 // Fully unrolled; group 0 arrives pre-loaded in `first`, later groups are double-buffered so the
 // fetch of group g+1 is in flight while group g's MFMAs issue.
-template <typename T, int NT, int MT, int KS, int G>
+template <typename T, int NT, int MT, int KS, int G, bool PIPE = false>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
                                                  const T* __restrict__ wl, int lane,
                                                  const T (&first)[G][NT],
@@ -225,10 +229,11 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt], b[g & 1][kk][nt], acc[mt][nt]);
     }
 #ifndef AMPC_X_NOSCHED
+    // (8-wave tiles only; measured neutral-to-negative with one wave per SIMD)
     // Issue order for this group: LDS fragment reads run one k-step pair AHEAD of the MFMAs that
     // consume them, weight loads for the next group are spread between MFMA clusters.
     //   masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read
-    if (KS >= 8) {
+    if (PIPE && KS >= 8) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll
       for (int i = 0; i < G / 2; ++i) {
@@ -291,7 +296,9 @@ struct TileNet {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-    T* act = lds + L.act;
+    T* act = lds + L.act;            // buffer the next layer reads
+    T* act_other = lds + L.act2;     // buffer the next epilogue may write (== act if single-buffered)
+    const bool pingpong = L.act2 != L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
     // Prefetch buffer for whatever comes next: the first group of the next hidden layer
@@ -322,7 +329,7 @@ struct TileNet {
     };
     // bias + activation + store of one layer's accumulators (activation kind hoisted out of
     // the element loops: one uniform branch per layer instead of one per element)
-    auto epilogue_k = [&](int l, acc_t (&acc)[MT][NT], auto kind_tag) {
+    auto epilogue_k = [&](int l, acc_t (&acc)[MT][NT], T* dst, auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
       const T* bias = lds + L.bias + l * m.hpad;
 #pragma unroll
@@ -335,17 +342,17 @@ struct TileNet {
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + acc_row<T>(q, r);
             const T z = acc[mt][nt][r] + bc;
-            act[row * as + col] = act_apply<T>(KIND, z);
+            dst[row * as + col] = act_apply<T>(KIND, z);
             if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(KIND, z);
           }
         }
     };
-    auto epilogue = [&](int l, acc_t (&acc)[MT][NT]) {
+    auto epilogue = [&](int l, acc_t (&acc)[MT][NT], T* dst) {
       switch (m.act) {
-        case 0: epilogue_k(l, acc, std::integral_constant<int, 0>{}); break;
-        case 1: epilogue_k(l, acc, std::integral_constant<int, 1>{}); break;
-        case 2: epilogue_k(l, acc, std::integral_constant<int, 2>{}); break;
-        default: epilogue_k(l, acc, std::integral_constant<int, 3>{}); break;
+        case 0: epilogue_k(l, acc, dst, std::integral_constant<int, 0>{}); break;
+        case 1: epilogue_k(l, acc, dst, std::integral_constant<int, 1>{}); break;
+        case 2: epilogue_k(l, acc, dst, std::integral_constant<int, 2>{}); break;
+        default: epilogue_k(l, acc, dst, std::integral_constant<int, 3>{}); break;
       }
     };
 
@@ -368,7 +375,7 @@ struct TileNet {
       }
       AMPC_MARK(2);
       prefetch_next(1);
-      epilogue(0, acc);
+      epilogue(0, acc, act);
     }
     lds_barrier();
     AMPC_MARK(3);
@@ -380,14 +387,17 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-      layer_mma_static<T, NT, MT, KSH, GH>(act, as, slice_h(m, l, w, lane), lane, pfn, acc);
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8)>(act, as, slice_h(m, l, w, lane), lane, pfn, acc);
       AMPC_MARK(4);
       prefetch_next(l + 1);
-      lds_barrier();  // every wave finished reading act before it is overwritten
+      // single buffer: every wave must finish reading act before it is overwritten;
+      // ping-pong: the epilogue writes the other buffer, no barrier needed here
+      if (!pingpong) lds_barrier();
       AMPC_MARK(5);
-      epilogue(l, acc);
+      epilogue(l, acc, act_other);
       lds_barrier();
       AMPC_MARK(6);
+      { T* tmp = act; act = act_other; act_other = tmp; }
     }
 
     // ---- output layer: K-split, wave w owns k-steps [w*KSW, (w+1)*KSW) -----------------------
