@@ -51,6 +51,7 @@ SIGNATURES = {
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
     "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
+    "ampc_mppi_plan_set_outputs": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_timing": (c_int, [c_void_p, _dp, _dp, _ip]),
     "ampc_mppi_closed_loop": (c_int, [c_void_p, c_void_p, _dp, c_int, c_uint64, _dp, _dp, _dp]),
@@ -292,6 +293,9 @@ class MppiPlan:
                                              dptr(init_obs), int(n_steps), int(seed), dptr(eps_all),
                                              dptr(obs), dptr(ctl)))
         return obs, ctl
+
+    def set_outputs(self, keep_eps_out=True):
+        check(self.lib.ampc_mppi_plan_set_outputs(self._p, int(bool(keep_eps_out))))
 
     def set_timing(self, enable=True):
         check(self.lib.ampc_mppi_plan_set_timing(self._p, int(bool(enable))))

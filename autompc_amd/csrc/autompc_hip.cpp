@@ -573,7 +573,9 @@ struct ampc_mppi_plan {
   std::vector<double> sigma, lmda;
   std::vector<long long> eps_off, epso_off, cost_off;
   long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
-  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out;
+  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part;
+  int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
+  bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
   int cur = 0;          // act[cur] is the input of the next solve
   bool costs_final = true;
   bool solved = false;
@@ -599,6 +601,12 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.term_mode = p->term_mode;
   a.max_h = p->max_h;
   a.cost_diag = h->cost_diag;
+  a.lds_eps = p->lds_eps;
+  a.lds_red = p->lds_red;
+  a.write_eps_out = (p->keep_eps_out || p->lds_eps < 0) ? 1 : 0;
+  a.hnu_stride = p->max_h * h->nu;
+  a.tile_stat = (T*)p->tile_stat.p;
+  a.tile_part = (T*)p->tile_part.p;
   a.costs_par = (const T*)h->cost_buf.p;
   a.bounds = (const T*)h->bounds_buf.p;
   a.probs = (const MppiProblem<T>*)p->probs.p;
@@ -626,6 +634,15 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
   p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);
   REQUIRE(p->lds_bytes <= kLdsLimit, "mppi plan: model + horizon do not fit the 160 KB LDS");
+  {  // fused update: keep the tile's clipped noise [max_h][M][nu] (+ 2M reduction slots) in LDS
+    const int e0 = round_up(p->lds_cost + h->cost_stride + 3 * nu, 4);
+    const size_t bytes = ((size_t)e0 + (size_t)p->max_h * M * nu + 2 * M) * sizeof(T);
+    if (bytes <= kLdsLimit && env_int("AMPC_FUSED_UPDATE", 1) != 0) {
+      p->lds_eps = e0;
+      p->lds_red = e0 + p->max_h * M * nu;
+      p->lds_bytes = bytes;
+    }
+  }
   std::vector<MppiProblem<T>> pr(p->B);
   std::vector<int> tile_prob;
   int tile = 0;
@@ -658,6 +675,8 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   HIP_OK(p->costs.reserve((size_t)p->sum_n * sizeof(T)));
   HIP_OK(p->term_last.reserve((size_t)p->B * sizeof(T)));
   HIP_OK(p->u_out.reserve((size_t)p->B * nu * sizeof(T)));
+  HIP_OK(p->tile_stat.reserve((size_t)p->n_tiles * 2 * sizeof(T)));
+  HIP_OK(p->tile_part.reserve((size_t)p->n_tiles * p->max_h * nu * sizeof(T)));
   HIP_OK(hipMemset(p->x0.p, 0, (size_t)p->B * nx * sizeof(T)));
   return 0;
 }
@@ -710,7 +729,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
-                    &p->eps_out, &p->costs, &p->term_last, &p->u_out};
+                    &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
@@ -782,7 +801,10 @@ template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
     hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
   });
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
-  {
+  if (p->lds_eps >= 0) {
+    hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
+                       16 * p->mt);
+  } else {
     int maxn = 0;
     for (int n : p->N) maxn = n > maxn ? n : maxn;
     const size_t ub = ((size_t)(maxn <= kUpdateMaxN ? maxn : 0) + kWaves + kWG) * sizeof(T);
@@ -829,6 +851,8 @@ extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u,
                                   double* eps_out) {
   REQUIRE(p, "ampc_mppi_download: NULL plan");
   REQUIRE(p->solved || (!u && !costs && !eps_out), "ampc_mppi_download: nothing solved yet");
+  REQUIRE(!eps_out || p->keep_eps_out || p->lds_eps < 0,
+          "ampc_mppi_download: eps_out was not kept (ampc_mppi_plan_set_outputs(plan, 0))");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_download_impl<double>(p, act_seq, u, costs, eps_out)
                                      : mppi_download_impl<float>(p, act_seq, u, costs, eps_out);
@@ -1180,4 +1204,10 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
   return p->h->precision == AMPC_F64
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
              : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls);
+}
+
+extern "C" int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out) {
+  REQUIRE(p, "ampc_mppi_plan_set_outputs: NULL plan");
+  p->keep_eps_out = keep_eps_out != 0;
+  return 0;
 }

@@ -18,6 +18,9 @@
 
 namespace ampc {
 
+constexpr int kWG = 256;      // threads of the update / combine / finalize kernels
+constexpr int kWaves = 4;
+
 template <typename T> struct MppiProblem {
   int N, H;            // samples, horizon
   int tile0;           // first rollout workgroup of this problem
@@ -39,6 +42,11 @@ template <typename T> struct MppiArgs {
   int obs_dim, cost_stride;     // cost block = Q[no*no] R[nu*nu] F[no*no] goal[no]
   int term_mode, max_h;
   int cost_diag;                // 1: every Q, R, F is diagonal -> O(n) stage cost
+  int lds_eps;                  // >= 0: clipped noise of the tile is kept in LDS ([max_h][M][nu]) and
+                                //       the softmin update is fused (tile partials + combine kernel)
+  int lds_red;                  // small reduction scratch: [M] costs, [M] weights
+  int write_eps_out;            // materialise the clipped noise in HBM (needed only for download)
+  int hnu_stride;               // max_h * nu: row length of tile_part
   const T* costs_par;           // [n_costs][cost_stride]
   const T* bounds;              // lo[nu] hi[nu] scale[nu]   (lo, hi already divided by scale)
   const MppiProblem<T>* probs;
@@ -51,7 +59,13 @@ template <typename T> struct MppiArgs {
   T* costs;                     // per-sample cost (terminal scalar of reference mode NOT included)
   T* term_last;                 // [B] terminal cost of the last particle (reference mode)
   T* u_out;                     // [B][nu] first action * scale (written by the update kernel)
+  T* tile_stat;                 // [n_tiles][2]  fused update: tile min cost, tile weight sum
+  T* tile_part;                 // [n_tiles][hnu_stride]  fused update: sum_m S_m eps[t][m][j]
 };
+
+template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
+template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch);
+template <typename T> __device__ __forceinline__ T wave_sum(T v);
 
 template <typename T, int NT, int MT, int W>
 __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> args) {
@@ -128,7 +142,8 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
         A = A < blo[j] ? blo[j] : A;
         A = A > bhi[j] ? bhi[j] : A;
         const T ec = A - a;
-        if (valid) epso[((size_t)t * N + n) * nu + j] = ec;
+        if (valid && args.write_eps_out) epso[((size_t)t * N + n) * nu + j] = ec;
+        if (args.lds_eps >= 0) lds[args.lds_eps + (t * M + m) * nu + j] = ec;
         ca_part += A * ec;
         const T u = A * bsc[j];
         xu[m * xs_ + nx + j] = u;
@@ -185,10 +200,85 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     args.costs[pr.cost_off + n] = c;
     if (n == N - 1) args.term_last[p] = term;
   }
+  if (args.lds_eps < 0) return;
+
+  // ---- fused softmin update, tile part (mppi.py:110-118): with the tile's own minimum m_w as the
+  // reference point, S_m = exp(-(c_m - m_w)/lmda); the tile publishes m_w, sum_m S_m and
+  // sum_m S_m eps[t][m][j].  mppi_combine_kernel rescales the tiles to the global minimum.
+  T* cred = lds + args.lds_red;
+  T* sred = cred + M;
+  if (r == 0) cred[m] = valid ? c : T(INFINITY);
+  __syncthreads();
+  T mw = cred[0];
+  for (int i = 1; i < M; ++i) mw = cred[i] < mw ? cred[i] : mw;
+  if (tid < M) sred[tid] = (first + tid < N) ? exp(pr.neg_inv_lambda * (cred[tid] - mw)) : T(0);
+  __syncthreads();
+  const T* el = lds + args.lds_eps;
+  T* tp = args.tile_part + (size_t)blockIdx.x * args.hnu_stride;
+  for (int e = tid; e < H * nu; e += NTHR) {
+    const int t = e / nu, j = e - t * nu;
+    T s = T(0);
+    for (int i = 0; i < M; ++i) s += sred[i] * el[(t * M + i) * nu + j];
+    tp[e] = s;
+  }
+  if (tid == 0) {
+    T ss = T(0);
+    for (int i = 0; i < M; ++i) ss += sred[i];
+    args.tile_stat[2 * blockIdx.x] = mw;
+    args.tile_stat[2 * blockIdx.x + 1] = ss;
+  }
 }
 
-constexpr int kWG = 256;      // threads of the update / finalize kernels
-constexpr int kWaves = 4;
+// Second half of the fused update.  grid = (max_h, B): block (t, p) rescales every tile's partial
+// sums for step t from the tile minimum to the global minimum and finishes
+// a[t] += (sum_tiles scale_w P_w[t]) / (sum_tiles scale_w s_w).  Each thread owns a strided set of
+// tiles (its nu values of a tile row are contiguous), then one shuffle/LDS reduction per block.
+constexpr int kMaxNu = 16;
+
+template <typename T>
+__global__ __launch_bounds__(kWG) void mppi_combine_kernel(const MppiArgs<T> args, int tile_m) {
+  __shared__ T scratch[kWaves];
+  __shared__ T red[kWaves][kMaxNu];
+  const int p = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const MppiProblem<T> pr = args.probs[p];
+  if (t >= pr.H) return;
+  const int nu = args.mlp.nu, H = pr.H;
+  const int tiles = (pr.N + tile_m - 1) / tile_m;
+  const T* st = args.tile_stat + 2 * (size_t)pr.tile0;
+  T vmin = st[0];
+  for (int i = tid; i < tiles; i += kWG) vmin = st[2 * i] < vmin ? st[2 * i] : vmin;
+  vmin = block_min(vmin, scratch);
+  const T* tp = args.tile_part + (size_t)pr.tile0 * args.hnu_stride + t * nu;
+  T ssum = T(0);
+  T acc[kMaxNu];
+#pragma unroll
+  for (int j = 0; j < kMaxNu; ++j) acc[j] = T(0);
+  for (int i = tid; i < tiles; i += kWG) {
+    const T sc = exp(pr.neg_inv_lambda * (st[2 * i] - vmin));
+    ssum += sc * st[2 * i + 1];
+    const T* row = tp + (size_t)i * args.hnu_stride;
+#pragma unroll
+    for (int j = 0; j < kMaxNu; ++j)
+      if (j < nu) acc[j] += sc * row[j];
+  }
+  ssum = block_sum(ssum, scratch);
+#pragma unroll
+  for (int j = 0; j < kMaxNu; ++j)
+    if (j < nu) {
+      const T s = wave_sum(acc[j]);
+      if ((tid & 63) == 0) red[tid >> 6][j] = s;
+    }
+  __syncthreads();
+  if (tid < nu) {
+    T s = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < kWaves; ++w) s += red[w][tid];
+    const int ts = (t + 1 < H) ? t + 1 : H - 1;
+    const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s / ssum;
+    args.act_out[pr.a_off + t * nu + tid] = a_new;
+    if (t == 0) args.u_out[p * nu + tid] = a_new * args.bounds[2 * nu + tid];
+  }
+}
 
 // ---- block-wide reductions built on wave shuffles ---------------------------------------------
 template <typename T> __device__ __forceinline__ T wave_min(T v) {
@@ -221,8 +311,6 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch) {
   for (int w = 1; w < kWaves; ++w) o += scratch[w];
   return o;
 }
-
-constexpr int kMaxNu = 16;
 
 // grid = (max_h, B).  Block (t, p) recomputes the softmin normaliser (N reads, L2 resident),
 // keeps the unnormalised weights S_n = exp(-(c_n - min c)/lmda) in LDS, and produces

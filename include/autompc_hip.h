@@ -110,6 +110,10 @@ int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev);
 int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples_per_wg,
                         double* flops, double* bytes);
 
+/* keep_eps_out = 0: do not materialise the clipped noise in HBM (it is only needed by
+ * ampc_mppi_download(eps_out); the solve itself keeps it in LDS).  Default 1. */
+int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out);
+
 /* Per-kernel timing for the roofline report: when enabled, every ampc_mppi_solve brackets the
  * rollout and update launches with HIP events on the handle's stream.  ampc_mppi_plan_timing
  * synchronises, returns the AVERAGE duration (ms) of each kernel over the solves since the last
