@@ -1056,10 +1056,15 @@ template <typename T> static int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     });
   }
   {
-    const int jrows = rows * nx, JM = 16, jtiles = (jrows + JM - 1) / JM;
+    // taller row tiles amortise the weight stream when there are enough rows to fill the chip
+    const int jrows = rows * nx;
     const int kinp = 16 * ((m.kin + 15) / 16);
+    int jmt = env_int("AMPC_JMT", 0);
+    if (jmt == 0) jmt = jrows / 64 >= 512 ? 4 : (jrows / 32 >= 512 ? 2 : 1);
+    while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
+    const int JM = 16 * jmt, jtiles = (jrows + JM - 1) / JM;
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, 1, {
+    AMPC_DISPATCH(h->nw, h->nt, jmt, {
       auto k = mlp_jacobian_kernel<T, NT, MT, W>;
       HIP_OK(allow_lds(k, jl));
       hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,

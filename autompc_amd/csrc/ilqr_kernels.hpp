@@ -158,7 +158,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     }
     if (tid == 0) scal[8] = T(0);
     __syncthreads();
-    for (int t = H - 1; t >= 0; --t) {
+    // stage J_t = [jx | ju], xbar_t, ubar_t into LDS (done one step ahead inside the loop)
+    auto stage_step = [&](int t) {
       const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
       const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
       for (int idx = tid; idx < nx * n; idx += NTHR) {
@@ -167,7 +168,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
       for (int a = tid; a < nx; a += NTHR) xbar[a] = st[(size_t)t * nx + a];
       for (int j = tid; j < nu; j += NTHR) ubar[j] = ct[(size_t)t * nu + j];
-      __syncthreads();
+    };
+    stage_step(H - 1);
+    __syncthreads();
+    const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
+    T* Aug = lu;                     // lu (nu*nu) and rhs (nu*(nx+1)) are contiguous: nu*nc values
+    for (int t = H - 1; t >= 0; --t) {
       for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
         const int a = idx / n, c = idx - a * n;
         T s = T(0);
@@ -197,43 +203,46 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         qt[c] = cc * dt + s;
       }
       __syncthreads();
-      // ---- LU of Quu with partial pivoting (what numpy.linalg.solve / LAPACK gesv does) -------
-      if (tid == 0) {
-        for (int i = 0; i < nu; ++i)
-          for (int j = 0; j < nu; ++j) lu[i * nu + j] = Qt[(nx + i) * n + nx + j];
+      // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
+      // numpy.linalg.solve / LAPACK gesv) on the augmented matrix, by wave 0, wave-synchronously:
+      // LDS operations of one wave execute in order, so only the compiler needs fencing.
+      if (tid < 64) {
+        const int lane = tid;
+        for (int e = lane; e < nu * nc; e += 64) {
+          const int i = e / nc, j = e - i * nc;
+          Aug[e] = j < nu ? Qt[(nx + i) * n + nx + j] : (j < nu + nx ? Qt[(nx + i) * n + (j - nu)] : qt[nx + i]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         int sing = 0;
-        for (int c = 0; c < nu; ++c) {
+        for (int c = 0; c < nu && !sing; ++c) {
           int pr = c;
-          T best = fabs(lu[c * nu + c]);
+          T best = fabs(Aug[c * nc + c]);
           for (int i = c + 1; i < nu; ++i) {
-            const T a = fabs(lu[i * nu + c]);
+            const T a = fabs(Aug[i * nc + c]);
             if (a > best) { best = a; pr = i; }
           }
-          piv[c] = pr;
           if (pr != c)
-            for (int j = 0; j < nu; ++j) { const T tmp = lu[c * nu + j]; lu[c * nu + j] = lu[pr * nu + j]; lu[pr * nu + j] = tmp; }
-          const T d = lu[c * nu + c];
-          if (d == T(0)) { sing = 1; continue; }
-          for (int i = c + 1; i < nu; ++i) {
-            const T f = lu[i * nu + c] / d;
-            lu[i * nu + c] = f;
-            for (int j = c + 1; j < nu; ++j) lu[i * nu + j] -= f * lu[c * nu + j];
+            for (int j = lane; j < nc; j += 64) {
+              const T tmp = Aug[c * nc + j];
+              Aug[c * nc + j] = Aug[pr * nc + j];
+              Aug[pr * nc + j] = tmp;
+            }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const T d = Aug[c * nc + c];
+          if (d == T(0)) { sing = 1; break; }
+          for (int e = lane; e < nu * nc; e += 64) {         // eliminate column c from every other row
+            const int i = e / nc, j = e - i * nc;
+            if (i != c && j > c) Aug[e] -= (Aug[i * nc + c] / d) * Aug[c * nc + j];
           }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (sing) { args.status[p] = 1; scal[8] = T(1); }
-      }
-      __syncthreads();
-      // ---- solve for the nx+1 right-hand sides: columns of Qux, then qu -----------------------
-      for (int c = tid; c <= nx; c += NTHR) {
-        T* y = rhs + c * nu;
-        for (int i = 0; i < nu; ++i) y[i] = c < nx ? Qt[(nx + i) * n + c] : qt[nx + i];
-        for (int i = 0; i < nu; ++i) { const int pr = piv[i]; if (pr != i) { const T tmp = y[i]; y[i] = y[pr]; y[pr] = tmp; } }
-        for (int i = 1; i < nu; ++i) { T s = y[i]; for (int j = 0; j < i; ++j) s -= lu[i * nu + j] * y[j]; y[i] = s; }
-        for (int i = nu - 1; i >= 0; --i) { T s = y[i]; for (int j = i + 1; j < nu; ++j) s -= lu[i * nu + j] * y[j]; y[i] = s / lu[i * nu + i]; }
-        for (int i = 0; i < nu; ++i) {
-          if (c < nx) Km[i * nx + c] = -y[i];
-          else kv[i] = -y[i];
+        for (int e = lane; e < nu * (nx + 1); e += 64) {
+          const int i = e / (nx + 1), jj = e - i * (nx + 1);
+          const T val = -Aug[i * nc + nu + jj] / Aug[i * nc + i];
+          if (jj < nx) Km[i * nx + jj] = val;
+          else kv[i] = val;
         }
+        if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
       }
       __syncthreads();
       for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
@@ -249,17 +258,23 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         wq[i] = s;
         kg[(size_t)t * nu + i] = kv[i];
       }
-      if (tid == 0) {
-        T l = T(0), qd = T(0);
-        for (int i = 0; i < nu; ++i) {
-          l += qt[nx + i] * kv[i];
+      if (tid < 64) {                                        // lin += qu.k ; quad += k'Quu k ; |k|^2
+        T l = T(0), qd = T(0), k2 = T(0);
+        if (tid < nu) {
+          const T ki = kv[tid];
           T s = T(0);
-          for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
-          qd += kv[i] * s;
-          ksn2 += kv[i] * kv[i];
+          for (int j = 0; j < nu; ++j) s += Qt[(nx + tid) * n + nx + j] * kv[j];
+          l = qt[nx + tid] * ki;
+          qd = ki * s;
+          k2 = ki * ki;
         }
-        lin += l;
-        quad += qd;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {              // nu <= 16
+          l += __shfl_xor(l, off);
+          qd += __shfl_xor(qd, off);
+          k2 += __shfl_xor(k2, off);
+        }
+        if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
       }
       __syncthreads();
       for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
@@ -275,6 +290,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
         v[a] = s;
       }
+      if (t > 0) stage_step(t - 1);                          // J, xbar, ubar are not read in this phase
       __syncthreads();
     }
     if (tid == 0) { scal[0] = lin; scal[1] = quad; scal[2] = sqrt(ksn2); }
