@@ -1,5 +1,12 @@
 // autompc_hip.cpp -- host side of libautompc_hip.so: handles, weight packing, launches.
 // C ABI declared in include/autompc_hip.h.  Built with hipcc for gfx950 only.
+//
+// The file is compiled several times in parallel (csrc/build.py):
+//   -DAMPC_TU_MAIN                      the C API and all host logic (plus the tiny kernels)
+//   -DAMPC_TU_FAMILY=n -DAMPC_TU_T=T    one heavy kernel family for one precision:
+//        1 = MLP forward / Jacobian launchers, 2 = MPPI rollout / update, 3 = iLQR iteration
+// The heavy launchers are ordinary function templates with external linkage; the main unit sees
+// `extern template` declarations and the family units hold the explicit instantiations.
 #include "../../include/autompc_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -21,7 +28,11 @@ using namespace ampc;
 // ---------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
+#ifdef AMPC_TU_MAIN
+thread_local std::string g_err;
+#else
+extern thread_local std::string g_err;
+#endif
 static int fail(const std::string& msg) {
   g_err = msg;
   return -1;
@@ -132,14 +143,21 @@ static hipError_t download_converted(double* dst, const void* src, size_t n, hip
   return hipSuccess;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
+#endif  // AMPC_TU_MAIN
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_version(void) { return 100; }
+#endif  // AMPC_TU_MAIN
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle** out) {
   REQUIRE(out != nullptr, "ampc_create: out is NULL");
   REQUIRE(precision == AMPC_F64 || precision == AMPC_F32, "ampc_create: bad precision");
@@ -163,9 +181,11 @@ extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle*
   *out = h;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 static void handle_free(ampc_handle* h);
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_destroy(ampc_handle* h) {
   if (!h) return 0;
   if (h->refs > 0) {
@@ -175,6 +195,7 @@ extern "C" int ampc_destroy(ampc_handle* h) {
   handle_free(h);
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 static void handle_release(ampc_handle* h) {
   if (--h->refs == 0 && h->dead) handle_free(h);
@@ -190,13 +211,17 @@ static void handle_free(ampc_handle* h) {
   delete h;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_synchronize(ampc_handle* h) {
   REQUIRE(h, "ampc_synchronize: NULL handle");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif  // AMPC_TU_MAIN
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : -1; }
+#endif  // AMPC_TU_MAIN
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host, double) -- layouts documented in mlp_tile.hpp
@@ -319,6 +344,7 @@ template <typename T> static int build_model(ampc_handle* h) {
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
                             int activation, const double* const* weights,
                             const double* const* biases, const double* xu_mean,
@@ -341,7 +367,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   // Workgroup shape: 8 waves (two per SIMD) whenever the padded width allows whole 16-column
   // tiles per wave, else 4 waves.  (W, NT) in {(4,1), (8,1), (4,3), (8,2)} for hpad 64..256.
   h->hpad = round_up(hmax, 64);
-  h->nw = (h->hpad % 128 == 0 && env_int("AMPC_WAVES", 8) == 8) ? 8 : 4;
+  h->nw = h->hpad % 128 == 0 ? 8 : 4;
   h->nt = h->hpad / (16 * h->nw);
   h->k1p = round_up(nx + nu, 8);
   h->nxp = round_up(nx, 16);
@@ -364,7 +390,9 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   h->has_mlp = true;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
                                    const double* R, const double* F, const double* goal) {
   REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
@@ -401,7 +429,9 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
   h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
   REQUIRE(h && lo && hi, "ampc_set_ctrl_bounds: NULL argument");
   REQUIRE(h->has_mlp, "ampc_set_ctrl_bounds: set the model first");
@@ -428,6 +458,7 @@ extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const doub
   h->has_bounds = true;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 // ---------------------------------------------------------------------------------------------
 // kernel dispatch on (NT, MT)
@@ -447,8 +478,6 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
       AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
       AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
       AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
-      AMPC_CASE(4, 2, 1, __VA_ARGS__) AMPC_CASE(4, 2, 2, __VA_ARGS__) AMPC_CASE(4, 2, 4, __VA_ARGS__) \
-      AMPC_CASE(4, 4, 1, __VA_ARGS__) AMPC_CASE(4, 4, 2, __VA_ARGS__) AMPC_CASE(4, 4, 4, __VA_ARGS__) \
       AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
       default: return fail("internal: unsupported (W, NT, MT) combination");  \
     }                                                                        \
@@ -481,10 +510,34 @@ static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_r
 }
 
 // ---------------------------------------------------------------------------------------------
+// heavy launchers: declared here, defined below, instantiated in their family's translation unit
+// ---------------------------------------------------------------------------------------------
+struct ampc_mppi_plan;
+struct ampc_ilqr_plan;
+template <typename T> int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                                    double* jx, double* ju, int n);
+template <typename T> int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u,
+                                         void* x_next, int B);
+template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p);
+template <typename T> int mppi_solve_impl(ampc_mppi_plan* p);
+template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode);
+#define AMPC_HEAVY_MLP(X, T)                                                                       \
+  X template int pred_impl<T>(ampc_handle*, const double*, const double*, double*, double*, double*, int); \
+  X template int surrogate_step<T>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);      \
+  X template int ilqr_refresh_jacobians<T>(ampc_ilqr_plan*);
+#define AMPC_HEAVY_MPPI(X, T) X template int mppi_solve_impl<T>(ampc_mppi_plan*);
+#define AMPC_HEAVY_ILQR(X, T) X template int ilqr_launch_iter<T>(ampc_ilqr_plan*, int);
+#ifdef AMPC_TU_MAIN
+AMPC_HEAVY_MLP(extern, double) AMPC_HEAVY_MLP(extern, float)
+AMPC_HEAVY_MPPI(extern, double) AMPC_HEAVY_MPPI(extern, float)
+AMPC_HEAVY_ILQR(extern, double) AMPC_HEAVY_ILQR(extern, float)
+#endif
+
+// ---------------------------------------------------------------------------------------------
 // Model.pred_batch / pred_diff_batch
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
                      double* jx, double* ju, int n) {
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu;
@@ -543,6 +596,7 @@ static int pred_impl(ampc_handle* h, const double* states, const double* ctrls, 
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
                                    double* out, int n) {
   REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
@@ -552,7 +606,9 @@ extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const d
   return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
                                   : pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
                                         double* out, double* jx, double* ju, int n) {
   REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
@@ -562,6 +618,7 @@ extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, co
   return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, jx, ju, n)
                                   : pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }
+#endif  // AMPC_TU_MAIN
 
 // ---------------------------------------------------------------------------------------------
 // MPPI plan
@@ -681,6 +738,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
                                      const int* horizon, const double* sigma, const double* lmda,
                                      const int* cost_index, int term_mode, ampc_mppi_plan** out) {
@@ -723,7 +781,9 @@ extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
   *out = p;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
@@ -737,6 +797,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   handle_release(h);
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 template <typename T>
 static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq,
@@ -749,6 +810,7 @@ static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* a
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
                                 const double* eps) {
   REQUIRE(p, "ampc_mppi_upload: NULL plan");
@@ -756,6 +818,7 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
   return p->h->precision == AMPC_F64 ? mppi_upload_impl<double>(p, x0, act_seq, eps)
                                      : mppi_upload_impl<float>(p, x0, act_seq, eps);
 }
+#endif  // AMPC_TU_MAIN
 
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
@@ -772,14 +835,16 @@ template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t 
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   REQUIRE(p, "ampc_mppi_generate_eps: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_generate_impl<double>(p, seed, stream)
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
+#endif  // AMPC_TU_MAIN
 
-template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
+template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   ampc_handle* h = p->h;
   MppiArgs<T> a = make_args<T>(p);
   hipEvent_t* e = nullptr;
@@ -820,11 +885,13 @@ template <typename T> static int mppi_solve_impl(ampc_mppi_plan* p) {
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_solve(ampc_mppi_plan* p) {
   REQUIRE(p, "ampc_mppi_solve: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_solve_impl<double>(p) : mppi_solve_impl<float>(p);
 }
+#endif  // AMPC_TU_MAIN
 
 template <typename T>
 static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
@@ -847,6 +914,7 @@ static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, dou
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
                                   double* eps_out) {
   REQUIRE(p, "ampc_mppi_download: NULL plan");
@@ -857,7 +925,9 @@ extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u,
   return p->h->precision == AMPC_F64 ? mppi_download_impl<double>(p, act_seq, u, costs, eps_out)
                                      : mppi_download_impl<float>(p, act_seq, u, costs, eps_out);
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {
   REQUIRE(p && x0_dev, "ampc_mppi_set_x0_dev: NULL argument");
   HIP_OK(hipSetDevice(p->h->device));
@@ -865,7 +935,9 @@ extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {
                         hipMemcpyDeviceToDevice, p->h->stream));
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples_per_wg,
                                    double* flops, double* bytes) {
   REQUIRE(p, "ampc_mppi_plan_info: NULL plan");
@@ -892,14 +964,18 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
   if (bytes) *bytes = by;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable) {
   REQUIRE(p, "ampc_mppi_plan_set_timing: NULL plan");
   p->timing = enable != 0;
   p->ev_used = 0;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms,
                                      int* count) {
   REQUIRE(p, "ampc_mppi_plan_timing: NULL plan");
@@ -920,14 +996,17 @@ extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, doub
   p->ev_used = 0;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 #ifdef AMPC_X_PHASETIME
 // experiment only: read back the phase marks of the rollout kernel (tools/phasetime.py)
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_x_phase_marks(long long* out) {
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -1002,6 +1081,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt,
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
@@ -1023,7 +1103,9 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   *out = p;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
@@ -1036,9 +1118,10 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   handle_release(h);
   return 0;
 }
+#endif  // AMPC_TU_MAIN
 
 // Jacobians of every (problem, t) row of the nominal trajectories whose problem asked for it.
-template <typename T> static int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
+template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
   ampc_handle* h = p->h;
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
@@ -1075,7 +1158,7 @@ template <typename T> static int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
   return 0;
 }
 
-template <typename T> static int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
+template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
   AMPC_DISPATCH(h->nw, h->nt, 1, {
@@ -1128,6 +1211,7 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   return 0;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess,
                                int max_iter, double* states, double* ctrls, double* Ks, double* ks,
                                int* converged, int* iters, int* status, double* objective) {
@@ -1137,6 +1221,25 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
   return p->h->precision == AMPC_F64
              ? ilqr_solve_impl<double>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective)
              : ilqr_solve_impl<float>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective);
+}
+#endif  // AMPC_TU_MAIN
+
+// x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
+template <typename T>
+int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
+  const MlpDev<T>& sm = model_of<T>(sur);
+  const int SM = 16, stiles = (B + SM - 1) / SM;
+  TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
+  const size_t slds = (size_t)SL.extra * sizeof(T);
+  const RowMap rm{B, 0, 0, nullptr};
+  AMPC_DISPATCH(sur->nw, sur->nt, 1, {
+    auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+    HIP_OK(allow_lds(k, slds));
+    hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)x,
+                       (const T*)u, (T*)x_next, (T*)nullptr, B, stiles * SM, rm);
+  });
+  HIP_OK(hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1148,8 +1251,7 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
                             double* traj_ctrls) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
-  const MlpDev<T>& sm = model_of<T>(sur);
-  DevBuf d_obs, d_ctl, d_next, d_dummy;
+  DevBuf d_obs, d_ctl, d_next;
   HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
   HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
   HIP_OK(d_next.reserve((size_t)B * nx * sizeof(T)));
@@ -1159,10 +1261,6 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   // traj_obs[:, 0, :] = init_obs
   HIP_OK(hipMemcpy2DAsync(d_obs.p, (size_t)T1 * nx * sizeof(T), p->x0.p, (size_t)nx * sizeof(T),
                           (size_t)nx * sizeof(T), B, hipMemcpyDeviceToDevice, h->stream));
-  const int smt = 1, SM = 16, stiles = (B + SM - 1) / SM;
-  TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
-  const size_t slds = (size_t)SL.extra * sizeof(T);
-  const RowMap rm{B, 0, 0, nullptr};
   int rc = 0;
   for (int s = 0; s < n_steps && rc == 0; ++s) {
     if (eps_all) {
@@ -1174,12 +1272,8 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
     rc = mppi_solve_impl<T>(p);
     if (rc) break;
     // x_next = surrogate.pred(x, u)
-    AMPC_DISPATCH(sur->nw, sur->nt, smt, {
-      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
-      HIP_OK(allow_lds(k, slds));
-      hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)p->x0.p,
-                         (const T*)p->u_out.p, (T*)d_next.p, (T*)nullptr, B, stiles * SM, rm);
-    });
+    rc = surrogate_step<T>(h, sur, p->x0.p, p->u_out.p, d_next.p, B);
+    if (rc) break;
     const int n = B * (nx > nu ? nx : nu);
     hipLaunchKernelGGL(closed_loop_record_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, h->stream,
                        (const T*)d_next.p, (const T*)p->u_out.p, (T*)p->x0.p, (T*)d_obs.p,
@@ -1195,6 +1289,7 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   return rc;
 }
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
                                      const double* init_obs, int n_steps, uint64_t seed,
                                      const double* eps_all, double* traj_obs, double* traj_ctrls) {
@@ -1210,9 +1305,27 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
              : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls);
 }
+#endif  // AMPC_TU_MAIN
 
+#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out) {
   REQUIRE(p, "ampc_mppi_plan_set_outputs: NULL plan");
   p->keep_eps_out = keep_eps_out != 0;
   return 0;
 }
+#endif  // AMPC_TU_MAIN
+
+// ---------------------------------------------------------------------------------------------
+// explicit instantiations of the heavy launchers (one family, one precision per translation unit)
+// ---------------------------------------------------------------------------------------------
+#ifndef AMPC_TU_MAIN
+#if AMPC_TU_FAMILY == 1
+AMPC_HEAVY_MLP(, AMPC_TU_T)
+#elif AMPC_TU_FAMILY == 2
+AMPC_HEAVY_MPPI(, AMPC_TU_T)
+#elif AMPC_TU_FAMILY == 3
+AMPC_HEAVY_ILQR(, AMPC_TU_T)
+#else
+#error "define AMPC_TU_MAIN, or AMPC_TU_FAMILY (1..3) and AMPC_TU_T (double|float)"
+#endif
+#endif

@@ -1,6 +1,6 @@
 """Every kernel instantiation the dispatcher can pick -- workgroup shapes (W waves, NT tiles per
 wave) and tile heights (MT) -- checked against the oracle.  The defaults only exercise a few of
-them; the overrides AMPC_WAVES / AMPC_MT force the rest (needs MI355X)."""
+them; the override AMPC_MT forces the rest (needs MI355X)."""
 import numpy as np
 import pytest
 
@@ -13,8 +13,7 @@ from oracle.mppi import MPPIOracle
 pytestmark = pytest.mark.gpu
 
 # hidden sizes -> padded width -> (W, NT) by default:  64->(4,1) 128->(8,1) 192->(4,3) 256->(8,2)
-SHAPES = [([40, 64], None), ([100, 128], None), ([150, 192], None), ([256, 200], None),
-          ([128, 100], "4"), ([256, 256], "4")]          # with AMPC_WAVES=4: (4,2) and (4,4)
+SHAPES = [([40, 64], None), ([100, 128], None), ([150, 192], None), ([256, 200], None)]
 
 
 def _handle(p, nx, nu, act, precision):
@@ -32,8 +31,6 @@ def test_forward_and_jacobian_all_instantiations(monkeypatch, hidden, waves, mt,
     if mt == "4" and precision == "f64" and max(hidden) > 128:
         pytest.skip("f64 tile of 64 samples x 256 hidden units exceeds the 160 KB LDS (by design)")
     monkeypatch.setenv("AMPC_MT", mt)
-    if waves:
-        monkeypatch.setenv("AMPC_WAVES", waves)
     nx, nu = 11, 3
     p = omlp.random_params(nx, nu, hidden, "tanh", seed=sum(hidden))
     rng = np.random.default_rng(1)
@@ -55,8 +52,6 @@ def test_mppi_solve_all_instantiations(monkeypatch, hidden, waves, mt, precision
         pytest.skip("f64 tile of 64 samples x 256 hidden units exceeds the 160 KB LDS (by design)")
     from autompc_amd import _lib
     monkeypatch.setenv("AMPC_MT", mt)
-    if waves:
-        monkeypatch.setenv("AMPC_WAVES", waves)
     nx, nu, N, H = 9, 4, 203, 7          # N is not a multiple of any tile height
     p = omlp.random_params(nx, nu, hidden, "relu", seed=7 + sum(hidden))
     rng = np.random.default_rng(2)

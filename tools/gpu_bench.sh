@@ -25,8 +25,3 @@ AMPC_MT=2 run c3_f64_b8_mt2 --steps 50 --warmup 5 --batch 8
 AMPC_MT=1 run c3_f32_b8_mt1 --steps 50 --warmup 5 --batch 8 --precision f32
 AMPC_MT=2 run c3_f32_b8_mt2 --steps 50 --warmup 5 --batch 8 --precision f32
 AMPC_MT=4 run c3_f32_b8_mt4 --steps 50 --warmup 5 --batch 8 --precision f32
-AMPC_WAVES=4 AMPC_MT=1 run c3_f64_w4 --steps 200 --warmup 20
-AMPC_WAVES=4 AMPC_MT=1 run c3_f64_b8_w4_mt1 --steps 50 --warmup 5 --batch 8
-AMPC_WAVES=4 AMPC_MT=2 run c3_f64_b8_w4_mt2 --steps 50 --warmup 5 --batch 8
-AMPC_WAVES=4 AMPC_MT=1 run c3_f32_b8_w4_mt1 --steps 50 --warmup 5 --batch 8 --precision f32
-AMPC_WAVES=4 AMPC_MT=2 run c3_f32_b8_w4_mt2 --steps 50 --warmup 5 --batch 8 --precision f32
