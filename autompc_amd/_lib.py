@@ -40,6 +40,10 @@ SIGNATURES = {
                              POINTER(_dp), _dp, _dp, _dp, _dp]),
     "ampc_mlp_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_mlp_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
+    "ampc_set_sindy": (c_int, [c_void_p, c_int, c_int, c_int, _ip, _ip, _ip, _dp, _dp, c_int, c_double,
+                               c_int]),
+    "ampc_sindy_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
+    "ampc_sindy_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]),
     "ampc_set_ctrl_bounds": (c_int, [c_void_p, _dp, _dp]),
     "ampc_mppi_plan_create": (c_int, [c_void_p, c_int, _ip, _ip, _dp, _dp, _ip, c_int,
@@ -171,6 +175,21 @@ class Handle:
                                     wp, bp, dptr(norm[0]), dptr(norm[1]), dptr(norm[2]),
                                     dptr(norm[3])))
         self.nx, self.nu = nx, nu
+        self._sindy = False
+
+    def set_sindy(self, nx, nu, kind, arg0, arg1, param, xi, continuous, dt, strict_reference=True):
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        arg0 = np.ascontiguousarray(arg0, dtype=np.int32)
+        arg1 = np.ascontiguousarray(arg1, dtype=np.int32)
+        param, xi = as_f64(param), as_f64(xi)
+        nf = kind.shape[0]
+        if xi.shape != (nx, nf) or arg0.shape != (nf,) or arg1.shape != (nf,) or param.shape != (nf,):
+            raise ValueError("SINDy descriptor shapes are inconsistent")
+        check(self.lib.ampc_set_sindy(self._h, nx, nu, nf, iptr(kind), iptr(arg0), iptr(arg1),
+                                      dptr(param), dptr(xi), int(bool(continuous)),
+                                      float(dt or 0.0), int(bool(strict_reference))))
+        self.nx, self.nu = nx, nu
+        self._sindy = True
 
     def pred_batch(self, states, ctrls):
         states, ctrls = as_f64(states), as_f64(ctrls)
@@ -179,7 +198,9 @@ class Handle:
             raise ValueError("pred_batch: states %r / ctrls %r do not match (n,%d)/(n,%d)"
                              % (states.shape, ctrls.shape, self.nx, self.nu))
         out = np.empty((n, self.nx))
-        check(self.lib.ampc_mlp_pred_batch(self._h, dptr(states), dptr(ctrls), dptr(out), n))
+        fn = self.lib.ampc_sindy_pred_batch if getattr(self, "_sindy", False) \
+            else self.lib.ampc_mlp_pred_batch
+        check(fn(self._h, dptr(states), dptr(ctrls), dptr(out), n))
         return out
 
     def pred_diff_batch(self, states, ctrls):
@@ -190,8 +211,9 @@ class Handle:
         out = np.empty((n, self.nx))
         jx = np.empty((n, self.nx, self.nx))
         ju = np.empty((n, self.nx, self.nu))
-        check(self.lib.ampc_mlp_pred_diff_batch(self._h, dptr(states), dptr(ctrls), dptr(out),
-                                                dptr(jx), dptr(ju), n))
+        fn = self.lib.ampc_sindy_pred_diff_batch if getattr(self, "_sindy", False) \
+            else self.lib.ampc_mlp_pred_diff_batch
+        check(fn(self._h, dptr(states), dptr(ctrls), dptr(out), dptr(jx), dptr(ju), n))
         return out, jx, ju
 
     # -- cost / bounds ----------------------------------------------------------

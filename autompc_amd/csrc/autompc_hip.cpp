@@ -22,6 +22,7 @@
 #include "ilqr_kernels.hpp"
 #include "mppi_kernels.hpp"
 #include "rng_kernels.hpp"
+#include "sindy_kernels.hpp"
 
 using namespace ampc;
 
@@ -92,6 +93,11 @@ struct ampc_handle {
 
   // model (host copy, double) ---------------------------------------------------------------
   bool has_mlp = false;
+  bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
+  bool has_model() const { return has_mlp || has_sindy; }
+  int s_nfeat = 0, s_continuous = 0, s_strict = 1;
+  double s_dt = 0.0;
+  DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
   int nx = 0, nu = 0, n_hidden = 0, act = 0;
   int hidden[kMaxHidden] = {0, 0, 0, 0};
   int hpad = 0, nt = 0, nw = 4, k1p = 0, nxp = 0;  // nw = waves per workgroup (4 or 8)
@@ -117,6 +123,17 @@ struct ampc_handle {
 template <typename T> static MlpDev<T>& model_of(ampc_handle* h);
 template <> MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }
 template <> MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
+
+template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
+  SindyDev<T> m;
+  m.nx = h->nx; m.nu = h->nu; m.n_feat = h->s_nfeat; m.continuous = h->s_continuous;
+  m.strict = h->s_strict; m.dt = (T)h->s_dt;
+  const int* ip = (const int*)h->sindy_int.p;
+  m.kind = ip; m.a0 = ip + h->s_nfeat; m.a1 = ip + 2 * h->s_nfeat;
+  const T* fp = (const T*)h->sindy_flt.p;
+  m.par = fp; m.xi = fp + h->s_nfeat;
+  return m;
+}
 
 template <typename T>
 static hipError_t upload_converted(void* dst, const double* src, size_t n, hipStream_t s) {
@@ -204,7 +221,7 @@ static void handle_release(ampc_handle* h) {
 static void handle_free(ampc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->model_buf, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
+  DevBuf* bufs[] = {&h->model_buf, &h->sindy_int, &h->sindy_flt, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
                     &h->s_ctrls,   &h->s_out,      &h->s_dz,     &h->s_jx,       &h->s_ju};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -388,6 +405,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   int rc = h->precision == AMPC_F64 ? build_model<double>(h) : build_model<float>(h);
   if (rc) return rc;
   h->has_mlp = true;
+  h->has_sindy = false;
   return 0;
 }
 #endif  // AMPC_TU_MAIN
@@ -396,7 +414,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
 extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
                                    const double* R, const double* F, const double* goal) {
   REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
-  REQUIRE(h->has_mlp, "ampc_set_quad_costs: set the model first");
+  REQUIRE(h->has_model(), "ampc_set_quad_costs: set the model first");
   REQUIRE(n_costs >= 1, "ampc_set_quad_costs: n_costs < 1");
   REQUIRE(obs_dim >= 1 && obs_dim <= h->nx, "ampc_set_quad_costs: obs_dim must be <= state dim");
   HIP_OK(hipSetDevice(h->device));
@@ -434,7 +452,7 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
 #ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
   REQUIRE(h && lo && hi, "ampc_set_ctrl_bounds: NULL argument");
-  REQUIRE(h->has_mlp, "ampc_set_ctrl_bounds: set the model first");
+  REQUIRE(h->has_model(), "ampc_set_ctrl_bounds: set the model first");
   HIP_OK(hipSetDevice(h->device));
   const int nu = h->nu;
   h->lo.assign(lo, lo + nu);
@@ -626,6 +644,7 @@ extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, co
 struct ampc_mppi_plan {
   ampc_handle* h = nullptr;
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
+  int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
   std::vector<int> N, H, cost_idx, a_off;
   std::vector<double> sigma, lmda;
   std::vector<long long> eps_off, epso_off, cost_off;
@@ -684,9 +703,19 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   const MlpDev<T>& m = model_of<T>(h);
   const int nu = h->nu, nx = h->nx;
   const size_t extra = (size_t)p->max_h * nu + h->cost_stride + 3 * nu + 8;
-  p->mt = choose_mt<T>(h, m, p->sum_n, extra);
+  if (h->has_sindy) {
+    p->mt = 4;
+  } else {
+    p->mt = choose_mt<T>(h, m, p->sum_n, extra);
+  }
   const int M = 16 * p->mt;
-  p->L = tile_lds_for<T>(h, m, M, extra);
+  p->tile_m = M;
+  if (h->has_sindy) {
+    std::memset(&p->L, 0, sizeof(p->L));
+    p->L.extra = (2 * nx + nu) * 64;        // per-thread columns: [x|u] and next x
+  } else {
+    p->L = tile_lds_for<T>(h, m, M, extra);
+  }
   p->lds_aseq = p->L.extra;
   p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
   p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);
@@ -694,7 +723,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   {  // fused update: keep the tile's clipped noise [max_h][M][nu] (+ 2M reduction slots) in LDS
     const int e0 = round_up(p->lds_cost + h->cost_stride + 3 * nu, 4);
     const size_t bytes = ((size_t)e0 + (size_t)p->max_h * M * nu + 2 * M) * sizeof(T);
-    if (bytes <= kLdsLimit && env_int("AMPC_FUSED_UPDATE", 1) != 0) {
+    if (!h->has_sindy && bytes <= kLdsLimit && env_int("AMPC_FUSED_UPDATE", 1) != 0) {
       p->lds_eps = e0;
       p->lds_red = e0 + p->max_h * M * nu;
       p->lds_bytes = bytes;
@@ -743,7 +772,7 @@ extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
                                      const int* horizon, const double* sigma, const double* lmda,
                                      const int* cost_index, int term_mode, ampc_mppi_plan** out) {
   REQUIRE(h && num_path && horizon && sigma && lmda && out, "ampc_mppi_plan_create: NULL argument");
-  REQUIRE(h->has_mlp && h->n_costs > 0 && h->has_bounds,
+  REQUIRE(h->has_model() && h->n_costs > 0 && h->has_bounds,
           "ampc_mppi_plan_create: model, cost and control bounds must be set first");
   REQUIRE(B >= 1, "ampc_mppi_plan_create: B < 1");
   REQUIRE(term_mode == 0 || term_mode == 1, "ampc_mppi_plan_create: bad term_mode");
@@ -860,15 +889,21 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
     p->ev_used += 3;
     HIP_OK(hipEventRecord(e[0], h->stream));
   }
-  AMPC_DISPATCH(h->nw, h->nt, p->mt, {
-    auto k = mppi_rollout_kernel<T, NT, MT, W>;
-    HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
-  });
+  if (h->has_sindy) {
+    const SindyDev<T> sm = sindy_of<T>(h);
+    const size_t lb = ((size_t)(2 * h->nx + h->nu) * 64 + h->cost_stride + 3 * h->nu) * sizeof(T);
+    hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
+  } else {
+    AMPC_DISPATCH(h->nw, h->nt, p->mt, {
+      auto k = mppi_rollout_kernel<T, NT, MT, W>;
+      HIP_OK(allow_lds(k, p->lds_bytes));
+      hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
+    });
+  }
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
   if (p->lds_eps >= 0) {
     hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
-                       16 * p->mt);
+                       p->tile_m);
   } else {
     int maxn = 0;
     for (int n : p->N) maxn = n > maxn ? n : maxn;
@@ -943,11 +978,11 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
   REQUIRE(p, "ampc_mppi_plan_info: NULL plan");
   const ampc_handle* h = p->h;
   if (n_workgroups) *n_workgroups = p->n_tiles;
-  if (samples_per_wg) *samples_per_wg = 16 * p->mt;
+  if (samples_per_wg) *samples_per_wg = p->tile_m;
   // Algorithmic work: per sample-step 2*sum(in*out) MLP flops plus the quadratic
   // stage cost; bytes = noise in + clipped noise out + costs + weights once.
-  double macs = 0;
-  for (int l = 0; l <= h->n_hidden; ++l) {
+  double macs = h->has_sindy ? (double)h->s_nfeat * h->nx : 0.0;
+  for (int l = 0; !h->has_sindy && l <= h->n_hidden; ++l) {
     const int in = l == 0 ? h->nx + h->nu : h->hidden[l - 1];
     const int out = l == h->n_hidden ? h->nx : h->hidden[l];
     macs += (double)in * out;
@@ -1086,6 +1121,7 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
+  REQUIRE(!h->has_sindy, "ampc_ilqr_plan_create: iLQR on SINDy models is not implemented on the device");
   REQUIRE(h->has_mlp && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
@@ -1227,6 +1263,14 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
 // x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
 template <typename T>
 int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
+  if (sur->has_sindy) {
+    const SindyDev<T> sd = sindy_of<T>(sur);
+    const size_t lb = (size_t)(2 * sur->nx + sur->nu) * 64 * sizeof(T);
+    hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((B + 63) / 64), dim3(64), lb, h->stream, sd,
+                       (const T*)x, (const T*)u, (T*)x_next, B);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   const MlpDev<T>& sm = model_of<T>(sur);
   const int SM = 16, stiles = (B + SM - 1) / SM;
   TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
@@ -1296,7 +1340,7 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
   REQUIRE(p && init_obs, "ampc_mppi_closed_loop: NULL argument");
   REQUIRE(n_steps >= 1, "ampc_mppi_closed_loop: n_steps < 1");
   ampc_handle* sur = surrogate ? surrogate : p->h;
-  REQUIRE(sur->has_mlp && sur->nx == p->h->nx && sur->nu == p->h->nu,
+  REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
           "ampc_mppi_closed_loop: surrogate model must have the controller model's dimensions");
   REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
           "ampc_mppi_closed_loop: surrogate must share the plan's device and precision");
@@ -1312,6 +1356,94 @@ extern "C" int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out) {
   REQUIRE(p, "ampc_mppi_plan_set_outputs: NULL plan");
   p->keep_eps_out = keep_eps_out != 0;
   return 0;
+}
+#endif  // AMPC_TU_MAIN
+
+
+// ---------------------------------------------------------------------------------------------
+// SINDy feature-library model
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int sindy_pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                           double* jx, double* ju, int n) {
+  const int nx = h->nx, nu = h->nu;
+  const SindyDev<T> m = sindy_of<T>(h);
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const size_t lb = (size_t)(2 * nx + nu) * 64 * sizeof(T);
+  hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((n + 63) / 64), dim3(64), lb, h->stream, m,
+                     (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
+  if (jx) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, h->stream, m,
+                       (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_jx.p, (T*)h->s_ju.p, n);
+  }
+  HIP_OK(hipGetLastError());
+  if (jx) {
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
+#ifdef AMPC_TU_MAIN
+extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind,
+                              const int* arg0, const int* arg1, const double* param,
+                              const double* xi, int continuous, double dt, int strict_reference) {
+  REQUIRE(h && kind && arg0 && arg1 && param && xi, "ampc_set_sindy: NULL argument");
+  REQUIRE(nx >= 1 && nx <= 32 && nu >= 1 && nu <= kMaxNu, "ampc_set_sindy: nx in 1..32, nu in 1..16");
+  REQUIRE(n_feat >= 1 && n_feat <= 4096, "ampc_set_sindy: n_feat in 1..4096");
+  for (int k = 0; k < n_feat; ++k)
+    REQUIRE(kind[k] >= 0 && kind[k] <= 5 && arg0[k] >= 0 && arg0[k] < nx + nu && arg1[k] >= 0 &&
+                arg1[k] < nx + nu, "ampc_set_sindy: bad feature descriptor");
+  HIP_OK(hipSetDevice(h->device));
+  std::vector<int> ints(3 * (size_t)n_feat);
+  std::memcpy(ints.data(), kind, n_feat * sizeof(int));
+  std::memcpy(ints.data() + n_feat, arg0, n_feat * sizeof(int));
+  std::memcpy(ints.data() + 2 * n_feat, arg1, n_feat * sizeof(int));
+  HIP_OK(h->sindy_int.reserve(ints.size() * sizeof(int)));
+  HIP_OK(hipMemcpy(h->sindy_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<double> flt((size_t)n_feat * (nx + 1));
+  std::memcpy(flt.data(), param, n_feat * 8);
+  std::memcpy(flt.data() + n_feat, xi, (size_t)n_feat * nx * 8);
+  HIP_OK(h->sindy_flt.reserve(flt.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->nx = nx; h->nu = nu; h->s_nfeat = n_feat; h->s_continuous = continuous ? 1 : 0;
+  h->s_dt = dt; h->s_strict = strict_reference ? 1 : 0;
+  std::memset(&h->md, 0, sizeof(h->md));
+  std::memset(&h->mf, 0, sizeof(h->mf));
+  h->md.nx = h->mf.nx = nx; h->md.nu = h->mf.nu = nu; h->md.kin = h->mf.kin = nx + nu;
+  h->n_hidden = 0;
+  h->has_sindy = true;
+  h->has_mlp = false;
+  return 0;
+}
+
+extern "C" int ampc_sindy_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                     double* out, int n) {
+  REQUIRE(h && states && ctrls && out, "ampc_sindy_pred_batch: NULL argument");
+  REQUIRE(h->has_sindy, "ampc_sindy_pred_batch: no SINDy model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? sindy_pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                  : sindy_pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+}
+
+extern "C" int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                          double* out, double* jx, double* ju, int n) {
+  REQUIRE(h && states && ctrls && out && jx && ju, "ampc_sindy_pred_diff_batch: NULL argument");
+  REQUIRE(h->has_sindy, "ampc_sindy_pred_diff_batch: no SINDy model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? sindy_pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                  : sindy_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }
 #endif  // AMPC_TU_MAIN
 

@@ -1,0 +1,185 @@
+// sindy_kernels.hpp -- SINDy feature-library dynamics on gfx950 (scalar path, one thread per sample).
+//
+// x' = Theta([x,u]) Xi'            (discrete)      reference: autompc/sysid/sindy.py:173-179
+// x' = x + dt Theta([x,u]) Xi'     (continuous)
+// Theta is the reference's CustomLibrary: identity, sin/cos(f v), the four trig interaction
+// terms v_a sin(f v_b) / v_a cos(f v_b) in both argument orders, powers v^d
+// (sindy.py:134-152, basis_funcs.py:8-126).  The model is tiny (CartPole: 5 variables, 55
+// features, 4x55 coefficients): this is VALU / latency-bound plumbing for BASELINE config 1, not
+// an MFMA workload, so one thread owns one sample and keeps its state in LDS columns
+// ([i][lane]: conflict-free).  PARITY UNPINNED: pysindy is absent from the image and the
+// reference tree (see oracle/sindy.py); checked against the oracle's restatement only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mppi_kernels.hpp"
+
+namespace ampc {
+
+enum { SF_ID = 0, SF_SIN = 1, SF_COS = 2, SF_XSIN = 3, SF_XCOS = 4, SF_POW = 5 };
+
+template <typename T> struct SindyDev {
+  int nx, nu, n_feat, continuous, strict;   // strict: reproduce the reference's Jacobian quirks
+  T dt;
+  const int* kind;      // [n_feat]
+  const int* a0;        // [n_feat] first variable (the multiplier for interaction terms)
+  const int* a1;        // [n_feat] second variable (argument of sin/cos for interaction terms)
+  const T* par;         // [n_feat] frequency / exponent
+  const T* xi;          // [nx][n_feat]
+};
+
+template <typename T>
+__device__ __forceinline__ T sindy_feature(int kind, T va, T vb, T par) {
+  switch (kind) {
+    case SF_ID: return va;
+    case SF_SIN: return sin(par * va);
+    case SF_COS: return cos(par * va);
+    case SF_XSIN: return va * sin(par * vb);
+    case SF_XCOS: return va * cos(par * vb);
+    default: return pow(va, par);
+  }
+}
+
+// v: this thread's variables, element i at v[i * vs]; out: next state at out[i * os].
+template <typename T>
+__device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int vs, T* out, int os) {
+  for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
+  for (int k = 0; k < m.n_feat; ++k) {
+    const T f = sindy_feature<T>(m.kind[k], v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
+    for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
+  }
+  if (m.continuous)
+    for (int i = 0; i < m.nx; ++i) out[i * os] = v[i * vs] + m.dt * out[i * os];
+}
+
+template <typename T>
+__global__ void sindy_forward_kernel(const SindyDev<T> m, const T* __restrict__ states,
+                                     const T* __restrict__ ctrls, T* __restrict__ out, int n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x, nv = m.nx + m.nu, bs = blockDim.x;
+  const int r = blockIdx.x * bs + lane;
+  T* v = lds + lane;                       // [nv][bs]
+  T* o = lds + nv * bs + lane;             // [nx][bs]
+  if (r < n) {
+    for (int i = 0; i < m.nx; ++i) v[i * bs] = states[(size_t)r * m.nx + i];
+    for (int j = 0; j < m.nu; ++j) v[(m.nx + j) * bs] = ctrls[(size_t)r * m.nu + j];
+    sindy_step<T>(m, v, bs, o, bs);
+    for (int i = 0; i < m.nx; ++i) out[(size_t)r * m.nx + i] = o[i * bs];
+  }
+}
+
+// Jacobian of the step wrt [x, u] (sindy.py:189-244).  strict: interaction features are counted
+// twice and the polynomial gradient omits the exponent factor, as the reference computes them.
+template <typename T>
+__global__ void sindy_jacobian_kernel(const SindyDev<T> m, const T* __restrict__ states,
+                                      const T* __restrict__ ctrls, T* __restrict__ jx,
+                                      T* __restrict__ ju, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int nx = m.nx, nu = m.nu;
+  T* Jx = jx + (size_t)r * nx * nx;
+  T* Ju = ju + (size_t)r * nx * nu;
+  for (int i = 0; i < nx * nx; ++i) Jx[i] = T(0);
+  for (int i = 0; i < nx * nu; ++i) Ju[i] = T(0);
+  auto var = [&](int c) { return c < nx ? states[(size_t)r * nx + c] : ctrls[(size_t)r * nu + (c - nx)]; };
+  auto add = [&](int i, int c, T g) {
+    if (c < nx) Jx[i * nx + c] += g;
+    else Ju[i * nu + (c - nx)] += g;
+  };
+  const T twice = m.strict ? T(2) : T(1);
+  for (int k = 0; k < m.n_feat; ++k) {
+    const int kind = m.kind[k], c0 = m.a0[k], c1 = m.a1[k];
+    const T va = var(c0), vb = var(c1), par = m.par[k];
+    T g0 = T(0), g1 = T(0);
+    switch (kind) {
+      case SF_ID: g0 = T(1); break;
+      case SF_SIN: g0 = par * cos(par * va); break;
+      case SF_COS: g0 = -par * sin(par * va); break;
+      case SF_XSIN: g0 = twice * sin(par * vb); g1 = twice * va * par * cos(par * vb); break;
+      case SF_XCOS: g0 = twice * cos(par * vb); g1 = -twice * va * par * sin(par * vb); break;
+      default: g0 = (m.strict ? T(1) : par) * pow(va, par - T(1)); break;
+    }
+    for (int i = 0; i < nx; ++i) {
+      const T c = m.xi[i * m.n_feat + k];
+      add(i, c0, c * g0);
+      if (kind == SF_XSIN || kind == SF_XCOS) add(i, c1, c * g1);
+    }
+  }
+  if (m.continuous) {
+    for (int i = 0; i < nx; ++i) {
+      for (int c = 0; c < nx; ++c) Jx[i * nx + c] = (i == c ? T(1) : T(0)) + m.dt * Jx[i * nx + c];
+      for (int c = 0; c < nu; ++c) Ju[i * nu + c] *= m.dt;
+    }
+  }
+}
+
+// MPPI rollout with SINDy dynamics: one thread per sample, one wave per workgroup.  Same
+// semantics as mppi_rollout_kernel (mppi.py:120-152); costs / term_last / eps_out go to HBM and
+// mppi_update_kernel finishes the solve.
+template <typename T>
+__global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T> args,
+                                                                const SindyDev<T> m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int BS = 64;
+  const int lane = threadIdx.x, nx = m.nx, nu = m.nu, nv = nx + nu, no = args.obs_dim;
+  const int p = args.tile_prob[blockIdx.x];
+  const MppiProblem<T> pr = args.probs[p];
+  const int n = (blockIdx.x - pr.tile0) * BS + lane;
+  const int H = pr.H, N = pr.N;
+  const bool valid = n < N;
+  T* v = lds + lane;                        // [nv][BS]  x | u
+  T* o = lds + nv * BS + lane;              // [nx][BS]  next state
+  T* cpar = lds + (nv + nx) * BS;           // Q R F goal | lo hi scale (shared)
+  for (int i = lane; i < args.cost_stride; i += BS)
+    cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
+  for (int i = lane; i < 3 * nu; i += BS) cpar[args.cost_stride + i] = args.bounds[i];
+  __syncthreads();
+  const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
+  const T* goal = Fm + no * no;
+  const T* blo = cpar + args.cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
+  for (int i = 0; i < nx; ++i) v[i * BS] = args.x0[p * nx + i];
+  const T* eps_row = args.eps + pr.eps_off + (size_t)(valid ? n : 0) * H * nu;
+  T* epso = args.eps_out + pr.epso_off;
+  T c = T(0), ca = T(0);
+  for (int t = 0; t < H; ++t) {
+    const int ts = (t + 1 < H) ? t + 1 : H - 1;               // a[:-1] = a[1:]; a[-1] = a[-2]
+    for (int j = 0; j < nu; ++j) {
+      const T a = args.act_in[pr.a_off + ts * nu + j];
+      T A = (valid ? eps_row[t * nu + j] : T(0)) + a;
+      A = A < blo[j] ? blo[j] : A;
+      A = A > bhi[j] ? bhi[j] : A;
+      const T ec = A - a;
+      if (valid) epso[((size_t)t * N + n) * nu + j] = ec;
+      ca += A * ec;
+      v[(nx + j) * BS] = A * bsc[j];
+    }
+    for (int i = 0; i < no; ++i) {
+      T s = T(0);
+      for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (v[j * BS] - goal[j]);
+      c += (v[i * BS] - goal[i]) * s;
+    }
+    for (int i = 0; i < nu; ++i) {
+      T s = T(0);
+      for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[(nx + j) * BS];
+      c += v[(nx + i) * BS] * s;
+    }
+    sindy_step<T>(m, v, BS, o, BS);
+    for (int i = 0; i < nx; ++i) v[i * BS] = o[i * BS];
+  }
+  T term = T(0);
+  for (int i = 0; i < no; ++i) {
+    T s = T(0);
+    for (int j = 0; j < no; ++j) s += Fm[i * no + j] * (v[j * BS] - goal[j]);
+    term += (v[i * BS] - goal[i]) * s;
+  }
+  c += pr.lam_over_sigma * ca;
+  if (args.term_mode == 1) c += term;
+  if (valid) {
+    args.costs[pr.cost_off + n] = c;
+    if (n == N - 1) args.term_last[p] = term;
+  }
+}
+
+}  // namespace ampc

@@ -65,6 +65,24 @@ int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrl
 int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
                              double* out, double* jx, double* ju, int n);
 
+/* ---- model: SINDy feature-library dynamics (alternative to ampc_set_mlp) -------------------
+ * Replaces the inference half of autompc.sysid.SINDy (sindy.py:173-244; the fit stays on the
+ * host).  Feature k is kind[k] applied to variables v = [x, u]:
+ *   0 v_a   1 sin(p v_a)   2 cos(p v_a)   3 v_a sin(p v_b)   4 v_a cos(p v_b)   5 v_a ** p
+ * with a = arg0[k], b = arg1[k], p = param[k]; xi [nx][n_feat] are the coefficients.
+ *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'
+ * strict_reference != 0 reproduces the reference Jacobian's quirks (interaction terms counted
+ * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25).  PARITY
+ * UNPINNED: pysindy is unavailable, see oracle/sindy.py.  MPPI plans and the closed loop work on
+ * a handle holding a SINDy model; iLQR plans do not yet. */
+int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind, const int* arg0,
+                   const int* arg1, const double* param, const double* xi, int continuous,
+                   double dt, int strict_reference);
+int ampc_sindy_pred_batch(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                          int n);
+int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                               double* out, double* jx, double* ju, int n);
+
 /* ---- cost / bounds ------------------------------------------------------------------------
  * Replaces QuadCost (quad_cost.py:7-51) as read through Cost.eval_* (cost.py:66-213).
  * n_costs blocks (one per tuning candidate), each Q[no][no], R[nu][nu], F[no][no], goal[no]. */
