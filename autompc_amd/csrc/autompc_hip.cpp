@@ -1033,16 +1033,6 @@ extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, doub
 }
 #endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_X_PHASETIME
-// experiment only: read back the phase marks of the rollout kernel (tools/phasetime.py)
-#ifdef AMPC_TU_MAIN
-extern "C" int ampc_x_phase_marks(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
-  return 0;
-}
-#endif  // AMPC_TU_MAIN
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // iLQR plan
@@ -1055,7 +1045,7 @@ struct ampc_ilqr_plan {
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz;
   // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
   TileLds L{};
-  int lds_work = 0;
+  int lds_work = 0, lds_xn = 0;
   size_t lds_bytes = 0;
   int last_iterations = 0;
 };
@@ -1065,6 +1055,8 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   IlqrArgs<T> a;
   std::memset(&a, 0, sizeof(a));
   a.mlp = model_of<T>(h);
+  if (h->has_sindy) a.sindy = sindy_of<T>(h);
+  a.lds_xn = p->lds_xn;
   a.lds = p->L;
   a.lds_work = p->lds_work;
   a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
@@ -1090,7 +1082,15 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
   const IlqrWork wk = make_ilqr_work(nx, nu, h->cost_stride);
-  p->L = tile_lds_for<T>(h, m, 16, (size_t)wk.total + 8);
+  if (h->has_sindy) {
+    std::memset(&p->L, 0, sizeof(p->L));
+    p->L.xu = 0;
+    p->L.xu_stride = nx + nu + 1;
+    p->lds_xn = round_up(16 * p->L.xu_stride, 4);
+    p->L.extra = round_up(p->lds_xn + 16 * nx, 4);
+  } else {
+    p->L = tile_lds_for<T>(h, m, 16, (size_t)wk.total + 8);
+  }
   p->lds_work = p->L.extra;
   p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
   REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
@@ -1112,7 +1112,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(hipMemset(p->flags.p, 0, (size_t)5 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
-  HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
+  if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
   return 0;
 }
 
@@ -1121,8 +1121,7 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
-  REQUIRE(!h->has_sindy, "ampc_ilqr_plan_create: iLQR on SINDy models is not implemented on the device");
-  REQUIRE(h->has_mlp && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
+  REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
   HIP_OK(hipSetDevice(h->device));
@@ -1163,6 +1162,13 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
   const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
   const int n_pad = round_up(rows, 64);
   const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
+  if (h->has_sindy) {
+    hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
+                       sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,
+                       (T*)p->ju.p, rows, rm);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   {
     const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
     TileLds L = tile_lds_for<T>(h, m, M, 0);
@@ -1197,6 +1203,13 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  if (h->has_sindy) {
+    auto k = ilqr_iter_kernel<T, 1, 4, 1>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->B), dim3(256), p->lds_bytes, h->stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   AMPC_DISPATCH(h->nw, h->nt, 1, {
     auto k = ilqr_iter_kernel<T, NT, W>;
     HIP_OK(allow_lds(k, p->lds_bytes));
@@ -1380,7 +1393,8 @@ static int sindy_pred_impl(ampc_handle* h, const double* states, const double* c
     HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
     HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
     hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, h->stream, m,
-                       (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_jx.p, (T*)h->s_ju.p, n);
+                       (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_jx.p, (T*)h->s_ju.p, n,
+                       RowMap{n, 0, 0, nullptr});
   }
   HIP_OK(hipGetLastError());
   if (jx) {
@@ -1446,6 +1460,16 @@ extern "C" int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, 
                                   : sindy_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }
 #endif  // AMPC_TU_MAIN
+
+#if defined(AMPC_X_PHASETIME) && !defined(AMPC_TU_MAIN) && AMPC_TU_FAMILY == 2 && defined(AMPC_TU_F64)
+// experiment only (tools/phasetime.py): read back the phase marks of the f64 rollout kernel; lives
+// in the unit that owns that kernel because __device__ variables are per code object.
+extern "C" int ampc_x_phase_marks(long long* out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
+  return 0;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // explicit instantiations of the heavy launchers (one family, one precision per translation unit)

@@ -17,7 +17,8 @@ SOURCE = os.path.join(HERE, "autompc_hip.cpp")
 HEADERS = ["mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp",
            "rng_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
 UNITS = [("main", ["-DAMPC_TU_MAIN"])] + [
-    ("f%d_%s" % (fam, t), ["-DAMPC_TU_FAMILY=%d" % fam, "-DAMPC_TU_T=%s" % t])
+    ("f%d_%s" % (fam, t), ["-DAMPC_TU_FAMILY=%d" % fam, "-DAMPC_TU_T=%s" % t] +
+     (["-DAMPC_TU_F64=1"] if t == "double" else []))
     for fam in (1, 2, 3) for t in ("double", "float")]
 
 

@@ -23,6 +23,7 @@
 // becomes the nominal trajectory and the Jacobians stay stale (ilqr.py:208-255).
 #pragma once
 #include "mlp_tile.hpp"
+#include "sindy_kernels.hpp"
 
 namespace ampc {
 
@@ -30,6 +31,8 @@ constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows o
 
 template <typename T> struct IlqrArgs {
   MlpDev<T> mlp;
+  SindyDev<T> sindy;             // used instead of the MLP tile when the kernel is built with DYN = 1
+  int lds_xn;                    // SINDy: [16][nx] next-state scratch (elements)
   TileLds lds;
   int lds_work;                  // start of the Riccati / line-search scratch (elements)
   int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
@@ -98,7 +101,9 @@ template <typename T> __device__ __forceinline__ T block_sum_any(T v, T* scratch
   return o;
 }
 
-template <typename T, int NT, int W>
+// DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
+// thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
+template <typename T, int NT, int W, int DYN = 0>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
@@ -127,8 +132,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
 
   Net net;
-  net.prefetch0(mlp);
-  tile_load_constants<T, W>(mlp, L, lds, M);
+  if constexpr (DYN == 0) {
+    net.prefetch0(mlp);
+    tile_load_constants<T, W>(mlp, L, lds, M);
+  } else {
+    for (int i = tid; i < M * L.xu_stride; i += NTHR) lds[L.xu + i] = T(0);
+  }
   for (int i = tid; i < args.cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * args.cost_stride + i];
   for (int i = tid; i < nu; i += NTHR) {
@@ -340,11 +349,22 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     // objective: dt * (stage costs)
     obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false) +
                            quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false));
-    net.run(mlp, L, lds);
-    for (int a = r; a < nx; a += TPS) {
-      const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
-      xu[m * xs_ + a] = xn;
-      if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+    if constexpr (DYN == 0) {
+      net.run(mlp, L, lds);
+      for (int a = r; a < nx; a += TPS) {
+        const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
+        xu[m * xs_ + a] = xn;
+        if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+      }
+    } else {
+      T* xnext = lds + args.lds_xn;
+      if (r == 0) sindy_step<T>(args.sindy, xu + m * xs_, 1, xnext + m * nx, 1);
+      __syncthreads();
+      for (int a = r; a < nx; a += TPS) {
+        const T xn = xnext[m * nx + a];
+        xu[m * xs_ + a] = xn;
+        if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+      }
     }
     __syncthreads();
   }

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "mlp_kernels.hpp"
 #include "mppi_kernels.hpp"
 
 namespace ampc {
@@ -74,10 +75,13 @@ __global__ void sindy_forward_kernel(const SindyDev<T> m, const T* __restrict__ 
 template <typename T>
 __global__ void sindy_jacobian_kernel(const SindyDev<T> m, const T* __restrict__ states,
                                       const T* __restrict__ ctrls, T* __restrict__ jx,
-                                      T* __restrict__ ju, int n) {
+                                      T* __restrict__ ju, int n, const RowMap rm) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
+  if (rm.mask != nullptr && rm.mask[r / rm.grp] == 0) return;
   const int nx = m.nx, nu = m.nu;
+  states += (size_t)(r / rm.grp) * rm.s_stride + (size_t)(r % rm.grp) * nx - (size_t)r * nx;
+  ctrls += (size_t)(r / rm.grp) * rm.c_stride + (size_t)(r % rm.grp) * nu - (size_t)r * nu;
   T* Jx = jx + (size_t)r * nx * nx;
   T* Ju = ju + (size_t)r * nx * nu;
   for (int i = 0; i < nx * nx; ++i) Jx[i] = T(0);

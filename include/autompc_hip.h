@@ -73,8 +73,8 @@ int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double*
  *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'
  * strict_reference != 0 reproduces the reference Jacobian's quirks (interaction terms counted
  * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25).  PARITY
- * UNPINNED: pysindy is unavailable, see oracle/sindy.py.  MPPI plans and the closed loop work on
- * a handle holding a SINDy model; iLQR plans do not yet. */
+ * UNPINNED: pysindy is unavailable, see oracle/sindy.py.  MPPI plans, iLQR plans and the closed
+ * loop all work on a handle holding a SINDy model. */
 int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind, const int* arg0,
                    const int* arg1, const double* param, const double* xi, int continuous,
                    double dt, int strict_reference);
