@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -732,7 +733,14 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   std::vector<MppiProblem<T>> pr(p->B);
   std::vector<int> tile_prob;
   int tile = 0;
-  for (int b = 0; b < p->B; ++b) {
+  // Workgroups are dispatched in blockIdx order and a tile's run time is proportional to its
+  // horizon: hand out the longest-horizon problems first (LPT) so heterogeneous candidate batches
+  // do not end on a tail of 30-step tiles.
+  std::vector<int> order(p->B);
+  for (int b = 0; b < p->B; ++b) order[b] = b;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return p->H[a] > p->H[b]; });
+  for (int oi = 0; oi < p->B; ++oi) {
+    const int b = order[oi];
     MppiProblem<T>& q = pr[b];
     std::memset(&q, 0, sizeof(q));
     q.N = p->N[b]; q.H = p->H[b]; q.tile0 = tile; q.cost_idx = p->cost_idx[b];
