@@ -1000,7 +1000,11 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
   double f = 0, by = 0;
   for (int b = 0; b < p->B; ++b) {
     f += (double)p->N[b] * p->H[b] * (2.0 * macs + fcost);
-    by += 2.0 * h->esz() * (double)p->N[b] * p->H[b] * nu + (double)h->esz() * p->N[b];
+    const bool writes_eps = p->keep_eps_out || p->lds_eps < 0;
+    by += (writes_eps ? 2.0 : 1.0) * h->esz() * (double)p->N[b] * p->H[b] * nu   // noise in (+ out)
+          + (double)h->esz() * p->N[b];                                            // costs
+    if (p->lds_eps >= 0)   // fused update: per-tile partial sums instead of re-reading the noise
+      by += (double)h->esz() * ((p->N[b] + p->tile_m - 1) / p->tile_m) * (p->H[b] * nu + 2);
   }
   by += (double)h->esz() * (macs + 0);
   if (flops) *flops = f;
