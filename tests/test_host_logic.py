@@ -1,0 +1,150 @@
+"""Host-side plugin surface on a CPU-only machine: construction, factories, state conventions,
+pickling / deepcopy (the tuner pickles controllers, pipeline_tuner.py:216-218; Pipeline deep-copies
+the task, pipeline.py:156) -- nothing here touches the GPU, device objects are created lazily."""
+import copy
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import make_system
+
+
+class _Cfg:
+    """Stand-in for a ConfigSpace Configuration: factories only call get_dictionary()."""
+
+    def __init__(self, **kw):
+        self._d = kw
+
+    def get_dictionary(self):
+        return dict(self._d)
+
+
+def _stack(nx=3, nu=2):
+    from autompc_amd import MLP, QuadCost, Task
+    system = make_system(nx, nu, dt=0.05)
+    model = MLP(system, n_hidden_layers=2, hidden_size_1=32, hidden_size_2=48, nonlintype="tanh")
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx), goal=np.ones(nx)))
+    task.set_ctrl_bounds(-np.ones(nu), 2 * np.ones(nu))
+    task.set_num_steps(10)
+    task.set_init_obs(np.zeros(nx))
+    return system, task, model
+
+
+def test_mppi_construction_matches_reference_conventions():
+    from autompc_amd import MPPI, MPPIFactory, zeros
+    system, task, model = _stack()
+    np.random.seed(3)
+    ref_draw = np.random.normal(scale=np.sqrt(0.5), size=(7, 2))
+    np.random.seed(3)
+    ctl = MPPIFactory(system)(_Cfg(horizon=7, sigma=0.5, lmda=0.3, num_path=50), task, model)
+    assert isinstance(ctl, MPPI) and ctl.H == 7 and ctl.num_path == 50 and ctl.lmda == 0.3
+    np.testing.assert_array_equal(ctl.act_sequence, ref_draw)      # random warm start, global stream
+    np.testing.assert_array_equal(ctl.ctrl_scale, [2.0, 2.0])       # controls in units of umax
+    assert ctl.state_dim == model.state_dim + system.ctrl_dim
+    traj = zeros(system, 4)
+    traj.obs[-1] = [1, 2, 3]
+    traj.ctrls[-1] = [0.5, -0.5]
+    np.testing.assert_array_equal(ctl.traj_to_state(traj), [1, 2, 3, 0.5, -0.5])
+    first = ctl.act_sequence.copy()
+    ctl.reset()                                                      # re-draws, like __init__
+    assert ctl.act_sequence.shape == (7, 2) and not np.array_equal(ctl.act_sequence, first)
+    assert ctl.step.__func__ is not None                             # newer-upstream alias of run()
+    # factory kwargs override the configuration (controller.py:30-33)
+    ctl2 = MPPIFactory(system, horizon=9)(_Cfg(horizon=7, num_path=20), task, model)
+    assert ctl2.H == 9
+
+
+def test_ilqr_construction_and_bounds_selection():
+    from autompc_amd import IterativeLQR, IterativeLQRFactory, Task, QuadCost
+    system, task, model = _stack()
+    ctl = IterativeLQRFactory(system)(_Cfg(horizon=12), task, model)
+    assert isinstance(ctl, IterativeLQR) and ctl.horizon == 12 and ctl.reuse_feedback == 0
+    np.testing.assert_array_equal(ctl.ubounds[0], [-1, -1])          # bounded task -> clip
+    free = Task(system)
+    free.set_cost(QuadCost(system, np.eye(3), np.eye(2), np.eye(3)))
+    assert IterativeLQR(system, free, model, 5).ubounds is None
+    assert IterativeLQR(system, task, model, 5, reuse_feedback=99).reuse_feedback == 5
+    with pytest.raises(NotImplementedError):
+        IterativeLQR(system, task, model, 5, mode="barrier")
+    with pytest.raises(Exception):
+        IterativeLQR(system, task, model, 5, mode="bogus")
+
+
+def test_controllers_and_models_pickle_and_deepcopy_without_device_state():
+    from autompc_amd import MPPI, IterativeLQR
+    system, task, model = _stack()
+    np.random.seed(0)
+    ctl = MPPI(system, task, model, horizon=6, num_path=30)
+    for clone in (pickle.loads(pickle.dumps(ctl)), copy.deepcopy(ctl)):
+        np.testing.assert_array_equal(clone.act_sequence, ctl.act_sequence)
+        assert clone._plan is None and clone._handle is None and clone.H == 6
+    il = pickle.loads(pickle.dumps(IterativeLQR(system, task, model, 8)))
+    assert il.horizon == 8 and il._plan is None
+    m2 = pickle.loads(pickle.dumps(model))
+    assert m2._handle is None and all(np.array_equal(a, b) for a, b in zip(m2.weights, model.weights))
+    t2 = copy.deepcopy(task)
+    assert t2.get_cost().get_goal().tolist() == [1, 1, 1] and t2.get_num_steps() == 10
+
+
+def test_mlp_parameter_dictionary_round_trip_uses_reference_keys():
+    from autompc_amd import MLP
+    system, _, model = _stack()
+    params = model.get_parameters()
+    assert sorted(params) == ["dy_means", "dy_std", "net_state", "xu_means", "xu_std"]
+    assert sorted(params["net_state"]) == ["layers.layer0.bias", "layers.layer0.weight",
+                                           "layers.layer1.bias", "layers.layer1.weight",
+                                           "output_layer.bias", "output_layer.weight"]
+    other = MLP(system, n_hidden_layers=2, hidden_size_1=32, hidden_size_2=48, nonlintype="tanh", seed=7)
+    assert not np.array_equal(other.weights[0], model.weights[0])
+    other.set_parameters(params)
+    assert all(np.array_equal(a, b) for a, b in zip(other.weights, model.weights))
+    bad = MLP(system, n_hidden_layers=1, hidden_size_1=16)
+    with pytest.raises((ValueError, KeyError)):
+        bad.set_parameters(params)
+    assert model.is_diff and not model.is_linear and model.state_dim == 3
+
+
+def test_non_quadratic_costs_and_foreign_models_are_rejected_loudly():
+    from autompc_amd import MPPI, Task, ThresholdCost
+    system, task, model = _stack()
+
+    class Foreign:                      # a model without device staging: no silent CPU path
+        state_dim = 3
+        system = None
+    with pytest.raises(TypeError):
+        MPPI(system, task, Foreign(), horizon=5)
+    t = Task(system)
+    t.set_cost(ThresholdCost(system, np.zeros(3), (0, 2), 0.1))
+    t.set_ctrl_bounds(-np.ones(2), np.ones(2))
+    ctl = MPPI(system, t, model, horizon=5, num_path=10)
+    from autompc_amd import _lib
+    with pytest.raises((TypeError, _lib.AmpcError)):     # AmpcError: no GPU here; TypeError on one
+        ctl.run(np.zeros(5), np.zeros(3))
+
+
+def test_simulate_drives_any_controller_like_the_reference_driver():
+    from autompc_amd import simulate, Controller
+
+    class Const(Controller):
+        def __init__(self, system):
+            super().__init__(system, None, None)
+
+        def traj_to_state(self, traj):
+            return np.concatenate([traj[-1].obs, traj[-1].ctrl])
+
+        def run(self, state, new_obs):
+            u = np.array([0.5, -0.25])
+            return u, np.concatenate([new_obs, u])
+
+        @property
+        def state_dim(self):
+            return 5
+    system = make_system(3, 2)
+    traj = simulate(Const(system), np.array([1.0, 0.0, 0.0]), dynamics=lambda x, u: x + 0.1 * u.sum(),
+                    max_steps=4)
+    assert len(traj) == 5 and np.allclose(traj.ctrls[:-1], [0.5, -0.25]) and np.all(traj.ctrls[-1] == 0)
+    np.testing.assert_allclose(traj.obs[-1], [1.1, 0.1, 0.1])
+    with pytest.raises(ValueError):
+        simulate(Const(system), np.zeros(3))
