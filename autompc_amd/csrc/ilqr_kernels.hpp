@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
         const int a = idx / n, c = idx - a * n;
         T s = T(0);
+#pragma unroll 8
         for (int b = 0; b < nx; ++b) s += V[a * nx + b] * Jm[b * n + c];
         VJ[idx] = s;
       }
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
         const int c = idx / n, d = idx - c * n;
         T s = T(0);
+#pragma unroll 8
         for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * VJ[a * n + d];
         T cc = T(0);
         if (c < no && d < no) cc = (Qm[c * no + d] + Qm[d * no + c]) * dt;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
       for (int c = tid; c < n; c += NTHR) {                  // qt = ct + J' v
         T s = T(0);
+#pragma unroll 8
         for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * v[a];
         T cc = T(0);
         if (c < no) {
@@ -239,9 +242,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           const T d = Aug[c * nc + c];
           if (d == T(0)) { sing = 1; break; }
+          const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
           for (int e = lane; e < nu * nc; e += 64) {         // eliminate column c from every other row
             const int i = e / nc, j = e - i * nc;
-            if (i != c && j > c) Aug[e] -= (Aug[i * nc + c] / d) * Aug[c * nc + j];
+            if (i != c && j > c) Aug[e] -= (Aug[i * nc + c] * rd) * Aug[c * nc + j];
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
         const int a = idx / nx, b = idx - a * nx;
         T s = Qt[a * n + b];
+#pragma unroll 4
         for (int j = 0; j < nu; ++j)
           s += Qt[a * n + nx + j] * Km[j * nx + b] + Km[j * nx + a] * Qt[(nx + j) * n + b] +
                Km[j * nx + a] * Wk[j * nx + b];
