@@ -120,13 +120,17 @@ def secondary_workload(args, rank, local_rank, world):
         unit_per_step = B
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
     else:
-        from autompc_amd.tuning import CandidateEvaluator, random_candidates
+        from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
         task.set_num_steps(200)
-        cands = random_candidates(system, B, seed=rank)
+        # BASELINE config 5: one candidate list for the whole job, contiguous shards of B per GPU,
+        # scores exchanged with one all-gather (RCCL over xGMI under the nccl backend)
+        cands = random_candidates(system, B * world, seed=0)
         ev = CandidateEvaluator(system, task, model, precision=args.precision, device=local_rank)
 
         def step(i):
-            ev.evaluate(cands, n_steps=200, seed=i)
+            scores = evaluate_sharded(lambda shard: ev.evaluate(shard, n_steps=200, seed=i), cands)
+            if not np.all(np.isfinite(scores)) or scores.shape[0] != B * world:
+                raise RuntimeError("candidate scores incomplete")
         label = ("c5: %d tuning candidates (MPPI horizon/sigma/lmda/num_path + QuadCost weights from "
                  "the reference's config ranges) x 200-step closed loop per step per GPU" % B)
         unit_per_step = B * 200
