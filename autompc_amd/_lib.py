@@ -59,6 +59,10 @@ SIGNATURES = {
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_timing": (c_int, [c_void_p, _dp, _dp, _ip]),
     "ampc_mppi_closed_loop": (c_int, [c_void_p, c_void_p, _dp, c_int, c_uint64, _dp, _dp, _dp]),
+    "ampc_score_trajectories": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp, _dp, c_int,
+                                        _ip, _dp, _dp]),
+    "ampc_mppi_closed_loop_scored": (c_int, [c_void_p, c_void_p, _dp, c_int, c_uint64, _dp, c_int,
+                                             _ip, _dp, _dp, _dp, _dp]),
     "ampc_ilqr_plan_create": (c_int, [c_void_p, c_int, c_int, c_double, _ip, c_int,
                                       POINTER(c_void_p)]),
     "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
@@ -234,6 +238,24 @@ class Handle:
         lo, hi = as_f64(lo), as_f64(hi)
         check(self.lib.ampc_set_ctrl_bounds(self._h, dptr(lo), dptr(hi)))
 
+    def score_trajectories(self, terms, obs, ctrls, obs_dim=None):
+        """Cost.__call__ (cost.py:27-41) of a batch of trajectories obs [B,T,ns], ctrls [B,T,nu]
+        under the cost given as `terms` = (kinds int32[n], params f64[...]) -- see
+        autompc_amd.costs.cost_terms.  Returns scores [B]."""
+        kinds, params = terms
+        obs, ctrls = as_f64(obs), as_f64(ctrls)
+        if obs.ndim != 3 or ctrls.ndim != 3 or obs.shape[:2] != ctrls.shape[:2]:
+            raise ValueError("obs [B,T,ns] and ctrls [B,T,nu] expected")
+        B, T, ns = obs.shape
+        no = ns if obs_dim is None else int(obs_dim)
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        params = as_f64(params)
+        out = np.empty(B)
+        check(self.lib.ampc_score_trajectories(
+            self._h, B, T, ns, no, ctrls.shape[2], dptr(obs), dptr(ctrls), len(kinds),
+            kinds.ctypes.data_as(_ip), dptr(params), dptr(out)))
+        return out
+
 
 class MppiPlan:
     """Device buffers + launch geometry for a batch of independent MPPI problems."""
@@ -315,6 +337,24 @@ class MppiPlan:
                                              dptr(init_obs), int(n_steps), int(seed), dptr(eps_all),
                                              dptr(obs), dptr(ctl)))
         return obs, ctl
+
+    def closed_loop_scored(self, init_obs, n_steps, terms, seed=0, eps_all=None, surrogate=None,
+                           return_trajectories=False):
+        """closed_loop + cost(traj) on the device (eval_cfg's simulate + score,
+        pipeline_tuner.py:222-233); only the B scores come back unless return_trajectories."""
+        nx, nu = self.handle.nx, self.handle.nu
+        init_obs = self._flat(init_obs, self.B * nx, "init_obs")
+        eps_all = self._flat(eps_all, n_steps * self.sum_nhnu, "eps_all")
+        kinds = np.ascontiguousarray(terms[0], dtype=np.int32)
+        params = as_f64(terms[1])
+        scores = np.empty(self.B)
+        obs = np.empty((self.B, n_steps + 1, nx)) if return_trajectories else None
+        ctl = np.empty((self.B, n_steps + 1, nu)) if return_trajectories else None
+        check(self.lib.ampc_mppi_closed_loop_scored(
+            self._p, surrogate._h if surrogate is not None else None, dptr(init_obs), int(n_steps),
+            int(seed), dptr(eps_all), len(kinds), kinds.ctypes.data_as(_ip), dptr(params),
+            dptr(scores), dptr(obs), dptr(ctl)))
+        return (scores, obs, ctl) if return_trajectories else scores
 
     def set_outputs(self, keep_eps_out=True):
         check(self.lib.ampc_mppi_plan_set_outputs(self._p, int(bool(keep_eps_out))))

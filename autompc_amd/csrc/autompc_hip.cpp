@@ -24,6 +24,7 @@
 #include "mppi_kernels.hpp"
 #include "rng_kernels.hpp"
 #include "sindy_kernels.hpp"
+#include "score_kernels.hpp"
 
 using namespace ampc;
 
@@ -1312,12 +1313,98 @@ int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Trajectory scoring (Cost.__call__, cost.py:27-41) on device-resident trajectories
+// ---------------------------------------------------------------------------------------------
+struct ScoreSpec {
+  int n_terms = 0;
+  const int* kinds = nullptr;
+  const double* params = nullptr;
+};
+
+static int score_spec_check(const ScoreSpec& sp, int no, int nu, std::vector<int>* offs, int* total) {
+  REQUIRE(sp.n_terms >= 1 && sp.kinds && sp.params, "score: empty cost specification");
+  int o = 0;
+  offs->clear();
+  for (int k = 0; k < sp.n_terms; ++k) {
+    const int sz = score_term_size(sp.kinds[k], no, nu);
+    REQUIRE(sz >= 0, "score: unknown cost term kind (0 quad, 1 threshold, 2 box)");
+    if (sp.kinds[k] == SCORE_THRESHOLD) {
+      const double lo = sp.params[o + no], hi = sp.params[o + no + 1];
+      REQUIRE(lo >= 0 && hi <= no && lo == (double)(int)lo && hi == (double)(int)hi,
+              "score: threshold term obs_range must lie inside [0, obs_dim]");
+    }
+    offs->push_back(o);
+    o += sz;
+  }
+  *total = o;
+  return 0;
+}
+
+// d_obs [B][T1][nx], d_ctl [B][T1][nu] in compute precision on h's device -> scores [B] (host)
+template <typename T>
+static int score_device(ampc_handle* h, const void* d_obs, const void* d_ctl, int B, int T1, int nx,
+                        int nu, int no, const ScoreSpec& sp, double* scores) {
+  std::vector<int> offs;
+  int total = 0;
+  if (int rc = score_spec_check(sp, no, nu, &offs, &total)) return rc;
+  DevBuf d_int, d_par, d_out;
+  HIP_OK(d_int.reserve((size_t)2 * sp.n_terms * sizeof(int)));
+  HIP_OK(d_par.reserve((size_t)total * sizeof(T)));
+  HIP_OK(d_out.reserve((size_t)B * sizeof(T)));
+  std::vector<int> ints(sp.kinds, sp.kinds + sp.n_terms);
+  ints.insert(ints.end(), offs.begin(), offs.end());
+  HIP_OK(hipMemcpyAsync(d_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(upload_converted<T>(d_par.p, sp.params, (size_t)total, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(score_trajectories_kernel<T>, dim3(B), dim3(kWG), 0, h->stream, (const T*)d_obs,
+                     (const T*)d_ctl, T1, nx, nu, no, sp.n_terms, (const int*)d_int.p,
+                     (const int*)d_int.p + sp.n_terms, (const T*)d_par.p, (T*)d_out.p);
+  HIP_OK(hipGetLastError());
+  HIP_OK(download_converted<T>(scores, d_out.p, (size_t)B, h->stream));
+  d_int.release(); d_par.release(); d_out.release();
+  return 0;
+}
+
+#ifdef AMPC_TU_MAIN
+template <typename T>
+static int score_host_impl(ampc_handle* h, int B, int T1, int nx, int nu, int no, const double* obs,
+                           const double* ctrls, const ScoreSpec& sp, double* scores) {
+  DevBuf d_obs, d_ctl;
+  HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
+  HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
+  HIP_OK(upload_converted<T>(d_obs.p, obs, (size_t)B * T1 * nx, h->stream));
+  HIP_OK(upload_converted<T>(d_ctl.p, ctrls, (size_t)B * T1 * nu, h->stream));
+  int rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, no, sp, scores);
+  (void)hipStreamSynchronize(h->stream);
+  d_obs.release(); d_ctl.release();
+  return rc;
+}
+
+extern "C" int ampc_score_trajectories(ampc_handle* h, int n_traj, int n_rows, int state_dim,
+                                       int obs_dim, int ctrl_dim, const double* obs,
+                                       const double* ctrls, int n_terms, const int* kinds,
+                                       const double* params, double* scores) {
+  REQUIRE(h && obs && ctrls && scores, "ampc_score_trajectories: NULL argument");
+  REQUIRE(n_traj >= 1 && n_rows >= 1, "ampc_score_trajectories: empty batch");
+  REQUIRE(obs_dim >= 1 && obs_dim <= state_dim && ctrl_dim >= 1,
+          "ampc_score_trajectories: need 1 <= obs_dim <= state_dim and ctrl_dim >= 1");
+  HIP_OK(hipSetDevice(h->device));
+  ScoreSpec sp;
+  sp.n_terms = n_terms; sp.kinds = kinds; sp.params = params;
+  return h->precision == AMPC_F64
+             ? score_host_impl<double>(h, n_traj, n_rows, state_dim, ctrl_dim, obs_dim, obs, ctrls, sp, scores)
+             : score_host_impl<float>(h, n_traj, n_rows, state_dim, ctrl_dim, obs_dim, obs, ctrls, sp, scores);
+}
+#endif  // AMPC_TU_MAIN
+
+// ---------------------------------------------------------------------------------------------
 // Closed loop on a surrogate model, device resident (simulate(), utils/simulation.py:11-64)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* init_obs, int n_steps,
                             uint64_t seed, const double* eps_all, double* traj_obs,
-                            double* traj_ctrls) {
+                            double* traj_ctrls, const ScoreSpec* score = nullptr,
+                            double* scores = nullptr) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
   DevBuf d_obs, d_ctl, d_next;
@@ -1353,6 +1440,8 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
     if (traj_obs) rc = download_converted<T>(traj_obs, d_obs.p, (size_t)B * T1 * nx, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
     if (rc == 0 && traj_ctrls) rc = download_converted<T>(traj_ctrls, d_ctl.p, (size_t)B * T1 * nu, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
   }
+  if (rc == 0 && score && scores)
+    rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, h->obs_dim, *score, scores);
   (void)hipStreamSynchronize(h->stream);
   d_obs.release(); d_ctl.release(); d_next.release();
   return rc;
@@ -1373,6 +1462,31 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
   return p->h->precision == AMPC_F64
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
              : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls);
+}
+#endif  // AMPC_TU_MAIN
+
+#ifdef AMPC_TU_MAIN
+extern "C" int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surrogate,
+                                            const double* init_obs, int n_steps, uint64_t seed,
+                                            const double* eps_all, int n_terms, const int* kinds,
+                                            const double* params, double* scores, double* traj_obs,
+                                            double* traj_ctrls) {
+  REQUIRE(p && init_obs && scores, "ampc_mppi_closed_loop_scored: NULL argument");
+  REQUIRE(n_steps >= 1, "ampc_mppi_closed_loop_scored: n_steps < 1");
+  ampc_handle* sur = surrogate ? surrogate : p->h;
+  REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
+          "ampc_mppi_closed_loop_scored: surrogate model must have the controller model's dimensions");
+  REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
+          "ampc_mppi_closed_loop_scored: surrogate must share the plan's device and precision");
+  ScoreSpec sp;
+  sp.n_terms = n_terms; sp.kinds = kinds; sp.params = params;
+  std::vector<int> offs;
+  int total = 0;
+  if (int rc = score_spec_check(sp, p->h->obs_dim, p->h->nu, &offs, &total)) return rc;
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls, &sp, scores)
+             : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls, &sp, scores);
 }
 #endif  // AMPC_TU_MAIN
 

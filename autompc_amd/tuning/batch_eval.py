@@ -7,8 +7,9 @@ max_steps=task.get_num_steps())`` and scores the trajectory with ``task.get_cost
 Here a whole batch of candidates -- each an MPPI hyper-parameter set (horizon, sigma, lmda,
 num_path; mppi.py:52-63) plus QuadCost weights (quad_cost_factory.py:64-95) -- is evaluated
 at once: every control step is ONE rollout launch covering all candidates' samples, the
-surrogate step and the trajectory bookkeeping stay on the device (ampc_mppi_closed_loop), and
-only the finished trajectories come back for scoring.
+surrogate step, the trajectory bookkeeping and the task-cost score (quadratic, threshold, box
+and sums of those: ampc_mppi_closed_loop_scored) stay on the device, and only the scores come
+back.
 
 Multi-GPU.  Candidates are independent, so they are partitioned into contiguous shards, one per
 rank (one process per GPU, torch.distributed).  There is no collective on the data path; the only
@@ -19,6 +20,7 @@ import numpy as np
 
 from .. import _lib
 from ..control.mppi import _quad_cost_blocks
+from ..costs.terms import cost_terms
 
 
 def shard_bounds(n_items, rank, world):
@@ -52,6 +54,22 @@ def score_trajectories(cost, obs, ctrls):
     return out
 
 
+def _task_goal(cost, obs_dim):
+    """Goal the candidates' quadratic costs are centred on: the task cost's goal (as
+    QuadCostFactory takes it, quad_cost_factory.py:64-66); for a sum without a shared goal the
+    first term that has one; the origin if none has."""
+    if getattr(cost, "is_quad", False):
+        return _quad_cost_blocks(cost)[3]
+    for c in [cost] + list(getattr(cost, "costs", [])):
+        try:
+            g = np.asarray(c.get_goal(), dtype=np.float64)
+        except Exception:
+            continue
+        if g.shape == (obs_dim,):
+            return g.copy()
+    return np.zeros(obs_dim)
+
+
 class CandidateEvaluator:
     """Evaluates MPPI + QuadCost candidates for one (system, task, model, surrogate) on one GPU."""
 
@@ -63,8 +81,7 @@ class CandidateEvaluator:
         self.precision, self.device = precision, device
         b = task.get_ctrl_bounds()
         self.umin, self.umax = b[:, 0].copy(), b[:, 1].copy()
-        _, _, _, self.goal = _quad_cost_blocks(task.get_cost()) if getattr(
-            task.get_cost(), "is_quad", False) else (None, None, None, task.get_cost().get_goal())
+        self.goal = _task_goal(task.get_cost(), system.obs_dim)
 
     def evaluate(self, candidates, n_steps=None, seed=0, init_obs=None, eps_all=None,
                  act_init=None, return_trajectories=False):
@@ -98,9 +115,19 @@ class CandidateEvaluator:
             act_init = np.concatenate([rng.normal(scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
                                        for i, c in enumerate(candidates)])
         plan.upload(act_seq=act_init)
-        obs, ctrls = plan.closed_loop(np.tile(init_obs, (B, 1)), n_steps, seed=seed, eps_all=eps_all,
-                                      surrogate=sur)
-        scores = score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
+        try:
+            terms = cost_terms(self.task.get_cost(), no, nu)
+        except TypeError:
+            terms = None                  # a user-defined cost object: score it through its own
+        if terms is not None:             # Python interface from the downloaded trajectories
+            res = plan.closed_loop_scored(np.tile(init_obs, (B, 1)), n_steps, terms, seed=seed,
+                                          eps_all=eps_all, surrogate=sur,
+                                          return_trajectories=return_trajectories)
+            scores, obs, ctrls = res if return_trajectories else (res, None, None)
+        else:
+            obs, ctrls = plan.closed_loop(np.tile(init_obs, (B, 1)), n_steps, seed=seed,
+                                          eps_all=eps_all, surrogate=sur)
+            scores = score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
         plan.close()
         if sur is not None:
             sur.close()

@@ -153,6 +153,32 @@ int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate, const doubl
                           int n_steps, uint64_t seed, const double* eps_all, double* traj_obs,
                           double* traj_ctrls);
 
+/* ---- trajectory scoring --------------------------------------------------------------------
+ * Cost.__call__ (costs/cost.py:27-41) for n_traj finished trajectories of n_rows rows each:
+ *   score = sum_t [eval_obs_cost(obs_t) + eval_ctrl_cost(ctrl_t)] + eval_term_obs_cost(obs_last)
+ * with the task cost given as a sum of n_terms terms (SumCost._sum_results, sum_cost.py:49-54);
+ * kinds[k] selects the term, its parameters are concatenated in `params` in term order:
+ *   0 quadratic  (quad_cost.py:7-51)        Q[no*no] R[nu*nu] F[no*no] goal[no]
+ *   1 threshold  (thresh_cost.py:8-38)      goal[no] obs_range_lo obs_range_hi threshold
+ *                1 per row where max_{lo<=i<hi} |obs_i - goal_i| > threshold
+ *   2 box        (thresh_cost.py:40-83)     lower[no] upper[no]  (+-inf allowed)
+ *                1 per row where any obs_i < lower_i or obs_i > upper_i
+ * obs [n_traj][n_rows][state_dim] (the observation is the first obs_dim entries of a row),
+ * ctrls [n_traj][n_rows][ctrl_dim], scores [n_traj].  The handle only provides the device,
+ * stream and precision; no model needs to be set. */
+int ampc_score_trajectories(ampc_handle* h, int n_traj, int n_rows, int state_dim, int obs_dim,
+                            int ctrl_dim, const double* obs, const double* ctrls, int n_terms,
+                            const int* kinds, const double* params, double* scores);
+
+/* ampc_mppi_closed_loop followed by ampc_score_trajectories on the device-resident trajectories:
+ * the whole of eval_cfg's simulate + cost(traj) (pipeline_tuner.py:222-233) with only the B
+ * scores coming back.  obs_dim is the one given to ampc_set_quad_costs.  traj_obs / traj_ctrls
+ * may be NULL. */
+int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surrogate, const double* init_obs,
+                                 int n_steps, uint64_t seed, const double* eps_all, int n_terms,
+                                 const int* kinds, const double* params, double* scores,
+                                 double* traj_obs, double* traj_ctrls);
+
 /* ---- iLQR ---------------------------------------------------------------------------------
  * B independent problems of horizon H (IterativeLQR.compute_ilqr_default, ilqr.py:100-265, with
  * its constants u_threshold 1e-3, ls_max_iter 10, ls_discount 0.2, ls_cost_threshold 0.3).

@@ -57,3 +57,51 @@ class QuadCostOracle:
         (the last row's ctrl is the zero row ``simulate`` appends) + terminal."""
         return (self.obs_cost_batch(obs).sum() + self.ctrl_cost_batch(ctrls).sum()
                 + self.eval_term_obs_cost(obs[-1]))
+
+
+def score_terms(kinds, params, obs, ctrls, obs_dim=None):
+    """Cost.__call__ (cost.py:27-41) of ONE trajectory obs [T,ns], ctrls [T,nu] under a flattened
+    sum of terms (layout of include/autompc_hip.h: ampc_score_trajectories): row by row, term by
+    term, exactly as SumCost._sum_results (sum_cost.py:49-54) fans the calls out.
+      0 quad       (quad_cost.py:7-51)   1 threshold (thresh_cost.py:27-32)
+      2 box        (thresh_cost.py:73-77)"""
+    obs, ctrls = np.asarray(obs, dtype=np.float64), np.asarray(ctrls, dtype=np.float64)
+    no = obs.shape[1] if obs_dim is None else obs_dim
+    nu = ctrls.shape[1]
+    terms, o = [], 0
+    for k in kinds:
+        if k == 0:
+            n = 2 * no * no + nu * nu + no
+            p = params[o:o + n]
+            terms.append((0, QuadCostOracle(p[:no * no].reshape(no, no),
+                                            p[no * no:no * no + nu * nu].reshape(nu, nu),
+                                            p[no * no + nu * nu:2 * no * no + nu * nu].reshape(no, no),
+                                            p[2 * no * no + nu * nu:])))
+        elif k == 1:
+            n = no + 3
+            p = params[o:o + n]
+            terms.append((1, (p[:no], int(p[no]), int(p[no + 1]), p[no + 2])))
+        elif k == 2:
+            n = 2 * no
+            p = params[o:o + n]
+            terms.append((2, (p[:no], p[no:])))
+        else:
+            raise ValueError("unknown term kind %r" % (k,))
+        o += n
+    total = 0.0
+    for t in range(obs.shape[0]):
+        x, u = obs[t, :no], ctrls[t]
+        for kind, d in terms:
+            if kind == 0:
+                total += d.eval_obs_cost(x) + d.eval_ctrl_cost(u)
+            elif kind == 1:
+                goal, lo, hi, thr = d
+                dev = np.abs(x[lo:hi] - goal[lo:hi])
+                total += 1.0 if dev.size and dev.max() > thr else 0.0
+            else:
+                lo, hi = d
+                total += 1.0 if ((x < lo).any() or (x > hi).any()) else 0.0
+    for kind, d in terms:
+        if kind == 0:
+            total += d.eval_term_obs_cost(obs[-1, :no])
+    return total

@@ -346,9 +346,45 @@ def gen_closed_loop():
     save("loop_ilqr", H=12, dt=0.05, obs=traj2.obs, ctrls=traj2.ctrls, score=cost(traj2), **common)
 
 
+# ------------------------------------------------------------------- score terms
+def gen_cost_terms():
+    """Cost.__call__ of threshold / box / summed costs on a batch of trajectories."""
+    from autompc.costs import ThresholdCost, BoxThresholdCost
+    system = make_system(5, 3)
+    rng = np.random.default_rng(77)
+    goal = rng.normal(scale=0.3, size=5)
+    A = rng.normal(size=(5, 5))
+    Q, F = A @ A.T / 5 + 0.1 * rng.normal(size=(5, 5)), np.diag(rng.uniform(0.5, 2.0, size=5))
+    R = np.diag(rng.uniform(0.01, 0.1, size=3)) + 0.002
+    quad = QuadCost(system, Q, R, F, goal=goal)
+    quad2 = QuadCost(system, np.eye(5), np.eye(3), 2 * np.eye(5), goal=-goal)
+    thr_lo, thr_hi, thr = 1, 4, 0.9
+    thresh = ThresholdCost(system, goal, [thr_lo, thr_hi], thr)
+    limits = np.array([[-1.0, 1.2], [-np.inf, 0.8], [-0.7, np.inf], [-np.inf, np.inf], [-1.5, 1.5]])
+    box = BoxThresholdCost(system, limits, goal=goal)
+    B, T = 6, 9
+    obs = rng.normal(scale=0.8, size=(B, T, 5))
+    ctrls = rng.normal(size=(B, T, 3))
+    obs[0, 3, 2] = goal[2] + thr          # exactly on the threshold: not counted (strict >)
+    obs[1, 4, 0] = limits[0, 1]           # exactly on a box limit: inside
+    costs = {"quad": quad, "thresh": thresh, "box": box, "sum_tb": thresh + box,
+             "sum_all": quad + thresh + box + quad2}
+    scores = {}
+    for name, c in costs.items():
+        out = np.zeros(B)
+        for b in range(B):
+            traj = ampc.zeros(system, T)
+            traj.obs[:] = obs[b]
+            traj.ctrls[:] = ctrls[b]
+            out[b] = c(traj)
+        scores["score_" + name] = out
+    save("cost_terms", Q=Q, R=R, F=F, goal=goal, thr_range=np.array([thr_lo, thr_hi]), thr=thr,
+         limits=limits, obs=obs, ctrls=ctrls, **scores)
+
+
+GENERATORS = {"mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+              "closed_loop": gen_closed_loop, "cost_terms": gen_cost_terms}
+
 if __name__ == "__main__":
-    gen_mlp()
-    gen_cost()
-    gen_mppi()
-    gen_ilqr()
-    gen_closed_loop()
+    for name in (sys.argv[1:] or list(GENERATORS)):
+        GENERATORS[name]()

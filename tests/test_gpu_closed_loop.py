@@ -122,3 +122,35 @@ def test_device_noise_closed_loop_is_reproducible():
     # a different seed gives a different, equally valid, evaluation
     s3 = ev.evaluate([cand, cand], seed=12)
     assert np.all(np.isfinite(s3)) and not np.allclose(s1, s3)
+
+
+def test_threshold_task_cost_is_scored_on_device():
+    """Task score = quadratic + threshold + box sum (the benchmark tasks' form, e.g.
+    benchmarks/cartpole.py:51): the device score of the device trajectories equals the oracle's
+    term-by-term score of the same trajectories."""
+    from autompc_amd import QuadCost, Task
+    from autompc_amd.costs import BoxThresholdCost, ThresholdCost, cost_terms
+    from autompc_amd.tuning import CandidateEvaluator
+    from oracle.costs import score_terms
+    nx, nu, T = 4, 1, 25
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [64, 64], "tanh", seed=5)
+    goal = np.array([0.1, 0.0, -0.1, 0.0])
+    limits = np.array([[-0.5, 0.5], [-np.inf, np.inf], [-0.4, np.inf], [-2.0, 2.0]])
+    cost = (ThresholdCost(system, goal, [0, 3], 0.15) + BoxThresholdCost(system, limits)
+            + QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx), goal=goal))
+    task = Task(system)
+    task.set_cost(cost)
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    task.set_init_obs(np.array([0.4, -0.2, 0.3, 0.1]))
+    task.set_num_steps(T)
+    ev = CandidateEvaluator(system, task, _hip_model(system, p))
+    cands = [dict(horizon=8 + 2 * i, sigma=0.4, lmda=0.5, num_path=128, Q=np.full(nx, 1.0 + i),
+                  R=np.full(nu, 0.05), F=np.ones(nx)) for i in range(4)]
+    scores, obs, ctrls = ev.evaluate(cands, seed=3, return_trajectories=True)
+    terms = cost_terms(cost, nx, nu)
+    assert terms[0].tolist() == [1, 2, 0]
+    for b in range(len(cands)):
+        ref = score_terms(terms[0], terms[1], obs[b], ctrls[b])
+        assert abs(scores[b] - ref) < 1e-10 * max(1.0, abs(ref))
+    np.testing.assert_array_equal(scores, ev.evaluate(cands, seed=3))
