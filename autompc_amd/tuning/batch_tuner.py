@@ -1,0 +1,90 @@
+"""Batch ask/tell tuner over the device-resident candidate evaluator.
+
+What it replaces.  ``PipelineTuner.run`` (reference autompc/tuning/pipeline_tuner.py:151-319)
+hands SMAC one ``eval_cfg(cfg)`` at a time (:213-258) and afterwards walks SMAC's run history
+into a ``PipelineTuneResult`` (:19-21, :273-313).  Here the search proposes candidates in
+batches (``ask``), a whole batch is evaluated at once -- sharded over the ranks of the default
+``torch.distributed`` group, one GPU each -- and reported back (``tell``); the same
+``PipelineTuneResult`` fields come out, filled in evaluation order.  The proposal rule is
+random search over the reference's configuration ranges (what SMAC's initial design is);
+any other proposer can drive ``ask``/``tell`` by passing ``sampler``.
+
+Scores that are not finite (a diverged rollout) count as ``inf``, as ``eval_cfg`` does for a
+controller that raises ``LinAlgError`` (:236-239).
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from .batch_eval import evaluate_sharded, random_candidates
+
+# same fields, same order as the reference's namedtuple (pipeline_tuner.py:19-21)
+PipelineTuneResult = namedtuple("PipelineTuneResult", [
+    "inc_cfg", "cfgs", "inc_cfgs", "costs", "inc_costs", "truedyn_costs", "inc_truedyn_costs",
+    "surr_trajs", "truedyn_trajs", "surr_tune_result"])
+
+
+class BatchPipelineTuner:
+    """``evaluator.evaluate(candidates, seed=...) -> scores`` is the only thing required of the
+    evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
+
+    def __init__(self, system, evaluator, batch_size=64, sampler=None):
+        self.system, self.evaluator = system, evaluator
+        self.batch_size = int(batch_size)
+        if self.batch_size < 1:
+            raise ValueError("batch_size must be >= 1")
+        self._sampler = sampler if sampler is not None else self._random_search
+        self.reset()
+
+    def reset(self):
+        self.cfgs, self.costs, self.inc_cfgs, self.inc_costs = [], [], [], []
+        self._inc_cfg, self._inc_cost = None, float("inf")
+
+    def _random_search(self, n, rng):
+        return random_candidates(self.system, n, seed=int(rng.integers(1 << 31)))
+
+    # -- ask / tell ---------------------------------------------------------------------------
+    def ask(self, n, rng):
+        """The next `n` candidates to evaluate."""
+        cands = list(self._sampler(int(n), rng))
+        if len(cands) != n:
+            raise ValueError("sampler returned %d candidates, %d asked" % (len(cands), n))
+        return cands
+
+    def tell(self, candidates, scores):
+        """Record evaluated candidates in order; keeps the incumbent trace the reference builds
+        from SMAC's run history (pipeline_tuner.py:279-291: strict improvement replaces)."""
+        scores = np.asarray(scores, dtype=np.float64)
+        if len(candidates) != scores.shape[0]:
+            raise ValueError("one score per candidate expected")
+        for cfg, s in zip(candidates, scores):
+            s = float(s) if np.isfinite(s) else float("inf")
+            if s < self._inc_cost or self._inc_cfg is None:
+                self._inc_cost, self._inc_cfg = s, cfg
+            self.cfgs.append(cfg)
+            self.costs.append(s)
+            self.inc_cfgs.append(self._inc_cfg)
+            self.inc_costs.append(self._inc_cost)
+
+    def result(self):
+        return PipelineTuneResult(inc_cfg=self._inc_cfg, cfgs=list(self.cfgs),
+                                  inc_cfgs=list(self.inc_cfgs), costs=list(self.costs),
+                                  inc_costs=list(self.inc_costs), truedyn_costs=[],
+                                  inc_truedyn_costs=[], surr_trajs=[], truedyn_trajs=[],
+                                  surr_tune_result=None)
+
+    # -- the loop -----------------------------------------------------------------------------
+    def run(self, n_iters, rng, seed=0):
+        """Evaluate `n_iters` candidates in batches of `batch_size`.  Every rank must call this
+        with an identically seeded `rng` (proposals are drawn redundantly on every rank so that
+        no broadcast is needed); each rank evaluates its contiguous shard of every batch and the
+        scores are all-gathered.  Returns (incumbent candidate, PipelineTuneResult)."""
+        done = 0
+        while done < n_iters:
+            n = min(self.batch_size, n_iters - done)
+            batch = self.ask(n, rng)
+            scores = evaluate_sharded(
+                lambda shard, s=seed + done: self.evaluator.evaluate(shard, seed=s), batch)
+            self.tell(batch, scores)
+            done += n
+        return self._inc_cfg, self.result()

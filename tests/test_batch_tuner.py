@@ -1,0 +1,108 @@
+"""Ask/tell batch tuner: host logic on CPU, single process and
+world_size 2 over gloo.  The evaluator is a stand-in with a closed-form score; what is under test
+is proposal batching, the incumbent trace (pipeline_tuner.py:279-291) and rank agreement."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_system
+from test_sharded_eval import _free_port
+
+
+class _FormulaEvaluator:
+    """score = |log10 sigma-ish distance| -- deterministic, candidate-intrinsic."""
+
+    def __init__(self):
+        self.calls = []
+
+    def evaluate(self, candidates, seed=0):
+        self.calls.append((len(candidates), seed))
+        out = []
+        for c in candidates:
+            s = abs(c["sigma"] - 0.7) + 0.01 * c["horizon"] + float(np.sum(np.log10(c["Q"])) ** 2) * 1e-3
+            out.append(np.nan if c["horizon"] == 13 else s)      # one "diverged" family
+        return np.array(out)
+
+
+def _run(n_iters, batch):
+    from autompc_amd.tuning import BatchPipelineTuner
+    system = make_system(3, 2)
+    ev = _FormulaEvaluator()
+    tuner = BatchPipelineTuner(system, ev, batch_size=batch)
+    best, res = tuner.run(n_iters, np.random.default_rng(4), seed=10)
+    return ev, best, res
+
+
+def test_result_fields_and_incumbent_trace():
+    from autompc_amd.tuning import PipelineTuneResult
+    ev, best, res = _run(50, 16)
+    assert [n for n, _ in ev.calls] == [16, 16, 16, 2]
+    assert [s for _, s in ev.calls] == [10, 26, 42, 58]
+    assert isinstance(res, PipelineTuneResult)
+    assert res._fields == ("inc_cfg", "cfgs", "inc_cfgs", "costs", "inc_costs", "truedyn_costs",
+                           "inc_truedyn_costs", "surr_trajs", "truedyn_trajs", "surr_tune_result")
+    assert len(res.cfgs) == len(res.costs) == len(res.inc_cfgs) == len(res.inc_costs) == 50
+    assert all(np.isinf(c) for c, cfg in zip(res.costs, res.cfgs) if cfg["horizon"] == 13)
+    running = np.minimum.accumulate(res.costs)
+    np.testing.assert_array_equal(res.inc_costs, running)
+    i_best = int(np.argmin(res.costs))
+    assert res.inc_cfg is res.cfgs[i_best] and best is res.inc_cfg
+    for i in range(50):          # incumbent at i is the first candidate attaining the running min
+        assert res.inc_cfgs[i] is res.cfgs[int(np.argmin(res.costs[:i + 1]))]
+
+
+def test_batching_does_not_change_the_search():
+    _, _, a = _run(40, 40)
+    _, _, b = _run(40, 40)
+    np.testing.assert_array_equal(a.costs, b.costs)
+
+
+def test_custom_sampler_and_validation():
+    from autompc_amd.tuning import BatchPipelineTuner
+    system = make_system(3, 2)
+    fixed = [dict(horizon=5 + i, sigma=0.1 * (i + 1), lmda=1.0, num_path=100, Q=np.ones(3),
+                  R=np.ones(2), F=np.ones(3)) for i in range(6)]
+    it = iter(fixed)
+    tuner = BatchPipelineTuner(system, _FormulaEvaluator(), batch_size=4,
+                               sampler=lambda n, rng: [next(it) for _ in range(n)])
+    best, res = tuner.run(6, np.random.default_rng(0))
+    assert res.cfgs == fixed and best is fixed[int(np.argmin(res.costs))]
+    with pytest.raises(ValueError):
+        BatchPipelineTuner(system, _FormulaEvaluator(), batch_size=0)
+    bad = BatchPipelineTuner(system, _FormulaEvaluator(), sampler=lambda n, rng: [])
+    with pytest.raises(ValueError):
+        bad.run(3, np.random.default_rng(0))
+    with pytest.raises(ValueError):
+        tuner.tell(fixed[:2], [1.0])
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ev, best, res = _run(21, 8)
+    q.put((rank, res.costs, [n for n, _ in ev.calls]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_agree_and_split_the_work():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, costs, sizes = q.get(timeout=120)
+        got[rank] = (costs, sizes)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, _, single = _run(21, 8)
+    np.testing.assert_array_equal(got[0][0], single.costs)
+    np.testing.assert_array_equal(got[1][0], single.costs)
+    assert got[0][1] == [4, 4, 3] and got[1][1] == [4, 4, 2]    # shards of batches 8, 8, 5
