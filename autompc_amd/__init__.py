@@ -9,11 +9,12 @@ from .trajectory import Trajectory, TimeStep, zeros, empty, extend
 from .task import Task
 from .costs import Cost, QuadCost, SumCost, ThresholdCost, BoxThresholdCost
 
-from .sysid import Model, ModelFactory, MLP, MLPFactory, SINDy, SINDyFactory
+from .sysid import (Model, ModelFactory, MLP, MLPFactory, SINDy, SINDyFactory, ARX, ARXFactory,
+                    Koopman, KoopmanFactory)
 from .control import (Controller, ControllerFactory, MPPI, MPPIFactory, IterativeLQR,
                       IterativeLQRFactory)
 from .utils import simulate
 
-__all__ = ["Model", "ModelFactory", "MLP", "MLPFactory", "SINDy", "SINDyFactory", "Controller", "ControllerFactory",
+__all__ = ["Model", "ModelFactory", "MLP", "MLPFactory", "SINDy", "SINDyFactory", "ARX", "ARXFactory", "Koopman", "KoopmanFactory", "Controller", "ControllerFactory",
            "MPPI", "MPPIFactory", "IterativeLQR", "IterativeLQRFactory", "simulate", "System", "Trajectory", "TimeStep", "zeros", "empty", "extend", "Task",
            "Cost", "QuadCost", "SumCost", "ThresholdCost", "BoxThresholdCost"]

@@ -38,6 +38,7 @@ SIGNATURES = {
     "ampc_precision": (c_int, [c_void_p]),
     "ampc_set_mlp": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(_dp),
                              POINTER(_dp), _dp, _dp, _dp, _dp]),
+    "ampc_set_linear": (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
     "ampc_mlp_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_mlp_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_sindy": (c_int, [c_void_p, c_int, c_int, c_int, _ip, _ip, _ip, _dp, _dp, c_int, c_double,
@@ -179,6 +180,16 @@ class Handle:
                                     wp, bp, dptr(norm[0]), dptr(norm[1]), dptr(norm[2]),
                                     dptr(norm[3])))
         self.nx, self.nu = nx, nu
+        self._sindy = False
+
+    def set_linear(self, A, B):
+        """x' = A x + B u (ARX / Koopman prediction, arx.py:151-154, koopman.py:170-173)."""
+        A, B = as_f64(A), as_f64(B)
+        nx = A.shape[0]
+        if A.ndim != 2 or A.shape != (nx, nx) or B.ndim != 2 or B.shape[0] != nx:
+            raise ValueError("A must be [nx, nx] and B [nx, nu]")
+        check(self.lib.ampc_set_linear(self._h, nx, B.shape[1], dptr(A), dptr(B)))
+        self.nx, self.nu = nx, B.shape[1]
         self._sindy = False
 
     def set_sindy(self, nx, nu, kind, arg0, arg1, param, xi, continuous, dt, strict_reference=True):

@@ -108,7 +108,11 @@ class IterativeLQR(Controller):
         return u, np.concatenate([state, u])
 
     def traj_to_state(self, traj):
-        return self.model.traj_to_state(traj)
+        # model state + last control, the layout run() consumes and returns.  (The reference
+        # returns the bare model state, ilqr.py:96-98, which run() then strips one control too
+        # short, :278 -- harmless for models whose update_state ignores the old state (MLP,
+        # Koopman), a shape error for ARX.)
+        return np.concatenate([self.model.traj_to_state(traj), traj[-1].ctrl])
 
     @property
     def state_dim(self):

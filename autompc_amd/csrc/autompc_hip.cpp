@@ -372,7 +372,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   REQUIRE(nx >= 1 && nx <= 32, "ampc_set_mlp: state dim must be in 1..32");
   REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_mlp: ctrl dim must be in 1..16");
   REQUIRE(n_hidden >= 1 && n_hidden <= kMaxHidden, "ampc_set_mlp: 1..4 hidden layers");
-  REQUIRE(activation >= 0 && activation <= 3, "ampc_set_mlp: unknown activation");
+  REQUIRE(activation >= 0 && activation <= 4, "ampc_set_mlp: unknown activation");
   REQUIRE(weights && biases && xu_mean && xu_std && dy_mean && dy_std && hidden_sizes,
           "ampc_set_mlp: NULL argument");
   HIP_OK(hipSetDevice(h->device));
@@ -409,6 +409,29 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   h->has_mlp = true;
   h->has_sindy = false;
   return 0;
+}
+
+// x' = A x + B u, staged as the one-hidden-layer identity-activation network
+//   x' = x + I * ([A - I | B] [x; u])
+// so that every kernel written for the MLP (rollout, Jacobians, iLQR, closed loop) serves the
+// linear models too.  Multiplying by the identity output layer is exact; A - I rounds once.
+extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
+  REQUIRE(h && A && B, "ampc_set_linear: NULL argument");
+  REQUIRE(nx >= 1 && nx <= 32, "ampc_set_linear: state dim must be in 1..32");
+  REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_linear: ctrl dim must be in 1..16");
+  const int kin = nx + nu;
+  std::vector<double> w0((size_t)nx * kin), w1((size_t)nx * nx, 0.0), b0(nx, 0.0);
+  for (int i = 0; i < nx; ++i) {
+    for (int j = 0; j < nx; ++j) w0[(size_t)i * kin + j] = A[(size_t)i * nx + j] - (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < nu; ++j) w0[(size_t)i * kin + nx + j] = B[(size_t)i * nu + j];
+    w1[(size_t)i * nx + i] = 1.0;
+  }
+  std::vector<double> zeros(kin, 0.0), ones(kin, 1.0);
+  const double* ws[2] = {w0.data(), w1.data()};
+  const double* bs[2] = {b0.data(), b0.data()};
+  const int hidden = nx;
+  return ampc_set_mlp(h, nx, nu, 1, &hidden, 4, ws, bs, zeros.data(), ones.data(), zeros.data(),
+                      ones.data());
 }
 #endif  // AMPC_TU_MAIN
 

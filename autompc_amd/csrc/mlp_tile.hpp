@@ -63,11 +63,14 @@ template <> __device__ __forceinline__ int acc_row<double>(int q, int r) { retur
 template <> __device__ __forceinline__ int acc_row<float>(int q, int r) { return 4 * q + r; }
 
 // ---- activations (torch semantics: ReLU, Tanh, Sigmoid, SELU; mlp.py:44-51) -------------
+// kind 4 = identity: a linear model x' = A x + B u (ARX arx.py:151-154, Koopman
+// koopman.py:170-173) staged as a one-hidden-layer linear network.
 template <typename T> __device__ __forceinline__ T act_apply(int kind, T z) {
   switch (kind) {
     case 0: return z > T(0) ? z : T(0);
     case 1: return tanh(z);
     case 2: return T(1) / (T(1) + exp(-z));
+    case 4: return z;
     default: {
       const T alpha = T(1.6732632423543772848170429916717);
       const T scale = T(1.0507009873554804934193349852946);
@@ -81,6 +84,7 @@ template <typename T> __device__ __forceinline__ T act_deriv(int kind, T z) {
     case 0: return z > T(0) ? T(1) : T(0);
     case 1: { T t = tanh(z); return T(1) - t * t; }
     case 2: { T s = T(1) / (T(1) + exp(-z)); return s * (T(1) - s); }
+    case 4: return T(1);
     default: {
       const T alpha = T(1.6732632423543772848170429916717);
       const T scale = T(1.0507009873554804934193349852946);
@@ -352,6 +356,7 @@ struct TileNet {
         case 0: epilogue_k(l, acc, dst, std::integral_constant<int, 0>{}); break;
         case 1: epilogue_k(l, acc, dst, std::integral_constant<int, 1>{}); break;
         case 2: epilogue_k(l, acc, dst, std::integral_constant<int, 2>{}); break;
+        case 4: epilogue_k(l, acc, dst, std::integral_constant<int, 4>{}); break;
         default: epilogue_k(l, acc, dst, std::integral_constant<int, 3>{}); break;
       }
     };

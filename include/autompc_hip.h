@@ -51,11 +51,22 @@ int ampc_precision(const ampc_handle* h);
 /* ---- model: MLP surrogate dynamics --------------------------------------------------------
  * Replaces the state held by autompc.sysid.MLP (mlp.py:137-165 net, :308-321 parameters).
  * weights[l] is torch.nn.Linear layout [out_l][in_l]; l = 0..n_hidden (last = output layer).
- * x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)          (mlp.py:219-236) */
+ * x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)          (mlp.py:219-236)
+ * activation: 0 relu, 1 tanh, 2 sigmoid, 3 selu (mlp.py:44-51); 4 identity (ampc_set_linear). */
 int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
                  int activation, const double* const* weights, const double* const* biases,
                  const double* xu_mean, const double* xu_std, const double* dy_mean,
                  const double* dy_std);
+
+/* ---- model: linear dynamics (alternative to ampc_set_mlp) ----------------------------------
+ * x' = A x + B u with A [nx][nx], B [nx][nu] row-major: the prediction of autompc.sysid.ARX
+ * (arx.py:151-164, state = stacked observation/control history + constant 1) and
+ * autompc.sysid.Koopman (koopman.py:170-184, state = lifted observation).  The model is staged
+ * as a one-hidden-layer identity-activation network (activation code 4), so the MLP entry
+ * points below (ampc_mlp_pred_batch / _pred_diff_batch, whose Jacobians are then A and B) and
+ * every solver serve it unchanged.  Costs see the first obs_dim state entries
+ * (mppi.py:73-82, ilqr.py:124-128). */
+int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B);
 
 /* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */
 int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls, double* out,

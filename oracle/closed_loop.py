@@ -22,7 +22,10 @@ def simulate(controller, init_obs, sim_model, max_steps, traj_to_constate=None):
             else obs[0].copy()
     else:
         constate = traj_to_constate(obs[0])
-    simstate = obs[0].copy()
+    # sim_model.traj_to_state of the one-row trajectory (simulation.py:44-47): the observation
+    # itself for the MLP, a lifted / stacked state for the linear models
+    lift = getattr(sim_model, "state_from_first_obs", None)
+    simstate = lift(obs[0]) if lift is not None else obs[0].copy()
     for _ in range(max_steps):
         u, constate = controller.run(constate, obs[-1])
         simstate = sim_model.pred(simstate, u)

@@ -382,7 +382,90 @@ def gen_cost_terms():
          limits=limits, obs=obs, ctrls=ctrls, **scores)
 
 
-GENERATORS = {"mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# ----------------------------------------------------------------- linear models
+def linear_train_trajs(system, n_traj=6, T=40, seed=123):
+    """Synthetic training set: a damped, weakly nonlinear oscillator driven by random controls."""
+    no, nu = system.obs_dim, system.ctrl_dim
+    rng = np.random.default_rng(seed)
+    S = rng.normal(size=(no, no))
+    M = np.eye(no) + 0.1 * (-0.4 * np.eye(no) + 0.5 * (S - S.T))
+    G = rng.normal(scale=0.3, size=(no, nu))
+    trajs = []
+    for _ in range(n_traj):
+        traj = ampc.zeros(system, T)
+        x = rng.uniform(-1.0, 1.0, size=no)
+        for t in range(T):
+            u = rng.uniform(-1.0, 1.0, size=nu)
+            traj[t].obs[:] = x
+            traj[t].ctrl[:] = u
+            x = M @ x + 0.05 * np.sin(2.0 * x[::-1]) + G @ u
+        trajs.append(traj)
+    return trajs
+
+
+def gen_linear():
+    from autompc.sysid.arx import ARX
+    from autompc.sysid.koopman import Koopman
+    system = make_system(3, 1)
+    trajs = linear_train_trajs(system)
+    train_obs = np.stack([t.obs for t in trajs])
+    train_ctrls = np.stack([t.ctrls for t in trajs])
+    models = {
+        "arx3": quiet(ARX, system, history=3),
+        "koop_full": quiet(Koopman, system, method="lstsq", poly_basis="true", poly_degree=3,
+                           trig_basis="true", trig_freq=2, product_terms="false"),
+        "koop_lasso": quiet(Koopman, system, method="lasso", lasso_alpha=1e-4, poly_basis="true",
+                            poly_degree=2, trig_basis="false", product_terms="false"),
+    }
+    rng = np.random.default_rng(9)
+    cost = make_cost(system, "dense", 700)
+    Q, R, F = cost.get_cost_matrices()
+    for tag, model in models.items():
+        quiet(model.train, trajs)
+        ns = model.state_dim
+        states = model.traj_to_states(trajs[1])[5:21].copy()
+        ctrls = rng.uniform(-1, 1, size=(16, 1))
+        d0 = model.pred_diff(states[0], ctrls[0])
+        out = dict(A=model.A, B=model.B, state_dim=ns,
+                   state_prefix7=model.traj_to_state(trajs[0][:7]),
+                   state_prefix1=model.traj_to_state(trajs[0][:1]),
+                   states_traj1=model.traj_to_states(trajs[1]),
+                   upd_state=model.update_state(states[3], ctrls[3], trajs[2][9].obs),
+                   upd_in_obs=trajs[2][9].obs, pb_states=states, pb_ctrls=ctrls,
+                   pred_batch=model.pred_batch(states, ctrls), pred0=model.pred(states[0], ctrls[0]),
+                   diff0_pred=d0[0], diff0_jx=d0[1], diff0_ju=d0[2])
+        # closed loops through the reference's simulate(): MPPI and iLQR on the linear model
+        task = Task(system)
+        task.set_cost(cost)
+        task.set_ctrl_bound("u0", -1.0, 1.0)
+        init = np.array([0.4, -0.3, 0.2])
+        np.random.seed(21)
+        ctl = quiet(MPPI, system, task, model, horizon=8, num_path=64, sigma=0.6, lmda=0.7)
+        out["mppi_act0"] = ctl.act_sequence.copy()
+        tr = quiet(simulate, ctl, init, sim_model=model, max_steps=6, silent=True)
+        out["mppi_obs"], out["mppi_ctrls"], out["mppi_score"] = tr.obs, tr.ctrls, cost(tr)
+        task2 = Task(system)
+        task2.set_cost(cost)
+        ctl2 = IterativeLQR(system, task2, model, 10)
+        one = ampc.zeros(system, 1)
+        one[0].obs[:] = init
+        x0 = model.traj_to_state(one)
+        conv, st, ct, Ks, ks = quiet(ctl2.compute_ilqr_default, x0, np.zeros((10, 1)), silent=True)
+        out.update(ilqr_x0=x0, ilqr_converged=conv, ilqr_states=st, ilqr_ctrls=ct, ilqr_Ks=Ks,
+                   ilqr_ks=ks)
+        if not tag.startswith("arx"):
+            # (the reference's iLQR cannot be simulated on ARX: its traj_to_state omits the
+            # control that run() strips again, ilqr.py:96-98 vs :278, so update_state is handed
+            # a state one entry short)
+            tr2 = quiet(simulate, ctl2, init, sim_model=model, max_steps=5, silent=True)
+            out["ilqr_loop_obs"], out["ilqr_loop_ctrls"] = tr2.obs, tr2.ctrls
+            out["ilqr_loop_score"] = cost(tr2)
+        save("linear_" + tag, train_obs=train_obs, train_ctrls=train_ctrls, Q=Q, R=R, F=F,
+             goal=cost.get_goal(), init=init, np_seed=21, N=64, H=8, sigma=0.6, lmda=0.7,
+             ilqr_H=10, dt=system.dt, **out)
+
+
+GENERATORS = {"linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "cost_terms": gen_cost_terms}
 
 if __name__ == "__main__":

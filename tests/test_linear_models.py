@@ -1,0 +1,235 @@
+"""Linear system-ID models (ARX, Koopman) -- SURVEY.md section 8 row f3.
+
+CPU: the oracle restatement and the host classes' fitting / state construction against vectors
+made by the reference's own ARX and Koopman (gen_golden.py gen_linear).  GPU: prediction,
+Jacobians, MPPI and iLQR on the device model against the same vectors."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from helpers import make_system, rel_err
+from oracle.closed_loop import simulate as oracle_simulate
+from oracle.costs import QuadCostOracle
+from oracle.ilqr import ILQROracle
+from oracle.linear import ARXOracle, KoopmanOracle
+from oracle.mppi import MPPIOracle
+
+CASES = ["arx3", "koop_full", "koop_lasso"]
+CFG = {
+    "arx3": dict(history=3),
+    "koop_full": dict(method="lstsq", poly_basis="true", poly_degree=3, trig_basis="true",
+                      trig_freq=2, product_terms="false"),
+    "koop_lasso": dict(method="lasso", lasso_alpha=1e-4, poly_basis="true", poly_degree=2,
+                       trig_basis="false", product_terms="false"),
+}
+FIT_TOL = {"arx3": 1e-8, "koop_full": 1e-6, "koop_lasso": 1e-6}
+
+
+class _Traj:
+    def __init__(self, obs, ctrls):
+        self.obs, self.ctrls = obs, ctrls
+
+
+def _oracle(tag, g, trained=True):
+    system = make_system(3, 1, dt=float(g["dt"]))
+    c = CFG[tag]
+    if tag.startswith("arx"):
+        m = ARXOracle(system, c["history"])
+        if trained:
+            m.train(list(g["train_obs"]), list(g["train_ctrls"]))
+    else:
+        m = KoopmanOracle(system, c["poly_basis"] == "true", c["poly_degree"], c["trig_basis"] == "true")
+        if trained:
+            m.train(list(g["train_obs"]), list(g["train_ctrls"]), c["method"], c.get("lasso_alpha"))
+    return system, m
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_fit_and_state_logic_match_reference(tag):
+    g = golden("linear_" + tag)
+    system, m = _oracle(tag, g)
+    assert m.state_dim == int(g["state_dim"])
+    assert rel_err(m.A, g["A"]) < FIT_TOL[tag] and rel_err(m.B, g["B"]) < FIT_TOL[tag]
+    m.A, m.B = g["A"], g["B"]          # everything below on the reference's own matrices
+    obs0, ctl0 = g["train_obs"][0], g["train_ctrls"][0]
+    assert rel_err(m.traj_to_state(_Traj(obs0[:7], ctl0[:7])), g["state_prefix7"]) < 1e-13
+    assert rel_err(m.traj_to_state(_Traj(obs0[:1], ctl0[:1])), g["state_prefix1"]) < 1e-13
+    np.testing.assert_allclose(m.state_from_first_obs(np.array([0.4, -0.3, 0.2]))[:3], [0.4, -0.3, 0.2])
+    obs1, ctl1 = g["train_obs"][1], g["train_ctrls"][1]
+    all_states = np.array([m.traj_to_state(_Traj(obs1[:t + 1], ctl1[:t + 1])) for t in range(len(obs1))])
+    assert rel_err(all_states, g["states_traj1"]) < 1e-13
+    got = m.update_state(g["pb_states"][3], g["pb_ctrls"][3], g["upd_in_obs"])
+    assert rel_err(got, g["upd_state"]) < 1e-13
+    assert rel_err(m.pred_batch(g["pb_states"], g["pb_ctrls"]), g["pred_batch"]) < 1e-13
+    assert rel_err(m.pred(g["pb_states"][0], g["pb_ctrls"][0]), g["pred0"]) < 1e-13
+    o, a, b = m.pred_diff(g["pb_states"][0], g["pb_ctrls"][0])
+    assert rel_err(o, g["diff0_pred"]) < 1e-13
+    np.testing.assert_array_equal(a, g["diff0_jx"])
+    np.testing.assert_array_equal(b, g["diff0_ju"])
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_oracle_solvers_on_linear_models_match_reference(tag):
+    g = golden("linear_" + tag)
+    system, m = _oracle(tag, g, trained=False)
+    m.A, m.B = g["A"], g["B"]
+    cost = QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"])
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPIOracle(m, cost, np.array([[-1.0, 1.0]]), horizon=int(g["H"]), num_path=int(g["N"]),
+                     sigma=float(g["sigma"]), lmda=float(g["lmda"]))
+    np.testing.assert_allclose(ctl.act_sequence, g["mppi_act0"], rtol=0, atol=0)
+    lift = m.state_from_first_obs
+    obs, ctrls = oracle_simulate(ctl, g["init"], m, 6,
+                                 traj_to_constate=lambda o: np.concatenate([lift(o), np.zeros(1)]))
+    assert rel_err(obs, g["mppi_obs"]) < 1e-9 and rel_err(ctrls, g["mppi_ctrls"]) < 1e-9
+    assert abs(cost.traj_cost(obs, ctrls) - g["mppi_score"]) < 1e-8 * abs(g["mppi_score"])
+    il = ILQROracle(m, cost, float(g["dt"]), int(g["ilqr_H"]))
+    conv, st, ct, Ks, ks = il.solve(g["ilqr_x0"], np.zeros((int(g["ilqr_H"]), 1)))
+    assert conv == bool(g["ilqr_converged"])
+    assert rel_err(st, g["ilqr_states"]) < 1e-7 and rel_err(ct, g["ilqr_ctrls"]) < 1e-7
+    assert rel_err(Ks, g["ilqr_Ks"]) < 1e-6
+    if "ilqr_loop_obs" in g:
+        il2 = ILQROracle(m, cost, float(g["dt"]), int(g["ilqr_H"]))
+        obs, ctrls = oracle_simulate(il2, g["init"], m, 5, traj_to_constate=lift)
+        assert rel_err(obs, g["ilqr_loop_obs"]) < 1e-7 and rel_err(ctrls, g["ilqr_loop_ctrls"]) < 1e-6
+
+
+def _host_model(tag, g, **kw):
+    from autompc_amd import ARX, Koopman
+    system = make_system(3, 1, dt=float(g["dt"]))
+    cls = ARX if tag.startswith("arx") else Koopman
+    return system, cls(system, **CFG[tag], **kw)
+
+
+def _trajs(system, g):
+    from autompc_amd import Trajectory
+    return [Trajectory(system, o.shape[0], o.copy(), c.copy())
+            for o, c in zip(g["train_obs"], g["train_ctrls"])]
+
+
+@pytest.mark.parametrize("tag", CASES)
+def test_host_classes_fit_and_state_logic_match_reference(tag):
+    g = golden("linear_" + tag)
+    system, m = _host_model(tag, g)
+    trajs = _trajs(system, g)
+    m.train(trajs)
+    assert m.state_dim == int(g["state_dim"]) and m.is_linear and m.is_diff
+    assert rel_err(m.A, g["A"]) < FIT_TOL[tag] and rel_err(m.B, g["B"]) < FIT_TOL[tag]
+    p = m.get_parameters()
+    m2 = _host_model(tag, g)[1]
+    m2.set_parameters(p)
+    np.testing.assert_array_equal(m2.A, m.A)
+    np.testing.assert_array_equal(m2.B, m.B)
+    if tag.startswith("arx"):
+        m.set_parameters({"coeffs": np.concatenate([g["A"][:3], g["B"][:3]], axis=1)})
+        np.testing.assert_array_equal(m.A, g["A"])
+        np.testing.assert_array_equal(m.B, g["B"])
+    else:
+        m.set_parameters({"A": g["A"], "B": g["B"]})
+    assert rel_err(m.traj_to_state(trajs[0][:7]), g["state_prefix7"]) < 1e-13
+    assert rel_err(m.traj_to_state(trajs[0][:1]), g["state_prefix1"]) < 1e-13
+    assert rel_err(m.traj_to_states(trajs[1]), g["states_traj1"]) < 1e-13
+    got = m.update_state(g["pb_states"][3], g["pb_ctrls"][3], g["upd_in_obs"])
+    assert rel_err(got, g["upd_state"]) < 1e-13
+    a, b = m.to_linear()
+    np.testing.assert_array_equal(a, g["A"])
+    a[0, 0] += 1.0
+    assert m.A[0, 0] == g["A"][0, 0]                       # copies, as the reference returns
+
+
+def test_koopman_documented_basis_and_validation():
+    from autompc_amd import Koopman
+    system = make_system(2, 1)
+    strict = Koopman(system, poly_basis=True, poly_degree=3, trig_basis=True, trig_freq=2)
+    assert strict.basis == [(0, 1), (1, 3), (1, 3), (2, 3), (3, 3), (2, 3), (3, 3), (2, 3), (3, 3)]
+    fixed = Koopman(system, poly_basis=True, poly_degree=3, trig_basis=True, trig_freq=2,
+                    strict_reference=False)
+    assert fixed.basis == [(0, 1), (1, 2), (1, 3), (2, 1), (3, 1), (2, 2), (3, 2)]
+    x = np.array([0.3, -0.5])
+    np.testing.assert_allclose(fixed._apply_basis(x)[2:6], np.concatenate([x ** 2, x ** 3]))
+    with pytest.raises(ValueError):
+        Koopman(system, method="bogus")
+    with pytest.raises(NotImplementedError):
+        Koopman(system, method="stable").train([])  # noqa
+
+
+# ------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("tag", CASES)
+def test_device_prediction_and_jacobians(tag, precision):
+    g = golden("linear_" + tag)
+    _, m = _host_model(tag, g, precision=precision)
+    if tag.startswith("arx"):
+        m.set_parameters({"coeffs": np.concatenate([g["A"][:3], g["B"][:3]], axis=1)})
+    else:
+        m.set_parameters({"A": g["A"], "B": g["B"]})
+    tol = 1e-13 if precision == "f64" else 3e-6
+    assert rel_err(m.pred_batch(g["pb_states"], g["pb_ctrls"]), g["pred_batch"]) < tol
+    assert rel_err(m.pred(g["pb_states"][0], g["pb_ctrls"][0]), g["pred0"]) < tol
+    o, jx, ju = m.pred_diff_batch(g["pb_states"], g["pb_ctrls"])
+    assert rel_err(o, g["pred_batch"]) < tol
+    for i in range(jx.shape[0]):
+        assert rel_err(jx[i], g["A"]) < tol and rel_err(ju[i], g["B"]) < tol
+    o0, a0, b0 = m.pred_diff(g["pb_states"][0], g["pb_ctrls"][0])
+    assert rel_err(o0, g["diff0_pred"]) < tol and rel_err(a0, g["diff0_jx"]) < tol
+
+
+def _task(system, g, bounded):
+    from autompc_amd import QuadCost, Task
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    if bounded:
+        task.set_ctrl_bound("u0", -1.0, 1.0)
+    return task
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_device_mppi_closed_loop_matches_reference(tag):
+    from autompc_amd import MPPI, simulate
+    g = golden("linear_" + tag)
+    system, m = _host_model(tag, g)
+    m.set_parameters({"coeffs": np.concatenate([g["A"][:3], g["B"][:3]], axis=1)}
+                     if tag.startswith("arx") else {"A": g["A"], "B": g["B"]})
+    task = _task(system, g, True)
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPI(system, task, m, horizon=int(g["H"]), num_path=int(g["N"]), sigma=float(g["sigma"]),
+               lmda=float(g["lmda"]))
+    np.testing.assert_allclose(ctl.act_sequence, g["mppi_act0"], rtol=0, atol=0)
+    traj = simulate(ctl, g["init"], sim_model=m, max_steps=6)
+    assert rel_err(traj.obs, g["mppi_obs"]) < 1e-8 and rel_err(traj.ctrls, g["mppi_ctrls"]) < 1e-8
+    assert abs(task.get_cost()(traj) - g["mppi_score"]) < 1e-7 * abs(g["mppi_score"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_device_ilqr_matches_reference(tag):
+    from autompc_amd import IterativeLQR, simulate
+    g = golden("linear_" + tag)
+    system, m = _host_model(tag, g)
+    m.set_parameters({"coeffs": np.concatenate([g["A"][:3], g["B"][:3]], axis=1)}
+                     if tag.startswith("arx") else {"A": g["A"], "B": g["B"]})
+    H = int(g["ilqr_H"])
+    ctl = IterativeLQR(system, _task(system, g, False), m, H)
+    conv, st, ct, Ks, ks = ctl.compute_ilqr_default(g["ilqr_x0"], np.zeros((H, 1)))
+    assert conv == bool(g["ilqr_converged"])
+    assert rel_err(st, g["ilqr_states"]) < 1e-6 and rel_err(ct, g["ilqr_ctrls"]) < 1e-6
+    assert rel_err(Ks, g["ilqr_Ks"]) < 1e-5
+    # closed loop; on ARX this is a path the reference itself cannot run (see IterativeLQR
+    # .traj_to_state), so only the Koopman cases have reference vectors
+    traj = simulate(ctl, g["init"], sim_model=m, max_steps=5)
+    if "ilqr_loop_obs" in g:
+        assert rel_err(traj.obs, g["ilqr_loop_obs"]) < 1e-6
+        assert rel_err(traj.ctrls, g["ilqr_loop_ctrls"]) < 1e-5
+    else:
+        assert traj.obs.shape == (6, 3) and np.all(np.isfinite(traj.obs))
+
+
+@pytest.mark.gpu
+def test_device_rejects_oversized_linear_state():
+    from autompc_amd import _lib
+    h = _lib.Handle(0, "f64")
+    with pytest.raises(_lib.AmpcError):
+        h.set_linear(np.eye(33), np.zeros((33, 1)))
+    h.close()
