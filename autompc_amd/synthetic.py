@@ -8,7 +8,7 @@ keeps 30-step rollouts bounded.
 import numpy as np
 
 from .costs import QuadCost
-from .sysid import MLP
+from .sysid import ARX, MLP
 from .system import System
 from .task import Task
 
@@ -18,6 +18,11 @@ WORKLOADS = {
                nx=2, nu=1, hidden=[64, 64], num_path=1024, horizon=30, bound=2.0),
     "c3": dict(label="HalfCheetah (17-dim state, 6-dim ctrl), MLP 2x256, MPPI 4096 samples x 30 horizon",
                nx=17, nu=6, hidden=[256, 256], num_path=4096, horizon=30, bound=1.0),
+    # a linear model through the same rollout kernel.  CartPole-sized ARX,
+    # history 4 => model state 4*4 + 3*1 + 1 = 20 entries, cost on the 4 observations.
+    "arx": dict(label="CartPole-sized ARX (history 4, 20-dim model state, 4 obs, 1 ctrl), "
+                      "MPPI 1024 samples x 30 horizon",
+                obs=4, nu=1, history=4, num_path=1024, horizon=30, bound=1.0),
 }
 
 
@@ -33,9 +38,33 @@ def random_mlp_params(nx, nu, hidden, seed=0, dy_std=0.1):
                 xu_std=np.ones(nx + nu), dy_means=np.zeros(nx), dy_std=np.full(nx, dy_std))
 
 
+def _make_arx_workload(spec, precision, device, seed):
+    no, nu, k = spec["obs"], spec["nu"], spec["history"]
+    system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
+    model = ARX(system, history=k, precision=precision, device=device)
+    rng = np.random.default_rng(seed)
+    # a stable random regression: obs' = 0.9 obs + small lag / control / constant terms
+    coeffs = rng.normal(scale=0.03, size=(no, model._get_fvec_size()))
+    coeffs[:, :no] += 0.9 * np.eye(no)
+    coeffs[:, -nu:] = rng.normal(scale=0.2, size=(no, nu))
+    model.set_parameters({"coeffs": coeffs})
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(no), 0.01 * np.eye(nu), np.eye(no), goal=np.zeros(no)))
+    task.set_ctrl_bounds(np.full(nu, -spec["bound"]), np.full(nu, spec["bound"]))
+    init = rng.uniform(-0.1, 0.1, size=no)
+    task.set_init_obs(init)
+    from .trajectory import zeros
+    one = zeros(system, 1)
+    one.obs[0, :] = init
+    return system, task, model, dict(spec, nx=model.state_dim, hidden=[], linear=(model.A, model.B),
+                                     x0=model.traj_to_state(one))
+
+
 def make_workload(name, precision="f64", device=0, seed=0):
     """(system, task, model, spec) for a named BASELINE configuration."""
     spec = WORKLOADS[name]
+    if name == "arx":
+        return _make_arx_workload(spec, precision, device, seed)
     nx, nu = spec["nx"], spec["nu"]
     system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
     p = random_mlp_params(nx, nu, spec["hidden"], seed=seed)

@@ -35,8 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "arx"],
                     help="c3 (default, headline): HalfCheetah MPPI 4096x30; c2: Pendulum MPPI; "
+                         "arx: MPPI on a linear ARX model (SURVEY 8 f3); "
                          "c4: HalfCheetah iLQR H=50, --batch problems per step; c5: --batch tuning "
                          "candidates x 200-step closed loop per step")
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
@@ -58,17 +59,24 @@ def cpu_baseline(workload, spec, n_solves):
     from oracle.mppi import MPPIOracle
     from autompc_amd import System
     nx, nu = spec["nx"], spec["nu"]
-    p = spec["params"]
-    params = make_params(p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"],
-                         p["dy_means"], p["dy_std"])
-    system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
-    cost = QuadCostOracle(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+    no = spec.get("obs", nx)
+    system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
+    if "linear" in spec:
+        from oracle.linear import ARXOracle
+        model = ARXOracle(system, spec["history"], *spec["linear"])
+        x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=no)
+        cs = np.concatenate([model.state_from_first_obs(x0), np.zeros(nu)])
+    else:
+        p = spec["params"]
+        model = MLPOracle(system, make_params(p["weights"], p["biases"], "relu", p["xu_means"],
+                                              p["xu_std"], p["dy_means"], p["dy_std"]))
+        x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
+        cs = np.concatenate([x0, np.zeros(nu)])
+    cost = QuadCostOracle(np.eye(no), 0.01 * np.eye(nu), np.eye(no), np.zeros(no))
     bnd = np.tile([-spec["bound"], spec["bound"]], (nu, 1))
     np.random.seed(0)
-    ctl = MPPIOracle(MLPOracle(system, params), cost, bnd, horizon=spec["horizon"],
+    ctl = MPPIOracle(model, cost, bnd, horizon=spec["horizon"],
                      num_path=spec["num_path"], sigma=1.0, lmda=1.0, strict_reference=True)
-    x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
-    cs = np.concatenate([x0, np.zeros(nu)])
     u, cs = ctl.run(cs, x0)                      # warm-up (BLAS threads, caches)
     if n_solves <= 0:
         t0 = time.perf_counter()
@@ -234,7 +242,9 @@ def main():
         nx, nu, N, H = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"]
         B = args.batch
         rng = np.random.default_rng(1000 + rank)
-        x0 = np.tile(task.get_init_obs(), (B, 1)) + rng.uniform(-0.01, 0.01, size=(B, nx))
+        x0 = np.tile(spec.get("x0", task.get_init_obs()), (B, 1))
+        if "linear" not in spec:      # (an ARX state repeats the observation: leave it consistent)
+            x0 = x0 + rng.uniform(-0.01, 0.01, size=(B, nx))
         np.random.seed(rank)
         act0 = np.random.normal(size=(B * H * nu))
         eps0 = np.random.normal(size=(B * N * H * nu)) if args.noise == "resident" else None
@@ -277,7 +287,8 @@ def main():
             h, plan, task, spec = build_plan(prec, 1)
             N, H, nu = spec["num_path"], spec["horizon"], spec["nu"]
             r = np.random.default_rng(7)
-            plan.upload(task.get_init_obs(), r.normal(size=H * nu), r.normal(size=N * H * nu))
+            plan.upload(spec.get("x0", task.get_init_obs()), r.normal(size=H * nu),
+                        r.normal(size=N * H * nu))
             plan.solve()
             a, _, c, _ = plan.download(costs=True)
             res[prec] = (a, c)
@@ -294,6 +305,8 @@ def main():
         solves = world * args.steps * B
         value = solves / elapsed
         rollout_s = kt["rollout_ms"] * 1e-3
+        if "linear" in spec:          # algorithmic work of x' = A x + B u, not of its staging
+            info["flops"] = float(B * N * H * 2 * nx * (nx + nu))
         achieved = info["flops"] / rollout_s / 1e12 if rollout_s > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         out = {
@@ -302,7 +315,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s: %s; random-weight relu MLP, QuadCost Q=I R=0.01I F=I, "
+            "config": {"workload": "%s: %s; random-weight model, QuadCost Q=I R=0.01I F=I, "
                                    "sigma=1 lmda=1, %d independent solve(s) per step per GPU, "
                                    "noise=%s" % (args.workload, spec["label"], B, args.noise),
                        "n_samples": N, "horizon": H, "state_dim": nx, "ctrl_dim": nu,

@@ -20,6 +20,7 @@ PY
 run c3_f64 --steps 200 --warmup 20
 run c3_f32 --steps 200 --warmup 20 --precision f32
 run c2_f64 --steps 200 --warmup 20 --workload c2
+run arx_f64 --steps 200 --warmup 20 --workload arx
 AMPC_MT=1 run c3_f64_b8_mt1 --steps 50 --warmup 5 --batch 8
 AMPC_MT=2 run c3_f64_b8_mt2 --steps 50 --warmup 5 --batch 8
 AMPC_MT=1 run c3_f32_b8_mt1 --steps 50 --warmup 5 --batch 8 --precision f32
