@@ -246,18 +246,27 @@ extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : 
 // weight packing (host, double) -- layouts documented in mlp_tile.hpp
 // ---------------------------------------------------------------------------------------------
 // B[k][n] supplied by a functor; N-split over W waves, NT tiles per wave.
+// own_first: wave w's stream starts at k-group w (8 k-steps per group) and wraps around -- the
+// order TileNet::run consumes a hidden layer in when TileNet::OWN holds.
 template <typename F>
-static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, int W, F B) {
-  const int KS = kpad / 4;
+static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, int W, F B,
+                        bool own_first = false) {
+  const int KS = kpad / 4, G = 8, NG = KS / G;
   dst.assign((size_t)kpad * hpad, 0.0);
   for (int w = 0; w < W; ++w)
-    for (int ks = 0; ks < KS; ++ks)
+    for (int pos = 0; pos < KS; ++pos)
       for (int lane = 0; lane < 64; ++lane)
         for (int nt = 0; nt < NT; ++nt) {
+          const int ks = own_first ? ((pos / G + w) % NG) * G + pos % G : pos;
           const int k = 4 * ks + (lane >> 4);
           const int n = 16 * (NT * w + nt) + (lane & 15);
-          dst[(((size_t)w * KS + ks) * 64 + lane) * NT + nt] = B(k, n);
+          dst[(((size_t)w * KS + pos) * 64 + lane) * NT + nt] = B(k, n);
         }
+}
+// mirrors TileNet::OWN (mlp_tile.hpp): own columns = one k-group, power-of-two group count
+static bool own_first_packing(int NT, int W) {
+  const int ng = (16 * NT * W / 4) / 8;
+  return 16 * NT == 32 && (ng & (ng - 1)) == 0;
 }
 // K-split over W waves, `tiles` 16-column tiles.
 template <typename F>
@@ -310,7 +319,7 @@ template <typename T> static int build_model(ampc_handle* h) {
     const int in = width_in(l), out = width_out(l);
     std::vector<double> pk;
     auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
-    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, W, Bt);
+    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, W, Bt, l > 0 && own_first_packing(NT, W));
     else pack_ksplit(pk, hpad, nxp / 16, W, Bt);
     push(std::move(pk));
   }

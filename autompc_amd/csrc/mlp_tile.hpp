@@ -204,13 +204,17 @@ __device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&
 // One N-split layer with compile-time k extent KS: acc[mt][nt] += A[16mt.., :] * Wpacked.
 // Fully unrolled; group 0 arrives pre-loaded in `first`, later groups are double-buffered so the
 // fetch of group g+1 is in flight while group g's MFMAs issue.
-template <typename T, int NT, int MT, int KS, int G, bool PIPE = false>
+// OWN: the fragment stream is packed starting at k-group `rot` (the group whose activations this
+// wave itself produced, see TileNet::run); group 0 of the stream is consumed BEFORE the tile-wide
+// barrier that publishes the other waves' activations, which is passed inside this function.
+template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
                                                  const T* __restrict__ wl, int lane,
                                                  const T (&first)[G][NT],
-                                                 typename Acc<T>::type (&acc)[MT][NT]) {
+                                                 typename Acc<T>::type (&acc)[MT][NT], int rot = 0) {
   static_assert(KS % G == 0, "group size must divide the k extent");
   constexpr int NG = KS / G;
+  static_assert(!OWN || (NG & (NG - 1)) == 0, "rotated k order needs a power-of-two group count");
   const int i = lane & 15, q = lane >> 4;
   const T* arow = A + i * a_stride + q;
   T b[2][G][NT];
@@ -221,12 +225,12 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     if (g + 1 < NG) load_group<T, NT, G>(wl, g + 1, b[(g + 1) & 1]);
+    const T* ag = OWN ? arow + 4 * G * ((g + rot) & (NG - 1)) : arow + 4 * G * g;
 #pragma unroll
     for (int kk = 0; kk < G; ++kk) {
-      const int ks = g * G + kk;
       T a[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt * 16 * a_stride + 4 * ks];
+      for (int mt = 0; mt < MT; ++mt) a[mt] = ag[mt * 16 * a_stride + 4 * kk];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -247,6 +251,7 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
       }
     }
 #endif
+    if (OWN && g == 0) lds_barrier();
   }
 }
 
@@ -272,6 +277,10 @@ struct TileNet {
   static constexpr int G0 = 2;                // first-layer group (k1p/4 is 2, 4, .. 12)
   static constexpr int GH = 8;                // hidden-layer group
   static constexpr int NOMAX = 2;             // nx <= 32
+  // A wave's own output columns [16 NT w, 16 NT (w+1)) are one whole k-group of the next hidden
+  // layer: that layer starts on them before the barrier (see run()).  Host packing must agree
+  // (own_first_packing() in autompc_hip.cpp).
+  static constexpr bool OWN = (16 * NT == 4 * GH) && (((KSH / GH) & (KSH / GH - 1)) == 0);
 
   T pf0[G0][NT];  // first group of layer 0, requested ahead of time (see prefetch0)
 
@@ -382,7 +391,11 @@ struct TileNet {
       prefetch_next(1);
       epilogue(0, acc, act);
     }
-    lds_barrier();
+    // Barrier placement.  A layer's epilogue leaves wave w's columns in LDS.  The output layer is
+    // K-split so that wave w consumes exactly those columns: no barrier before it.  A hidden
+    // layer needs every wave's columns, but (OWN) starts with its own group and takes the
+    // barrier after it, inside layer_mma_static, so barrier skew is covered by MFMA work.
+    if (!OWN && m.n_hidden > 1) lds_barrier();
     AMPC_MARK(3);
 
     // ---- hidden -> hidden layers ---------------------------------------------------------------
@@ -392,7 +405,8 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8)>(act, as, slice_h(m, l, w, lane), lane, pfn, acc);
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN>(act, as, slice_h(m, l, w, lane), lane, pfn,
+                                                          acc, w);
       AMPC_MARK(4);
       prefetch_next(l + 1);
       // single buffer: every wave must finish reading act before it is overwritten;
@@ -400,7 +414,7 @@ struct TileNet {
       if (!pingpong) lds_barrier();
       AMPC_MARK(5);
       epilogue(l, acc, act_other);
-      lds_barrier();
+      if (!OWN && l + 1 < m.n_hidden) lds_barrier();
       AMPC_MARK(6);
       { T* tmp = act; act = act_other; act_other = tmp; }
     }
