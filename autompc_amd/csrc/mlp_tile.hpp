@@ -274,7 +274,7 @@ struct TileNet {
   static constexpr int HP = 16 * NT * W;      // padded hidden width
   static constexpr int KSH = HP / 4;          // k-steps of a hidden->hidden layer
   static constexpr int KSW = KSH / W;         // output-layer k-steps per wave (= 4*NT)
-  static constexpr int G0 = 2;                // first-layer group (k1p/4 is 2, 4, .. 12)
+  static constexpr int KS0MAX = 12;           // first-layer k-steps (k1p/4 is 2, 4, .. 12)
   static constexpr int GH = 8;                // hidden-layer group
   static constexpr int NOMAX = 2;             // nx <= 32
   // A wave's own output columns [16 NT w, 16 NT (w+1)) are one whole k-group of the next hidden
@@ -282,7 +282,11 @@ struct TileNet {
   // (own_first_packing() in autompc_hip.cpp).
   static constexpr bool OWN = (16 * NT == 4 * GH) && (((KSH / GH) & (KSH / GH - 1)) == 0);
 
-  T pf0[G0][NT];  // first group of layer 0, requested ahead of time (see prefetch0)
+  // Layer 0's fragments requested ahead of time (prefetch0): the whole layer in f32 (its few
+  // MFMAs cannot cover an in-loop L2 round trip; measured +3 %), only the first two k-steps in
+  // f64, where the extra 40 live VGPRs cost more than the latency they hide (measured -4 %).
+  static constexpr bool FULL0 = sizeof(T) == 4;
+  T pf0[FULL0 ? KS0MAX : 2][NT];
 
   __device__ __forceinline__ static const T* slice0(const MlpDev<T>& m, int w, int lane) {
     return m.w[0] + ((size_t)w * (m.k1p / 4) * 64 + lane) * NT;
@@ -290,13 +294,31 @@ struct TileNet {
   __device__ __forceinline__ static const T* slice_h(const MlpDev<T>& m, int l, int w, int lane) {
     return m.w[l] + ((size_t)w * KSH * 64 + lane) * NT;
   }
+  template <int KS> __device__ __forceinline__ const T (&first0() const)[KS][NT] {
+    return reinterpret_cast<const T(&)[KS][NT]>(pf0);
+  }
+  template <int KS> __device__ __forceinline__ T (&first0())[KS][NT] {
+    return reinterpret_cast<T(&)[KS][NT]>(pf0);
+  }
 
-  // Request the first weight group of layer 0.  Call before the barrier/phase that precedes
-  // run(); the loads complete while other work proceeds.
+  // Request layer 0's weights.  Call before the barrier/phase that precedes run(); the loads
+  // complete while other work proceeds.
   __device__ __forceinline__ void prefetch0(const MlpDev<T>& m) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    load_group<T, NT, G0>(slice0(m, w, lane), 0, pf0);
+    const T* wl = slice0(m, w, lane);
+    if constexpr (!FULL0) {
+      load_group<T, NT, 2>(wl, 0, first0<2>());
+      return;
+    }
+    switch (m.k1p) {
+      case 8: load_group<T, NT, 2>(wl, 0, first0<2>()); break;
+      case 16: load_group<T, NT, 4>(wl, 0, first0<4>()); break;
+      case 24: load_group<T, NT, 6>(wl, 0, first0<6>()); break;
+      case 32: load_group<T, NT, 8>(wl, 0, first0<8>()); break;
+      case 40: load_group<T, NT, 10>(wl, 0, first0<10>()); break;
+      default: load_group<T, NT, 12>(wl, 0, first0<12>()); break;
+    }
   }
 
   // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, pf0 has been requested and every
@@ -379,13 +401,24 @@ struct TileNet {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
       const T* wl = slice0(m, w, lane);
       const T* A = lds + L.xu;
-      switch (m.k1p) {   // one fully unrolled variant per padded input width
-        case 8: layer_mma_static<T, NT, MT, 2, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
-        case 16: layer_mma_static<T, NT, MT, 4, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
-        case 24: layer_mma_static<T, NT, MT, 6, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
-        case 32: layer_mma_static<T, NT, MT, 8, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
-        case 40: layer_mma_static<T, NT, MT, 10, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
-        default: layer_mma_static<T, NT, MT, 12, G0>(A, L.xu_stride, wl, lane, pf0, acc); break;
+      if constexpr (FULL0) {
+        switch (m.k1p) {   // one fully unrolled variant per padded input width
+          case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 16: layer_mma_static<T, NT, MT, 4, 4>(A, L.xu_stride, wl, lane, first0<4>(), acc); break;
+          case 24: layer_mma_static<T, NT, MT, 6, 6>(A, L.xu_stride, wl, lane, first0<6>(), acc); break;
+          case 32: layer_mma_static<T, NT, MT, 8, 8>(A, L.xu_stride, wl, lane, first0<8>(), acc); break;
+          case 40: layer_mma_static<T, NT, MT, 10, 10>(A, L.xu_stride, wl, lane, first0<10>(), acc); break;
+          default: layer_mma_static<T, NT, MT, 12, 12>(A, L.xu_stride, wl, lane, first0<12>(), acc); break;
+        }
+      } else {
+        switch (m.k1p) {
+          case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 16: layer_mma_static<T, NT, MT, 4, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 24: layer_mma_static<T, NT, MT, 6, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 32: layer_mma_static<T, NT, MT, 8, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 40: layer_mma_static<T, NT, MT, 10, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          default: layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+        }
       }
       AMPC_MARK(2);
       prefetch_next(1);
