@@ -15,7 +15,7 @@ OUT = os.path.join(PKG, "libautompc_hip.so")
 OBJ = os.path.join(HERE, "build")
 SOURCE = os.path.join(HERE, "autompc_hip.cpp")
 HEADERS = ["mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp",
-           "rng_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
+           "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
 UNITS = [("main", ["-DAMPC_TU_MAIN"])] + [
     ("f%d_%s" % (fam, t), ["-DAMPC_TU_FAMILY=%d" % fam, "-DAMPC_TU_T=%s" % t] +
      (["-DAMPC_TU_F64=1"] if t == "double" else []))

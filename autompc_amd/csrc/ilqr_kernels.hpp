@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
 
   Net net;
   if constexpr (DYN == 0) {
-    net.prefetch0(mlp);
+    net.init(mlp);
     tile_load_constants<T, W>(mlp, L, lds, M);
   } else {
     for (int i = tid; i < M * L.xu_stride; i += NTHR) lds[L.xu + i] = T(0);

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   const int first = blockIdx.x * M;
   T* xu = lds + L.xu;
   Net net;
-  net.prefetch0(mlp);
+  net.init(mlp);
   tile_load_constants<T, W>(mlp, L, lds, M);
   __syncthreads();
   for (int i = tid; i < M * nx; i += NTHR) {

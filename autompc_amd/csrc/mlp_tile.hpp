@@ -301,6 +301,28 @@ struct TileNet {
     return reinterpret_cast<T(&)[KS][NT]>(pf0);
   }
 
+  // This wave's output-layer fragments (K-split: k-steps [w*KSW, (w+1)*KSW), up to two 16-column
+  // tiles).  They are the same for every call, so they stay in registers for the kernel's
+  // lifetime: fetching them per call put a 64 KB-per-CU burst on L2 right before the output
+  // MFMAs needed them (measured ~1 us exposed per rollout step).
+  T wout[KSW][NOMAX];
+
+  // Once per kernel, before the first run(): resident output weights + the first prefetch.
+  __device__ __forceinline__ void init(const MlpDev<T>& m) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (m.nxp == 16) {
+      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
+#pragma unroll
+      for (int ks = 0; ks < KSW; ++ks) { wout[ks][0] = wl[ks * 64]; wout[ks][1] = T(0); }
+    } else {
+      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, wout[ks]);
+    }
+    prefetch0(m);
+  }
+
   // Request layer 0's weights.  Call before the barrier/phase that precedes run(); the loads
   // complete while other work proceeds.
   __device__ __forceinline__ void prefetch0(const MlpDev<T>& m) {
@@ -321,7 +343,7 @@ struct TileNet {
     }
   }
 
-  // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, pf0 has been requested and every
+  // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, init() has been called and every
   // thread has passed a barrier after the last write to lds[L.xu].  On exit
   // lds[L.part + (w*M + row)*nxp + col] holds wave w's partial of the output layer (bias NOT
   // added), pf0 has been re-requested for the next call, and a barrier has been passed.
@@ -336,31 +358,10 @@ struct TileNet {
     const bool pingpong = L.act2 != L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
-    // Prefetch buffer for whatever comes next: the first group of the next hidden layer
-    // ([GH][NT]) or all of this wave's output-layer fragments ([KSW][2]); both are 8*NT values.
+    // Prefetch buffer: the first group of the next hidden layer.
     T pfn[GH][NT];
-    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");
-
     auto prefetch_next = [&](int l_next) {
-      if (l_next < m.n_hidden) {
-        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
-      } else {
-        T* flat = &pfn[0][0];
-        if (no == 1) {
-          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
-#pragma unroll
-          for (int ks = 0; ks < KSW; ++ks) { flat[2 * ks] = wl[ks * 64]; flat[2 * ks + 1] = T(0); }
-        } else {
-          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
-#pragma unroll
-          for (int ks = 0; ks < KSW; ++ks) {
-            T two[2];
-            load_frag<T, 2>(wl + ks * 128, two);
-            flat[2 * ks] = two[0];
-            flat[2 * ks + 1] = two[1];
-          }
-        }
-      }
+      if (l_next < m.n_hidden) load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
     };
     // bias + activation + store of one layer's accumulators (activation kind hoisted out of
     // the element loops: one uniform branch per layer instead of one per element)
@@ -401,6 +402,7 @@ struct TileNet {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
       const T* wl = slice0(m, w, lane);
       const T* A = lds + L.xu;
+      prefetch_next(1);   // first group of hidden layer 1: in flight under layer 0's MFMAs
       if constexpr (FULL0) {
         switch (m.k1p) {   // one fully unrolled variant per padded input width
           case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
@@ -421,7 +423,6 @@ struct TileNet {
         }
       }
       AMPC_MARK(2);
-      prefetch_next(1);
       epilogue(0, acc, act);
     }
     // Barrier placement.  A layer's epilogue leaves wave w's columns in LDS.  The output layer is
@@ -459,22 +460,21 @@ struct TileNet {
 #pragma unroll
       for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
     {
-      const T* pfo = &pfn[0][0];
       const T* arow = act + i * as + q + 4 * w * KSW;
       if (no == 1) {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], pfo[2 * ks], oacc[mt][0]);
+            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], wout[ks][0], oacc[mt][0]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const T a = arow[mt * 16 * as + 4 * ks];
-            oacc[mt][0] = mfma16(a, pfo[2 * ks], oacc[mt][0]);
-            oacc[mt][1] = mfma16(a, pfo[2 * ks + 1], oacc[mt][1]);
+            oacc[mt][0] = mfma16(a, wout[ks][0], oacc[mt][0]);
+            oacc[mt][1] = mfma16(a, wout[ks][1], oacc[mt][1]);
           }
       }
     }
@@ -494,6 +494,7 @@ struct TileNet {
             part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
           }
         }
+    AMPC_MARK(13);
     lds_barrier();
     AMPC_MARK(9);
   }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   const int H = pr.H, N = pr.N;
 
   Net net;
-  net.prefetch0(mlp);
+  net.init(mlp);
 
   T* aseq = lds + args.lds_aseq;              // [H][nu] shifted warm start
   T* cpar = lds + args.lds_cost;              // Q R F goal | lo hi scale
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
         c_part += Qm[i * no + i] * d * d;
       }
     }
+    AMPC_MARK(12);
     if (t + 1 < H) actions(t + 1);
     AMPC_MARK(10);
     lds_barrier();

@@ -25,8 +25,12 @@ marks = (ctypes.c_longlong * 64)()
 lib = _lib.load()
 lib.ampc_x_phase_marks.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks(marks)
-m = np.array(marks[:12], dtype=np.int64)
-names = ["cost", "layer0 mma", "epi0+bar", "hidden mma", "bar", "epi1+bar", "out mma", "pf0+bar", "partials+bar", "update+actions", "bar"]
+m = np.array(marks[:16], dtype=np.int64)
+# mark ids in program order (mlp_tile.hpp / mppi_kernels.hpp AMPC_MARK)
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 9, 12, 10, 11]
+names = {1: "dense cost", 2: "layer0 mma", 3: "epi0 (+bar)", 4: "hidden mma (+bar inside)", 5: "prefetch (+bar)",
+         6: "epi1", 7: "out mma", 8: "prefetch0", 13: "partials write", 9: "barrier", 12: "reduce + state update",
+         10: "actions", 11: "barrier"}
 print("precision", prec, "batch", batch, "total cycles/step", m[11] - m[0])
-for i, nme in enumerate(names):
-    print("  %-16s %6d" % (nme, m[i + 1] - m[i]))
+for a, b in zip(order[:-1], order[1:]):
+    print("  %-26s %6d" % (names[b], m[b] - m[a]))
