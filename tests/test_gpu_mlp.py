@@ -78,3 +78,16 @@ def test_set_parameters_restages_weights():
     m.set_parameters(params)
     b = m.pred_batch(s, c)
     assert rel_err(b, omlp.pred_batch(p2, s, c)) < F64_TOL and rel_err(a, b) > 1e-3
+
+
+def test_empty_batch_returns_empty_arrays():
+    """Zero rows in, zero rows out (numpy semantics of the reference's pred_batch on an empty
+    batch): no launch, correctly shaped outputs."""
+    nx, nu = 5, 2
+    m = _model(nx, nu, omlp.random_params(nx, nu, [64, 64], "tanh", seed=2))
+    out = m.pred_batch(np.zeros((0, nx)), np.zeros((0, nu)))
+    assert out.shape == (0, nx)
+    o, jx, ju = m.pred_diff_batch(np.zeros((0, nx)), np.zeros((0, nu)))
+    assert o.shape == (0, nx) and jx.shape == (0, nx, nx) and ju.shape == (0, nx, nu)
+    with pytest.raises(ValueError):
+        m.pred_batch(np.zeros((3, nx + 1)), np.zeros((3, nu)))
