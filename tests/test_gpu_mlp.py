@@ -84,7 +84,7 @@ def test_empty_batch_returns_empty_arrays():
     """Zero rows in, zero rows out (numpy semantics of the reference's pred_batch on an empty
     batch): no launch, correctly shaped outputs."""
     nx, nu = 5, 2
-    m = _model(nx, nu, omlp.random_params(nx, nu, [64, 64], "tanh", seed=2))
+    m = _hip_model(omlp.random_params(nx, nu, [64, 64], "tanh", seed=2), nx, nu, "f64")
     out = m.pred_batch(np.zeros((0, nx)), np.zeros((0, nu)))
     assert out.shape == (0, nx)
     o, jx, ju = m.pred_diff_batch(np.zeros((0, nx)), np.zeros((0, nu)))
