@@ -167,22 +167,42 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     }
     if (tid == 0) scal[8] = T(0);
     __syncthreads();
-    // stage J_t = [jx | ju], xbar_t, ubar_t into LDS (done one step ahead inside the loop)
-    auto stage_step = [&](int t) {
+    // J_t = [jx | ju], xbar_t, ubar_t are staged into LDS one step ahead, through registers: the
+    // global loads for step t-1 are issued at the top of step t and land in LDS at its end, so
+    // their latency is covered by the step's arithmetic (barriers in the loop are LDS-only).
+    constexpr int JR = (32 * 48 + NTHR - 1) / NTHR;      // nx <= 32, n <= 48
+    T jreg[JR];
+    T xreg = T(0), ureg = T(0);
+    auto fetch_step = [&](int t) {
       const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
       const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
-      for (int idx = tid; idx < nx * n; idx += NTHR) {
-        const int a = idx / n, c = idx - a * n;
-        Jm[idx] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
+#pragma unroll
+      for (int k = 0; k < JR; ++k) {
+        const int idx = tid + k * NTHR;
+        if (idx < nx * n) {
+          const int a = idx / n, c = idx - a * n;
+          jreg[k] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
+        }
       }
-      for (int a = tid; a < nx; a += NTHR) xbar[a] = st[(size_t)t * nx + a];
-      for (int j = tid; j < nu; j += NTHR) ubar[j] = ct[(size_t)t * nu + j];
+      if (tid < nx) xreg = st[(size_t)t * nx + tid];
+      if (tid < nu) ureg = ct[(size_t)t * nu + tid];
     };
-    stage_step(H - 1);
+    auto commit_step = [&]() {
+#pragma unroll
+      for (int k = 0; k < JR; ++k) {
+        const int idx = tid + k * NTHR;
+        if (idx < nx * n) Jm[idx] = jreg[k];
+      }
+      if (tid < nx) xbar[tid] = xreg;
+      if (tid < nu) ubar[tid] = ureg;
+    };
+    fetch_step(H - 1);
+    commit_step();
     __syncthreads();
     const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
     T* Aug = lu;                     // lu (nu*nu) and rhs (nu*(nx+1)) are contiguous: nu*nc values
     for (int t = H - 1; t >= 0; --t) {
+      if (t > 0) fetch_step(t - 1);
       for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
         const int a = idx / n, c = idx - a * n;
         T s = T(0);
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         for (int b = 0; b < nx; ++b) s += V[a * nx + b] * Jm[b * n + c];
         VJ[idx] = s;
       }
-      __syncthreads();
+      lds_barrier();
       for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
         const int c = idx / n, d = idx - c * n;
         T s = T(0);
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         }
         qt[c] = cc * dt + s;
       }
-      __syncthreads();
+      lds_barrier();
       // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
       // numpy.linalg.solve / LAPACK gesv) on the augmented matrix, by wave 0, wave-synchronously:
       // LDS operations of one wave execute in order, so only the compiler needs fencing.
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         }
         if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
       }
-      __syncthreads();
+      lds_barrier();
       for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
         const int i = idx / nx, b = idx - i * nx;
         T s = T(0);
@@ -289,7 +309,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         }
         if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
       }
-      __syncthreads();
+      lds_barrier();
       for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
         const int a = idx / nx, b = idx - a * nx;
         T s = Qt[a * n + b];
@@ -304,8 +324,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
         v[a] = s;
       }
-      if (t > 0) stage_step(t - 1);                          // J, xbar, ubar are not read in this phase
-      __syncthreads();
+      if (t > 0) commit_step();                              // J, xbar, ubar are not read in this phase
+      lds_barrier();
     }
     if (tid == 0) { scal[0] = lin; scal[1] = quad; scal[2] = sqrt(ksn2); }
     __syncthreads();

@@ -16,6 +16,10 @@ timeout 300 python bench.py --batch 8 --steps 50 --warmup 5 --no-cpu-baseline > 
 timeout 300 python bench.py --workload arx > $OUT/bench_arx_f64.json 2> $OUT/bench_arx_f64.err
 timeout 600 python bench.py --workload c4 --steps 3 --warmup 1 > $OUT/bench_c4_ilqr_f64.json 2> $OUT/bench_c4.err
 timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_candidates_f64.json 2> $OUT/bench_c5.err
+# launcher plumbing: the driver's N>1 command line with two ranks mapped onto this box's one GPU
+# (gloo for the barriers; RCCL refuses two ranks on one device).  Not a performance number.
+AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $OUT/bench_2rank_plumbing.json 2> $OUT/bench_2rank_plumbing.err
+AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- $BENCH > $OUT/prof_trace.log 2>&1
