@@ -1629,6 +1629,15 @@ extern "C" int ampc_x_phase_marks(long long* out) {
 }
 #endif
 
+#if defined(AMPC_X_PHASETIME) && !defined(AMPC_TU_MAIN) && AMPC_TU_FAMILY == 3 && defined(AMPC_TU_F64)
+// experiment only (tools/phasetime_ilqr.py): the f64 iLQR kernel's copy of the marks
+extern "C" int ampc_x_phase_marks_ilqr(long long* out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
+  return 0;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // explicit instantiations of the heavy launchers (one family, one precision per translation unit)
 // ---------------------------------------------------------------------------------------------

@@ -202,6 +202,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
     T* Aug = lu;                     // lu (nu*nu) and rhs (nu*(nx+1)) are contiguous: nu*nc values
     for (int t = H - 1; t >= 0; --t) {
+#ifdef AMPC_X_PHASETIME
+      if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
+#endif
+      AMPC_MARK(20);
       if (t > 0) fetch_step(t - 1);
       for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
         const int a = idx / n, c = idx - a * n;
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         VJ[idx] = s;
       }
       lds_barrier();
+      AMPC_MARK(21);
       for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
         const int c = idx / n, d = idx - c * n;
         T s = T(0);
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         qt[c] = cc * dt + s;
       }
       lds_barrier();
+      AMPC_MARK(22);
       // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
       // numpy.linalg.solve / LAPACK gesv) on the augmented matrix, by wave 0, wave-synchronously:
       // LDS operations of one wave execute in order, so only the compiler needs fencing.
@@ -277,7 +283,9 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         }
         if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
       }
+      AMPC_MARK(23);
       lds_barrier();
+      AMPC_MARK(24);
       for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
         const int i = idx / nx, b = idx - i * nx;
         T s = T(0);
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
       }
       lds_barrier();
+      AMPC_MARK(25);
       for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
         const int a = idx / nx, b = idx - a * nx;
         T s = Qt[a * n + b];
@@ -326,6 +335,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
       if (t > 0) commit_step();                              // J, xbar, ubar are not read in this phase
       lds_barrier();
+      AMPC_MARK(26);
     }
     if (tid == 0) { scal[0] = lin; scal[1] = quad; scal[2] = sqrt(ksn2); }
     __syncthreads();

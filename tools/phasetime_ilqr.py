@@ -1,0 +1,29 @@
+"""Experiment: per-phase shader-clock breakdown of one backward Riccati step of the f64 iLQR
+kernel (needs the AMPC_X_PHASETIME build: tools/variants.sh -> variants/lib_phasetime.so)."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["AMPC_LIB"] = os.path.join(ROOT, "variants", "lib_phasetime.so")
+from autompc_amd import _lib
+from autompc_amd.synthetic import make_workload
+system, task, model, spec = make_workload("c3", precision="f64")
+h = _lib.Handle(0, "f64")
+model.stage_into(h)
+Q, R, F = task.get_cost().get_cost_matrices()
+h.set_quad_costs(Q, R, F, task.get_cost().get_goal())
+B, H, nx, nu = 64, 50, spec["nx"], spec["nu"]
+plan = _lib.IlqrPlan(h, B, H, system.dt)
+x0 = np.tile(task.get_init_obs(), (B, 1)) + np.random.default_rng(0).uniform(-0.01, 0.01, size=(B, nx))
+plan.solve(x0, np.zeros((B, H, nu)), 5)
+h.synchronize()
+marks = (ctypes.c_longlong * 64)()
+lib = _lib.load()
+lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+lib.ampc_x_phase_marks_ilqr(marks)
+m = np.array(marks[:32], dtype=np.int64)
+names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
+         24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
+print("Riccati step, cycles:", m[26] - m[20], "(each line includes ~440 of mark overhead)")
+for a in range(21, 27):
+    print("  %-32s %6d" % (names[a], m[a] - m[a - 1]))
