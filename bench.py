@@ -92,6 +92,26 @@ def cpu_baseline(workload, spec, n_solves):
                       "OpenBLAS threads = host cores), %.1f s" % (n_solves, workload, dt)}
 
 
+def measured_traffic(args, batch):
+    """HBM bytes per rollout launch from the committed PMC passes (profiles/r01_hbm_traffic.json,
+    written by tools/summarize_profiles.py from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    runs of this same command).  Counters cannot be collected from inside the timed process, so
+    the figure is reported only for the configuration it was measured on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+    if not (args.workload == "c3" and args.precision == "f64" and batch == 1 and args.noise == "device"
+            and os.path.exists(path)):
+        return None
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        for name, v in d["kernels"].items():
+            if "mppi_rollout_kernel" in name:
+                return {"bytes": v["bytes"], "source": "profiles/r01_hbm_traffic.json (%s)" % d["method"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def secondary_workload(args, rank, local_rank, world):
     """c4 / c5: the other BASELINE configurations, same timing contract (barrier + sync on both
     sides, max over ranks), reported with their own unit of work."""
@@ -309,6 +329,7 @@ def main():
             info["flops"] = float(B * N * H * 2 * nx * (nx + nu))
         achieved = info["flops"] / rollout_s / 1e12 if rollout_s > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
+        traffic = measured_traffic(args, B)
         out = {
             "metric": "MPC solves/sec (MPPI, n_samples x horizon rollouts + update per solve)",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
@@ -321,7 +342,8 @@ def main():
                        "n_samples": N, "horizon": H, "state_dim": nx, "ctrl_dim": nu,
                        "hidden": spec["hidden"], "parallelism": "independent solves per GPU (dp%d)" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "mppi_rollout_kernel", "kernel_ms": kt["rollout_ms"],
                          "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"],
                          "algorithmic_flops_per_launch": info["flops"],

@@ -20,6 +20,7 @@ for d in ("prof_pmc_sq", "prof_pmc_fetch", "prof_pmc_write", "prof_pmc_lds"):
         for k, v in agg.items():
             for c, x in v.items():
                 vals[k][c] = sum(x) / len(x)
+traffic = {}
 print("\n## PMC (separate passes), average per launch")
 for k, v in vals.items():
     if "rollout" not in k and "update" not in k:
@@ -33,4 +34,18 @@ for k, v in vals.items():
         print("    -> kernel cycles (per XCD)        %.4g" % cyc)
         print("    -> MFMA busy fraction             %.3f" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)))
     if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
-        print("    -> HBM bytes (FETCH+WRITE, KB->B) %.4g" % (1024.0 * (v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0))))
+        # MI355X_MICROARCH.md, "HBM": both counters are in KB; on gfx950 FETCH_SIZE tallies the
+        # 128-B requests of wide coalesced reads at 64 B, i.e. reports half the bytes -> doubled.
+        # WRITE_SIZE is uncalibrated there and taken as reported.
+        fetch = 2.0 * 1024.0 * v.get("FETCH_SIZE", 0)
+        write = 1024.0 * v.get("WRITE_SIZE", 0)
+        print("    -> HBM bytes per launch: fetch %.4g (2 x FETCH_SIZE KB, gfx950 correction) + write %.4g = %.4g"
+              % (fetch, write, fetch + write))
+        traffic[k] = {"fetch_bytes": fetch, "write_bytes": write, "bytes": fetch + write,
+                      "fetch_size_kb_raw": v.get("FETCH_SIZE", 0), "write_size_kb_raw": v.get("WRITE_SIZE", 0)}
+if traffic:
+    import json
+    json.dump({"command": "python bench.py --steps 50 --warmup 5 --no-cpu-baseline (c3, f64, 1 solve per step)",
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, average per launch; "
+                         "fetch doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B)",
+               "kernels": traffic}, open(out + "/hbm_traffic.json", "w"), indent=1)
