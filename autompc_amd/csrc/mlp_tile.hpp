@@ -305,20 +305,29 @@ struct TileNet {
   // tiles).  They are the same for every call, so they stay in registers for the kernel's
   // lifetime: fetching them per call put a 64 KB-per-CU burst on L2 right before the output
   // MFMAs needed them (measured ~1 us exposed per rollout step).
-  T wout[KSW][NOMAX];
+  // (Not in the 64-row f64 tile: its accumulators leave no room, the copy would spill.)
+  static constexpr bool RESIDENT_OUT = !(MT == 4 && sizeof(T) == 8);
+  T wout[KSW][NOMAX];            // dead (never written or read) when not resident
 
-  // Once per kernel, before the first run(): resident output weights + the first prefetch.
-  __device__ __forceinline__ void init(const MlpDev<T>& m) {
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __device__ __forceinline__ static void load_out(const MlpDev<T>& m, int w, int lane,
+                                                  T (&dst)[KSW][NOMAX]) {
     if (m.nxp == 16) {
       const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
-      for (int ks = 0; ks < KSW; ++ks) { wout[ks][0] = wl[ks * 64]; wout[ks][1] = T(0); }
+      for (int ks = 0; ks < KSW; ++ks) { dst[ks][0] = wl[ks * 64]; dst[ks][1] = T(0); }
     } else {
       const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
-      for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, wout[ks]);
+      for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, dst[ks]);
+    }
+  }
+
+  // Once per kernel, before the first run(): resident output weights + the first prefetch.
+  __device__ __forceinline__ void init(const MlpDev<T>& m) {
+    if constexpr (RESIDENT_OUT) {
+      const int lane = threadIdx.x & 63;
+      const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      load_out(m, w, lane, wout);
     }
     prefetch0(m);
   }
@@ -358,10 +367,36 @@ struct TileNet {
     const bool pingpong = L.act2 != L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
-    // Prefetch buffer: the first group of the next hidden layer.
+    // Prefetch buffer: the first group of the next hidden layer (and, when they are not resident,
+    // the output-layer fragments).
     T pfn[GH][NT];
+    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");
     auto prefetch_next = [&](int l_next) {
-      if (l_next < m.n_hidden) load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
+      if (l_next < m.n_hidden) {
+        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
+      } else if constexpr (!RESIDENT_OUT) {
+        // not resident: the output fragments ([KSW][2]) reuse the hidden prefetch buffer
+        // ([GH][NT], the same 8*NT values) -- one register range for whatever comes next
+        T* flat = &pfn[0][0];
+        if (m.nxp == 16) {
+          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
+#pragma unroll
+          for (int ks = 0; ks < KSW; ++ks) { flat[2 * ks] = wl[ks * 64]; flat[2 * ks + 1] = T(0); }
+        } else {
+          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
+#pragma unroll
+          for (int ks = 0; ks < KSW; ++ks) {
+            T two[2];
+            load_frag<T, 2>(wl + ks * 128, two);
+            flat[2 * ks] = two[0];
+            flat[2 * ks + 1] = two[1];
+          }
+        }
+      }
+    };
+    auto wo = [&](int ks, int n) -> T {
+      if constexpr (RESIDENT_OUT) return wout[ks][n];
+      else return (&pfn[0][0])[2 * ks + n];
     };
     // bias + activation + store of one layer's accumulators (activation kind hoisted out of
     // the element loops: one uniform branch per layer instead of one per element)
@@ -402,7 +437,9 @@ struct TileNet {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
       const T* wl = slice0(m, w, lane);
       const T* A = lds + L.xu;
-      prefetch_next(1);   // first group of hidden layer 1: in flight under layer 0's MFMAs
+      // first group of hidden layer 1: in flight under layer 0's MFMAs (64-row tiles have no
+      // registers to spare for that and fetch it after the MFMAs instead)
+      if constexpr (MT < 4) prefetch_next(1);
       if constexpr (FULL0) {
         switch (m.k1p) {   // one fully unrolled variant per padded input width
           case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
@@ -423,6 +460,7 @@ struct TileNet {
         }
       }
       AMPC_MARK(2);
+      if constexpr (MT >= 4) prefetch_next(1);
       epilogue(0, acc, act);
     }
     // Barrier placement.  A layer's epilogue leaves wave w's columns in LDS.  The output layer is
@@ -466,15 +504,15 @@ struct TileNet {
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], wout[ks][0], oacc[mt][0]);
+            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], wo(ks, 0), oacc[mt][0]);
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const T a = arow[mt * 16 * as + 4 * ks];
-            oacc[mt][0] = mfma16(a, wout[ks][0], oacc[mt][0]);
-            oacc[mt][1] = mfma16(a, wout[ks][1], oacc[mt][1]);
+            oacc[mt][0] = mfma16(a, wo(ks, 0), oacc[mt][0]);
+            oacc[mt][1] = mfma16(a, wo(ks, 1), oacc[mt][1]);
           }
       }
     }
