@@ -105,7 +105,7 @@ def measured_traffic(args, batch):
         with open(path) as f:
             d = json.load(f)
         for name, v in d["kernels"].items():
-            if "mppi_rollout_kernel" in name:
+            if "mppi_rollout_kernel<double" in name:
                 return {"bytes": v["bytes"], "source": "profiles/r01_hbm_traffic.json (%s)" % d["method"]}
     except (OSError, ValueError, KeyError):
         pass
