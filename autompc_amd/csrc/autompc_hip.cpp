@@ -1105,7 +1105,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.lds = p->L;
   a.lds_work = p->lds_work;
   a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
-  a.ls_n = p->ls_n; a.mode = mode;
+  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag;
   a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
   for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
   a.costs_par = (const T*)h->cost_buf.p;

@@ -36,6 +36,7 @@ template <typename T> struct IlqrArgs {
   TileLds lds;
   int lds_work;                  // start of the Riccati / line-search scratch (elements)
   int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
+  int cost_diag;                 // 1: Q, R, F of every cost block are diagonal -> O(n) objective
   T dt, u_threshold, ls_cost_threshold;
   T alphas[kIlqrMaxLs];          // step sizes discount**j, computed on the host like the reference
   const T* costs_par;            // [n_costs][cost_stride]: Q R F goal
@@ -101,6 +102,16 @@ template <typename T> __device__ __forceinline__ T block_sum_any(T v, T* scratch
   return o;
 }
 
+// Value of `v` in lane `lane` (wave-uniform index), broadcast to the whole wave.
+__device__ __forceinline__ float readlane_t(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double readlane_t(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
 template <typename T, int NT, int W, int DYN = 0>
@@ -133,9 +144,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
 
   Net net;
   if constexpr (DYN == 0) {
-    net.init(mlp);
-    tile_load_constants<T, W>(mlp, L, lds, M);
-  } else {
+    tile_load_constants<T, W>(mlp, L, lds, M);   // (net.init: after the Riccati sweep, which
+  } else {                                       //  wants the registers for itself)
     for (int i = tid; i < M * L.xu_stride; i += NTHR) lds[L.xu + i] = T(0);
   }
   for (int i = tid; i < args.cost_stride; i += NTHR)
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
 
   // =========================== backward Riccati sweep (ilqr.py:159-187) ========================
+  AMPC_MARK_ALWAYS(30);
   if (args.mode == 1) {
     const T dt = args.dt;
     for (int idx = tid; idx < nx * nx; idx += NTHR) {
@@ -200,7 +211,6 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     commit_step();
     __syncthreads();
     const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
-    T* Aug = lu;                     // lu (nu*nu) and rhs (nu*(nx+1)) are contiguous: nu*nc values
     for (int t = H - 1; t >= 0; --t) {
 #ifdef AMPC_X_PHASETIME
       if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
@@ -242,44 +252,55 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       lds_barrier();
       AMPC_MARK(22);
       // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
-      // numpy.linalg.solve / LAPACK gesv) on the augmented matrix, by wave 0, wave-synchronously:
-      // LDS operations of one wave execute in order, so only the compiler needs fencing.
+      // numpy.linalg.solve / LAPACK gesv) on the augmented matrix [Quu | Qux | qu], by wave 0,
+      // entirely in registers: lane j owns column j (nc = nu + nx + 1 <= 49 columns), its nu
+      // entries are col[0..nu).  Column c's entries reach the other lanes by readlane; rows are
+      // swapped by uniform-branch register moves.  No LDS round trips inside the elimination.
       if (tid < 64) {
         const int lane = tid;
-        for (int e = lane; e < nu * nc; e += 64) {
-          const int i = e / nc, j = e - i * nc;
-          Aug[e] = j < nu ? Qt[(nx + i) * n + nx + j] : (j < nu + nx ? Qt[(nx + i) * n + (j - nu)] : qt[nx + i]);
+        T col[kMaxNu];
+#pragma unroll
+        for (int i = 0; i < kMaxNu; ++i) {
+          col[i] = T(0);
+          if (i < nu && lane < nc)
+            col[i] = lane < nu ? Qt[(nx + i) * n + nx + lane]
+                               : (lane < nu + nx ? Qt[(nx + i) * n + (lane - nu)] : qt[nx + i]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         int sing = 0;
-        for (int c = 0; c < nu && !sing; ++c) {
+#pragma unroll
+        for (int c = 0; c < kMaxNu; ++c) {
+          if (c >= nu || sing) break;
+          // pivot row: first maximum of |Aug[i][c]|, i >= c (lane c holds that column)
+          T best = fabs(col[c]);
           int pr = c;
-          T best = fabs(Aug[c * nc + c]);
-          for (int i = c + 1; i < nu; ++i) {
-            const T a = fabs(Aug[i * nc + c]);
+#pragma unroll
+          for (int i = c + 1; i < kMaxNu; ++i) {
+            if (i >= nu) break;
+            const T a = fabs(col[i]);
             if (a > best) { best = a; pr = i; }
           }
-          if (pr != c)
-            for (int j = lane; j < nc; j += 64) {
-              const T tmp = Aug[c * nc + j];
-              Aug[c * nc + j] = Aug[pr * nc + j];
-              Aug[pr * nc + j] = tmp;
-            }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          const T d = Aug[c * nc + c];
+          pr = __builtin_amdgcn_readlane(pr, c);
+#pragma unroll
+          for (int i = c + 1; i < kMaxNu; ++i)
+            if (pr == i) { const T tmp = col[c]; col[c] = col[i]; col[i] = tmp; }
+          const T d = readlane_t(col[c], c);
           if (d == T(0)) { sing = 1; break; }
           const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
-          for (int e = lane; e < nu * nc; e += 64) {         // eliminate column c from every other row
-            const int i = e / nc, j = e - i * nc;
-            if (i != c && j > c) Aug[e] -= (Aug[i * nc + c] * rd) * Aug[c * nc + j];
+          const T rowc = col[c];
+#pragma unroll
+          for (int i = 0; i < kMaxNu; ++i) {                 // eliminate column c from every other row
+            if (i >= nu) break;
+            if (i == c) continue;
+            const T f = readlane_t(col[i], c) * rd;
+            if (lane > c) col[i] -= f * rowc;
           }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        for (int e = lane; e < nu * (nx + 1); e += 64) {
-          const int i = e / (nx + 1), jj = e - i * (nx + 1);
-          const T val = -Aug[i * nc + nu + jj] / Aug[i * nc + i];
-          if (jj < nx) Km[i * nx + jj] = val;
-          else kv[i] = val;
+#pragma unroll
+        for (int i = 0; i < kMaxNu; ++i) {
+          if (i >= nu) break;
+          const T val = -col[i] / readlane_t(col[i], i);
+          if (lane >= nu && lane < nu + nx) Km[i * nx + (lane - nu)] = val;
+          else if (lane == nu + nx) kv[i] = val;
         }
         if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
       }
@@ -346,6 +367,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
 
   // =========================== forward rollout(s) (ilqr.py:141-149, 196-205) ===================
+  AMPC_MARK_ALWAYS(31);
+  if constexpr (DYN == 0) net.init(mlp);
   const int rows = args.mode == 0 ? 1 : args.ls_n;
   const int m = tid / TPS, r = tid % TPS;        // row-in-tile, helper index (same wave)
   T obj_part = T(0);
@@ -357,13 +380,39 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   __syncthreads();
   T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
   T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
-  for (int t = 0; t < H; ++t) {
-    if (args.mode == 1) {
-      for (int idx = tid; idx < nu * nx; idx += NTHR) Km[idx] = Kg[(size_t)t * nu * nx + idx];
-      for (int j = tid; j < nu; j += NTHR) { kv[j] = kg[(size_t)t * nu + j]; ubar[j] = ct[(size_t)t * nu + j]; }
-      for (int a = tid; a < nx; a += NTHR) xbar[a] = st[(size_t)t * nx + a];
-      __syncthreads();
+  // K_t, k_t, ubar_t, xbar_t reach LDS one step ahead, through registers (as in the sweep): the
+  // global loads for step t+1 are issued at the top of step t and committed at its end; the
+  // barriers inside the loop are LDS-only, so neither these loads nor the line-search stores
+  // (lss / lsc) stall a step.
+  constexpr int KR = (16 * 32 + NTHR - 1) / NTHR;        // nu <= 16, nx <= 32
+  T kreg[KR];
+  T kvr = T(0), ubr = T(0), xbr = T(0);
+  auto fetch_ls = [&](int t) {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int idx = tid + k * NTHR;
+      if (idx < nu * nx) kreg[k] = Kg[(size_t)t * nu * nx + idx];
     }
+    if (tid < nu) { kvr = kg[(size_t)t * nu + tid]; ubr = ct[(size_t)t * nu + tid]; }
+    if (tid < nx) xbr = st[(size_t)t * nx + tid];
+  };
+  auto commit_ls = [&]() {
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      const int idx = tid + k * NTHR;
+      if (idx < nu * nx) Km[idx] = kreg[k];
+    }
+    if (tid < nu) { kv[tid] = kvr; ubar[tid] = ubr; }
+    if (tid < nx) xbar[tid] = xbr;
+  };
+  if (args.mode == 1) {
+    fetch_ls(0);
+    commit_ls();
+    __syncthreads();
+  }
+  const bool cdiag = args.cost_diag != 0;
+  for (int t = 0; t < H; ++t) {
+    if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
     // controls for this step
     for (int a = r; a < nu; a += TPS) {
       T u;
@@ -380,10 +429,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     }
     if (args.mode == 1 && m < rows)
       for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
-    __syncthreads();
+    lds_barrier();
     // objective: dt * (stage costs)
-    obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false) +
-                           quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false));
+    obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, cdiag) +
+                           quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, cdiag));
     if constexpr (DYN == 0) {
       net.run(mlp, L, lds);
       for (int a = r; a < nx; a += TPS) {
@@ -401,11 +450,14 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
       }
     }
-    __syncthreads();
+    // every thread passed the barrier above after its last read of K, k, ubar, xbar
+    if (args.mode == 1 && t + 1 < H) commit_ls();
+    lds_barrier();
   }
+  AMPC_MARK_ALWAYS(32);
   if (args.mode == 1 && m < rows)
     for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
-  obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, false);
+  obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, cdiag);
 #pragma unroll
   for (int off = TPS / 2; off > 0; off >>= 1) obj_part += __shfl_xor(obj_part, off);
   if (r == 0) lsobj[m] = obj_part;

@@ -262,8 +262,15 @@ __device__ long long g_phase_marks[64];
     if (blockIdx.x == 7 && threadIdx.x == 0 && g_phase_marks[63] == 1)              \
       g_phase_marks[idx] = (long long)__builtin_amdgcn_s_memtime();                 \
   } while (0)
+// unconditional variant for coarse, once-per-kernel marks
+#define AMPC_MARK_ALWAYS(idx)                                                       \
+  do {                                                                              \
+    if (blockIdx.x == 7 && threadIdx.x == 0)                                        \
+      g_phase_marks[idx] = (long long)__builtin_amdgcn_s_memtime();                 \
+  } while (0)
 #else
 #define AMPC_MARK(idx) do { } while (0)
+#define AMPC_MARK_ALWAYS(idx) do { } while (0)
 #endif
 
 // ---- the fused network on one tile -------------------------------------------------------------

@@ -21,9 +21,10 @@ marks = (ctypes.c_longlong * 64)()
 lib = _lib.load()
 lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks_ilqr(marks)
-m = np.array(marks[:32], dtype=np.int64)
+m = np.array(marks[:40], dtype=np.int64)
 names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
          24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
 print("Riccati step, cycles:", m[26] - m[20], "(each line includes ~440 of mark overhead)")
 for a in range(21, 27):
     print("  %-32s %6d" % (names[a], m[a] - m[a - 1]))
+print("whole kernel (block 7): Riccati sweep %d cycles, line-search rollout %d cycles" % (m[31] - m[30], m[32] - m[31]))
