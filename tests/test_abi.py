@@ -70,3 +70,31 @@ def test_host_types_and_costs_known_answers():
     assert res == 8 and (jac == np.array([-4, 12])).all() and (hess == np.diag([4, 12])).all()
     assert (c1 + c2).is_quad and (c1 + c2).has_goal and not (c1 + c3).is_quad
     assert not (c1 + c3).has_goal and (c1 + c3).is_convex and (c1 + c3).is_twice_diff
+
+
+def test_header_is_plain_c99_and_links_from_c(lib_path, tmp_path):
+    """The boundary is a C ABI: the header compiles as strict C99 and a C program (no C++, no
+    torch types) links against the library and calls the device-free entry points."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "autompc_hip.h"\n'
+        "int main(void) {\n"
+        "  ampc_handle* h = 0;\n"
+        "  int v = ampc_version();\n"
+        "  int n = ampc_device_count();\n"
+        "  int rc = n > 0 ? 0 : ampc_create(0, 0, 0, &h);\n"          # must fail without a GPU
+        '  printf("%d %d %d %s\\n", v, n, rc, ampc_last_error());\n'
+        "  return v >= 100 ? 0 : 1;\n}\n")
+    exe = tmp_path / "abi_probe"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I",
+                    os.path.join(ROOT, "include"), str(src), "-o", str(exe), lib_path,
+                    "-Wl,-rpath," + os.path.dirname(lib_path), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
+    assert int(out[0]) >= 100
+    if int(out[1]) == 0:
+        assert int(out[2]) != 0 and len(out) == 4 and out[3].strip()     # loud failure + message
