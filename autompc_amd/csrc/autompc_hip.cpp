@@ -893,13 +893,22 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
   const int nu = h->nu;
+  long long max_pairs = 0;
   for (int b = 0; b < p->B; ++b) {
-    const long long count = (long long)p->N[b] * p->H[b] * nu;
-    const long long pairs = (count + 1) / 2;
-    const int blocks = (int)((pairs + 255) / 256);
-    hipLaunchKernelGGL(philox_normal_kernel<T>, dim3(blocks), dim3(256), 0, h->stream,
-                       (T*)p->eps.p + p->eps_off[b], count, (T)std::sqrt(p->sigma[b]), seed,
-                       stream * 65536ull + (uint64_t)b);
+    const long long pairs = ((long long)p->N[b] * p->H[b] * nu + 1) / 2;
+    max_pairs = pairs > max_pairs ? pairs : max_pairs;
+  }
+  if (p->B <= 65535) {          // one launch for the whole plan (grid.y = problem)
+    hipLaunchKernelGGL(philox_normal_batch_kernel<T>, dim3((unsigned)((max_pairs + 255) / 256), p->B),
+                       dim3(256), 0, h->stream, (T*)p->eps.p, (const MppiProblem<T>*)p->probs.p, nu,
+                       seed, stream * 65536ull);
+  } else {
+    for (int b = 0; b < p->B; ++b) {
+      const long long count = (long long)p->N[b] * p->H[b] * nu;
+      hipLaunchKernelGGL(philox_normal_kernel<T>, dim3((unsigned)(((count + 1) / 2 + 255) / 256)),
+                         dim3(256), 0, h->stream, (T*)p->eps.p + p->eps_off[b], count,
+                         (T)std::sqrt(p->sigma[b]), seed, stream * 65536ull + (uint64_t)b);
+    }
   }
   HIP_OK(hipGetLastError());
   return 0;

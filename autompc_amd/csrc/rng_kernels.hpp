@@ -8,6 +8,8 @@
 // but not bit-identical, and results obtained with it are compared distributionally only.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "mppi_kernels.hpp"
 #include <stdint.h>
 
 namespace ampc {
@@ -39,9 +41,8 @@ __host__ __device__ inline Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_
 
 // One Philox block -> two uniforms in (0,1) with 53 (f64) bits -> two standard normals.
 template <typename T>
-__global__ void philox_normal_kernel(T* __restrict__ out, long long count, T scale, uint64_t seed,
-                                     uint64_t stream) {
-  const long long pair = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void philox_normal_pair(T* __restrict__ out, long long count, T scale,
+                                                   uint64_t seed, uint64_t stream, long long pair) {
   const long long e0 = 2 * pair;
   if (e0 >= count) return;
   Philox4 c;
@@ -59,6 +60,25 @@ __global__ void philox_normal_kernel(T* __restrict__ out, long long count, T sca
   sincospi(2.0 * u2, &s, &cth);
   out[e0] = (T)(rad * cth) * scale;
   if (e0 + 1 < count) out[e0 + 1] = (T)(rad * s) * scale;
+}
+
+template <typename T>
+__global__ void philox_normal_kernel(T* __restrict__ out, long long count, T scale, uint64_t seed,
+                                     uint64_t stream) {
+  philox_normal_pair<T>(out, count, scale, seed, stream,
+                        (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// The noise of every problem of a plan in one launch: blockIdx.y = problem; problem b draws
+// N_b*H_b*nu values of std sqrt(sigma_b) from stream stream_base + b -- the same values as B
+// separate philox_normal_kernel launches, without B launch latencies.
+template <typename T>
+__global__ void philox_normal_batch_kernel(T* __restrict__ eps, const MppiProblem<T>* __restrict__ probs,
+                                           int nu, uint64_t seed, uint64_t stream_base) {
+  const MppiProblem<T> pr = probs[blockIdx.y];
+  philox_normal_pair<T>(eps + pr.eps_off, (long long)pr.N * pr.H * nu, pr.sqrt_sigma, seed,
+                        stream_base + (uint64_t)blockIdx.y,
+                        (long long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 }  // namespace ampc
