@@ -366,6 +366,16 @@ struct TileNet {
   // If DERIV, act'(z) of hidden layer l is written to dz[l*dz_layer_stride + row*hpad + col].
   __device__ __forceinline__ void run(const MlpDev<T>& m, const TileLds& L, T* lds,
                                       T* __restrict__ dz = nullptr, size_t dz_layer_stride = 0) {
+    run_side(m, L, lds, [] {}, dz, dz_layer_stride);
+  }
+
+  // As run(); `side()` is executed by every thread after the output layer's MFMAs have been
+  // issued and before their results are read: work placed there (the caller's bookkeeping for the
+  // next step -- anything that does not depend on this call's output and does not touch the
+  // activation / partials buffers) runs while the matrix pipe drains instead of after it.
+  template <typename Side>
+  __device__ __forceinline__ void run_side(const MlpDev<T>& m, const TileLds& L, T* lds, Side&& side,
+                                           T* __restrict__ dz = nullptr, size_t dz_layer_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -525,6 +535,7 @@ struct TileNet {
     }
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
+    side();
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
     T* part = lds + L.part + w * M * m.nxp;

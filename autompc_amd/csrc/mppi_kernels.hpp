@@ -172,7 +172,10 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
 #endif
     AMPC_MARK(1);
     // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
-    net.run(mlp, L, lds);
+    // The next step's actions do not depend on this step's output: they are formed while the
+    // output layer's MFMAs drain.  (The control columns of xu were last read by layer 0, several
+    // barriers ago; the dense-cost path reads them above, before run.)
+    net.run_side(mlp, L, lds, [&] { if (t + 1 < H) actions(t + 1); });
     for (int i = r; i < nx; i += TPS) {
       const T xn = xu[m * xs_ + i] + Net::output(mlp, L, lds, m, i);
       xu[m * xs_ + i] = xn;
@@ -182,7 +185,6 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
       }
     }
     AMPC_MARK(12);
-    if (t + 1 < H) actions(t + 1);
     AMPC_MARK(10);
     lds_barrier();
     AMPC_MARK(11);
