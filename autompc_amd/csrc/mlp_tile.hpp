@@ -329,13 +329,22 @@ struct TileNet {
     }
   }
 
-  // Once per kernel, before the first run(): resident output weights + the first prefetch.
+  // Hidden-layer biases of this lane's columns, resident: accumulators start from them, so the
+  // epilogue has neither an LDS read nor an add between the last MFMA and the activation.
+  // (16-row tiles only: the taller tiles are register-bound and keep reading the bias from LDS.)
+  static constexpr bool RESIDENT_BIAS = (MT == 1);
+  T bias_r[kMaxHidden][NT];
+
+  // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
   __device__ __forceinline__ void init(const MlpDev<T>& m) {
-    if constexpr (RESIDENT_OUT) {
-      const int lane = threadIdx.x & 63;
-      const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-      load_out(m, w, lane, wout);
-    }
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int l = 0; l < kMaxHidden; ++l)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        bias_r[l][nt] = (RESIDENT_BIAS && l < m.n_hidden) ? m.b[l][16 * (NT * w + nt) + (lane & 15)] : T(0);
+    if constexpr (RESIDENT_OUT) load_out(m, w, lane, wout);
     prefetch0(m);
   }
 
@@ -425,11 +434,11 @@ struct TileNet {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int col = 16 * (NT * w + nt) + i;
-          const T bc = bias[col];
+          const T bc = RESIDENT_BIAS ? T(0) : bias[col];   // resident: the accumulator started from it
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + acc_row<T>(q, r);
-            const T z = acc[mt][nt][r] + bc;
+            const T z = RESIDENT_BIAS ? acc[mt][nt][r] : acc[mt][nt][r] + bc;
             dst[row * as + col] = act_apply<T>(KIND, z);
             if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(KIND, z);
           }
@@ -451,7 +460,7 @@ struct TileNet {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{bias_r[0][nt], bias_r[0][nt], bias_r[0][nt], bias_r[0][nt]};
       const T* wl = slice0(m, w, lane);
       const T* A = lds + L.xu;
       // first group of hidden layer 1: in flight under layer 0's MFMAs (64-row tiles have no
@@ -493,7 +502,12 @@ struct TileNet {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
+        for (int nt = 0; nt < NT; ++nt) {
+          T b = bias_r[0][nt];                  // bias_r[l][nt] with l a loop variable: selected
+#pragma unroll                                  // by compares so the array stays in registers
+          for (int k = 1; k < kMaxHidden; ++k) b = (l == k) ? bias_r[k][nt] : b;
+          acc[mt][nt] = acc_t{b, b, b, b};
+        }
       layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN>(act, as, slice_h(m, l, w, lane), lane, pfn,
                                                           acc, w);
       AMPC_MARK(4);
