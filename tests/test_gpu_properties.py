@@ -93,3 +93,40 @@ def test_clipped_noise_respects_bounds_and_solve_is_repeatable():
     np.testing.assert_array_equal(a2, a1)
     np.testing.assert_array_equal(c2, c1)
     plan.close(); h.close()
+
+
+def test_ilqr_on_linear_dynamics_recovers_finite_horizon_lqr():
+    """On x' = A x + B u with a quadratic cost the iLQR step is an exact Newton step: the feedback
+    gains must equal the finite-horizon discrete LQR gains (closed-form backward Riccati in numpy),
+    the solve must converge in a handful of iterations and the trajectory must follow u = K x."""
+    from autompc_amd import _lib
+    rng = np.random.default_rng(5)
+    nx, nu, Hh, dt = 12, 3, 50, 0.05
+    S = rng.normal(size=(nx, nx))
+    A = np.eye(nx) + 0.1 * (-0.3 * np.eye(nx) + 0.4 * (S - S.T))
+    B = rng.normal(scale=0.3, size=(nx, nu))
+    Q = np.diag(rng.uniform(0.5, 2.0, size=nx))
+    R = np.diag(rng.uniform(0.05, 0.2, size=nu))
+    F = np.diag(rng.uniform(1.0, 3.0, size=nx))
+    h = _lib.Handle(0, "f64")
+    h.set_linear(A, B)
+    h.set_quad_costs(Q, R, F, np.zeros(nx))
+    plan = _lib.IlqrPlan(h, 1, Hh, dt)
+    x0 = rng.uniform(-1.0, 1.0, size=nx)
+    out = plan.solve(x0[None, :], np.zeros((1, Hh, nu)), 50)
+    assert out["status"][0] == 0 and out["converged"][0] == 1 and out["iters"][0] <= 4
+    # closed form: V_H = 2F;  K_t = -(2 R dt + B'VB)^-1 B'VA;  V <- 2 Q dt + A'VA + A'VB K_t
+    V = 2.0 * F
+    Ks = np.zeros((Hh, nu, nx))
+    for t in range(Hh - 1, -1, -1):
+        G = 2.0 * R * dt + B.T @ V @ B
+        Ks[t] = -np.linalg.solve(G, B.T @ V @ A)
+        V = 2.0 * Q * dt + A.T @ V @ A + A.T @ V @ B @ Ks[t]
+    assert rel_err(out["Ks"][0], Ks) < 1e-9
+    x = x0.copy()
+    for t in range(Hh):
+        u = Ks[t] @ x
+        assert np.max(np.abs(out["ctrls"][0, t] - u)) < 1e-8 * max(1.0, np.max(np.abs(u)))
+        assert np.max(np.abs(out["states"][0, t] - x)) < 1e-8
+        x = A @ x + B @ u
+    plan.close(); h.close()
