@@ -38,7 +38,8 @@ class BatchPipelineTuner:
 
     def reset(self):
         self.cfgs, self.costs, self.inc_cfgs, self.inc_costs = [], [], [], []
-        self._inc_cfg, self._inc_cost = None, float("inf")
+        self.truedyn_costs, self.inc_truedyn_costs = [], []
+        self._inc_cfg, self._inc_cost, self._inc_truedyn = None, float("inf"), None
 
     def _random_search(self, n, rng):
         return random_candidates(self.system, n, seed=int(rng.integers(1 << 31)))
@@ -51,40 +52,79 @@ class BatchPipelineTuner:
             raise ValueError("sampler returned %d candidates, %d asked" % (len(cands), n))
         return cands
 
-    def tell(self, candidates, scores):
+    def tell(self, candidates, scores, truedyn_scores=None):
         """Record evaluated candidates in order; keeps the incumbent trace the reference builds
-        from SMAC's run history (pipeline_tuner.py:279-291: strict improvement replaces)."""
+        from SMAC's run history (pipeline_tuner.py:279-291: strict improvement replaces).
+        truedyn_scores (optional) are recorded next to the surrogate scores and never steer the
+        search (pipeline_tuner.py:181-184)."""
         scores = np.asarray(scores, dtype=np.float64)
         if len(candidates) != scores.shape[0]:
             raise ValueError("one score per candidate expected")
-        for cfg, s in zip(candidates, scores):
+        if truedyn_scores is not None and len(truedyn_scores) != len(candidates):
+            raise ValueError("one true-dynamics score per candidate expected")
+        for i, (cfg, s) in enumerate(zip(candidates, scores)):
             s = float(s) if np.isfinite(s) else float("inf")
+            td = None if truedyn_scores is None else float(truedyn_scores[i])
             if s < self._inc_cost or self._inc_cfg is None:
-                self._inc_cost, self._inc_cfg = s, cfg
+                self._inc_cost, self._inc_cfg, self._inc_truedyn = s, cfg, td
             self.cfgs.append(cfg)
             self.costs.append(s)
             self.inc_cfgs.append(self._inc_cfg)
             self.inc_costs.append(self._inc_cost)
+            if td is not None:
+                self.truedyn_costs.append(td)
+                self.inc_truedyn_costs.append(self._inc_truedyn)
 
     def result(self):
         return PipelineTuneResult(inc_cfg=self._inc_cfg, cfgs=list(self.cfgs),
                                   inc_cfgs=list(self.inc_cfgs), costs=list(self.costs),
-                                  inc_costs=list(self.inc_costs), truedyn_costs=[],
-                                  inc_truedyn_costs=[], surr_trajs=[], truedyn_trajs=[],
-                                  surr_tune_result=None)
+                                  inc_costs=list(self.inc_costs),
+                                  truedyn_costs=list(self.truedyn_costs),
+                                  inc_truedyn_costs=list(self.inc_truedyn_costs), surr_trajs=[],
+                                  truedyn_trajs=[], surr_tune_result=None)
 
     # -- the loop -----------------------------------------------------------------------------
-    def run(self, n_iters, rng, seed=0):
+    def truedyn_score(self, cand, truedyn, seed=0):
+        """Score of one candidate's controller against the true dynamics ``truedyn(obs, ctrl) ->
+        obs`` (eval_cfg's second branch, pipeline_tuner.py:241-256): the MPPI solves run on the
+        device, the dynamics callback runs on the host between them."""
+        from .. import MPPI, QuadCost, Task, simulate
+        ev = self.evaluator
+        no, nu = self.system.obs_dim, self.system.ctrl_dim
+
+        def mat(v, n):
+            v = np.asarray(v, dtype=np.float64)
+            return np.diag(v) if v.ndim == 1 else v.reshape(n, n)
+        task = Task(self.system)
+        task.set_cost(QuadCost(self.system, mat(cand["Q"], no), mat(cand["R"], nu), mat(cand["F"], no),
+                               goal=ev.goal))
+        task.set_ctrl_bounds(ev.umin, ev.umax)
+        ctl = MPPI(self.system, task, ev.model, horizon=int(cand["horizon"]),
+                   num_path=int(cand["num_path"]), sigma=float(cand["sigma"]),
+                   lmda=float(cand["lmda"]), noise="device", seed=seed,
+                   precision=ev.precision, device=ev.device)
+        ctl.reset()
+        kw = {"max_steps": ev.task.get_num_steps()} if ev.task.has_num_steps() else {}
+        traj = simulate(ctl, ev.task.get_init_obs(), ev.task.term_cond, dynamics=truedyn, **kw)
+        return float(ev.task.get_cost()(traj))
+
+    def run(self, n_iters, rng, seed=0, truedyn=None):
         """Evaluate `n_iters` candidates in batches of `batch_size`.  Every rank must call this
         with an identically seeded `rng` (proposals are drawn redundantly on every rank so that
         no broadcast is needed); each rank evaluates its contiguous shard of every batch and the
-        scores are all-gathered.  Returns (incumbent candidate, PipelineTuneResult)."""
+        scores are all-gathered.  With `truedyn`, every candidate is also scored against the true
+        dynamics (recorded, not used by the search).  Returns (incumbent, PipelineTuneResult)."""
         done = 0
         while done < n_iters:
             n = min(self.batch_size, n_iters - done)
             batch = self.ask(n, rng)
             scores = evaluate_sharded(
                 lambda shard, s=seed + done: self.evaluator.evaluate(shard, seed=s), batch)
-            self.tell(batch, scores)
+            td = None
+            if truedyn is not None:
+                td = evaluate_sharded(
+                    lambda shard, s=seed + done: [self.truedyn_score(c, truedyn, seed=s) for c in shard],
+                    batch)
+            self.tell(batch, scores, td)
             done += n
         return self._inc_cfg, self.result()

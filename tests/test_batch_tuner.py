@@ -106,3 +106,21 @@ def test_two_ranks_agree_and_split_the_work():
     np.testing.assert_array_equal(got[0][0], single.costs)
     np.testing.assert_array_equal(got[1][0], single.costs)
     assert got[0][1] == [4, 4, 3] and got[1][1] == [4, 4, 2]    # shards of batches 8, 8, 5
+
+
+def test_truedyn_scores_are_recorded_but_do_not_steer(monkeypatch):
+    from autompc_amd.tuning import BatchPipelineTuner
+    system = make_system(3, 2)
+    tuner = BatchPipelineTuner(system, _FormulaEvaluator(), batch_size=8)
+    # true-dynamics score = negative surrogate rank: the worst surrogate candidate looks best
+    monkeypatch.setattr(BatchPipelineTuner, "truedyn_score",
+                        lambda self, c, truedyn, seed=0: -abs(c["sigma"] - 0.7) - c["horizon"])
+    best, res = tuner.run(20, np.random.default_rng(4), seed=10, truedyn=lambda o, u: o)
+    _, _, plain = _run(20, 8)
+    np.testing.assert_array_equal(res.costs, plain.costs)           # same search
+    assert len(res.truedyn_costs) == len(res.inc_truedyn_costs) == 20
+    for i in range(20):                # incumbent's own true-dynamics score, not the best one
+        j = res.cfgs.index(res.inc_cfgs[i])
+        assert res.inc_truedyn_costs[i] == res.truedyn_costs[j]
+    with pytest.raises(ValueError):
+        tuner.tell(res.cfgs[:2], [1.0, 2.0], truedyn_scores=[1.0])

@@ -154,3 +154,35 @@ def test_threshold_task_cost_is_scored_on_device():
         ref = score_terms(terms[0], terms[1], obs[b], ctrls[b])
         assert abs(scores[b] - ref) < 1e-10 * max(1.0, abs(ref))
     np.testing.assert_array_equal(scores, ev.evaluate(cands, seed=3))
+
+
+def test_batch_tuner_with_true_dynamics_scores():
+    """BatchPipelineTuner end to end on the device: surrogate scores from the batched closed
+    loop, true-dynamics scores from MPPI.run() against a host callback."""
+    from autompc_amd import QuadCost, Task
+    from autompc_amd.tuning import BatchPipelineTuner, CandidateEvaluator
+    nx, nu, T = 3, 1, 12
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [64, 64], "tanh", seed=8)
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx)))
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    task.set_init_obs(np.array([0.5, -0.4, 0.3]))
+    task.set_num_steps(T)
+    ev = CandidateEvaluator(system, task, _hip_model(system, p))
+    truth = MLPOracle(system, p)
+    tuner = BatchPipelineTuner(system, ev, batch_size=4,
+                               sampler=lambda n, rng: [dict(horizon=int(rng.integers(5, 12)),
+                                                            sigma=float(rng.uniform(0.1, 1.0)),
+                                                            lmda=float(rng.uniform(0.2, 1.5)),
+                                                            num_path=128, Q=np.ones(nx), R=0.1 * np.ones(nu),
+                                                            F=np.ones(nx)) for _ in range(n)])
+    np.random.seed(0)
+    best, res = tuner.run(6, np.random.default_rng(1), truedyn=lambda o, u: truth.pred(o, u))
+    assert len(res.costs) == len(res.truedyn_costs) == 6
+    assert np.all(np.isfinite(res.costs)) and np.all(np.isfinite(res.truedyn_costs))
+    assert best is res.cfgs[int(np.argmin(res.costs))]
+    # true dynamics == surrogate here, so both scores measure the same closed loop up to the
+    # different noise streams: same order of magnitude
+    ratio = np.array(res.truedyn_costs) / np.array(res.costs)
+    assert np.all(ratio > 0.3) and np.all(ratio < 3.0)
