@@ -323,6 +323,23 @@ template <typename T> static int build_model(ampc_handle* h) {
     else pack_ksplit(pk, hpad, nxp / 16, W, Bt);
     push(std::move(pk));
   }
+  // tail fragments for the 4x4x4 output path (MlpDev::wt): f64, 16 < nx <= 20
+  const bool tail4 = sizeof(T) == 8 && nx > 16 && nx <= 20 && env_int("AMPC_TAIL4", 1) != 0;
+  {
+    const int KSW = hpad / 4 / W;
+    std::vector<double> wt((size_t)W * KSW * 64, 0.0);
+    if (tail4) {
+      const std::vector<double>& Wl = Wf[L];
+      const int in = width_in(L);
+      for (int w = 0; w < W; ++w)
+        for (int ksl = 0; ksl < KSW; ++ksl)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int k = 4 * (w * KSW + ksl) + lane / 16, col = 16 + lane % 4;
+            wt[((size_t)w * KSW + ksl) * 64 + lane] = (col < nx && k < in) ? Wl[(size_t)col * in + k] : 0.0;
+          }
+    }
+    push(std::move(wt));
+  }
   // biases b[0..L]
   for (int l = 0; l <= L; ++l) {
     std::vector<double> bb(l < L ? hpad : nxp, 0.0);
@@ -366,6 +383,8 @@ template <typename T> static int build_model(ampc_handle* h) {
   const T* base = (const T*)h->model_buf.p;
   size_t idx = 0;
   for (int l = 0; l <= L; ++l) m.w[l] = base + off[idx++];
+  m.wt = base + off[idx++];
+  m.tail4 = tail4 ? 1 : 0;
   for (int l = 0; l <= L; ++l) m.b[l] = base + off[idx++];
   for (int l = 0; l < L; ++l) m.wj[l] = base + off[idx++];
   h->wout_plain = (const void*)(base + off[idx++]);

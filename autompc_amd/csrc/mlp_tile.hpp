@@ -56,6 +56,25 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
 }
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products (blocks); 16 cycles against the 64 of
+// the 16x16x4.  Lane layout (probed on gfx950, tools/mfma44_probe.cpp), block = (lane/4)%4:
+//   A[i][k]: i = lane%4, k = lane/16      B[k][j]: k = lane/16, j = lane%4
+//   D[i][j]: i = lane/16, j = lane%4
+// With rows 4*block + i the A operand is act[row = lane%16][k = lane/16] -- exactly the fragment
+// the 16x16x4 MFMA takes -- so the same register feeds both; B is shared by the four blocks and
+// D gives 16 rows x 4 columns, one value per lane.
+__device__ __forceinline__ double mfma4(double a, double b, double c) {
+#ifdef AMPC_X_NOMFMA
+  return c + a * b;
+#else
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ float mfma4(float, float, float c) { return c; }   // f64 only (tail4 is never set for f32)
+// row / column (relative to 16) of the value mfma4 leaves in this lane
+__device__ __forceinline__ int tail_row(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ int tail_col(int lane) { return lane & 3; }
+
 // Row of accumulator register r held by lane-quad q (= lane >> 4); column is lane & 15.
 //   f64 16x16x4: row = q + 4 r      f32 16x16x4: row = 4 q + r
 template <typename T> __device__ __forceinline__ int acc_row(int q, int r);
@@ -104,6 +123,11 @@ template <typename T> struct MlpDev {
   const T* w[kMaxHidden + 1];   // packed fragments, layer 0..n_hidden (last = output layer)
   const T* b[kMaxHidden + 1];   // padded biases (normalisers folded in)
   const T* wj[kMaxHidden + 1];  // packed fragments for the Jacobian chain (transposed use)
+  // f64, 16 < nx <= 20: output columns 16..19 come from v_mfma_f64_4x4x4_4b (see mfma4 below)
+  // instead of a second, mostly empty 16-column tile.  wt [W][KSW][64]: lane l of k-step ks holds
+  // W_out'[k = 4 ks + l/16][col = 16 + l%4].
+  const T* wt;
+  int tail4;
 };
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
@@ -327,6 +351,11 @@ struct TileNet {
       const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, dst[ks]);
+      if (m.tail4) {          // second slot: the 4x4x4 tail fragment instead of tile 1
+        const T* wt = m.wt + ((size_t)w * KSW * 64 + lane);
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) dst[ks][1] = wt[ks * 64];
+      }
     }
   }
 
@@ -417,6 +446,11 @@ struct TileNet {
             load_frag<T, 2>(wl + ks * 128, two);
             flat[2 * ks] = two[0];
             flat[2 * ks + 1] = two[1];
+          }
+          if (m.tail4) {
+            const T* wt = m.wt + ((size_t)w * KSW * 64 + lane);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) flat[2 * ks + 1] = wt[ks * 64];
           }
         }
       }
@@ -525,10 +559,13 @@ struct TileNet {
 
     // ---- output layer: K-split, wave w owns k-steps [w*KSW, (w+1)*KSW) -----------------------
     acc_t oacc[MT][NOMAX];
+    T tacc[MT];                      // tail4: columns 16..19, one value per lane
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+      tacc[mt] = T(0);
 #pragma unroll
       for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
+    }
     {
       const T* arow = act + i * as + q + 4 * w * KSW;
       if (no == 1) {
@@ -537,6 +574,15 @@ struct TileNet {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], wo(ks, 0), oacc[mt][0]);
+      } else if (m.tail4) {
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const T a = arow[mt * 16 * as + 4 * ks];
+            oacc[mt][0] = mfma16(a, wo(ks, 0), oacc[mt][0]);
+            tacc[mt] = mfma4(a, wo(ks, 1), tacc[mt]);
+          }
       } else {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
@@ -554,17 +600,20 @@ struct TileNet {
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
     T* part = lds + L.part + w * M * m.nxp;
+    const int nfull = m.tail4 ? 1 : no;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int n = 0; n < NOMAX; ++n)
-        if (n < no) {
+        if (n < nfull) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + acc_row<T>(q, r);
             part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
           }
         }
+      if (m.tail4) part[(16 * mt + tail_row(lane)) * m.nxp + 16 + tail_col(lane)] = tacc[mt];
+    }
     AMPC_MARK(13);
     lds_barrier();
     AMPC_MARK(9);
