@@ -1,71 +1,83 @@
 """System-ID model plugin interface.
 
-Same contract as the reference's ``Model`` / ``ModelFactory`` ABCs (reference:
-autompc/sysid/model.py:8-53 factory, :55-244 model): controllers call
-``traj_to_state``, ``update_state``, ``pred``, ``pred_batch``, ``pred_diff``,
-``pred_diff_batch`` and read ``state_dim`` / ``is_diff`` / ``is_linear``.
-``pred_parallel`` / ``pred_diff_parallel`` are the newer-upstream names for the
-batched calls and are provided as aliases.
+What the controllers, ``simulate`` and the tuner call on a dynamics model (reference:
+autompc/sysid/model.py:8-53 factory, :55-244 model):
+
+    state  = model.traj_to_state(traj)                  model state from history
+    state  = model.update_state(state, ctrl, new_obs)   fold in a new observation
+    x'     = model.pred(state, ctrl)                    one step
+    X'     = model.pred_batch(states, ctrls)            N steps at once
+    x',A,B = model.pred_diff(state, ctrl)               step + Jacobians
+    X',A,B = model.pred_diff_batch(states, ctrls)
+    model.state_dim / is_diff / is_linear / to_linear() / get_parameters() / set_parameters()
+
+``pred_parallel`` / ``pred_diff_parallel`` are the newer-upstream names of the batched calls
+ and are provided as aliases.  The batched defaults below loop over the single-row
+calls, as the reference's do; the device models override them with one launch.
 """
-from abc import ABC, abstractmethod
+import abc
 
 import numpy as np
 
 
-class ModelFactory(ABC):
+class ModelFactory(abc.ABC):
+    """Builds (and trains) models from a configuration.  Subclasses provide ``Model`` (the class)
+    and ``name``; keyword arguments given to the factory override configuration entries."""
+
     def __init__(self, system, **kwargs):
-        self.system = system
-        self.kwargs = kwargs
+        self.system, self.kwargs = system, kwargs
 
     def __call__(self, cfg, train_trajs, silent=False, skip_train_model=False):
-        model_args = dict(cfg.get_dictionary())
-        model_args.update(self.kwargs)
-        model = self.Model(self.system, **model_args)
+        settings = {**dict(cfg.get_dictionary()), **self.kwargs}
+        model = self.Model(self.system, **settings)
         model.factory = self
         if not skip_train_model:
             model.train(train_trajs, silent=silent)
         return model
 
-    @abstractmethod
+    @abc.abstractmethod
     def get_configuration_space(self):
-        raise NotImplementedError
+        """ConfigSpace with the model's hyper-parameters (optional dependency)."""
 
 
-class Model(ABC):
+class Model(abc.ABC):
     def __init__(self, system):
         self.system = system
 
-    @abstractmethod
+    # -- state ------------------------------------------------------------------------------
+    @property
+    @abc.abstractmethod
+    def state_dim(self):
+        """Length of the model state vector (>= system.obs_dim)."""
+
+    @abc.abstractmethod
     def traj_to_state(self, traj):
-        raise NotImplementedError
+        """Model state after observing `traj`."""
 
-    @abstractmethod
+    @abc.abstractmethod
     def update_state(self, state, new_ctrl, new_obs):
-        raise NotImplementedError
+        """Model state after applying `new_ctrl` in `state` and then observing `new_obs`."""
 
-    @abstractmethod
+    # -- prediction -------------------------------------------------------------------------
+    @abc.abstractmethod
     def pred(self, state, ctrl):
-        raise NotImplementedError
+        """Next model state."""
 
     def pred_batch(self, states, ctrls):
-        out = np.empty((states.shape[0], self.state_dim))
-        for i in range(states.shape[0]):
-            out[i, :] = self.pred(states[i, :], ctrls[i, :])
-        return out
+        rows = [self.pred(s, c) for s, c in zip(states, ctrls)]
+        return np.array(rows).reshape(len(rows), self.state_dim)
 
     def pred_diff(self, state, ctrl):
+        """(next state, d next / d state, d next / d ctrl); differentiable models override."""
         raise NotImplementedError
 
     def pred_diff_batch(self, states, ctrls):
-        m, n = states.shape[0], self.state_dim
-        out = np.empty((m, n))
-        jx = np.empty((m, n, n))
-        ju = np.empty((m, n, self.system.ctrl_dim))
-        for i in range(m):
-            out[i], jx[i], ju[i] = self.pred_diff(states[i, :], ctrls[i, :])
-        return out, jx, ju
+        n, ns, nu = len(states), self.state_dim, self.system.ctrl_dim
+        nxt, jac_x, jac_u = np.empty((n, ns)), np.empty((n, ns, ns)), np.empty((n, ns, nu))
+        for k, (s, c) in enumerate(zip(states, ctrls)):
+            nxt[k], jac_x[k], jac_u[k] = self.pred_diff(s, c)
+        return nxt, jac_x, jac_u
 
-    # newer-upstream spellings
     def pred_parallel(self, states, ctrls):
         return self.pred_batch(states, ctrls)
 
@@ -73,8 +85,19 @@ class Model(ABC):
         return self.pred_diff_batch(states, ctrls)
 
     def to_linear(self):
+        """(A, B) of x' = A x + B u; linear models override."""
         raise NotImplementedError
 
+    # -- capabilities: derived from what the subclass overrides -------------------------------
+    @property
+    def is_diff(self):
+        return type(self).pred_diff is not Model.pred_diff
+
+    @property
+    def is_linear(self):
+        return type(self).to_linear is not Model.to_linear
+
+    # -- fitting / persistence ----------------------------------------------------------------
     def train(self, trajs, silent=False):
         raise NotImplementedError
 
@@ -83,16 +106,3 @@ class Model(ABC):
 
     def set_parameters(self, params):
         raise NotImplementedError
-
-    @property
-    @abstractmethod
-    def state_dim(self):
-        raise NotImplementedError
-
-    @property
-    def is_linear(self):
-        return type(self).to_linear is not Model.to_linear
-
-    @property
-    def is_diff(self):
-        return type(self).pred_diff is not Model.pred_diff
