@@ -1,0 +1,113 @@
+"""Randomised parity sweep on the GPU box: many random model shapes / solver settings, HIP path
+(through the Python mirrors -> C ABI) against the oracle.  Prints the worst relative errors and
+exits non-zero on a violation.  Usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from autompc_amd import MLP, MPPI, IterativeLQR, QuadCost, System, Task
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+from oracle.ilqr import ILQROracle
+from oracle.mlp import MLPOracle
+from oracle.mppi import MPPIOracle
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {"pred": 0.0, "jac": 0.0, "mppi_cost": 0.0, "mppi_act": 0.0, "ilqr": 0.0}
+    bad = []
+    for case in range(n_cases):
+        nx = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 18, 19, 20, 21, 25, 32]))
+        nu = int(rng.choice([1, 2, 3, 6, 9, 16]))
+        if nx + nu > 48:
+            nu = 48 - nx
+        nl = int(rng.integers(1, 5))
+        hidden = [int(rng.choice([16, 33, 64, 100, 128, 150, 192, 256])) for _ in range(nl)]
+        act = str(rng.choice(["relu", "tanh", "sigmoid", "selu"]))
+        prec = "f64" if rng.random() < 0.7 else "f32"
+        tol = 1e-9 if prec == "f64" else 2e-4
+        os.environ["AMPC_MT"] = str(rng.choice([0, 1, 2, 4]))
+        system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+        p = omlp.random_params(nx, nu, hidden, act, seed=int(rng.integers(1 << 30)))
+        p["xu_means"] = rng.normal(scale=0.2, size=nx + nu)
+        p["xu_std"] = rng.uniform(0.5, 2.0, size=nx + nu)
+        p["dy_means"] = rng.normal(scale=0.02, size=nx)
+        p["dy_std"] = rng.uniform(0.05, 0.2, size=nx)
+        m = MLP(system, n_hidden_layers=nl, nonlintype=act, precision=prec,
+                **{"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)})
+        m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+        tag = "case %d nx=%d nu=%d hidden=%s %s %s MT=%s" % (case, nx, nu, hidden, act, prec, os.environ["AMPC_MT"])
+        try:
+            n = int(rng.choice([1, 7, 16, 33, 200]))
+            s, c = rng.normal(size=(n, nx)), rng.normal(size=(n, nu))
+            e = rel(m.pred_batch(s, c), omlp.pred_batch(p, s, c))
+            worst["pred"] = max(worst["pred"], e / tol)
+            o, jx, ju = m.pred_diff_batch(s, c)
+            eo, ejx, eju = omlp.pred_diff_batch(p, s, c)
+            ej = max(rel(jx, ejx), rel(ju, eju))
+            worst["jac"] = max(worst["jac"], ej / (10 * tol))
+            if e > tol or ej > 10 * tol:
+                bad.append((tag, "pred/jac", e, ej))
+            # MPPI
+            Q = np.diag(rng.uniform(0.5, 2.0, size=nx)) if rng.random() < 0.6 else \
+                (lambda A: A @ A.T / nx + 0.1 * np.eye(nx))(rng.normal(size=(nx, nx)))
+            R = np.diag(rng.uniform(0.01, 0.1, size=nu))
+            F = np.diag(rng.uniform(0.5, 2.0, size=nx))
+            goal = rng.normal(scale=0.1, size=nx)
+            task = Task(system)
+            task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+            lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
+            task.set_ctrl_bounds(np.full(nu, lo), np.full(nu, hi))
+            N, H = int(rng.choice([17, 64, 100, 300])), int(rng.integers(2, 20))   # (H = 1 raises in the reference: a[-2])
+            sigma, lmda = float(rng.uniform(0.2, 1.5)), float(rng.uniform(0.2, 2.0))
+            seed = int(rng.integers(1 << 30))
+            omodel = MLPOracle(system, p)
+            np.random.seed(seed)
+            orc = MPPIOracle(omodel, QuadCostOracle(Q, R, F, goal), np.tile([lo, hi], (nu, 1)),
+                             horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+            np.random.seed(seed)
+            ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+            obs = rng.uniform(-0.1, 0.1, size=nx)
+            cs = np.concatenate([obs, np.zeros(nu)])
+            st = np.random.get_state()
+            uo, _ = orc.run(cs, obs)
+            np.random.set_state(st)
+            uh, _ = ctl.run(cs, obs, return_details=True)
+            ec, ea = rel(ctl.last_costs, orc.last_costs), rel(ctl.act_sequence, orc.act_sequence)
+            worst["mppi_cost"] = max(worst["mppi_cost"], ec / tol)
+            worst["mppi_act"] = max(worst["mppi_act"], ea / (100 * tol))
+            if ec > tol or ea > 100 * tol:
+                bad.append((tag + " N=%d H=%d" % (N, H), "mppi", ec, ea))
+            # iLQR (f64 only; a few iterations, compare the first accepted trajectory loosely)
+            if prec == "f64" and case % 3 == 0:
+                Hh = int(rng.integers(3, 15))
+                t2 = Task(system)
+                t2.set_cost(QuadCost(system, Q, R, F, goal=goal))
+                il = IterativeLQR(system, t2, m, Hh)
+                oil = ILQROracle(omodel, QuadCostOracle(Q, R, F, goal), system.dt, Hh, max_iter=2)
+                r1 = il._device().solve(obs[None, :], np.zeros((1, Hh, nu)), 2)
+                co, so, uo2, Ko, ko = oil.solve(obs, np.zeros((Hh, nu)))
+                ei = max(rel(r1["states"][0], so), rel(r1["Ks"][0], Ko))
+                worst["ilqr"] = max(worst["ilqr"], ei / 1e-6)
+                if ei > 1e-6:
+                    bad.append((tag + " H=%d" % Hh, "ilqr", ei, 0.0))
+        except Exception as ex:          # noqa: BLE001 -- report and continue
+            bad.append((tag, "exception", repr(ex)[:200], 0.0))
+    print("worst error / tolerance:", {k: float("%.3g" % v) for k, v in worst.items()})
+    for b in bad:
+        print("VIOLATION", b)
+    print("%d cases, %d violations" % (n_cases, len(bad)))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
