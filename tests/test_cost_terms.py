@@ -88,3 +88,35 @@ def test_device_scorer_rejects_bad_terms():
         h.score_trajectories((np.array([1], dtype=np.int32),
                               np.concatenate([np.zeros(4), [0, 9, 0.5]])), obs, ctl)
     h.close()
+
+
+def test_reference_style_cost_objects_flatten_too():
+    """cost_terms recognises terms structurally, so the reference's own objects (attributes
+    _obs_range / _threshold / _limits, a `costs` property on sums) work unchanged."""
+    class RefThreshold:                       # attribute layout of autompc.costs.ThresholdCost
+        def __init__(self, goal, obs_range, threshold):
+            self._goal, self._obs_range, self._threshold = np.array(goal), list(obs_range), threshold
+            self.is_quad = False
+
+    class RefBox:                             # ... of autompc.costs.BoxThresholdCost
+        def __init__(self, limits):
+            self._limits = np.array(limits)
+            self.is_quad = False
+
+    class RefSum:                             # ... of autompc.costs.SumCost
+        def __init__(self, costs):
+            self._costs = costs
+
+        @property
+        def costs(self):
+            return self._costs[:]
+
+    g = golden("cost_terms")
+    ref = RefSum([RefThreshold(g["goal"], g["thr_range"], float(g["thr"])), RefBox(g["limits"])])
+    kinds, params = cost_terms(ref, 5, 3)
+    _, own = _costs(g)
+    k2, p2 = cost_terms(own["sum_tb"], 5, 3)
+    np.testing.assert_array_equal(kinds, k2)
+    np.testing.assert_array_equal(params, p2)
+    for b in range(g["obs"].shape[0]):
+        assert score_terms(kinds, params, g["obs"][b], g["ctrls"][b]) == g["score_sum_tb"][b]
