@@ -70,6 +70,14 @@ struct DevBuf {
   }
 };
 
+// function-local device scratch: freed on every exit path (HIP_OK / REQUIRE return early)
+struct ScopedBuf : DevBuf {
+  ScopedBuf() = default;
+  ScopedBuf(const ScopedBuf&) = delete;
+  ScopedBuf& operator=(const ScopedBuf&) = delete;
+  ~ScopedBuf() { release(); }
+};
+
 static constexpr size_t kLdsLimit = 160 * 1024;
 
 static int env_int(const char* name, int dflt) {
@@ -1409,7 +1417,7 @@ static int score_device(ampc_handle* h, const void* d_obs, const void* d_ctl, in
   std::vector<int> offs;
   int total = 0;
   if (int rc = score_spec_check(sp, no, nu, &offs, &total)) return rc;
-  DevBuf d_int, d_par, d_out;
+  ScopedBuf d_int, d_par, d_out;
   HIP_OK(d_int.reserve((size_t)2 * sp.n_terms * sizeof(int)));
   HIP_OK(d_par.reserve((size_t)total * sizeof(T)));
   HIP_OK(d_out.reserve((size_t)B * sizeof(T)));
@@ -1423,7 +1431,6 @@ static int score_device(ampc_handle* h, const void* d_obs, const void* d_ctl, in
                      (const int*)d_int.p + sp.n_terms, (const T*)d_par.p, (T*)d_out.p);
   HIP_OK(hipGetLastError());
   HIP_OK(download_converted<T>(scores, d_out.p, (size_t)B, h->stream));
-  d_int.release(); d_par.release(); d_out.release();
   return 0;
 }
 
@@ -1431,14 +1438,13 @@ static int score_device(ampc_handle* h, const void* d_obs, const void* d_ctl, in
 template <typename T>
 static int score_host_impl(ampc_handle* h, int B, int T1, int nx, int nu, int no, const double* obs,
                            const double* ctrls, const ScoreSpec& sp, double* scores) {
-  DevBuf d_obs, d_ctl;
+  ScopedBuf d_obs, d_ctl;
   HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
   HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
   HIP_OK(upload_converted<T>(d_obs.p, obs, (size_t)B * T1 * nx, h->stream));
   HIP_OK(upload_converted<T>(d_ctl.p, ctrls, (size_t)B * T1 * nu, h->stream));
   int rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, no, sp, scores);
   (void)hipStreamSynchronize(h->stream);
-  d_obs.release(); d_ctl.release();
   return rc;
 }
 
@@ -1469,7 +1475,7 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
                             double* scores = nullptr) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
-  DevBuf d_obs, d_ctl, d_next;
+  ScopedBuf d_obs, d_ctl, d_next;
   HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
   HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
   HIP_OK(d_next.reserve((size_t)B * nx * sizeof(T)));
@@ -1505,7 +1511,6 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   if (rc == 0 && score && scores)
     rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, h->obs_dim, *score, scores);
   (void)hipStreamSynchronize(h->stream);
-  d_obs.release(); d_ctl.release(); d_next.release();
   return rc;
 }
 
