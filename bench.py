@@ -179,8 +179,22 @@ def secondary_workload(args, rank, local_rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
+        mlp_macs = sum(a * b for a, b in zip([nx + nu] + spec["hidden"], spec["hidden"] + [nx]))
         if args.workload == "c4":
-            extra["mean_iterations_per_solve"] = float(np.mean(iters))
+            # algorithmic work of one iteration of one problem: Jacobian chain over H
+            # rows + the 10-candidate line-search rollout + the accepted-trajectory forward pass
+            it = float(np.mean(iters))
+            hid = sum(a * b for a, b in zip(spec["hidden"], spec["hidden"][1:]))
+            jac = 50 * 2 * nx * (hid + spec["hidden"][0] * (nx + nu))
+            per_iter = jac + 10 * 50 * 2 * mlp_macs + 50 * 2 * mlp_macs
+            extra["mean_iterations_per_solve"] = it
+            extra["algorithmic_tflops"] = world * steps * B * it * per_iter / elapsed / 1e12
+        else:
+            # every MPPI solve of candidate c is N_c x H_c model steps (+ the stage costs)
+            per_ctrl_step = sum(c["num_path"] * c["horizon"] for c in cands) / world
+            flops = per_ctrl_step * (2 * mlp_macs + 2 * (nx * nx + nx) + 2 * nu * nu + 2 * nu)
+            extra["algorithmic_tflops"] = world * steps * 200 * flops / elapsed / 1e12
+        extra["mfma_peak_tflops"] = PEAK_TFLOPS[args.precision]
         out = {"metric": metric, "value": world * steps * unit_per_step / elapsed, "unit": unit,
                "n_gpus": world, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
