@@ -1123,7 +1123,7 @@ struct ampc_ilqr_plan {
   int B = 0, H = 0, ls_n = 10, bounded = 0;
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
-  DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz;
+  DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
   // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
   TileLds L{};
   int lds_work = 0, lds_xn = 0;
@@ -1155,6 +1155,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   int* f = (int*)p->flags.p;
   a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
   a.refresh = f + 4 * p->B;
+  a.ric = (T*)p->ric.p;
   return a;
 }
 
@@ -1194,6 +1195,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
   if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
+  HIP_OK(p->ric.reserve((size_t)4 * p->B * e));
   return 0;
 }
 
@@ -1227,7 +1229,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
-                    &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz};
+                    &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric};
   for (DevBuf* b : bufs) b->release();
   ampc_handle* h = p->h;
   delete p;
@@ -1286,6 +1288,14 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
+    const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
+    const size_t rb = (size_t)wk.total * sizeof(T);
+    auto rk = ilqr_riccati_kernel<T>;
+    HIP_OK(allow_lds(rk, rb));
+    hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    HIP_OK(hipGetLastError());
+  }
   if (h->has_sindy) {
     auto k = ilqr_iter_kernel<T, 1, 4, 1>;
     HIP_OK(allow_lds(k, p->lds_bytes));

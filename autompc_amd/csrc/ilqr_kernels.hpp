@@ -27,6 +27,7 @@
 
 namespace ampc {
 
+constexpr int kRicThreads = 512;  // workgroup of the backward-sweep kernel
 constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows of one MFMA tile
 
 template <typename T> struct IlqrArgs {
@@ -56,6 +57,7 @@ template <typename T> struct IlqrArgs {
   int* iters;                    // [B]
   int* status;                   // [B] 0 ok, 1 singular Quu, 2 no line-search candidate
   int* refresh;                  // [B] Jacobians must be recomputed for this problem
+  T* ric;                        // [B][4] sweep -> line search: lin, quad, |k|, singular flag
 };
 
 // Scratch map inside the work region (offsets in elements of T), nx/nu/n known at run time.
@@ -112,6 +114,236 @@ __device__ __forceinline__ double readlane_t(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Backward Riccati sweep of one problem per workgroup (ilqr.py:159-187).  A kernel of its own:
+// it needs none of the MLP tile's registers or LDS, so it is compiled once per precision, keeps
+// the Quu solve in registers without spilling, and leaves K_t, k_t (global) and the expected-
+// reduction sums `ric[p] = {lin, quad, |k|, singular}` for the line-search kernel.
+template <typename T>
+__global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArgs<T> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Wr = reinterpret_cast<T*>(smem_raw);
+  constexpr int NTHR = kRicThreads;
+  const MlpDev<T>& mlp = args.mlp;
+  const int tid = threadIdx.x, p = blockIdx.x;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = args.obs_dim, H = args.H;
+  if (args.active[p] == 0) return;
+  const IlqrWork wk = make_ilqr_work(nx, nu, args.cost_stride);
+  T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
+  T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
+  T* Wk = Wr + wk.Wk; T* wq = Wr + wk.wq;
+  T* xbar = Wr + wk.xbar; T* ubar = Wr + wk.ubar; T* cpar = Wr + wk.cpar; T* scal = Wr + wk.scal;
+  const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
+  const T* goal = Fm + no * no;
+  for (int i = tid; i < args.cost_stride; i += NTHR)
+    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * args.cost_stride + i];
+  __syncthreads();
+  const T* st = args.states + (size_t)p * (H + 1) * nx;
+  const T* ct = args.ctrls + (size_t)p * H * nu;
+  T* Kg = args.Ks + (size_t)p * H * nu * nx;
+  T* kg = args.ks + (size_t)p * H * nu;
+  T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
+  const T dt = args.dt;
+  for (int idx = tid; idx < nx * nx; idx += NTHR) {
+    const int a = idx / nx, b = idx - a * nx;
+    V[idx] = (a < no && b < no) ? Fm[a * no + b] + Fm[b * no + a] : T(0);
+  }
+  for (int a = tid; a < nx; a += NTHR) {
+    T s = T(0);
+    if (a < no)
+      for (int b = 0; b < no; ++b) s += (Fm[a * no + b] + Fm[b * no + a]) * st[(size_t)H * nx + b];
+    v[a] = s;     // NOTE: no goal subtraction -- the reference's terminal gradient quirk
+  }
+  if (tid == 0) scal[8] = T(0);
+  __syncthreads();
+  // J_t = [jx | ju], xbar_t, ubar_t are staged into LDS one step ahead, through registers: the
+  // global loads for step t-1 are issued at the top of step t and land in LDS at its end, so
+  // their latency is covered by the step's arithmetic (barriers in the loop are LDS-only).
+  constexpr int JR = (32 * 48 + NTHR - 1) / NTHR;      // nx <= 32, n <= 48
+  T jreg[JR];
+  T xreg = T(0), ureg = T(0);
+  auto fetch_step = [&](int t) {
+    const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
+    const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
+#pragma unroll
+    for (int k = 0; k < JR; ++k) {
+      const int idx = tid + k * NTHR;
+      if (idx < nx * n) {
+        const int a = idx / n, c = idx - a * n;
+        jreg[k] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
+      }
+    }
+    if (tid < nx) xreg = st[(size_t)t * nx + tid];
+    if (tid < nu) ureg = ct[(size_t)t * nu + tid];
+  };
+  auto commit_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < JR; ++k) {
+      const int idx = tid + k * NTHR;
+      if (idx < nx * n) Jm[idx] = jreg[k];
+    }
+    if (tid < nx) xbar[tid] = xreg;
+    if (tid < nu) ubar[tid] = ureg;
+  };
+  fetch_step(H - 1);
+  commit_step();
+  __syncthreads();
+  const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
+  for (int t = H - 1; t >= 0; --t) {
+#ifdef AMPC_X_PHASETIME
+    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
+#endif
+    AMPC_MARK(20);
+    if (t > 0) fetch_step(t - 1);
+    for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
+      const int a = idx / n, c = idx - a * n;
+      T s = T(0);
+#pragma unroll 8
+      for (int b = 0; b < nx; ++b) s += V[a * nx + b] * Jm[b * n + c];
+      VJ[idx] = s;
+    }
+    lds_barrier();
+    AMPC_MARK(21);
+    for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
+      const int c = idx / n, d = idx - c * n;
+      T s = T(0);
+#pragma unroll 8
+      for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * VJ[a * n + d];
+      T cc = T(0);
+      if (c < no && d < no) cc = (Qm[c * no + d] + Qm[d * no + c]) * dt;
+      else if (c >= nx && d >= nx) cc = (Rm[(c - nx) * nu + (d - nx)] + Rm[(d - nx) * nu + (c - nx)]) * dt;
+      Qt[idx] = cc + s;
+    }
+    for (int c = tid; c < n; c += NTHR) {                  // qt = ct + J' v
+      T s = T(0);
+#pragma unroll 8
+      for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * v[a];
+      T cc = T(0);
+      if (c < no) {
+        for (int b = 0; b < no; ++b) cc += (Qm[c * no + b] + Qm[b * no + c]) * (xbar[b] - goal[b]);
+      } else if (c >= nx) {
+        const int cj = c - nx;
+        for (int j = 0; j < nu; ++j) cc += (Rm[cj * nu + j] + Rm[j * nu + cj]) * ubar[j];
+      }
+      qt[c] = cc * dt + s;
+    }
+    lds_barrier();
+    AMPC_MARK(22);
+    // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
+    // numpy.linalg.solve / LAPACK gesv) on the augmented matrix [Quu | Qux | qu], by wave 0,
+    // entirely in registers: lane j owns column j (nc = nu + nx + 1 <= 49 columns), its nu
+    // entries are col[0..nu).  Column c's entries reach the other lanes by readlane; rows are
+    // swapped by uniform-branch register moves.  No LDS round trips inside the elimination.
+    if (tid < 64) {
+      const int lane = tid;
+      T col[kMaxNu];
+#pragma unroll
+      for (int i = 0; i < kMaxNu; ++i) {
+        col[i] = T(0);
+        if (i < nu && lane < nc)
+          col[i] = lane < nu ? Qt[(nx + i) * n + nx + lane]
+                             : (lane < nu + nx ? Qt[(nx + i) * n + (lane - nu)] : qt[nx + i]);
+      }
+      int sing = 0;
+#pragma unroll
+      for (int c = 0; c < kMaxNu; ++c) {
+        if (c >= nu || sing) break;
+        // pivot row: first maximum of |Aug[i][c]|, i >= c (lane c holds that column)
+        T best = fabs(col[c]);
+        int pr = c;
+#pragma unroll
+        for (int i = c + 1; i < kMaxNu; ++i) {
+          if (i >= nu) break;
+          const T a = fabs(col[i]);
+          if (a > best) { best = a; pr = i; }
+        }
+        pr = __builtin_amdgcn_readlane(pr, c);
+#pragma unroll
+        for (int i = c + 1; i < kMaxNu; ++i)
+          if (pr == i) { const T tmp = col[c]; col[c] = col[i]; col[i] = tmp; }
+        const T d = readlane_t(col[c], c);
+        if (d == T(0)) { sing = 1; break; }
+        const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
+        const T rowc = col[c];
+#pragma unroll
+        for (int i = 0; i < kMaxNu; ++i) {                 // eliminate column c from every other row
+          if (i >= nu) break;
+          if (i == c) continue;
+          const T f = readlane_t(col[i], c) * rd;
+          if (lane > c) col[i] -= f * rowc;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxNu; ++i) {
+        if (i >= nu) break;
+        const T val = -col[i] / readlane_t(col[i], i);
+        if (lane >= nu && lane < nu + nx) Km[i * nx + (lane - nu)] = val;
+        else if (lane == nu + nx) kv[i] = val;
+      }
+      if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
+    }
+    AMPC_MARK(23);
+    lds_barrier();
+    AMPC_MARK(24);
+    for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
+      const int i = idx / nx, b = idx - i * nx;
+      T s = T(0);
+      for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * Km[j * nx + b];
+      Wk[idx] = s;
+      Kg[(size_t)t * nu * nx + idx] = Km[idx];
+    }
+    for (int i = tid; i < nu; i += NTHR) {                 // wq = qu + Quu k ; store k
+      T s = qt[nx + i];
+      for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
+      wq[i] = s;
+      kg[(size_t)t * nu + i] = kv[i];
+    }
+    if (tid < 64) {                                        // lin += qu.k ; quad += k'Quu k ; |k|^2
+      T l = T(0), qd = T(0), k2 = T(0);
+      if (tid < nu) {
+        const T ki = kv[tid];
+        T s = T(0);
+        for (int j = 0; j < nu; ++j) s += Qt[(nx + tid) * n + nx + j] * kv[j];
+        l = qt[nx + tid] * ki;
+        qd = ki * s;
+        k2 = ki * ki;
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {              // nu <= 16
+        l += __shfl_xor(l, off);
+        qd += __shfl_xor(qd, off);
+        k2 += __shfl_xor(k2, off);
+      }
+      if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
+    }
+    lds_barrier();
+    AMPC_MARK(25);
+    for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
+      const int a = idx / nx, b = idx - a * nx;
+      T s = Qt[a * n + b];
+#pragma unroll 4
+      for (int j = 0; j < nu; ++j)
+        s += Qt[a * n + nx + j] * Km[j * nx + b] + Km[j * nx + a] * Qt[(nx + j) * n + b] +
+             Km[j * nx + a] * Wk[j * nx + b];
+      V[idx] = s;
+    }
+    for (int a = tid; a < nx; a += NTHR) {                 // v <- qx + Qxu k + K'(qu + Quu k)
+      T s = qt[a];
+      for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
+      v[a] = s;
+    }
+    if (t > 0) commit_step();                              // J, xbar, ubar are not read in this phase
+    lds_barrier();
+    AMPC_MARK(26);
+  }
+  if (tid == 0) {
+    T* out = args.ric + (size_t)p * 4;
+    out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = scal[8];
+    if (scal[8] != T(0)) {        // singular Quu: the reference raises LinAlgError here
+      args.active[p] = 0; args.refresh[p] = 0;
+    }
+  }
+}
+
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
 template <typename T, int NT, int W, int DYN = 0>
@@ -162,208 +394,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   T* kg = args.ks + (size_t)p * H * nu;
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
 
-  // =========================== backward Riccati sweep (ilqr.py:159-187) ========================
-  AMPC_MARK_ALWAYS(30);
+  // (backward Riccati sweep: ilqr_riccati_kernel above, launched just before this kernel)
   if (args.mode == 1) {
-    const T dt = args.dt;
-    for (int idx = tid; idx < nx * nx; idx += NTHR) {
-      const int a = idx / nx, b = idx - a * nx;
-      V[idx] = (a < no && b < no) ? Fm[a * no + b] + Fm[b * no + a] : T(0);
-    }
-    for (int a = tid; a < nx; a += NTHR) {
-      T s = T(0);
-      if (a < no)
-        for (int b = 0; b < no; ++b) s += (Fm[a * no + b] + Fm[b * no + a]) * st[(size_t)H * nx + b];
-      v[a] = s;     // NOTE: no goal subtraction -- the reference's terminal gradient quirk
-    }
-    if (tid == 0) scal[8] = T(0);
+    const T* rin = args.ric + (size_t)p * 4;
+    if (rin[3] != T(0)) return;     // singular Quu: the sweep already retired this problem
+    if (tid == 0) { scal[0] = rin[0]; scal[1] = rin[1]; scal[2] = rin[2]; }
     __syncthreads();
-    // J_t = [jx | ju], xbar_t, ubar_t are staged into LDS one step ahead, through registers: the
-    // global loads for step t-1 are issued at the top of step t and land in LDS at its end, so
-    // their latency is covered by the step's arithmetic (barriers in the loop are LDS-only).
-    constexpr int JR = (32 * 48 + NTHR - 1) / NTHR;      // nx <= 32, n <= 48
-    T jreg[JR];
-    T xreg = T(0), ureg = T(0);
-    auto fetch_step = [&](int t) {
-      const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
-      const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
-#pragma unroll
-      for (int k = 0; k < JR; ++k) {
-        const int idx = tid + k * NTHR;
-        if (idx < nx * n) {
-          const int a = idx / n, c = idx - a * n;
-          jreg[k] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
-        }
-      }
-      if (tid < nx) xreg = st[(size_t)t * nx + tid];
-      if (tid < nu) ureg = ct[(size_t)t * nu + tid];
-    };
-    auto commit_step = [&]() {
-#pragma unroll
-      for (int k = 0; k < JR; ++k) {
-        const int idx = tid + k * NTHR;
-        if (idx < nx * n) Jm[idx] = jreg[k];
-      }
-      if (tid < nx) xbar[tid] = xreg;
-      if (tid < nu) ubar[tid] = ureg;
-    };
-    fetch_step(H - 1);
-    commit_step();
-    __syncthreads();
-    const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
-    for (int t = H - 1; t >= 0; --t) {
-#ifdef AMPC_X_PHASETIME
-      if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
-#endif
-      AMPC_MARK(20);
-      if (t > 0) fetch_step(t - 1);
-      for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
-        const int a = idx / n, c = idx - a * n;
-        T s = T(0);
-#pragma unroll 8
-        for (int b = 0; b < nx; ++b) s += V[a * nx + b] * Jm[b * n + c];
-        VJ[idx] = s;
-      }
-      lds_barrier();
-      AMPC_MARK(21);
-      for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
-        const int c = idx / n, d = idx - c * n;
-        T s = T(0);
-#pragma unroll 8
-        for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * VJ[a * n + d];
-        T cc = T(0);
-        if (c < no && d < no) cc = (Qm[c * no + d] + Qm[d * no + c]) * dt;
-        else if (c >= nx && d >= nx) cc = (Rm[(c - nx) * nu + (d - nx)] + Rm[(d - nx) * nu + (c - nx)]) * dt;
-        Qt[idx] = cc + s;
-      }
-      for (int c = tid; c < n; c += NTHR) {                  // qt = ct + J' v
-        T s = T(0);
-#pragma unroll 8
-        for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * v[a];
-        T cc = T(0);
-        if (c < no) {
-          for (int b = 0; b < no; ++b) cc += (Qm[c * no + b] + Qm[b * no + c]) * (xbar[b] - goal[b]);
-        } else if (c >= nx) {
-          const int cj = c - nx;
-          for (int j = 0; j < nu; ++j) cc += (Rm[cj * nu + j] + Rm[j * nu + cj]) * ubar[j];
-        }
-        qt[c] = cc * dt + s;
-      }
-      lds_barrier();
-      AMPC_MARK(22);
-      // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
-      // numpy.linalg.solve / LAPACK gesv) on the augmented matrix [Quu | Qux | qu], by wave 0,
-      // entirely in registers: lane j owns column j (nc = nu + nx + 1 <= 49 columns), its nu
-      // entries are col[0..nu).  Column c's entries reach the other lanes by readlane; rows are
-      // swapped by uniform-branch register moves.  No LDS round trips inside the elimination.
-      if (tid < 64) {
-        const int lane = tid;
-        T col[kMaxNu];
-#pragma unroll
-        for (int i = 0; i < kMaxNu; ++i) {
-          col[i] = T(0);
-          if (i < nu && lane < nc)
-            col[i] = lane < nu ? Qt[(nx + i) * n + nx + lane]
-                               : (lane < nu + nx ? Qt[(nx + i) * n + (lane - nu)] : qt[nx + i]);
-        }
-        int sing = 0;
-#pragma unroll
-        for (int c = 0; c < kMaxNu; ++c) {
-          if (c >= nu || sing) break;
-          // pivot row: first maximum of |Aug[i][c]|, i >= c (lane c holds that column)
-          T best = fabs(col[c]);
-          int pr = c;
-#pragma unroll
-          for (int i = c + 1; i < kMaxNu; ++i) {
-            if (i >= nu) break;
-            const T a = fabs(col[i]);
-            if (a > best) { best = a; pr = i; }
-          }
-          pr = __builtin_amdgcn_readlane(pr, c);
-#pragma unroll
-          for (int i = c + 1; i < kMaxNu; ++i)
-            if (pr == i) { const T tmp = col[c]; col[c] = col[i]; col[i] = tmp; }
-          const T d = readlane_t(col[c], c);
-          if (d == T(0)) { sing = 1; break; }
-          const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
-          const T rowc = col[c];
-#pragma unroll
-          for (int i = 0; i < kMaxNu; ++i) {                 // eliminate column c from every other row
-            if (i >= nu) break;
-            if (i == c) continue;
-            const T f = readlane_t(col[i], c) * rd;
-            if (lane > c) col[i] -= f * rowc;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < kMaxNu; ++i) {
-          if (i >= nu) break;
-          const T val = -col[i] / readlane_t(col[i], i);
-          if (lane >= nu && lane < nu + nx) Km[i * nx + (lane - nu)] = val;
-          else if (lane == nu + nx) kv[i] = val;
-        }
-        if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
-      }
-      AMPC_MARK(23);
-      lds_barrier();
-      AMPC_MARK(24);
-      for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
-        const int i = idx / nx, b = idx - i * nx;
-        T s = T(0);
-        for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * Km[j * nx + b];
-        Wk[idx] = s;
-        Kg[(size_t)t * nu * nx + idx] = Km[idx];
-      }
-      for (int i = tid; i < nu; i += NTHR) {                 // wq = qu + Quu k ; store k
-        T s = qt[nx + i];
-        for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
-        wq[i] = s;
-        kg[(size_t)t * nu + i] = kv[i];
-      }
-      if (tid < 64) {                                        // lin += qu.k ; quad += k'Quu k ; |k|^2
-        T l = T(0), qd = T(0), k2 = T(0);
-        if (tid < nu) {
-          const T ki = kv[tid];
-          T s = T(0);
-          for (int j = 0; j < nu; ++j) s += Qt[(nx + tid) * n + nx + j] * kv[j];
-          l = qt[nx + tid] * ki;
-          qd = ki * s;
-          k2 = ki * ki;
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {              // nu <= 16
-          l += __shfl_xor(l, off);
-          qd += __shfl_xor(qd, off);
-          k2 += __shfl_xor(k2, off);
-        }
-        if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
-      }
-      lds_barrier();
-      AMPC_MARK(25);
-      for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
-        const int a = idx / nx, b = idx - a * nx;
-        T s = Qt[a * n + b];
-#pragma unroll 4
-        for (int j = 0; j < nu; ++j)
-          s += Qt[a * n + nx + j] * Km[j * nx + b] + Km[j * nx + a] * Qt[(nx + j) * n + b] +
-               Km[j * nx + a] * Wk[j * nx + b];
-        V[idx] = s;
-      }
-      for (int a = tid; a < nx; a += NTHR) {                 // v <- qx + Qxu k + K'(qu + Quu k)
-        T s = qt[a];
-        for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
-        v[a] = s;
-      }
-      if (t > 0) commit_step();                              // J, xbar, ubar are not read in this phase
-      lds_barrier();
-      AMPC_MARK(26);
-    }
-    if (tid == 0) { scal[0] = lin; scal[1] = quad; scal[2] = sqrt(ksn2); }
-    __syncthreads();
-    if (scal[8] != T(0)) {          // singular Quu: the reference raises LinAlgError here
-      if (tid == 0) { args.active[p] = 0; args.refresh[p] = 0; }
-      return;
-    }
   }
 
   // =========================== forward rollout(s) (ilqr.py:141-149, 196-205) ===================
