@@ -114,6 +114,68 @@ __device__ __forceinline__ double readlane_t(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Quu [K | k] = -[Qux | qu] for one Riccati step, by ONE wave, entirely in registers.
+// Gauss-Jordan with partial pivoting (the pivot sequence of numpy.linalg.solve / LAPACK gesv) on
+// the augmented matrix [Quu | Qux | qu]: lane j owns column j (nu + nx + 1 <= 49 columns) and
+// keeps its nu entries in col[].  Column c's entries reach the other lanes by readlane, rows are
+// swapped by uniform-branch register moves; there is no LDS round trip inside the elimination.
+// NU > 0: the control dimension as a compile-time constant (fully unrolled, static register
+// indices); NU == 0: any nu <= kMaxNu at run time.
+// Reads Qt [n][n], qt [n]; writes Km [nu][nx], kv [nu].  Returns 1 when a pivot is exactly zero.
+template <typename T, int NU>
+__device__ __attribute__((noinline)) int quu_solve(const T* __restrict__ Qt, const T* __restrict__ qt,
+                                         T* __restrict__ Km, T* __restrict__ kv, int lane, int nx,
+                                         int nu_rt) {
+  constexpr int NB = NU > 0 ? NU : kMaxNu;
+  const int nu = NU > 0 ? NU : nu_rt;
+  const int n = nx + nu, nc = nu + nx + 1;
+  T col[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    col[i] = T(0);
+    if (i < nu && lane < nc)
+      col[i] = lane < nu ? Qt[(nx + i) * n + nx + lane]
+                         : (lane < nu + nx ? Qt[(nx + i) * n + (lane - nu)] : qt[nx + i]);
+  }
+  int sing = 0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (c >= nu || sing) break;
+    // pivot row: first maximum of |Aug[i][c]|, i >= c (lane c holds that column)
+    T best = fabs(col[c]);
+    int pr = c;
+#pragma unroll
+    for (int i = c + 1; i < NB; ++i) {
+      if (i >= nu) break;
+      const T a = fabs(col[i]);
+      if (a > best) { best = a; pr = i; }
+    }
+    pr = __builtin_amdgcn_readlane(pr, c);
+#pragma unroll
+    for (int i = c + 1; i < NB; ++i)
+      if (pr == i) { const T tmp = col[c]; col[c] = col[i]; col[i] = tmp; }
+    const T d = readlane_t(col[c], c);
+    if (d == T(0)) { sing = 1; break; }
+    const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
+    const T rowc = col[c];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {                 // eliminate column c from every other row
+      if (i >= nu) break;
+      if (i == c) continue;
+      const T f = readlane_t(col[i], c) * rd;
+      if (lane > c) col[i] -= f * rowc;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    if (i >= nu) break;
+    const T val = -col[i] / readlane_t(col[i], i);
+    if (lane >= nu && lane < nu + nx) Km[i * nx + (lane - nu)] = val;
+    else if (lane == nu + nx) kv[i] = val;
+  }
+  return sing;
+}
+
 // Backward Riccati sweep of one problem per workgroup (ilqr.py:159-187).  A kernel of its own:
 // it needs none of the MLP tile's registers or LDS, so it is compiled once per precision, keeps
 // the Quu solve in registers without spilling, and leaves K_t, k_t (global) and the expected-
@@ -187,7 +249,6 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   fetch_step(H - 1);
   commit_step();
   __syncthreads();
-  const int nc = nu + nx + 1;      // augmented system [Quu | Qux | qu]
   for (int t = H - 1; t >= 0; --t) {
 #ifdef AMPC_X_PHASETIME
     if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
@@ -203,17 +264,25 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     }
     lds_barrier();
     AMPC_MARK(21);
-    for (int idx = tid; idx < n * n; idx += NTHR) {        // Qt = Ct + J' VJ
-      const int c = idx / n, d = idx - c * n;
+    // Qt = Ct + J' V J is symmetric (V is, up to rounding): only the upper triangle is computed
+    // and mirrored.  Rows r and n-1-r are folded into one row of n+1 tasks, so the triangle is
+    // ceil(n/2) x (n+1) tasks -- one round for n <= 30 (for odd n the middle row is done twice,
+    // with identical results).
+    const int fold_rows = (n + 1) / 2;
+    for (int idx = tid; idx < fold_rows * (n + 1); idx += NTHR) {
+      const int r = idx / (n + 1), j = idx - r * (n + 1);
+      const int c = (j - 1 >= r) ? r : n - 1 - r;
+      const int d = (j - 1 >= r) ? j - 1 : n - 1 - j;
       T s = T(0);
 #pragma unroll 8
       for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * VJ[a * n + d];
       T cc = T(0);
       if (c < no && d < no) cc = (Qm[c * no + d] + Qm[d * no + c]) * dt;
       else if (c >= nx && d >= nx) cc = (Rm[(c - nx) * nu + (d - nx)] + Rm[(d - nx) * nu + (c - nx)]) * dt;
-      Qt[idx] = cc + s;
+      Qt[c * n + d] = cc + s;
+      Qt[d * n + c] = cc + s;
     }
-    for (int c = tid; c < n; c += NTHR) {                  // qt = ct + J' v
+    for (int c = NTHR - 1 - tid; c < n; c += NTHR) {       // qt = ct + J' v  (threads from the far end)
       T s = T(0);
 #pragma unroll 8
       for (int a = 0; a < nx; ++a) s += Jm[a * n + c] * v[a];
@@ -234,52 +303,17 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     // entries are col[0..nu).  Column c's entries reach the other lanes by readlane; rows are
     // swapped by uniform-branch register moves.  No LDS round trips inside the elimination.
     if (tid < 64) {
-      const int lane = tid;
-      T col[kMaxNu];
-#pragma unroll
-      for (int i = 0; i < kMaxNu; ++i) {
-        col[i] = T(0);
-        if (i < nu && lane < nc)
-          col[i] = lane < nu ? Qt[(nx + i) * n + nx + lane]
-                             : (lane < nu + nx ? Qt[(nx + i) * n + (lane - nu)] : qt[nx + i]);
+      int sing;
+      switch (nu) {     // the usual control dimensions get fully unrolled solvers
+        case 1: sing = quu_solve<T, 1>(Qt, qt, Km, kv, tid, nx, nu); break;
+        case 2: sing = quu_solve<T, 2>(Qt, qt, Km, kv, tid, nx, nu); break;
+        case 3: sing = quu_solve<T, 3>(Qt, qt, Km, kv, tid, nx, nu); break;
+        case 4: sing = quu_solve<T, 4>(Qt, qt, Km, kv, tid, nx, nu); break;
+        case 6: sing = quu_solve<T, 6>(Qt, qt, Km, kv, tid, nx, nu); break;
+        case 8: sing = quu_solve<T, 8>(Qt, qt, Km, kv, tid, nx, nu); break;
+        default: sing = quu_solve<T, 0>(Qt, qt, Km, kv, tid, nx, nu); break;
       }
-      int sing = 0;
-#pragma unroll
-      for (int c = 0; c < kMaxNu; ++c) {
-        if (c >= nu || sing) break;
-        // pivot row: first maximum of |Aug[i][c]|, i >= c (lane c holds that column)
-        T best = fabs(col[c]);
-        int pr = c;
-#pragma unroll
-        for (int i = c + 1; i < kMaxNu; ++i) {
-          if (i >= nu) break;
-          const T a = fabs(col[i]);
-          if (a > best) { best = a; pr = i; }
-        }
-        pr = __builtin_amdgcn_readlane(pr, c);
-#pragma unroll
-        for (int i = c + 1; i < kMaxNu; ++i)
-          if (pr == i) { const T tmp = col[c]; col[c] = col[i]; col[i] = tmp; }
-        const T d = readlane_t(col[c], c);
-        if (d == T(0)) { sing = 1; break; }
-        const T rd = T(1) / d;      // LAPACK's getf2 scales by the reciprocal pivot as well
-        const T rowc = col[c];
-#pragma unroll
-        for (int i = 0; i < kMaxNu; ++i) {                 // eliminate column c from every other row
-          if (i >= nu) break;
-          if (i == c) continue;
-          const T f = readlane_t(col[i], c) * rd;
-          if (lane > c) col[i] -= f * rowc;
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < kMaxNu; ++i) {
-        if (i >= nu) break;
-        const T val = -col[i] / readlane_t(col[i], i);
-        if (lane >= nu && lane < nu + nx) Km[i * nx + (lane - nu)] = val;
-        else if (lane == nu + nx) kv[i] = val;
-      }
-      if (sing && lane == 0) { args.status[p] = 1; scal[8] = T(1); }
+      if (sing && tid == 0) { args.status[p] = 1; scal[8] = T(1); }
     }
     AMPC_MARK(23);
     lds_barrier();
