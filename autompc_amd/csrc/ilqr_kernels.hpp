@@ -318,14 +318,16 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     AMPC_MARK(23);
     lds_barrier();
     AMPC_MARK(24);
-    for (int idx = tid; idx < nu * nx; idx += NTHR) {      // Wk = Quu K ; store K
+    // three independent pieces on disjoint waves: sums on wave 0, wq on wave 1, Wk on waves 2..
+    for (int idx = tid - 128; idx < nu * nx; idx += NTHR - 128) {   // Wk = Quu K ; store K
+      if (idx < 0) break;
       const int i = idx / nx, b = idx - i * nx;
       T s = T(0);
       for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * Km[j * nx + b];
       Wk[idx] = s;
       Kg[(size_t)t * nu * nx + idx] = Km[idx];
     }
-    for (int i = tid; i < nu; i += NTHR) {                 // wq = qu + Quu k ; store k
+    for (int i = tid - 64; i >= 0 && i < nu; i += NTHR) {  // wq = qu + Quu k ; store k
       T s = qt[nx + i];
       for (int j = 0; j < nu; ++j) s += Qt[(nx + i) * n + nx + j] * kv[j];
       wq[i] = s;
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
              Km[j * nx + a] * Wk[j * nx + b];
       V[idx] = s;
     }
-    for (int a = tid; a < nx; a += NTHR) {                 // v <- qx + Qxu k + K'(qu + Quu k)
+    for (int a = NTHR - 1 - tid; a < nx; a += NTHR) {      // v <- qx + Qxu k + K'(qu + Quu k)
       T s = qt[a];
       for (int j = 0; j < nu; ++j) s += Qt[a * n + nx + j] * kv[j] + Km[j * nx + a] * wq[j];
       v[a] = s;
