@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   T* kg = args.ks + (size_t)p * H * nu;
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
   const T dt = args.dt;
+  AMPC_MARK_ALWAYS(30);
   for (int idx = tid; idx < nx * nx; idx += NTHR) {
     const int a = idx / nx, b = idx - a * nx;
     V[idx] = (a < no && b < no) ? Fm[a * no + b] + Fm[b * no + a] : T(0);
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     lds_barrier();
     AMPC_MARK(26);
   }
+  AMPC_MARK_ALWAYS(33);
   if (tid == 0) {
     T* out = args.ric + (size_t)p * 4;
     out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = scal[8];

@@ -27,4 +27,4 @@ names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jo
 print("Riccati step, cycles:", m[26] - m[20], "(each line includes ~440 of mark overhead)")
 for a in range(21, 27):
     print("  %-32s %6d" % (names[a], m[a] - m[a - 1]))
-print("whole kernel (block 7): Riccati sweep %d cycles, line-search rollout %d cycles" % (m[31] - m[30], m[32] - m[31]))
+print("problem 7, last iteration: Riccati sweep %d cycles (ilqr_riccati_kernel), line-search rollout %d cycles (ilqr_iter_kernel)" % (m[33] - m[30], m[32] - m[31]))
