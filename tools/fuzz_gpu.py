@@ -102,6 +102,94 @@ def main():
                     bad.append((tag + " H=%d" % Hh, "ilqr", ei, 0.0))
         except Exception as ex:          # noqa: BLE001 -- report and continue
             bad.append((tag, "exception", repr(ex)[:200], 0.0))
+    # ---- linear models, closed loop and device scoring ------------------------------------------
+    from autompc_amd import Koopman, simulate
+    from autompc_amd.costs import BoxThresholdCost, ThresholdCost, cost_terms
+    from autompc_amd.tuning import CandidateEvaluator
+    from oracle.costs import score_terms
+    from oracle.linear import LinearOracle
+    worst.update({"lin_pred": 0.0, "lin_mppi": 0.0, "loop_score": 0.0})
+    os.environ["AMPC_MT"] = "0"
+    for case in range(max(4, n_cases // 10)):
+        ns, nu = int(rng.integers(1, 33)), int(rng.integers(1, 9))
+        if ns + nu > 48:
+            nu = 48 - ns
+        no = int(rng.integers(1, ns + 1))
+        system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
+        S = rng.normal(size=(ns, ns))
+        A = np.eye(ns) * 0.9 + 0.1 * (S - S.T) / max(1.0, np.sqrt(ns))
+        B = rng.normal(scale=0.3, size=(ns, nu))
+        tag = "linear case %d ns=%d no=%d nu=%d" % (case, ns, no, nu)
+        try:
+            m = Koopman(system)                      # used as a carrier of (A, B) on the device
+            m.set_parameters({"A": A, "B": B})
+            m._apply_basis = lambda o, ns=ns: np.concatenate([np.asarray(o), np.zeros(ns - len(o))])
+            type(m).state_dim = property(lambda self: self.A.shape[0])
+            orc_m = LinearOracle(system, A, B)
+            orc_m.state_dim = ns
+            orc_m.update_state = lambda st, c, o, ns=ns: np.concatenate([np.asarray(o), np.zeros(ns - len(o))])
+            s_, c_ = rng.normal(size=(9, ns)), rng.normal(size=(9, nu))
+            e = rel(m.pred_batch(s_, c_), orc_m.pred_batch(s_, c_))
+            o_, jx, ju = m.pred_diff_batch(s_, c_)
+            e = max(e, rel(jx[3], A), rel(ju[5], B))
+            worst["lin_pred"] = max(worst["lin_pred"], e / 1e-12)
+            if e > 1e-12:
+                bad.append((tag, "linear pred/jac", e, 0.0))
+            Q, R, F = np.diag(rng.uniform(0.5, 2, size=no)), np.diag(rng.uniform(0.01, 0.1, size=nu)), np.eye(no)
+            goal = rng.normal(scale=0.1, size=no)
+            task = Task(system)
+            task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+            task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+            N, H = int(rng.choice([32, 100])), int(rng.integers(2, 12))
+            seed = int(rng.integers(1 << 30))
+            np.random.seed(seed)
+            orc = MPPIOracle(orc_m, QuadCostOracle(Q, R, F, goal), np.tile([-1.0, 1.0], (nu, 1)),
+                             horizon=H, num_path=N, sigma=0.5, lmda=0.8)
+            np.random.seed(seed)
+            ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=0.5, lmda=0.8)
+            obs = rng.uniform(-0.5, 0.5, size=no)
+            cs = np.concatenate([obs, np.zeros(ns - no), np.zeros(nu)])
+            st = np.random.get_state()
+            uo, _ = orc.run(cs, obs)
+            np.random.set_state(st)
+            uh, _ = ctl.run(cs, obs, return_details=True)
+            e = max(rel(ctl.last_costs, orc.last_costs), rel(uh, uo) / 100)
+            worst["lin_mppi"] = max(worst["lin_mppi"], e / 1e-9)
+            if e > 1e-9:
+                bad.append((tag, "linear mppi", e, 0.0))
+        except Exception as ex:      # noqa: BLE001
+            bad.append((tag, "exception", repr(ex)[:200], 0.0))
+    # closed loop with a summed indicator + quadratic task cost, scored on the device
+    for case in range(max(3, n_cases // 20)):
+        nx, nu = int(rng.integers(2, 9)), int(rng.integers(1, 4))
+        system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+        p = omlp.random_params(nx, nu, [64, 64], "tanh", seed=int(rng.integers(1 << 30)))
+        m = MLP(system, n_hidden_layers=2, nonlintype="tanh", hidden_size_1=64, hidden_size_2=64)
+        m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+        goal = rng.normal(scale=0.1, size=nx)
+        lim = np.stack([-rng.uniform(0.2, 1.0, size=nx), rng.uniform(0.2, 1.0, size=nx)], axis=1)
+        cost = (ThresholdCost(system, goal, [0, int(rng.integers(1, nx + 1))], float(rng.uniform(0.05, 0.5)))
+                + BoxThresholdCost(system, lim) + QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx), goal=goal))
+        task = Task(system)
+        task.set_cost(cost)
+        task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+        task.set_init_obs(rng.uniform(-0.5, 0.5, size=nx))
+        task.set_num_steps(int(rng.integers(5, 30)))
+        ev = CandidateEvaluator(system, task, m)
+        cands = [dict(horizon=int(rng.integers(3, 12)), sigma=0.4, lmda=0.6, num_path=int(rng.choice([48, 100])),
+                      Q=np.ones(nx), R=0.1 * np.ones(nu), F=np.ones(nx)) for _ in range(int(rng.integers(1, 6)))]
+        try:
+            scores, obs_t, ctl_t = ev.evaluate(cands, seed=case, return_trajectories=True)
+            terms = cost_terms(cost, nx, nu)
+            for b in range(len(cands)):
+                ref = score_terms(terms[0], terms[1], obs_t[b], ctl_t[b])
+                e = abs(scores[b] - ref) / max(1.0, abs(ref))
+                worst["loop_score"] = max(worst["loop_score"], e / 1e-10)
+                if e > 1e-10:
+                    bad.append(("closed loop case %d cand %d" % (case, b), "score", e, 0.0))
+        except Exception as ex:      # noqa: BLE001
+            bad.append(("closed loop case %d" % case, "exception", repr(ex)[:200], 0.0))
     print("worst error / tolerance:", {k: float("%.3g" % v) for k, v in worst.items()})
     for b in bad:
         print("VIOLATION", b)
