@@ -654,10 +654,9 @@ int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double*
   if (deriv) {
     HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
     HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
-    const int rows = n * nx;
     const int jmt = 1;
     const int JM = 16 * jmt;
-    const int jtiles = (rows + JM - 1) / JM;
+    const int jtiles = ((n + JM - 1) / JM) * nx;       // (sample block, output index) tiles
     const int kinp = 16 * ((m.kin + 15) / 16);
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
     AMPC_DISPATCH(h->nw, h->nt, jmt, {
@@ -1267,12 +1266,11 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     // 16-row tiles: their 33 KB of LDS lets four workgroups share a CU, so one tile's set-up
     // (global loads of dz / W_out) and reduction overlap another's MFMAs; measured 4 % faster on
     // c4 than 32- or 64-row tiles (AMPC_JMT overrides for experiments).
-    const int jrows = rows * nx;
     const int kinp = 16 * ((m.kin + 15) / 16);
     int jmt = env_int("AMPC_JMT", 0);
     if (jmt == 0) jmt = 1;
     while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
-    const int JM = 16 * jmt, jtiles = (jrows + JM - 1) / JM;
+    const int JM = 16 * jmt, jtiles = ((rows + JM - 1) / JM) * nx;   // (sample block, output) tiles
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
     AMPC_DISPATCH(h->nw, h->nt, jmt, {
       auto k = mlp_jacobian_kernel<T, NT, MT, W>;

@@ -84,7 +84,8 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
   }
 }
 
-// rows = n * nx flattened (s, i); tile = 16*MT rows.
+// Tile = 16*MT samples x ONE output index i: blockIdx.x = sample_block * nx + i.  Every row of a
+// tile then shares the W_out row (a broadcast) and maps to its sample without a division.
 // wout_plain: folded output weights [nx][hpad] (zero padded); dz: [layer][n_pad][hpad] from
 // mlp_forward_kernel<DERIV>.  jx[n][nx][nx], ju[n][nx][nu].
 template <typename T, int NT, int MT, int W>
@@ -104,20 +105,19 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
   const int nx = mlp.nx, nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
+  constexpr int HP = Net::HP;                      // == hpad for this instantiation
   const int gs = hpad + (sizeof(T) == 8 ? 1 : 2);  // same padding rule as TileLds::act_stride
-  const int rows_total = n * nx;
-  const int first = blockIdx.x * M;
+  const int i_out = blockIdx.x % nx;               // the output index of this tile
+  const int s0 = (blockIdx.x / nx) * M;            // its first sample
   const size_t lstride = (size_t)n_pad * hpad;
 
-  // G_L[(s,i)][k] = W_out'[i][k] * d_L[s][k]
-  for (int e = tid; e < M * hpad; e += NTHR) {
-    const int row = e / hpad, k = e - row * hpad;
-    const int gr = first + row;
+  // G_L[s][k] = W_out'[i][k] * d_L[s][k]
+  for (int e = tid; e < M * HP; e += NTHR) {
+    const int row = e / HP, k = e % HP;
+    const int sidx = s0 + row;
     T v = T(0);
-    if (gr < rows_total) {
-      const int s = gr / nx, i = gr - s * nx;
-      v = wout_plain[i * hpad + k] * dz[(size_t)(Lh - 1) * lstride + (size_t)s * hpad + k];
-    }
+    if (sidx < n)
+      v = wout_plain[i_out * hpad + k] * dz[(size_t)(Lh - 1) * lstride + (size_t)sidx * hpad + k];
     G[row * gs + k] = v;
   }
   __syncthreads();
@@ -141,9 +141,8 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * mt + acc_row<T>(q, r);
-          const int gr = first + row;
           T d = T(0);
-          if (gr < rows_total) d = dz[(size_t)(l - 1) * lstride + (size_t)(gr / nx) * hpad + col];
+          if (s0 + row < n) d = dz[(size_t)(l - 1) * lstride + (size_t)(s0 + row) * hpad + col];
           G[row * gs + col] = acc[mt][nt][r] * d;
         }
       }
@@ -174,9 +173,8 @@ __global__ __launch_bounds__(64 * W) void mlp_jacobian_kernel(const MlpDev<T> ml
   __syncthreads();
   for (int e = tid; e < M * mlp.kin; e += NTHR) {
     const int row = e / mlp.kin, c = e - row * mlp.kin;
-    const int gr = first + row;
-    if (gr >= rows_total) continue;
-    const int s = gr / nx, i = gr - s * nx;
+    const int s = s0 + row, i = i_out;
+    if (s >= n) continue;
     if (rm.mask != nullptr && rm.mask[s / rm.grp] == 0) continue;
     T v = T(0);
 #pragma unroll
