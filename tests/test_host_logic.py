@@ -148,3 +148,37 @@ def test_simulate_drives_any_controller_like_the_reference_driver():
     np.testing.assert_allclose(traj.obs[-1], [1.1, 0.1, 0.1])
     with pytest.raises(ValueError):
         simulate(Const(system), np.zeros(3))
+
+
+def test_mlp_training_fits_a_linear_system_on_the_host():
+    """MLP.train (PyTorch, mlp.py:177-217: Adam + SmoothL1 on normalised deltas) produces weights
+    and normalisers that predict a simple system; checked with the oracle's forward pass, so no
+    GPU is needed.  (Training is outside the MPC inner loop and is not a HIP kernel.)"""
+    from autompc_amd import MLP, zeros
+    from oracle import mlp as omlp
+    system = make_system(2, 1)
+    A = np.array([[0.95, 0.1], [-0.1, 0.9]])
+    Bm = np.array([[0.0], [0.2]])
+    rng = np.random.default_rng(0)
+    trajs = []
+    for _ in range(8):
+        tr = zeros(system, 40)
+        x = rng.uniform(-1, 1, size=2)
+        for t in range(40):
+            u = rng.uniform(-1, 1, size=1)
+            tr.obs[t], tr.ctrls[t] = x, u
+            x = A @ x + Bm @ u
+        trajs.append(tr)
+    m = MLP(system, n_hidden_layers=2, hidden_size=32, nonlintype="tanh", n_train_iters=60,
+            n_batch=32, lr=5e-3)
+    before = [w.copy() for w in m.weights]
+    m.train(trajs)
+    assert any(not np.array_equal(a, b) for a, b in zip(before, m.weights))
+    p = omlp.make_params(m.weights, m.biases, "tanh", m.xu_means, m.xu_std, m.dy_means, m.dy_std)
+    s = rng.uniform(-1, 1, size=(64, 2))
+    c = rng.uniform(-1, 1, size=(64, 1))
+    pred = omlp.pred_batch(p, s, c)
+    truth = s @ A.T + c @ Bm.T
+    assert np.sqrt(np.mean((pred - truth) ** 2)) < 0.05
+    keys = m.get_parameters()
+    assert set(keys) == {"net_state", "xu_means", "xu_std", "dy_means", "dy_std"}
