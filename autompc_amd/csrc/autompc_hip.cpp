@@ -453,9 +453,24 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
 // linear models too.  Multiplying by the identity output layer is exact; A - I rounds once.
 extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
   REQUIRE(h && A && B, "ampc_set_linear: NULL argument");
-  REQUIRE(nx >= 1 && nx <= 32, "ampc_set_linear: state dim must be in 1..32");
+  REQUIRE(nx >= 1 && nx <= 64, "ampc_set_linear: state dim must be in 1..64");
   REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_linear: ctrl dim must be in 1..16");
   const int kin = nx + nu;
+  if (nx > 32) {
+    // Wider than the MFMA tile's output (long-history ARX, large Koopman lifts): staged as a
+    // feature-library model with the nx + nu identity features and Xi = [A | B], i.e. the scalar
+    // one-thread-per-sample path of sindy_kernels.hpp (MPPI, prediction, Jacobians, closed loop;
+    // the iLQR plan is limited to 32 states).
+    std::vector<int> kind(kin, 0), a0(kin), a1(kin, 0);
+    std::vector<double> par(kin, 1.0), xi((size_t)nx * kin);
+    for (int k = 0; k < kin; ++k) a0[k] = k;
+    for (int i = 0; i < nx; ++i) {
+      for (int j = 0; j < nx; ++j) xi[(size_t)i * kin + j] = A[(size_t)i * nx + j];
+      for (int j = 0; j < nu; ++j) xi[(size_t)i * kin + nx + j] = B[(size_t)i * nu + j];
+    }
+    return ampc_set_sindy(h, nx, nu, kin, kind.data(), a0.data(), a1.data(), par.data(), xi.data(), 0,
+                          1.0, 0);
+  }
   std::vector<double> w0((size_t)nx * kin), w1((size_t)nx * nx, 0.0), b0(nx, 0.0);
   for (int i = 0; i < nx; ++i) {
     for (int j = 0; j < nx; ++j) w0[(size_t)i * kin + j] = A[(size_t)i * nx + j] - (i == j ? 1.0 : 0.0);
@@ -678,6 +693,7 @@ int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double*
 extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
                                    double* out, int n) {
   REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
+  if (h->has_sindy) return ampc_sindy_pred_batch(h, states, ctrls, out, n);   // wide linear models
   REQUIRE(h->has_mlp, "ampc_mlp_pred_batch: no model set");
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(h->device));
@@ -690,6 +706,7 @@ extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const d
 extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
                                         double* out, double* jx, double* ju, int n) {
   REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
+  if (h->has_sindy) return ampc_sindy_pred_diff_batch(h, states, ctrls, out, jx, ju, n);
   REQUIRE(h->has_mlp, "ampc_mlp_pred_diff_batch: no model set");
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(h->device));
@@ -974,6 +991,7 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);
     const size_t lb = ((size_t)(2 * h->nx + h->nu) * 64 + h->cost_stride + 3 * h->nu) * sizeof(T);
+    HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
     hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
   } else {
     AMPC_DISPATCH(h->nw, h->nt, p->mt, {
@@ -1209,6 +1227,7 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
+  REQUIRE(h && h->nx <= 32, "ampc_ilqr_plan_create: the iLQR kernels hold Riccati matrices in LDS and take model states of at most 32 entries");
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
@@ -1376,6 +1395,7 @@ int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* 
   if (sur->has_sindy) {
     const SindyDev<T> sd = sindy_of<T>(sur);
     const size_t lb = (size_t)(2 * sur->nx + sur->nu) * 64 * sizeof(T);
+    HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
     hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((B + 63) / 64), dim3(64), lb, h->stream, sd,
                        (const T*)x, (const T*)u, (T*)x_next, B);
     HIP_OK(hipGetLastError());
@@ -1594,6 +1614,7 @@ static int sindy_pred_impl(ampc_handle* h, const double* states, const double* c
   HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
   HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
   const size_t lb = (size_t)(2 * nx + nu) * 64 * sizeof(T);
+  HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
   hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((n + 63) / 64), dim3(64), lb, h->stream, m,
                      (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
   if (jx) {
@@ -1617,7 +1638,7 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
                               const int* arg0, const int* arg1, const double* param,
                               const double* xi, int continuous, double dt, int strict_reference) {
   REQUIRE(h && kind && arg0 && arg1 && param && xi, "ampc_set_sindy: NULL argument");
-  REQUIRE(nx >= 1 && nx <= 32 && nu >= 1 && nu <= kMaxNu, "ampc_set_sindy: nx in 1..32, nu in 1..16");
+  REQUIRE(nx >= 1 && nx <= 64 && nu >= 1 && nu <= kMaxNu, "ampc_set_sindy: nx in 1..64, nu in 1..16");
   REQUIRE(n_feat >= 1 && n_feat <= 4096, "ampc_set_sindy: n_feat in 1..4096");
   for (int k = 0; k < n_feat; ++k)
     REQUIRE(kind[k] >= 0 && kind[k] <= 5 && arg0[k] >= 0 && arg0[k] < nx + nu && arg1[k] >= 0 &&

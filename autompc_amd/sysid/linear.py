@@ -11,7 +11,9 @@ through basis functions (koopman.py:112-122).  Fitting (least squares / lasso) i
 host computation; ``pred`` / ``pred_batch`` / ``pred_diff`` / ``pred_diff_batch`` and every MPPI /
 iLQR solve built on them go through the C ABI (``ampc_set_linear``), where the pair (A, B) is
 staged as a one-hidden-layer identity-activation network so that the MFMA rollout, Jacobian and
-iLQR kernels serve it unchanged.  The device path takes model states of up to 32 entries.
+iLQR kernels serve it unchanged.  That path takes model states of up to 32 entries; 33..64
+entries (long histories, large lifts) are staged as a feature-library model and served by the
+scalar kernels instead (prediction, Jacobians, MPPI, closed loop; not iLQR).
 """
 import numpy as np
 

@@ -65,7 +65,11 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
  * as a one-hidden-layer identity-activation network (activation code 4), so the MLP entry
  * points below (ampc_mlp_pred_batch / _pred_diff_batch, whose Jacobians are then A and B) and
  * every solver serve it unchanged.  Costs see the first obs_dim state entries
- * (mppi.py:73-82, ilqr.py:124-128). */
+ * (mppi.py:73-82, ilqr.py:124-128).
+ * nx <= 32: MFMA path as described.  32 < nx <= 64 (long-history ARX, large Koopman lifts): the
+ * model is staged as a feature-library model (nx + nu identity features, Xi = [A | B]; see
+ * ampc_set_sindy) and served by the scalar kernels -- prediction, Jacobians, MPPI plans and the
+ * closed loop work, ampc_ilqr_plan_create refuses (its Riccati workspace is sized for 32). */
 int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B);
 
 /* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */
@@ -81,7 +85,7 @@ int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double*
  * host).  Feature k is kind[k] applied to variables v = [x, u]:
  *   0 v_a   1 sin(p v_a)   2 cos(p v_a)   3 v_a sin(p v_b)   4 v_a cos(p v_b)   5 v_a ** p
  * with a = arg0[k], b = arg1[k], p = param[k]; xi [nx][n_feat] are the coefficients.
- *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'
+ *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'        (nx <= 64)
  * strict_reference != 0 reproduces the reference Jacobian's quirks (interaction terms counted
  * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25).  PARITY
  * UNPINNED: pysindy is unavailable, see oracle/sindy.py.  MPPI plans, iLQR plans and the closed

@@ -227,9 +227,71 @@ def test_device_ilqr_matches_reference(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,nu,no", [(41, 6, 17), (64, 16, 5), (33, 1, 33)])
+def test_wide_linear_states_run_on_the_scalar_path(ns, nu, no):
+    """33..64 model states (ARX history 2 on a 17-observation / 6-control system is 41): staged as
+    a feature-library model; prediction, Jacobians and an MPPI solve against the oracle."""
+    from autompc_amd import MPPI, QuadCost, Task, _lib
+    from oracle.linear import LinearOracle
+    rng = np.random.default_rng(ns)
+    S = rng.normal(size=(ns, ns))
+    A = 0.9 * np.eye(ns) + 0.1 * (S - S.T) / np.sqrt(ns)
+    B = rng.normal(scale=0.3, size=(ns, nu))
+    h = _lib.Handle(0, "f64")
+    h.set_linear(A, B)
+    s_, c_ = rng.normal(size=(70, ns)), rng.normal(size=(70, nu))
+    assert rel_err(h.pred_batch(s_, c_), s_ @ A.T + c_ @ B.T) < 1e-13
+    o, jx, ju = h.pred_diff_batch(s_[:5], c_[:5])
+    assert rel_err(o, s_[:5] @ A.T + c_[:5] @ B.T) < 1e-13
+    for k in range(5):
+        np.testing.assert_array_equal(jx[k], A)
+        np.testing.assert_array_equal(ju[k], B)
+    with pytest.raises(_lib.AmpcError):                 # the iLQR workspace is sized for 32 states
+        h.set_quad_costs(np.eye(no), np.eye(nu), np.eye(no), np.zeros(no))
+        _lib.IlqrPlan(h, 1, 5, 0.05)
+    h.close()
+    # MPPI through the plugin classes
+    system = make_system(no, nu)
+
+    class Carrier:                       # minimal device-stageable model around (A, B)
+        def __init__(self):
+            self.system, self.state_dim, self.precision, self.device = system, ns, "f64", 0
+
+        def stage_into(self, handle):
+            handle.set_linear(A, B)
+
+        def update_state(self, state, ctrl, obs):
+            return np.concatenate([np.asarray(obs), np.asarray(state)[no:]])
+
+        def traj_to_state(self, traj):
+            return np.concatenate([traj[-1].obs, np.zeros(ns - no)])
+    orc_m = LinearOracle(system, A, B)
+    orc_m.state_dim = ns
+    orc_m.update_state = Carrier().update_state
+    Q, R, F = np.diag(rng.uniform(0.5, 2, size=no)), np.diag(rng.uniform(0.01, 0.1, size=nu)), np.eye(no)
+    goal = rng.normal(scale=0.1, size=no)
+    task = Task(system)
+    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    np.random.seed(3)
+    orc = MPPIOracle(orc_m, QuadCostOracle(Q, R, F, goal), np.tile([-1.0, 1.0], (nu, 1)), horizon=9,
+                     num_path=150, sigma=0.5, lmda=0.8)
+    np.random.seed(3)
+    ctl = MPPI(system, task, Carrier(), horizon=9, num_path=150, sigma=0.5, lmda=0.8)
+    obs = rng.uniform(-0.5, 0.5, size=no)
+    cs = np.concatenate([obs, rng.uniform(-0.2, 0.2, size=ns - no), np.zeros(nu)])
+    st = np.random.get_state()
+    uo, cso = orc.run(cs, obs)
+    np.random.set_state(st)
+    uh, csh = ctl.run(cs, obs, return_details=True)
+    assert rel_err(ctl.last_costs, orc.last_costs) < 1e-10
+    assert rel_err(uh, uo) < 1e-9 and rel_err(csh, cso) < 1e-9
+
+
+@pytest.mark.gpu
 def test_device_rejects_oversized_linear_state():
     from autompc_amd import _lib
     h = _lib.Handle(0, "f64")
     with pytest.raises(_lib.AmpcError):
-        h.set_linear(np.eye(33), np.zeros((33, 1)))
+        h.set_linear(np.eye(65), np.zeros((65, 1)))
     h.close()
