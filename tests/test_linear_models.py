@@ -295,3 +295,52 @@ def test_device_rejects_oversized_linear_state():
     with pytest.raises(_lib.AmpcError):
         h.set_linear(np.eye(65), np.zeros((65, 1)))
     h.close()
+
+
+@pytest.mark.gpu
+def test_arx_history_two_on_a_halfcheetah_sized_system_closed_loop():
+    """The case the 32-state limit used to exclude: 17 observations, 6 controls, history 2 ->
+    41 model states.  Host ARX class (fit, state bookkeeping) + device MPPI, against the oracle's
+    ARX + MPPI in lock-step over a short closed loop."""
+    from autompc_amd import ARX, MPPI, QuadCost, Task, Trajectory
+    no, nu, k = 17, 6, 2
+    system = make_system(no, nu)
+    rng = np.random.default_rng(12)
+    M = 0.92 * np.eye(no) + 0.05 * rng.normal(size=(no, no)) / np.sqrt(no)
+    G = rng.normal(scale=0.2, size=(no, nu))
+    trajs = []
+    for _ in range(6):
+        obs = np.zeros((60, no))
+        ctl = rng.uniform(-1, 1, size=(60, nu))
+        x = rng.uniform(-1, 1, size=no)
+        for t in range(60):
+            obs[t] = x
+            x = M @ x + G @ ctl[t] + 0.02 * np.sin(x[::-1])
+        trajs.append(Trajectory(system, 60, obs, ctl))
+    model = ARX(system, history=k)
+    model.train(trajs)
+    assert model.state_dim == 41
+    oracle_m = ARXOracle(system, k, model.A, model.B)
+    task = Task(system)
+    Q, R, F = np.eye(no), 0.05 * np.eye(nu), 2.0 * np.eye(no)
+    task.set_cost(QuadCost(system, Q, R, F))
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    np.random.seed(5)
+    orc = MPPIOracle(oracle_m, QuadCostOracle(Q, R, F, np.zeros(no)), np.tile([-1.0, 1.0], (nu, 1)),
+                     horizon=10, num_path=200, sigma=0.6, lmda=0.7)
+    np.random.seed(5)
+    ctl = MPPI(system, task, model, horizon=10, num_path=200, sigma=0.6, lmda=0.7)
+    obs = rng.uniform(-0.5, 0.5, size=no)
+    one = Trajectory(system, 1, obs[None, :].copy(), np.zeros((1, nu)))
+    cs_h = ctl.traj_to_state(one)
+    cs_o = np.concatenate([oracle_m.state_from_first_obs(obs), np.zeros(nu)])
+    np.testing.assert_allclose(cs_h, cs_o, rtol=0, atol=0)
+    for _ in range(4):
+        st = np.random.get_state()
+        uo, cs_o = orc.run(cs_o, obs)
+        np.random.set_state(st)
+        uh, cs_h = ctl.run(cs_h, obs)
+        assert rel_err(uh, uo) < 1e-8 and rel_err(cs_h, cs_o) < 1e-8
+        ctl.act_sequence = orc.act_sequence          # lock-step: per-solve error only
+        cs_h = cs_o.copy()
+        obs = M @ obs + G @ uo
