@@ -1199,6 +1199,8 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   p->lds_work = p->L.extra;
   p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
   REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
+  REQUIRE((size_t)wk.total * sizeof(T) <= kLdsLimit,
+          "ilqr plan: the Riccati workspace for this state dimension does not fit the 160 KB LDS");
   const size_t e = sizeof(T);
   HIP_OK(p->d_cost_idx.reserve(B * sizeof(int)));
   HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), B * sizeof(int), hipMemcpyHostToDevice));
@@ -1227,7 +1229,8 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
-  REQUIRE(h && h->nx <= 32, "ampc_ilqr_plan_create: the iLQR kernels hold Riccati matrices in LDS and take model states of at most 32 entries");
+  REQUIRE(h->nx + h->nu + 1 <= 64,
+          "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
@@ -1314,9 +1317,15 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
     const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
     const size_t rb = (size_t)wk.total * sizeof(T);
-    auto rk = ilqr_riccati_kernel<T>;
-    HIP_OK(allow_lds(rk, rb));
-    hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    if (h->nx > 32) {
+      auto rk = ilqr_riccati_kernel<T, true>;
+      HIP_OK(allow_lds(rk, rb));
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    } else {
+      auto rk = ilqr_riccati_kernel<T, false>;
+      HIP_OK(allow_lds(rk, rb));
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    }
     HIP_OK(hipGetLastError());
   }
   if (h->has_sindy) {

@@ -180,7 +180,7 @@ __device__ __attribute__((noinline)) int quu_solve(const T* __restrict__ Qt, con
 // it needs none of the MLP tile's registers or LDS, so it is compiled once per precision, keeps
 // the Quu solve in registers without spilling, and leaves K_t, k_t (global) and the expected-
 // reduction sums `ric[p] = {lin, quad, |k|, singular}` for the line-search kernel.
-template <typename T>
+template <typename T, bool WIDE = false>     // WIDE: model states above 32 (longer register staging)
 __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Wr = reinterpret_cast<T*>(smem_raw);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   // J_t = [jx | ju], xbar_t, ubar_t are staged into LDS one step ahead, through registers: the
   // global loads for step t-1 are issued at the top of step t and land in LDS at its end, so
   // their latency is covered by the step's arithmetic (barriers in the loop are LDS-only).
-  constexpr int JR = (32 * 48 + NTHR - 1) / NTHR;      // nx <= 32, n <= 48
+  constexpr int JR = ((WIDE ? 64 * 80 : 32 * 48) + NTHR - 1) / NTHR;   // predicated on nx * n
   T jreg[JR];
   T xreg = T(0), ureg = T(0);
   auto fetch_step = [&](int t) {
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // global loads for step t+1 are issued at the top of step t and committed at its end; the
   // barriers inside the loop are LDS-only, so neither these loads nor the line-search stores
   // (lss / lsc) stall a step.
-  constexpr int KR = (16 * 32 + NTHR - 1) / NTHR;        // nu <= 16, nx <= 32
+  // nu <= 16; nx <= 32 with the MLP tile, <= 64 on the feature-library path (predicated on nu * nx)
+  constexpr int KR = (16 * (DYN == 1 ? 64 : 32) + NTHR - 1) / NTHR;
   T kreg[KR];
   T kvr = T(0), ubr = T(0), xbr = T(0);
   auto fetch_ls = [&](int t) {

@@ -13,7 +13,7 @@ iLQR solve built on them go through the C ABI (``ampc_set_linear``), where the p
 staged as a one-hidden-layer identity-activation network so that the MFMA rollout, Jacobian and
 iLQR kernels serve it unchanged.  That path takes model states of up to 32 entries; 33..64
 entries (long histories, large lifts) are staged as a feature-library model and served by the
-scalar kernels instead (prediction, Jacobians, MPPI, closed loop; not iLQR).
+scalar kernels instead (prediction, Jacobians, MPPI, closed loop, and iLQR while nx + nu <= 63).
 """
 import numpy as np
 

@@ -69,7 +69,8 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
  * nx <= 32: MFMA path as described.  32 < nx <= 64 (long-history ARX, large Koopman lifts): the
  * model is staged as a feature-library model (nx + nu identity features, Xi = [A | B]; see
  * ampc_set_sindy) and served by the scalar kernels -- prediction, Jacobians, MPPI plans and the
- * closed loop work, ampc_ilqr_plan_create refuses (its Riccati workspace is sized for 32). */
+ * closed loop work; iLQR plans work while the Riccati workspace fits LDS and nx + nu <= 63
+ * (e.g. 41 states + 6 controls in f64). */
 int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B);
 
 /* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */

@@ -130,3 +130,36 @@ def test_ilqr_on_linear_dynamics_recovers_finite_horizon_lqr():
         assert np.max(np.abs(out["states"][0, t] - x)) < 1e-8
         x = A @ x + B @ u
     plan.close(); h.close()
+
+
+def test_ilqr_on_a_wide_linear_model_recovers_lqr_too():
+    """41 states + 6 controls (ARX history 2 on a HalfCheetah-sized system): the model runs on the
+    scalar feature-library path, the Riccati sweep holds 47 x 47 matrices in LDS and the Quu solve
+    uses 48 lanes; the gains must still be the closed-form finite-horizon LQR gains."""
+    from autompc_amd import _lib
+    rng = np.random.default_rng(9)
+    nx, nu, no, Hh, dt = 41, 6, 17, 20, 0.05
+    S = rng.normal(size=(nx, nx))
+    A = 0.95 * np.eye(nx) + 0.05 * (S - S.T) / np.sqrt(nx)
+    B = rng.normal(scale=0.2, size=(nx, nu))
+    Q = np.diag(rng.uniform(0.5, 2.0, size=no))
+    R = np.diag(rng.uniform(0.05, 0.2, size=nu))
+    F = np.diag(rng.uniform(1.0, 3.0, size=no))
+    h = _lib.Handle(0, "f64")
+    h.set_linear(A, B)
+    h.set_quad_costs(Q, R, F, np.zeros(no))
+    plan = _lib.IlqrPlan(h, 2, Hh, dt)
+    x0 = rng.uniform(-1.0, 1.0, size=(2, nx))
+    out = plan.solve(x0, np.zeros((2, Hh, nu)), 50)
+    assert np.all(out["status"] == 0) and np.all(out["converged"] == 1) and np.all(out["iters"] <= 4)
+    Qx, Fx = np.zeros((nx, nx)), np.zeros((nx, nx))
+    Qx[:no, :no], Fx[:no, :no] = Q, F               # the cost sees the first obs_dim state entries
+    V = 2.0 * Fx
+    Ks = np.zeros((Hh, nu, nx))
+    for t in range(Hh - 1, -1, -1):
+        G = 2.0 * R * dt + B.T @ V @ B
+        Ks[t] = -np.linalg.solve(G, B.T @ V @ A)
+        V = 2.0 * Qx * dt + A.T @ V @ A + A.T @ V @ B @ Ks[t]
+    for b in range(2):
+        assert rel_err(out["Ks"][b], Ks) < 1e-8
+    plan.close(); h.close()
