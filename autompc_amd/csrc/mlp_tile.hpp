@@ -298,8 +298,9 @@ __device__ long long g_phase_marks[64];
 #endif
 
 // ---- the fused network on one tile -------------------------------------------------------------
-// LEAN: keep nothing resident between calls (callers that need the registers themselves).
-template <typename T, int NT, int MT, int W, bool DERIV = false, bool LEAN = false>
+// LEAN: what stays resident in registers between calls, for callers that need registers
+// themselves: 0 output fragments + hidden biases, 1 output fragments only, 2 nothing.
+template <typename T, int NT, int MT, int W, bool DERIV = false, int LEAN = 0>
 struct TileNet {
   using acc_t = typename Acc<T>::type;
   static constexpr int M = 16 * MT;
@@ -338,7 +339,7 @@ struct TileNet {
   // lifetime: fetching them per call put a 64 KB-per-CU burst on L2 right before the output
   // MFMAs needed them (measured ~1 us exposed per rollout step).
   // (Not in the 64-row f64 tile: its accumulators leave no room, the copy would spill.)
-  static constexpr bool RESIDENT_OUT = !LEAN && !(MT == 4 && sizeof(T) == 8);
+  static constexpr bool RESIDENT_OUT = LEAN < 2 && !(MT == 4 && sizeof(T) == 8);
   T wout[KSW][NOMAX];            // dead (never written or read) when not resident
 
   __device__ __forceinline__ static void load_out(const MlpDev<T>& m, int w, int lane,
@@ -362,7 +363,7 @@ struct TileNet {
   // Hidden-layer biases of this lane's columns, resident: accumulators start from them, so the
   // epilogue has neither an LDS read nor an add between the last MFMA and the activation.
   // (16-row tiles only: the taller tiles are register-bound and keep reading the bias from LDS.)
-  static constexpr bool RESIDENT_BIAS = !LEAN && (MT == 1);
+  static constexpr bool RESIDENT_BIAS = LEAN < 1 && (MT == 1);
   T bias_r[kMaxHidden][NT];
 
   // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
