@@ -487,6 +487,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
   const bool cdiag = args.cost_diag != 0;
   for (int t = 0; t < H; ++t) {
+#ifdef AMPC_X_PHASETIME
+    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (args.mode == 1 && t == H / 2) ? 1 : 0;
+#endif
+    AMPC_MARK(40);
     if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
     // controls for this step
     for (int a = r; a < nu; a += TPS) {
@@ -494,8 +498,18 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       if (args.mode == 0) {
         u = ct[(size_t)t * nu + a];
       } else {
-        T fb = T(0);
-        for (int b = 0; b < nx; ++b) fb += Km[a * nx + b] * (xu[m * xs_ + b] - xbar[b]);
+        // four partial sums over interleaved b: the LDS reads of a whole group are in flight
+        // together instead of one dependent round trip per term
+        T f0 = T(0), f1 = T(0), f2 = T(0), f3 = T(0);
+        int b = 0;
+        for (; b + 4 <= nx; b += 4) {
+          const T k0 = Km[a * nx + b], k1 = Km[a * nx + b + 1], k2 = Km[a * nx + b + 2], k3 = Km[a * nx + b + 3];
+          const T d0 = xu[m * xs_ + b] - xbar[b], d1 = xu[m * xs_ + b + 1] - xbar[b + 1];
+          const T d2 = xu[m * xs_ + b + 2] - xbar[b + 2], d3 = xu[m * xs_ + b + 3] - xbar[b + 3];
+          f0 += k0 * d0; f1 += k1 * d1; f2 += k2 * d2; f3 += k3 * d3;
+        }
+        for (; b < nx; ++b) f0 += Km[a * nx + b] * (xu[m * xs_ + b] - xbar[b]);
+        const T fb = (f0 + f1) + (f2 + f3);
         u = alpha * kv[a] + ubar[a] + fb;
         if (args.bounded) { u = u < blo[a] ? blo[a] : u; u = u > bhi[a] ? bhi[a] : u; }
         if (m < rows) lsc[((size_t)m * H + t) * nu + a] = u;
@@ -504,12 +518,16 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     }
     if (args.mode == 1 && m < rows)
       for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
+    AMPC_MARK(41);
     lds_barrier();
+    AMPC_MARK(42);
     // objective: dt * (stage costs)
     obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, cdiag) +
                            quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, cdiag));
+    AMPC_MARK(43);
     if constexpr (DYN == 0) {
       net.run(mlp, L, lds);
+      AMPC_MARK(44);
       for (int a = r; a < nx; a += TPS) {
         const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
         xu[m * xs_ + a] = xn;
@@ -526,8 +544,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
     }
     // every thread passed the barrier above after its last read of K, k, ubar, xbar
+    AMPC_MARK(45);
     if (args.mode == 1 && t + 1 < H) commit_ls();
     lds_barrier();
+    AMPC_MARK(46);
   }
   AMPC_MARK_ALWAYS(32);
   if (args.mode == 1 && m < rows)

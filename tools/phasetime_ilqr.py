@@ -21,10 +21,15 @@ marks = (ctypes.c_longlong * 64)()
 lib = _lib.load()
 lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks_ilqr(marks)
-m = np.array(marks[:40], dtype=np.int64)
+m = np.array(marks[:50], dtype=np.int64)
 names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
          24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
 print("Riccati step, cycles:", m[26] - m[20], "(each line includes ~440 of mark overhead)")
 for a in range(21, 27):
     print("  %-32s %6d" % (names[a], m[a] - m[a - 1]))
 print("problem 7, last iteration: Riccati sweep %d cycles (ilqr_riccati_kernel), line-search rollout %d cycles (ilqr_iter_kernel)" % (m[33] - m[30], m[32] - m[31]))
+ls = {41: "fetch issue + controls + lss stores", 42: "barrier", 43: "objective", 44: "network (net.run)",
+      45: "reduce + state update", 46: "commit + barrier"}
+print("line-search step, cycles:", m[46] - m[40], "(each line includes ~440 of mark overhead; net.run has its own marks inside)")
+for a in range(41, 47):
+    print("  %-36s %6d" % (ls[a], m[a] - m[a - 1]))
