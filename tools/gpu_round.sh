@@ -20,7 +20,7 @@ timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline
 # (gloo for the barriers; RCCL refuses two ranks on one device).  Not a performance number.
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 50 --warmup 5 > $OUT/bench_2rank_plumbing.json 2> $OUT/bench_2rank_plumbing.err
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"   # default 200 timed + 20 warm-up solves, as the headline run
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- $BENCH > $OUT/prof_trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/prof_pmc_sq -- $BENCH > $OUT/prof_pmc_sq.log 2>&1
