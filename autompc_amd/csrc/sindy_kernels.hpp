@@ -27,7 +27,52 @@ template <typename T> struct SindyDev {
   const int* a1;        // [n_feat] second variable (argument of sin/cos for interaction terms)
   const T* par;         // [n_feat] frequency / exponent
   const T* xi;          // [nx][n_feat]
+  // Trig table: the distinct (variable, frequency) arguments the library's sin / cos terms use
+  // (CartPole: 5 of them for 40 trigonometric features).  sindy_step evaluates each once per step
+  // and the features read the pair; n_trig == 0 evaluates every feature directly.
+  int n_trig;
+  const int* tidx;      // [n_feat] feature -> table slot (or -1)
+  const int* tvar;      // [n_trig] variable index
+  const T* tpar;        // [n_trig] frequency
+  int stage;            // 1: the kernels copy the program to LDS first (sindy_stage)
 };
+constexpr int kSindyMaxTrig = 64;   // table slots kept per thread (2 values each, in LDS)
+constexpr int kSindyStageBytes = 48 * 1024;   // programs up to this size are copied to LDS
+
+// Elements of T the staged program occupies (floats first, then the int arrays, 8-byte aligned).
+__host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_trig, size_t tsize) {
+  const size_t flt = (size_t)n_feat * (nx + 1) + n_trig;
+  const size_t ints = (size_t)4 * n_feat + n_trig;
+  return flt + (ints * sizeof(int) + tsize - 1) / tsize + 1;
+}
+
+// Copy the feature program (descriptors, coefficients, trig table) from global memory into the
+// workgroup's LDS and return a descriptor that points there.  Every per-feature operand of
+// sindy_step is wave-uniform; from global memory each is a dependent scalar-load round trip per
+// feature, from LDS a broadcast read (measured 5x on the CartPole library).  Must be called by
+// all threads; ends with a barrier.  g.stage == 0 (program too large): returns g unchanged.
+template <typename T>
+__device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area, int tid, int nthr);
+
+template <typename T>
+__device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area, int tid, int nthr) {
+  if (!g.stage) return g;
+  const int nf = g.n_feat, nt = g.n_trig, nx = g.nx;
+  T* par = area;
+  T* xi = par + nf;
+  T* tpar = xi + (size_t)nx * nf;
+  int* kind = reinterpret_cast<int*>(tpar + nt + 1);
+  int* a0 = kind + nf; int* a1 = a0 + nf; int* tidx = a1 + nf; int* tvar = tidx + nf;
+  for (int k = tid; k < nf; k += nthr) {
+    par[k] = g.par[k]; kind[k] = g.kind[k]; a0[k] = g.a0[k]; a1[k] = g.a1[k]; tidx[k] = g.tidx[k];
+  }
+  for (int e = tid; e < nx * nf; e += nthr) xi[e] = g.xi[e];
+  for (int j = tid; j < nt; j += nthr) { tpar[j] = g.tpar[j]; tvar[j] = g.tvar[j]; }
+  __syncthreads();
+  SindyDev<T> s = g;
+  s.par = par; s.xi = xi; s.tpar = tpar; s.kind = kind; s.a0 = a0; s.a1 = a1; s.tidx = tidx; s.tvar = tvar;
+  return s;
+}
 
 template <typename T>
 __device__ __forceinline__ T sindy_feature(int kind, T va, T vb, T par) {
@@ -41,12 +86,29 @@ __device__ __forceinline__ T sindy_feature(int kind, T va, T vb, T par) {
   }
 }
 
-// v: this thread's variables, element i at v[i * vs]; out: next state at out[i * os].
+// v: this thread's variables, element i at v[i * vs]; out: next state at out[i * os];
+// tr: this thread's trig scratch (2 * n_trig values, element j at tr[j * ts]).
 template <typename T>
-__device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int vs, T* out, int os) {
+__device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int vs, T* out, int os,
+                                           T* tr, int ts) {
+  for (int j = 0; j < m.n_trig; ++j) {
+    const T arg = m.tpar[j] * v[m.tvar[j] * vs];
+    tr[(2 * j) * ts] = sin(arg);
+    tr[(2 * j + 1) * ts] = cos(arg);
+  }
+  auto feature = [&](int k) -> T {
+    const int kind = m.kind[k];
+    if (m.n_trig > 0 && kind >= SF_SIN && kind <= SF_XCOS) {
+      const int slot = 2 * m.tidx[k] + ((kind == SF_COS || kind == SF_XCOS) ? 1 : 0);
+      T f = tr[slot * ts];
+      if (kind >= SF_XSIN) f *= v[m.a0[k] * vs];
+      return f;
+    }
+    return sindy_feature<T>(kind, v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
+  };
   for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
   for (int k = 0; k < m.n_feat; ++k) {
-    const T f = sindy_feature<T>(m.kind[k], v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
+    const T f = feature(k);
     for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
   }
   if (m.continuous)
@@ -54,18 +116,21 @@ __device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int
 }
 
 template <typename T>
-__global__ void sindy_forward_kernel(const SindyDev<T> m, const T* __restrict__ states,
+__global__ void sindy_forward_kernel(const SindyDev<T> mg, const T* __restrict__ states,
                                      const T* __restrict__ ctrls, T* __restrict__ out, int n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
+  const SindyDev<T> m = sindy_stage<T>(mg, lds + (2 * mg.nx + mg.nu + 2 * mg.n_trig) * blockDim.x,
+                                       threadIdx.x, blockDim.x);
   const int lane = threadIdx.x, nv = m.nx + m.nu, bs = blockDim.x;
   const int r = blockIdx.x * bs + lane;
   T* v = lds + lane;                       // [nv][bs]
   T* o = lds + nv * bs + lane;             // [nx][bs]
+  T* tr = lds + (nv + m.nx) * bs + lane;   // [2 n_trig][bs]
   if (r < n) {
     for (int i = 0; i < m.nx; ++i) v[i * bs] = states[(size_t)r * m.nx + i];
     for (int j = 0; j < m.nu; ++j) v[(m.nx + j) * bs] = ctrls[(size_t)r * m.nu + j];
-    sindy_step<T>(m, v, bs, o, bs);
+    sindy_step<T>(m, v, bs, o, bs, tr, bs);
     for (int i = 0; i < m.nx; ++i) out[(size_t)r * m.nx + i] = o[i * bs];
   }
 }
@@ -123,10 +188,12 @@ __global__ void sindy_jacobian_kernel(const SindyDev<T> m, const T* __restrict__
 // mppi_update_kernel finishes the solve.
 template <typename T>
 __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T> args,
-                                                                const SindyDev<T> m) {
+                                                                const SindyDev<T> mg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int BS = 64;
+  const SindyDev<T> m = sindy_stage<T>(
+      mg, lds + (2 * mg.nx + mg.nu + 2 * mg.n_trig) * BS + args.cost_stride + 3 * mg.nu + 1, threadIdx.x, BS);
   const int lane = threadIdx.x, nx = m.nx, nu = m.nu, nv = nx + nu, no = args.obs_dim;
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
@@ -135,7 +202,8 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   const bool valid = n < N;
   T* v = lds + lane;                        // [nv][BS]  x | u
   T* o = lds + nv * BS + lane;              // [nx][BS]  next state
-  T* cpar = lds + (nv + nx) * BS;           // Q R F goal | lo hi scale (shared)
+  T* tr = lds + (nv + nx) * BS + lane;      // [2 n_trig][BS]  trig table
+  T* cpar = lds + (nv + nx + 2 * m.n_trig) * BS;   // Q R F goal | lo hi scale (shared)
   for (int i = lane; i < args.cost_stride; i += BS)
     cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
   for (int i = lane; i < 3 * nu; i += BS) cpar[args.cost_stride + i] = args.bounds[i];
@@ -169,7 +237,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
       for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[(nx + j) * BS];
       c += v[(nx + i) * BS] * s;
     }
-    sindy_step<T>(m, v, BS, o, BS);
+    sindy_step<T>(m, v, BS, o, BS, tr, BS);
     for (int i = 0; i < nx; ++i) v[i * BS] = o[i * BS];
   }
   T term = T(0);

@@ -35,8 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5", "arx"],
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c4", "c5", "arx"],
                     help="c3 (default, headline): HalfCheetah MPPI 4096x30; c2: Pendulum MPPI; "
+                         "c1: CartPole SINDy MPPI 256x20 (scalar kernels); "
                          "arx: MPPI on a linear ARX model (SURVEY 8 f3); "
                          "c4: HalfCheetah iLQR H=50, --batch problems per step; c5: --batch tuning "
                          "candidates x 200-step closed loop per step")
@@ -61,7 +62,14 @@ def cpu_baseline(workload, spec, n_solves):
     nx, nu = spec["nx"], spec["nu"]
     no = spec.get("obs", nx)
     system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
-    if "linear" in spec:
+    if "sindy" in spec:
+        from oracle.sindy import SINDyOracle
+        sd = spec["sindy"]
+        model = SINDyOracle(system, sd["Xi"], trig_freq=sd["trig_freq"], trig_interaction=sd["trig_interaction"],
+                            poly_degree=sd["poly_degree"], time_mode="discrete")
+        x0 = np.array([0.0, 0.2, 0.0, 0.0])
+        cs = np.concatenate([x0, np.zeros(nu)])
+    elif "linear" in spec:
         from oracle.linear import ARXOracle
         model = ARXOracle(system, spec["history"], *spec["linear"])
         x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=no)
@@ -73,6 +81,8 @@ def cpu_baseline(workload, spec, n_solves):
         x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
         cs = np.concatenate([x0, np.zeros(nu)])
     cost = QuadCostOracle(np.eye(no), 0.01 * np.eye(nu), np.eye(no), np.zeros(no))
+    if "sindy" in spec:
+        cost = QuadCostOracle(np.diag([1.0, 10.0, 0.1, 0.1]), 0.01 * np.eye(nu), np.eye(no), np.zeros(no))
     bnd = np.tile([-spec["bound"], spec["bound"]], (nu, 1))
     np.random.seed(0)
     ctl = MPPIOracle(model, cost, bnd, horizon=spec["horizon"],
@@ -341,6 +351,8 @@ def main():
         rollout_s = kt["rollout_ms"] * 1e-3
         if "linear" in spec:          # algorithmic work of x' = A x + B u, not of its staging
             info["flops"] = float(B * N * H * 2 * nx * (nx + nu))
+        if "sindy" in spec:           # library evaluation + Theta Xi' (VALU path: no MFMA roofline)
+            info["flops"] = float(B * N * H * 2 * nx * spec["sindy"]["n_feat"])
         achieved = info["flops"] / rollout_s / 1e12 if rollout_s > 0 else 0.0
         peak = PEAK_TFLOPS[args.precision]
         traffic = measured_traffic(args, B)

@@ -14,6 +14,7 @@ timeout 300 python bench.py --precision f32 --no-cpu-baseline > $OUT/bench_c3_f3
 timeout 300 python bench.py --workload c2 > $OUT/bench_c2_f64.json 2> $OUT/bench_c2_f64.err
 timeout 300 python bench.py --batch 8 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_c3_f64_batch8.json 2> $OUT/bench_c3_f64_batch8.err
 timeout 300 python bench.py --workload arx > $OUT/bench_arx_f64.json 2> $OUT/bench_arx_f64.err
+timeout 300 python bench.py --workload c1 > $OUT/bench_c1_sindy_f64.json 2> $OUT/bench_c1_sindy_f64.err
 timeout 600 python bench.py --workload c4 --steps 3 --warmup 1 > $OUT/bench_c4_ilqr_f64.json 2> $OUT/bench_c4.err
 timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_c5_candidates_f64.json 2> $OUT/bench_c5.err
 # launcher plumbing: the driver's N>1 command line with two ranks mapped onto this box's one GPU
