@@ -87,6 +87,13 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   const int first = (blockIdx.x - pr.tile0) * M;
   const int H = pr.H, N = pr.N;
 
+  // The two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs
+  // cyclically) get different issue priorities, so they drift half a phase apart and one's
+  // epilogue / LDS traffic overlaps the other's MFMAs (measured +0.7 % f64, +1 % f32).
+  if (W == 8) {
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
   Net net;
   net.init(mlp);
 
