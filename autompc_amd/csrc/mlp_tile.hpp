@@ -231,51 +231,62 @@ __device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&
 // OWN: the fragment stream is packed starting at k-group `rot` (the group whose activations this
 // wave itself produced, see TileNet::run); group 0 of the stream is consumed BEFORE the tile-wide
 // barrier that publishes the other waves' activations, which is passed inside this function.
-template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false>
+// SG: streaming granularity after the pre-loaded first group.  The double buffer holds two
+// sub-groups of SG k-steps; tall f64 tiles (MT >= 2) have enough MFMA work per k-step to cover an
+// L2 round trip with SG = 4, which halves the buffer's registers (64 VGPRs).
+template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false, int SG = G>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
                                                  const T* __restrict__ wl, int lane,
                                                  const T (&first)[G][NT],
                                                  typename Acc<T>::type (&acc)[MT][NT], int rot = 0) {
-  static_assert(KS % G == 0, "group size must divide the k extent");
-  constexpr int NG = KS / G;
+  static_assert(KS % G == 0 && G % SG == 0, "group sizes must divide the k extent");
+  constexpr int NG = KS / G;       // groups (the unit of the rotated k order)
+  constexpr int NS = KS / SG;      // sub-groups (the unit of the weight stream)
+  constexpr int FS = G / SG;       // sub-groups that arrive pre-loaded in `first`
   static_assert(!OWN || (NG & (NG - 1)) == 0, "rotated k order needs a power-of-two group count");
   const int i = lane & 15, q = lane >> 4;
   const T* arow = A + i * a_stride + q;
-  T b[2][G][NT];
+  T b[2][SG][NT];
+  if constexpr (FS == 1) {       // whole-group streaming: the pre-loaded group IS buffer 0
 #pragma unroll
-  for (int kk = 0; kk < G; ++kk)
+    for (int kk = 0; kk < SG; ++kk)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[0][kk][nt] = first[kk][nt];
+      for (int nt = 0; nt < NT; ++nt) b[0][kk][nt] = first[kk][nt];
+  }
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    if (g + 1 < NG) load_group<T, NT, G>(wl, g + 1, b[(g + 1) & 1]);
-    const T* ag = OWN ? arow + 4 * G * ((g + rot) & (NG - 1)) : arow + 4 * G * g;
+  for (int sgi = 0; sgi < NS; ++sgi) {
+    if (sgi + 1 >= FS && sgi + 1 < NS) load_group<T, NT, SG>(wl, sgi + 1, b[(sgi + 1) & 1]);
+    const int g = sgi / FS;
+    const T* ag = (OWN ? arow + 4 * G * ((g + rot) & (NG - 1)) : arow + 4 * G * g) + 4 * SG * (sgi % FS);
 #pragma unroll
-    for (int kk = 0; kk < G; ++kk) {
+    for (int kk = 0; kk < SG; ++kk) {
       T a[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) a[mt] = ag[mt * 16 * a_stride + 4 * kk];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(a[mt], b[g & 1][kk][nt], acc[mt][nt]);
+        for (int nt = 0; nt < NT; ++nt) {
+          const T bv = (FS > 1 && sgi < FS) ? first[sgi * SG + kk][nt] : b[sgi & 1][kk][nt];
+          acc[mt][nt] = mfma16(a[mt], bv, acc[mt][nt]);
+        }
     }
 #ifndef AMPC_X_NOSCHED
     // (8-wave tiles only; measured neutral-to-negative with one wave per SIMD)
-    // Issue order for this group: LDS fragment reads run one k-step pair AHEAD of the MFMAs that
-    // consume them, weight loads for the next group are spread between MFMA clusters.
+    // Issue order for this sub-group: LDS fragment reads run one k-step pair AHEAD of the MFMAs
+    // that consume them, weight loads for the next sub-group are spread between MFMA clusters.
     //   masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read
     if (PIPE && KS >= 8) {
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll
-      for (int i = 0; i < G / 2; ++i) {
+      for (int i = 0; i < SG / 2; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
       }
     }
 #endif
-    if (OWN && g == 0) lds_barrier();
+    if (OWN && sgi == FS - 1) lds_barrier();
   }
 }
 
@@ -544,8 +555,10 @@ struct TileNet {
           for (int k = 1; k < kMaxHidden; ++k) b = (l == k) ? bias_r[k][nt] : b;
           acc[mt][nt] = acc_t{b, b, b, b};
         }
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN>(act, as, slice_h(m, l, w, lane), lane, pfn,
-                                                          acc, w);
+      // tall f64 tiles stream the weights in half-groups (64 VGPRs less: the 64-row tile stops
+      // spilling, +2 %); f32 keeps whole groups (half-groups measured -4 % there)
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, ((MT >= 2 && sizeof(T) == 8) ? GH / 2 : GH)>(
+          act, as, slice_h(m, l, w, lane), lane, pfn, acc, w);
       AMPC_MARK(4);
       prefetch_next(l + 1);
       // single buffer: every wave must finish reading act before it is overwritten;
