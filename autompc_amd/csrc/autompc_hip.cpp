@@ -608,6 +608,7 @@ static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_r
     const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
     if (bytes > kLdsLimit) break;
     if (forced == mt) return mt;
+    if (mt == 4 && h->nt == 3 && sizeof(T) == 8) break;   // 12 f64 accumulator tiles per wave spill
     if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
   }
   return best;
