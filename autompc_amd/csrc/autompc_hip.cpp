@@ -105,7 +105,7 @@ struct ampc_handle {
   bool has_mlp = false;
   bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
   bool has_model() const { return has_mlp || has_sindy; }
-  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0;
+  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0;
   double s_dt = 0.0;
   DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
   int nx = 0, nu = 0, n_hidden = 0, act = 0;
@@ -136,7 +136,8 @@ template <> MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
 
 // LDS bytes the kernels need on top of their own regions for the staged feature program
 template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
-  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, sizeof(T)) * sizeof(T);
+  if (h->s_ntab == 0) return 0;
+  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, sizeof(T)) * sizeof(T);
   return b <= (size_t)kSindyStageBytes ? b + 2 * sizeof(T) : 0;
 }
 
@@ -145,13 +146,15 @@ template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
   m.nx = h->nx; m.nu = h->nu; m.n_feat = h->s_nfeat; m.continuous = h->s_continuous;
   m.strict = h->s_strict; m.dt = (T)h->s_dt;
   const int* ip = (const int*)h->sindy_int.p;
-  m.kind = ip; m.a0 = ip + h->s_nfeat; m.a1 = ip + 2 * h->s_nfeat;
-  m.tidx = ip + 3 * h->s_nfeat; m.tvar = ip + 4 * h->s_nfeat;
+  const int nf = h->s_nfeat;
+  m.kind = ip; m.a0 = ip + nf; m.a1 = ip + 2 * nf;
+  m.fx = ip + 3 * nf; m.fy = ip + 4 * nf; m.tvar = ip + 5 * nf; m.pvar = ip + 6 * nf;
   const T* fp = (const T*)h->sindy_flt.p;
-  m.par = fp; m.xi = fp + h->s_nfeat;
-  m.tpar = fp + (size_t)h->s_nfeat * (h->nx + 1);
-  m.n_trig = h->s_ntrig;
-  m.stage = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, sizeof(T)) * sizeof(T) <= (size_t)kSindyStageBytes;
+  m.par = fp; m.xi = fp + nf;
+  m.tpar = fp + (size_t)nf * (h->nx + 1);
+  m.ppar = m.tpar + nf;
+  m.n_trig = h->s_ntrig; m.n_pow = h->s_npow; m.n_tab = h->s_ntab;
+  m.stage = sindy_stage_bytes<T>(h) > 0;
   return m;
 }
 
@@ -806,7 +809,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   p->tile_m = M;
   if (h->has_sindy) {
     std::memset(&p->L, 0, sizeof(p->L));
-    p->L.extra = (2 * nx + nu + 2 * h->s_ntrig) * 64;   // per-thread columns: [x|u], next x, trig table
+    p->L.extra = (2 * nx + nu + h->s_ntab) * 64;   // per-thread columns: [x|u], next x, value table
   } else {
     p->L = tile_lds_for<T>(h, m, M, extra);
   }
@@ -1001,7 +1004,7 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   }
   if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);
-    const size_t lb = ((size_t)(2 * h->nx + h->nu + 2 * h->s_ntrig) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
+    const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
                       sindy_stage_bytes<T>(h);
     HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
     hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
@@ -1204,7 +1207,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
     p->L.xu = 0;
     p->L.xu_stride = nx + nu + 1;
     p->lds_xn = round_up(16 * p->L.xu_stride, 4);
-    p->L.extra = round_up(p->lds_xn + 16 * nx + 16 * 2 * h->s_ntrig, 4);   // xnext + trig scratch
+    p->L.extra = round_up(p->lds_xn + 16 * nx + 16 * h->s_ntab, 4);   // xnext + table scratch
   } else {
     p->L = tile_lds_for<T>(h, m, 16, (size_t)wk.total + 8);
   }
@@ -1415,7 +1418,7 @@ template <typename T>
 int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
   if (sur->has_sindy) {
     const SindyDev<T> sd = sindy_of<T>(sur);
-    const size_t lb = (size_t)(2 * sur->nx + sur->nu + 2 * sur->s_ntrig) * 64 * sizeof(T) + sindy_stage_bytes<T>(sur);
+    const size_t lb = (size_t)(2 * sur->nx + sur->nu + sur->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(sur);
     HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
     hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((B + 63) / 64), dim3(64), lb, h->stream, sd,
                        (const T*)x, (const T*)u, (T*)x_next, B);
@@ -1634,7 +1637,7 @@ static int sindy_pred_impl(ampc_handle* h, const double* states, const double* c
   HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
   HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
   HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
-  const size_t lb = (size_t)(2 * nx + nu + 2 * h->s_ntrig) * 64 * sizeof(T) + sindy_stage_bytes<T>(h);
+  const size_t lb = (size_t)(2 * nx + nu + h->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(h);
   HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
   hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((n + 63) / 64), dim3(64), lb, h->stream, m,
                      (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
@@ -1665,32 +1668,57 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
     REQUIRE(kind[k] >= 0 && kind[k] <= 5 && arg0[k] >= 0 && arg0[k] < nx + nu && arg1[k] >= 0 &&
                 arg1[k] < nx + nu, "ampc_set_sindy: bad feature descriptor");
   HIP_OK(hipSetDevice(h->device));
-  // trig table: distinct (variable, frequency) arguments of the sin / cos terms
-  std::vector<int> tidx(n_feat, -1), tvar;
-  std::vector<double> tpar;
+  // product form (SindyDev): distinct trig arguments and powers, two factor indices per feature
+  std::vector<int> tvar, pvar, fx(n_feat, 0), fy(n_feat, 0), tslot(n_feat, -1);
+  std::vector<double> tpar, ppar;
   for (int k = 0; k < n_feat; ++k) {
-    if (kind[k] < 1 || kind[k] > 4) continue;
-    const int var = kind[k] <= 2 ? arg0[k] : arg1[k];     // sin/cos(p v_a) vs v_a sin/cos(p v_b)
-    int slot = -1;
-    for (size_t j = 0; j < tvar.size(); ++j)
-      if (tvar[j] == var && tpar[j] == param[k]) { slot = (int)j; break; }
-    if (slot < 0) { slot = (int)tvar.size(); tvar.push_back(var); tpar.push_back(param[k]); }
-    tidx[k] = slot;
+    if (kind[k] >= 1 && kind[k] <= 4) {
+      const int var = kind[k] <= 2 ? arg0[k] : arg1[k];   // sin/cos(p v_a) vs v_a sin/cos(p v_b)
+      int slot = -1;
+      for (size_t j = 0; j < tvar.size(); ++j)
+        if (tvar[j] == var && tpar[j] == param[k]) { slot = (int)j; break; }
+      if (slot < 0) { slot = (int)tvar.size(); tvar.push_back(var); tpar.push_back(param[k]); }
+      tslot[k] = slot;
+    } else if (kind[k] == 5) {
+      int slot = -1;
+      for (size_t j = 0; j < pvar.size(); ++j)
+        if (pvar[j] == arg0[k] && ppar[j] == param[k]) { slot = (int)j; break; }
+      if (slot < 0) { slot = (int)pvar.size(); pvar.push_back(arg0[k]); ppar.push_back(param[k]); }
+      tslot[k] = slot;
+    }
   }
-  const int n_trig = (int)tvar.size() <= kSindyMaxTrig ? (int)tvar.size() : 0;   // 0: no table
-  std::vector<int> ints(5 * (size_t)n_feat, 0);
+  int n_trig = (int)tvar.size(), n_pow = (int)pvar.size();
+  int n_tab = 2 * n_trig + n_pow + 1;
+  if (n_tab > kSindyMaxTab) n_trig = n_pow = n_tab = 0;      // direct evaluation instead
+  if (n_tab > 0) {
+    const int one = n_tab - 1;
+    for (int k = 0; k < n_feat; ++k) {
+      switch (kind[k]) {
+        case 0: fx[k] = arg0[k]; fy[k] = one; break;
+        case 1: fx[k] = -(2 * tslot[k]) - 1; fy[k] = one; break;
+        case 2: fx[k] = -(2 * tslot[k] + 1) - 1; fy[k] = one; break;
+        case 3: fx[k] = arg0[k]; fy[k] = 2 * tslot[k]; break;
+        case 4: fx[k] = arg0[k]; fy[k] = 2 * tslot[k] + 1; break;
+        default: fx[k] = -(2 * n_trig + tslot[k]) - 1; fy[k] = one; break;
+      }
+    }
+  }
+  std::vector<int> ints(7 * (size_t)n_feat, 0);
   std::memcpy(ints.data(), kind, n_feat * sizeof(int));
   std::memcpy(ints.data() + n_feat, arg0, n_feat * sizeof(int));
   std::memcpy(ints.data() + 2 * n_feat, arg1, n_feat * sizeof(int));
-  std::memcpy(ints.data() + 3 * n_feat, tidx.data(), n_feat * sizeof(int));
-  if (n_trig > 0) std::memcpy(ints.data() + 4 * n_feat, tvar.data(), n_trig * sizeof(int));
+  std::memcpy(ints.data() + 3 * n_feat, fx.data(), n_feat * sizeof(int));
+  std::memcpy(ints.data() + 4 * n_feat, fy.data(), n_feat * sizeof(int));
+  if (n_trig > 0) std::memcpy(ints.data() + 5 * n_feat, tvar.data(), n_trig * sizeof(int));
+  if (n_pow > 0) std::memcpy(ints.data() + 6 * n_feat, pvar.data(), n_pow * sizeof(int));
   HIP_OK(h->sindy_int.reserve(ints.size() * sizeof(int)));
   HIP_OK(hipMemcpy(h->sindy_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
-  std::vector<double> flt((size_t)n_feat * (nx + 2), 0.0);
+  std::vector<double> flt((size_t)n_feat * (nx + 3), 0.0);
   std::memcpy(flt.data(), param, n_feat * 8);
   std::memcpy(flt.data() + n_feat, xi, (size_t)n_feat * nx * 8);
   if (n_trig > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 1), tpar.data(), n_trig * 8);
-  h->s_ntrig = n_trig;
+  if (n_pow > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 2), ppar.data(), n_pow * 8);
+  h->s_ntrig = n_trig; h->s_npow = n_pow; h->s_ntab = n_tab;
   HIP_OK(h->sindy_flt.reserve(flt.size() * h->esz()));
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
   else HIP_OK(upload_converted<float>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       T* xnext = lds + args.lds_xn;
       if (r == 0)
         sindy_step<T>(args.sindy, xu + m * xs_, 1, xnext + m * nx, 1,
-                      xnext + M * nx + m * 2 * args.sindy.n_trig, 1);   // trig scratch after xnext
+                      xnext + M * nx + m * args.sindy.n_tab, 1);   // table scratch after xnext
       __syncthreads();
       for (int a = r; a < nx; a += TPS) {
         const T xn = xnext[m * nx + a];

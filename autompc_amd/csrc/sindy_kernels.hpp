@@ -27,23 +27,30 @@ template <typename T> struct SindyDev {
   const int* a1;        // [n_feat] second variable (argument of sin/cos for interaction terms)
   const T* par;         // [n_feat] frequency / exponent
   const T* xi;          // [nx][n_feat]
-  // Trig table: the distinct (variable, frequency) arguments the library's sin / cos terms use
-  // (CartPole: 5 of them for 40 trigonometric features).  sindy_step evaluates each once per step
-  // and the features read the pair; n_trig == 0 evaluates every feature directly.
-  int n_trig;
-  const int* tidx;      // [n_feat] feature -> table slot (or -1)
-  const int* tvar;      // [n_trig] variable index
-  const T* tpar;        // [n_trig] frequency
+  // Product form (n_tab > 0).  Per step a thread first fills a small table -- sin / cos of the
+  // distinct (variable, frequency) arguments the library uses (CartPole: 5 for 40 trigonometric
+  // features), the distinct powers, and a constant 1 -- and then every feature is the product of
+  // two entries: fx[k] >= 0 selects variable fx[k], fx[k] < 0 table entry -fx[k]-1; fy[k] is a
+  // table entry (the constant for single-factor features).  No data-dependent branches, so the
+  // feature loop unrolls and its loads overlap.  n_tab == 0: features are evaluated directly from
+  // (kind, a0, a1, par) -- libraries whose table would not fit.
+  int n_trig, n_pow, n_tab;   // n_tab = 2 n_trig + n_pow + 1
+  const int* fx;        // [n_feat]
+  const int* fy;        // [n_feat]
+  const int* tvar;      // [n_trig] variable index of a trig argument
+  const T* tpar;        // [n_trig] its frequency
+  const int* pvar;      // [n_pow] variable index of a power
+  const T* ppar;        // [n_pow] its exponent
   int stage;            // 1: the kernels copy the program to LDS first (sindy_stage)
 };
-constexpr int kSindyMaxTrig = 64;   // table slots kept per thread (2 values each, in LDS)
+constexpr int kSindyMaxTab = 160;   // table entries kept per thread (in LDS columns)
 constexpr int kSindyStageBytes = 48 * 1024;   // programs up to this size are copied to LDS
 
 // Elements of T the staged program occupies (floats first, then the int arrays, 8-byte aligned).
-__host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_trig, size_t tsize) {
-  const size_t flt = (size_t)n_feat * (nx + 1) + n_trig;
-  const size_t ints = (size_t)4 * n_feat + n_trig;
-  return flt + (ints * sizeof(int) + tsize - 1) / tsize + 1;
+__host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_trig, int n_pow, size_t tsize) {
+  const size_t flt = (size_t)n_feat * nx + n_trig + n_pow;
+  const size_t ints = (size_t)2 * n_feat + n_trig + n_pow;
+  return flt + (ints * sizeof(int) + tsize - 1) / tsize + 2;
 }
 
 // Copy the feature program (descriptors, coefficients, trig table) from global memory into the
@@ -57,20 +64,19 @@ __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area
 template <typename T>
 __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area, int tid, int nthr) {
   if (!g.stage) return g;
-  const int nf = g.n_feat, nt = g.n_trig, nx = g.nx;
-  T* par = area;
-  T* xi = par + nf;
+  const int nf = g.n_feat, nt = g.n_trig, np = g.n_pow, nx = g.nx;
+  T* xi = area;
   T* tpar = xi + (size_t)nx * nf;
-  int* kind = reinterpret_cast<int*>(tpar + nt + 1);
-  int* a0 = kind + nf; int* a1 = a0 + nf; int* tidx = a1 + nf; int* tvar = tidx + nf;
-  for (int k = tid; k < nf; k += nthr) {
-    par[k] = g.par[k]; kind[k] = g.kind[k]; a0[k] = g.a0[k]; a1[k] = g.a1[k]; tidx[k] = g.tidx[k];
-  }
+  T* ppar = tpar + nt;
+  int* fx = reinterpret_cast<int*>(ppar + np + 1);
+  int* fy = fx + nf; int* tvar = fy + nf; int* pvar = tvar + nt;
+  for (int k = tid; k < nf; k += nthr) { fx[k] = g.fx[k]; fy[k] = g.fy[k]; }
   for (int e = tid; e < nx * nf; e += nthr) xi[e] = g.xi[e];
   for (int j = tid; j < nt; j += nthr) { tpar[j] = g.tpar[j]; tvar[j] = g.tvar[j]; }
+  for (int j = tid; j < np; j += nthr) { ppar[j] = g.ppar[j]; pvar[j] = g.pvar[j]; }
   __syncthreads();
   SindyDev<T> s = g;
-  s.par = par; s.xi = xi; s.tpar = tpar; s.kind = kind; s.a0 = a0; s.a1 = a1; s.tidx = tidx; s.tvar = tvar;
+  s.xi = xi; s.tpar = tpar; s.ppar = ppar; s.fx = fx; s.fy = fy; s.tvar = tvar; s.pvar = pvar;
   return s;
 }
 
@@ -87,29 +93,60 @@ __device__ __forceinline__ T sindy_feature(int kind, T va, T vb, T par) {
 }
 
 // v: this thread's variables, element i at v[i * vs]; out: next state at out[i * os];
-// tr: this thread's trig scratch (2 * n_trig values, element j at tr[j * ts]).
+// tr: this thread's table scratch (n_tab values, element j at tr[j * ts]).
 template <typename T>
 __device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int vs, T* out, int os,
                                            T* tr, int ts) {
-  for (int j = 0; j < m.n_trig; ++j) {
-    const T arg = m.tpar[j] * v[m.tvar[j] * vs];
-    tr[(2 * j) * ts] = sin(arg);
-    tr[(2 * j + 1) * ts] = cos(arg);
-  }
-  auto feature = [&](int k) -> T {
-    const int kind = m.kind[k];
-    if (m.n_trig > 0 && kind >= SF_SIN && kind <= SF_XCOS) {
-      const int slot = 2 * m.tidx[k] + ((kind == SF_COS || kind == SF_XCOS) ? 1 : 0);
-      T f = tr[slot * ts];
-      if (kind >= SF_XSIN) f *= v[m.a0[k] * vs];
-      return f;
+  constexpr int NR = 8;
+  if (m.n_tab > 0) {
+    // pass 1: the table
+    for (int j = 0; j < m.n_trig; ++j) {
+      const T arg = m.tpar[j] * v[m.tvar[j] * vs];
+      tr[(2 * j) * ts] = sin(arg);
+      tr[(2 * j + 1) * ts] = cos(arg);
     }
-    return sindy_feature<T>(kind, v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
-  };
-  for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
-  for (int k = 0; k < m.n_feat; ++k) {
-    const T f = feature(k);
-    for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
+    for (int j = 0; j < m.n_pow; ++j) tr[(2 * m.n_trig + j) * ts] = pow(v[m.pvar[j] * vs], m.ppar[j]);
+    tr[(m.n_tab - 1) * ts] = T(1);
+    // pass 2: features as products of two entries
+    auto feature = [&](int k) -> T {
+      const int ix = m.fx[k], iy = m.fy[k];
+      const T xv = v[(ix >= 0 ? ix : 0) * vs];
+      const T xt = tr[(ix >= 0 ? 0 : -ix - 1) * ts];
+      return (ix >= 0 ? xv : xt) * tr[iy * ts];
+    };
+    if (m.nx <= NR) {
+      // few outputs (CartPole: 4): accumulate in registers; through `out` every term would be an
+      // LDS read-modify-write in a dependent chain.  Coefficient loads are unguarded (row index
+      // clamped) so that they are all in flight together; rows >= nx are never stored.
+      T acc[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) acc[i] = T(0);
+      const int last = m.nx - 1;
+#pragma unroll 4
+      for (int k = 0; k < m.n_feat; ++k) {
+        T c[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) c[i] = m.xi[(i < last ? i : last) * m.n_feat + k];
+        const T f = feature(k);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc[i] += c[i] * f;
+      }
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < m.nx) out[i * os] = m.continuous ? v[i * vs] + m.dt * acc[i] : acc[i];
+      return;
+    }
+    for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
+    for (int k = 0; k < m.n_feat; ++k) {
+      const T f = feature(k);
+      for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
+    }
+  } else {
+    for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
+    for (int k = 0; k < m.n_feat; ++k) {
+      const T f = sindy_feature<T>(m.kind[k], v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
+      for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
+    }
   }
   if (m.continuous)
     for (int i = 0; i < m.nx; ++i) out[i * os] = v[i * vs] + m.dt * out[i * os];
@@ -120,13 +157,13 @@ __global__ void sindy_forward_kernel(const SindyDev<T> mg, const T* __restrict__
                                      const T* __restrict__ ctrls, T* __restrict__ out, int n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  const SindyDev<T> m = sindy_stage<T>(mg, lds + (2 * mg.nx + mg.nu + 2 * mg.n_trig) * blockDim.x,
+  const SindyDev<T> m = sindy_stage<T>(mg, lds + (2 * mg.nx + mg.nu + mg.n_tab) * blockDim.x,
                                        threadIdx.x, blockDim.x);
   const int lane = threadIdx.x, nv = m.nx + m.nu, bs = blockDim.x;
   const int r = blockIdx.x * bs + lane;
   T* v = lds + lane;                       // [nv][bs]
   T* o = lds + nv * bs + lane;             // [nx][bs]
-  T* tr = lds + (nv + m.nx) * bs + lane;   // [2 n_trig][bs]
+  T* tr = lds + (nv + m.nx) * bs + lane;   // [n_tab][bs]
   if (r < n) {
     for (int i = 0; i < m.nx; ++i) v[i * bs] = states[(size_t)r * m.nx + i];
     for (int j = 0; j < m.nu; ++j) v[(m.nx + j) * bs] = ctrls[(size_t)r * m.nu + j];
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int BS = 64;
   const SindyDev<T> m = sindy_stage<T>(
-      mg, lds + (2 * mg.nx + mg.nu + 2 * mg.n_trig) * BS + args.cost_stride + 3 * mg.nu + 1, threadIdx.x, BS);
+      mg, lds + (2 * mg.nx + mg.nu + mg.n_tab) * BS + args.cost_stride + 3 * mg.nu + 1, threadIdx.x, BS);
   const int lane = threadIdx.x, nx = m.nx, nu = m.nu, nv = nx + nu, no = args.obs_dim;
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
@@ -202,8 +239,8 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   const bool valid = n < N;
   T* v = lds + lane;                        // [nv][BS]  x | u
   T* o = lds + nv * BS + lane;              // [nx][BS]  next state
-  T* tr = lds + (nv + nx) * BS + lane;      // [2 n_trig][BS]  trig table
-  T* cpar = lds + (nv + nx + 2 * m.n_trig) * BS;   // Q R F goal | lo hi scale (shared)
+  T* tr = lds + (nv + nx) * BS + lane;      // [n_tab][BS]  per-thread table
+  T* cpar = lds + (nv + nx + m.n_tab) * BS;   // Q R F goal | lo hi scale (shared)
   for (int i = lane; i < args.cost_stride; i += BS)
     cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
   for (int i = lane; i < 3 * nu; i += BS) cpar[args.cost_stride + i] = args.bounds[i];
