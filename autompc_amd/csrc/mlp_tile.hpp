@@ -376,6 +376,12 @@ struct TileNet {
   // (16-row tiles only: the taller tiles are register-bound and keep reading the bias from LDS.)
   static constexpr bool RESIDENT_BIAS = LEAN < 1 && (MT == 1);
   T bias_r[kMaxHidden][NT];
+  // Prefetch buffer: the first group of the next hidden layer (and, when they are not resident,
+  // the output-layer fragments).  A member, not a local of run(): the first group of hidden layer 1
+  // for the NEXT call is requested at the end of a call, together with layer 0's fragments, so it
+  // has the caller's whole inter-call phase to arrive (measured +1 % f64, +3 % f32 on c3).
+  T pfn[GH][NT];
+  bool pfn_ready = false;
 
   // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
   __device__ __forceinline__ void init(const MlpDev<T>& m) {
@@ -435,10 +441,7 @@ struct TileNet {
     const bool pingpong = L.act2 != L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
-    // Prefetch buffer: the first group of the next hidden layer (and, when they are not resident,
-    // the output-layer fragments).
-    T pfn[GH][NT];
-    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");
+    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");   // pfn holds either
     auto prefetch_next = [&](int l_next) {
       if (l_next < m.n_hidden) {
         load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
@@ -512,7 +515,7 @@ struct TileNet {
       const T* A = lds + L.xu;
       // first group of hidden layer 1: in flight under layer 0's MFMAs (64-row tiles have no
       // registers to spare for that and fetch it after the MFMAs instead)
-      if constexpr (MT < 4) prefetch_next(1);
+      if (!pfn_ready) prefetch_next(1);   // first call only; later calls were served at the previous call's end
       if constexpr (FULL0) {
         switch (m.k1p) {   // one fully unrolled variant per padded input width
           case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
@@ -533,7 +536,6 @@ struct TileNet {
         }
       }
       AMPC_MARK(2);
-      if constexpr (MT >= 4) prefetch_next(1);
       epilogue(0, acc, act);
     }
     // Barrier placement.  A layer's epilogue leaves wave w's columns in LDS.  The output layer is
@@ -555,9 +557,10 @@ struct TileNet {
           for (int k = 1; k < kMaxHidden; ++k) b = (l == k) ? bias_r[k][nt] : b;
           acc[mt][nt] = acc_t{b, b, b, b};
         }
-      // tall f64 tiles stream the weights in half-groups (64 VGPRs less: the 64-row tile stops
-      // spilling, +2 %); f32 keeps whole groups (half-groups measured -4 % there)
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, ((MT >= 2 && sizeof(T) == 8) ? GH / 2 : GH)>(
+      // f64 streams the weights in half-groups (32-64 VGPRs less: the 64-row tile stops spilling,
+      // +2 %, and the 16-row tile has room for the early prefetch); f32 keeps whole groups
+      // (half-groups measured -4 % there)
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, (sizeof(T) == 8 ? GH / 2 : GH)>(
           act, as, slice_h(m, l, w, lane), lane, pfn, acc, w);
       AMPC_MARK(4);
       prefetch_next(l + 1);
@@ -610,6 +613,7 @@ struct TileNet {
     }
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
+    if (m.n_hidden > 1) { prefetch_next(1); pfn_ready = true; }
     side();
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
