@@ -1,203 +1,30 @@
-// autompc_hip.cpp -- host side of libautompc_hip.so: handles, weight packing, launches.
-// C ABI declared in include/autompc_hip.h.  Built with hipcc for gfx950 only.
-//
-// The file is compiled several times in parallel (csrc/build.py):
-//   -DAMPC_TU_MAIN                      the C API and all host logic (plus the tiny kernels)
-//   -DAMPC_TU_FAMILY=n -DAMPC_TU_T=T    one heavy kernel family for one precision:
-//        1 = MLP forward / Jacobian launchers, 2 = MPPI rollout / update, 3 = iLQR iteration
-// The heavy launchers are ordinary function templates with external linkage; the main unit sees
-// `extern template` declarations and the family units hold the explicit instantiations.
-#include "../../include/autompc_hip.h"
+// api.cpp -- the C ABI of libautompc_hip.so (include/autompc_hip.h): handles, weight packing,
+// plans, uploads / downloads, the closed loop and the small kernels' launches.  The heavy kernel
+// families are launched through the templates declared in host_common.hpp (launch_*.cpp).
+// Built with hipcc for gfx950 only.
+#include "host_common.hpp"
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "mlp_kernels.hpp"
-#include "ilqr_kernels.hpp"
-#include "mppi_kernels.hpp"
-#include "rng_kernels.hpp"
-#include "sindy_kernels.hpp"
-#include "score_kernels.hpp"
-
-using namespace ampc;
-
-// ---------------------------------------------------------------------------------------------
-// errors
-// ---------------------------------------------------------------------------------------------
-#ifdef AMPC_TU_MAIN
 thread_local std::string g_err;
-#else
-extern thread_local std::string g_err;
-#endif
-static int fail(const std::string& msg) {
-  g_err = msg;
-  return -1;
-}
-#define HIP_OK(expr)                                                                     \
-  do {                                                                                   \
-    hipError_t e_ = (expr);                                                              \
-    if (e_ != hipSuccess)                                                                \
-      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
-  } while (0)
-#define REQUIRE(cond, msg) \
-  do {                     \
-    if (!(cond)) return fail(msg); \
-  } while (0)
 
-struct DevBuf {
-  void* p = nullptr;
-  size_t bytes = 0;
-  hipError_t reserve(size_t n) {
-    if (n <= bytes) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-    hipError_t e = hipMalloc(&p, n ? n : 16);
-    if (e == hipSuccess) bytes = n;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-};
+extern template int pred_impl<double>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
+extern template int pred_impl<float>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
+extern template int surrogate_step<double>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);
+extern template int surrogate_step<float>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);
+extern template int ilqr_refresh_jacobians<double>(ampc_ilqr_plan*);
+extern template int ilqr_refresh_jacobians<float>(ampc_ilqr_plan*);
+extern template int mppi_solve_impl<double>(ampc_mppi_plan*);
+extern template int mppi_solve_impl<float>(ampc_mppi_plan*);
+extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
+extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
-// function-local device scratch: freed on every exit path (HIP_OK / REQUIRE return early)
-struct ScopedBuf : DevBuf {
-  ScopedBuf() = default;
-  ScopedBuf(const ScopedBuf&) = delete;
-  ScopedBuf& operator=(const ScopedBuf&) = delete;
-  ~ScopedBuf() { release(); }
-};
-
-static constexpr size_t kLdsLimit = 160 * 1024;
-
-static int env_int(const char* name, int dflt) {
-  const char* v = std::getenv(name);
-  return v ? std::atoi(v) : dflt;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// handle
-// ---------------------------------------------------------------------------------------------
-struct ampc_handle {
-  int device = 0;
-  int precision = AMPC_F64;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  size_t esz() const { return precision == AMPC_F64 ? 8 : 4; }
-  // Plans hold raw pointers to their handle.  Language bindings with garbage collection may
-  // destroy a handle before the plans built on it, so the handle is reference counted: it is
-  // actually freed when ampc_destroy has been called AND the last plan is gone.
-  int refs = 0;
-  bool dead = false;
-
-  // model (host copy, double) ---------------------------------------------------------------
-  bool has_mlp = false;
-  bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
-  bool has_model() const { return has_mlp || has_sindy; }
-  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0;
-  double s_dt = 0.0;
-  DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
-  int nx = 0, nu = 0, n_hidden = 0, act = 0;
-  int hidden[kMaxHidden] = {0, 0, 0, 0};
-  int hpad = 0, nt = 0, nw = 4, k1p = 0, nxp = 0;  // nw = waves per workgroup (4 or 8)
-  std::vector<std::vector<double>> W, b;
-  std::vector<double> norm;
-  DevBuf model_buf;   // all packed arrays, contiguous
-  const void* wout_plain = nullptr;  // [nx][hpad] view into model_buf (Jacobian chain)
-  MlpDev<double> md{};
-  MlpDev<float> mf{};
-
-  // cost blocks / bounds ----------------------------------------------------------------------
-  int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0;
-  DevBuf cost_buf;
-  bool has_bounds = false;
-  std::vector<double> lo, hi;
-  DevBuf bounds_buf;  // lo/scale, hi/scale, scale   (MPPI units)
-  DevBuf ubounds_buf; // lo, hi                     (iLQR clips in physical units)
-
-  // scratch for the batched model calls -----------------------------------------------------------
-  DevBuf s_states, s_ctrls, s_out, s_dz, s_jx, s_ju;
-};
-
-template <typename T> static MlpDev<T>& model_of(ampc_handle* h);
-template <> MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }
-template <> MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
-
-// LDS bytes the kernels need on top of their own regions for the staged feature program
-template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
-  if (h->s_ntab == 0) return 0;
-  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, sizeof(T)) * sizeof(T);
-  return b <= (size_t)kSindyStageBytes ? b + 2 * sizeof(T) : 0;
-}
-
-template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
-  SindyDev<T> m;
-  m.nx = h->nx; m.nu = h->nu; m.n_feat = h->s_nfeat; m.continuous = h->s_continuous;
-  m.strict = h->s_strict; m.dt = (T)h->s_dt;
-  const int* ip = (const int*)h->sindy_int.p;
-  const int nf = h->s_nfeat;
-  m.kind = ip; m.a0 = ip + nf; m.a1 = ip + 2 * nf;
-  m.fx = ip + 3 * nf; m.fy = ip + 4 * nf; m.tvar = ip + 5 * nf; m.pvar = ip + 6 * nf;
-  const T* fp = (const T*)h->sindy_flt.p;
-  m.par = fp; m.xi = fp + nf;
-  m.tpar = fp + (size_t)nf * (h->nx + 1);
-  m.ppar = m.tpar + nf;
-  m.n_trig = h->s_ntrig; m.n_pow = h->s_npow; m.n_tab = h->s_ntab;
-  m.stage = sindy_stage_bytes<T>(h) > 0;
-  return m;
-}
-
-template <typename T>
-static hipError_t upload_converted(void* dst, const double* src, size_t n, hipStream_t s) {
-  if (sizeof(T) == 8) return hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, s);
-  std::vector<float> tmp(n);
-  for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
-  hipError_t e = hipMemcpyAsync(dst, tmp.data(), n * 4, hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
-  return hipStreamSynchronize(s);  // tmp goes out of scope
-}
-template <typename T>
-static hipError_t download_converted(double* dst, const void* src, size_t n, hipStream_t s) {
-  if (sizeof(T) == 8) {
-    hipError_t e = hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(s);
-  }
-  std::vector<float> tmp(n);
-  hipError_t e = hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, s);
-  if (e != hipSuccess) return e;
-  e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return e;
-  for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
-  return hipSuccess;
-}
-
-#ifdef AMPC_TU_MAIN
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-#endif  // AMPC_TU_MAIN
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_version(void) { return 100; }
-#endif  // AMPC_TU_MAIN
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle** out) {
   REQUIRE(out != nullptr, "ampc_create: out is NULL");
   REQUIRE(precision == AMPC_F64 || precision == AMPC_F32, "ampc_create: bad precision");
@@ -221,11 +48,9 @@ extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle*
   *out = h;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
 static void handle_free(ampc_handle* h);
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_destroy(ampc_handle* h) {
   if (!h) return 0;
   if (h->refs > 0) {
@@ -235,7 +60,6 @@ extern "C" int ampc_destroy(ampc_handle* h) {
   handle_free(h);
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
 static void handle_release(ampc_handle* h) {
   if (--h->refs == 0 && h->dead) handle_free(h);
@@ -251,17 +75,13 @@ static void handle_free(ampc_handle* h) {
   delete h;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_synchronize(ampc_handle* h) {
   REQUIRE(h, "ampc_synchronize: NULL handle");
   HIP_OK(hipSetDevice(h->device));
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
-#endif  // AMPC_TU_MAIN
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : -1; }
-#endif  // AMPC_TU_MAIN
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host, double) -- layouts documented in mlp_tile.hpp
@@ -412,7 +232,6 @@ template <typename T> static int build_model(ampc_handle* h) {
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
                             int activation, const double* const* weights,
                             const double* const* biases, const double* xu_mean,
@@ -497,9 +316,7 @@ extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, 
   return ampc_set_mlp(h, nx, nu, 1, &hidden, 4, ws, bs, zeros.data(), ones.data(), zeros.data(),
                       ones.data());
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
                                    const double* R, const double* F, const double* goal) {
   REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
@@ -536,9 +353,7 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
   h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
   REQUIRE(h && lo && hi, "ampc_set_ctrl_bounds: NULL argument");
   REQUIRE(h->has_model(), "ampc_set_ctrl_bounds: set the model first");
@@ -565,145 +380,7 @@ extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const doub
   h->has_bounds = true;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-// ---------------------------------------------------------------------------------------------
-// kernel dispatch on (NT, MT)
-// ---------------------------------------------------------------------------------------------
-template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
-// (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.
-#define AMPC_CASE(WV, NTV, MTV, ...) \
-  case (WV) * 100 + (NTV) * 10 + (MTV): { constexpr int W = WV, NT = NTV, MT = MTV; __VA_ARGS__; } break;
-#define AMPC_DISPATCH(WV, NTV, MTV, ...)                                     \
-  do {                                                                       \
-    switch ((WV) * 100 + (NTV) * 10 + (MTV)) {                               \
-      AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
-      AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
-      AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
-      AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
-      default: return fail("internal: unsupported (W, NT, MT) combination");  \
-    }                                                                        \
-  } while (0)
-
-// Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
-// LDS map for a tile: separate partials region when it fits the 160 KB, else aliased onto `act`.
-template <typename T>
-static TileLds tile_lds_for(const ampc_handle* h, const MlpDev<T>& m, int M, size_t extra_elems) {
-  // richest map first: ping-pong activations + separate partials, then drop one at a time
-  TileLds L = make_tile_lds(m, M, h->nw, true, env_int("AMPC_PINGPONG", 1) != 0);
-  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, true, false);
-  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, false, false);
-  return L;
-}
-
-template <typename T>
-static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_rows,
-                     size_t extra_elems) {
-  const int forced = env_int("AMPC_MT", 0);
-  int best = 1;
-  for (int mt : {1, 2, 4}) {
-    TileLds L = tile_lds_for<T>(h, m, 16 * mt, extra_elems);
-    const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
-    if (bytes > kLdsLimit) break;
-    if (forced == mt) return mt;
-    if (mt == 4 && h->nt == 3 && sizeof(T) == 8) break;   // 12 f64 accumulator tiles per wave spill
-    if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
-  }
-  return best;
-}
-
-// ---------------------------------------------------------------------------------------------
-// heavy launchers: declared here, defined below, instantiated in their family's translation unit
-// ---------------------------------------------------------------------------------------------
-struct ampc_mppi_plan;
-struct ampc_ilqr_plan;
-template <typename T> int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
-                                    double* jx, double* ju, int n);
-template <typename T> int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u,
-                                         void* x_next, int B);
-template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p);
-template <typename T> int mppi_solve_impl(ampc_mppi_plan* p);
-template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode);
-#define AMPC_HEAVY_MLP(X, T)                                                                       \
-  X template int pred_impl<T>(ampc_handle*, const double*, const double*, double*, double*, double*, int); \
-  X template int surrogate_step<T>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);      \
-  X template int ilqr_refresh_jacobians<T>(ampc_ilqr_plan*);
-#define AMPC_HEAVY_MPPI(X, T) X template int mppi_solve_impl<T>(ampc_mppi_plan*);
-#define AMPC_HEAVY_ILQR(X, T) X template int ilqr_launch_iter<T>(ampc_ilqr_plan*, int);
-#ifdef AMPC_TU_MAIN
-AMPC_HEAVY_MLP(extern, double) AMPC_HEAVY_MLP(extern, float)
-AMPC_HEAVY_MPPI(extern, double) AMPC_HEAVY_MPPI(extern, float)
-AMPC_HEAVY_ILQR(extern, double) AMPC_HEAVY_ILQR(extern, float)
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// Model.pred_batch / pred_diff_batch
-// ---------------------------------------------------------------------------------------------
-template <typename T>
-int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
-                     double* jx, double* ju, int n) {
-  const MlpDev<T>& m = model_of<T>(h);
-  const int nx = h->nx, nu = h->nu;
-  const bool deriv = jx != nullptr;
-  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
-  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
-  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
-  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
-  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
-  const int mt = choose_mt<T>(h, m, n, 0);
-  const int M = 16 * mt;
-  const int tiles = (n + M - 1) / M;
-  const int n_pad = tiles * M;
-  TileLds L = tile_lds_for<T>(h, m, M, 0);
-  const size_t lds_bytes = (size_t)L.extra * sizeof(T);
-  if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
-  T* dz = (T*)h->s_dz.p;
-  const RowMap rm{n, 0, 0, nullptr};
-  AMPC_DISPATCH(h->nw, h->nt, mt, {
-    if (deriv) {
-      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
-      HIP_OK(allow_lds(k, lds_bytes));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
-                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
-                         n_pad, rm);
-    } else {
-      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
-      HIP_OK(allow_lds(k, lds_bytes));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
-                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
-                         (T*)nullptr, n, n_pad, rm);
-    }
-  });
-  HIP_OK(hipGetLastError());
-  if (deriv) {
-    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
-    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
-    const int jmt = 1;
-    const int JM = 16 * jmt;
-    const int jtiles = ((n + JM - 1) / JM) * nx;       // (sample block, output index) tiles
-    const int kinp = 16 * ((m.kin + 15) / 16);
-    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, jmt, {
-      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
-      HIP_OK(allow_lds(k, jl));
-      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m,
-                         (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
-                         (T*)h->s_ju.p, rm);
-    });
-    HIP_OK(hipGetLastError());
-    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
-    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
-  }
-  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
-  return 0;
-}
-
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
                                    double* out, int n) {
   REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
@@ -714,9 +391,7 @@ extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const d
   return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
                                   : pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
                                         double* out, double* jx, double* ju, int n) {
   REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
@@ -726,67 +401,6 @@ extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, co
   HIP_OK(hipSetDevice(h->device));
   return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, jx, ju, n)
                                   : pred_impl<float>(h, states, ctrls, out, jx, ju, n);
-}
-#endif  // AMPC_TU_MAIN
-
-// ---------------------------------------------------------------------------------------------
-// MPPI plan
-// ---------------------------------------------------------------------------------------------
-struct ampc_mppi_plan {
-  ampc_handle* h = nullptr;
-  int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
-  int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
-  std::vector<int> N, H, cost_idx, a_off;
-  std::vector<double> sigma, lmda;
-  std::vector<long long> eps_off, epso_off, cost_off;
-  long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
-  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part;
-  int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
-  bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
-  int cur = 0;          // act[cur] is the input of the next solve
-  bool costs_final = true;
-  bool solved = false;
-  size_t lds_bytes = 0;
-  TileLds L{};
-  int lds_aseq = 0, lds_cost = 0;
-  // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
-  bool timing = false;
-  std::vector<hipEvent_t> ev;   // 3 per solve: before rollout, after rollout, after update
-  size_t ev_used = 0;
-};
-
-template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
-  ampc_handle* h = p->h;
-  MppiArgs<T> a;
-  std::memset(&a, 0, sizeof(a));
-  a.mlp = model_of<T>(h);
-  a.lds = p->L;
-  a.lds_aseq = p->lds_aseq;
-  a.lds_cost = p->lds_cost;
-  a.obs_dim = h->obs_dim;
-  a.cost_stride = h->cost_stride;
-  a.term_mode = p->term_mode;
-  a.max_h = p->max_h;
-  a.cost_diag = h->cost_diag;
-  a.lds_eps = p->lds_eps;
-  a.lds_red = p->lds_red;
-  a.write_eps_out = (p->keep_eps_out || p->lds_eps < 0) ? 1 : 0;
-  a.hnu_stride = p->max_h * h->nu;
-  a.tile_stat = (T*)p->tile_stat.p;
-  a.tile_part = (T*)p->tile_part.p;
-  a.costs_par = (const T*)h->cost_buf.p;
-  a.bounds = (const T*)h->bounds_buf.p;
-  a.probs = (const MppiProblem<T>*)p->probs.p;
-  a.tile_prob = (const int*)p->tile_prob.p;
-  a.x0 = (const T*)p->x0.p;
-  a.act_in = (const T*)p->act[p->cur].p;
-  a.act_out = (T*)p->act[p->cur ^ 1].p;
-  a.eps = (const T*)p->eps.p;
-  a.eps_out = (T*)p->eps_out.p;
-  a.costs = (T*)p->costs.p;
-  a.term_last = (T*)p->term_last.p;
-  a.u_out = (T*)p->u_out.p;
-  return a;
 }
 
 template <typename T> static int plan_build(ampc_mppi_plan* p) {
@@ -871,7 +485,6 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
                                      const int* horizon, const double* sigma, const double* lmda,
                                      const int* cost_index, int term_mode, ampc_mppi_plan** out) {
@@ -914,9 +527,7 @@ extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
   *out = p;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
@@ -930,7 +541,6 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   handle_release(h);
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
 template <typename T>
 static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq,
@@ -943,7 +553,6 @@ static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* a
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
                                 const double* eps) {
   REQUIRE(p, "ampc_mppi_upload: NULL plan");
@@ -951,7 +560,6 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
   return p->h->precision == AMPC_F64 ? mppi_upload_impl<double>(p, x0, act_seq, eps)
                                      : mppi_upload_impl<float>(p, x0, act_seq, eps);
 }
-#endif  // AMPC_TU_MAIN
 
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
@@ -977,71 +585,17 @@ template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t 
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   REQUIRE(p, "ampc_mppi_generate_eps: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_generate_impl<double>(p, seed, stream)
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
-#endif  // AMPC_TU_MAIN
-
-template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
-  ampc_handle* h = p->h;
-  MppiArgs<T> a = make_args<T>(p);
-  hipEvent_t* e = nullptr;
-  if (p->timing) {
-    if (p->ev_used + 3 > p->ev.size()) {
-      for (int i = 0; i < 3; ++i) {
-        hipEvent_t x;
-        HIP_OK(hipEventCreate(&x));
-        p->ev.push_back(x);
-      }
-    }
-    e = &p->ev[p->ev_used];
-    p->ev_used += 3;
-    HIP_OK(hipEventRecord(e[0], h->stream));
-  }
-  if (h->has_sindy) {
-    const SindyDev<T> sm = sindy_of<T>(h);
-    const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
-                      sindy_stage_bytes<T>(h);
-    HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
-    hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
-  } else {
-    AMPC_DISPATCH(h->nw, h->nt, p->mt, {
-      auto k = mppi_rollout_kernel<T, NT, MT, W>;
-      HIP_OK(allow_lds(k, p->lds_bytes));
-      hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
-    });
-  }
-  if (e) HIP_OK(hipEventRecord(e[1], h->stream));
-  if (p->lds_eps >= 0) {
-    hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
-                       p->tile_m);
-  } else {
-    int maxn = 0;
-    for (int n : p->N) maxn = n > maxn ? n : maxn;
-    const size_t ub = ((size_t)(maxn <= kUpdateMaxN ? maxn : 0) + kWaves + kWG) * sizeof(T);
-    auto uk = mppi_update_kernel<T>;
-    HIP_OK(allow_lds(uk, ub));
-    hipLaunchKernelGGL(uk, dim3(p->max_h, p->B), dim3(kWG), ub, h->stream, a);
-  }
-  if (e) HIP_OK(hipEventRecord(e[2], h->stream));
-  HIP_OK(hipGetLastError());
-  p->cur ^= 1;
-  p->costs_final = false;
-  p->solved = true;
-  return 0;
-}
-
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_solve(ampc_mppi_plan* p) {
   REQUIRE(p, "ampc_mppi_solve: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_solve_impl<double>(p) : mppi_solve_impl<float>(p);
 }
-#endif  // AMPC_TU_MAIN
 
 template <typename T>
 static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
@@ -1064,7 +618,6 @@ static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, dou
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
                                   double* eps_out) {
   REQUIRE(p, "ampc_mppi_download: NULL plan");
@@ -1075,9 +628,7 @@ extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u,
   return p->h->precision == AMPC_F64 ? mppi_download_impl<double>(p, act_seq, u, costs, eps_out)
                                      : mppi_download_impl<float>(p, act_seq, u, costs, eps_out);
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {
   REQUIRE(p && x0_dev, "ampc_mppi_set_x0_dev: NULL argument");
   HIP_OK(hipSetDevice(p->h->device));
@@ -1085,9 +636,7 @@ extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {
                         hipMemcpyDeviceToDevice, p->h->stream));
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, int* samples_per_wg,
                                    double* flops, double* bytes) {
   REQUIRE(p, "ampc_mppi_plan_info: NULL plan");
@@ -1118,18 +667,14 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
   if (bytes) *bytes = by;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable) {
   REQUIRE(p, "ampc_mppi_plan_set_timing: NULL plan");
   p->timing = enable != 0;
   p->ev_used = 0;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms,
                                      int* count) {
   REQUIRE(p, "ampc_mppi_plan_timing: NULL plan");
@@ -1149,52 +694,6 @@ extern "C" int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, doub
   if (count) *count = (int)n;
   p->ev_used = 0;
   return 0;
-}
-#endif  // AMPC_TU_MAIN
-
-
-// ---------------------------------------------------------------------------------------------
-// iLQR plan
-// ---------------------------------------------------------------------------------------------
-struct ampc_ilqr_plan {
-  ampc_handle* h = nullptr;
-  int B = 0, H = 0, ls_n = 10, bounded = 0;
-  double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
-  std::vector<int> cost_idx;
-  DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
-  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
-  TileLds L{};
-  int lds_work = 0, lds_xn = 0;
-  size_t lds_bytes = 0;
-  int last_iterations = 0;
-};
-
-template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {
-  ampc_handle* h = p->h;
-  IlqrArgs<T> a;
-  std::memset(&a, 0, sizeof(a));
-  a.mlp = model_of<T>(h);
-  if (h->has_sindy) a.sindy = sindy_of<T>(h);
-  a.lds_xn = p->lds_xn;
-  a.lds = p->L;
-  a.lds_work = p->lds_work;
-  a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
-  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag;
-  a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
-  for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
-  a.costs_par = (const T*)h->cost_buf.p;
-  a.cost_idx = (const int*)p->d_cost_idx.p;
-  a.ubounds = (const T*)h->ubounds_buf.p;
-  a.states = (T*)p->states.p; a.ctrls = (T*)p->ctrls.p;
-  a.jx = (const T*)p->jx.p; a.ju = (const T*)p->ju.p;
-  a.Ks = (T*)p->Ks.p; a.ks = (T*)p->ks.p;
-  a.ls_states = (T*)p->ls_states.p; a.ls_ctrls = (T*)p->ls_ctrls.p;
-  a.obj = (T*)p->obj.p;
-  int* f = (int*)p->flags.p;
-  a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
-  a.refresh = f + 4 * p->B;
-  a.ric = (T*)p->ric.p;
-  return a;
 }
 
 template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
@@ -1239,7 +738,6 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt,
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
@@ -1263,9 +761,7 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   *out = p;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
@@ -1276,86 +772,6 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   ampc_handle* h = p->h;
   delete p;
   handle_release(h);
-  return 0;
-}
-#endif  // AMPC_TU_MAIN
-
-// Jacobians of every (problem, t) row of the nominal trajectories whose problem asked for it.
-template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
-  ampc_handle* h = p->h;
-  const MlpDev<T>& m = model_of<T>(h);
-  const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
-  const int n_pad = round_up(rows, 64);
-  const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
-  if (h->has_sindy) {
-    hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
-                       sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,
-                       (T*)p->ju.p, rows, rm);
-    HIP_OK(hipGetLastError());
-    return 0;
-  }
-  {
-    const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
-    TileLds L = tile_lds_for<T>(h, m, M, 0);
-    const size_t lb = (size_t)L.extra * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, mt, {
-      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
-      HIP_OK(allow_lds(k, lb));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
-                         (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
-    });
-  }
-  {
-    // 16-row tiles: their 33 KB of LDS lets four workgroups share a CU, so one tile's set-up
-    // (global loads of dz / W_out) and reduction overlap another's MFMAs; measured 4 % faster on
-    // c4 than 32- or 64-row tiles (AMPC_JMT overrides for experiments).
-    const int kinp = 16 * ((m.kin + 15) / 16);
-    int jmt = env_int("AMPC_JMT", 0);
-    if (jmt == 0) jmt = 1;
-    while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
-    const int JM = 16 * jmt, jtiles = ((rows + JM - 1) / JM) * nx;   // (sample block, output) tiles
-    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, jmt, {
-      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
-      HIP_OK(allow_lds(k, jl));
-      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
-                         (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
-    });
-  }
-  HIP_OK(hipGetLastError());
-  return 0;
-}
-
-template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
-  ampc_handle* h = p->h;
-  IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
-  if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
-    const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
-    const size_t rb = (size_t)wk.total * sizeof(T);
-    if (h->nx > 32) {
-      auto rk = ilqr_riccati_kernel<T, true>;
-      HIP_OK(allow_lds(rk, rb));
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
-    } else {
-      auto rk = ilqr_riccati_kernel<T, false>;
-      HIP_OK(allow_lds(rk, rb));
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
-    }
-    HIP_OK(hipGetLastError());
-  }
-  if (h->has_sindy) {
-    auto k = ilqr_iter_kernel<T, 1, 4, 1>;
-    HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->B), dim3(256), p->lds_bytes, h->stream, a);
-    HIP_OK(hipGetLastError());
-    return 0;
-  }
-  AMPC_DISPATCH(h->nw, h->nt, 1, {
-    auto k = ilqr_iter_kernel<T, NT, W>;
-    HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
-  });
-  HIP_OK(hipGetLastError());
   return 0;
 }
 
@@ -1400,7 +816,6 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess,
                                int max_iter, double* states, double* ctrls, double* Ks, double* ks,
                                int* converged, int* iters, int* status, double* objective) {
@@ -1410,34 +825,6 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
   return p->h->precision == AMPC_F64
              ? ilqr_solve_impl<double>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective)
              : ilqr_solve_impl<float>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective);
-}
-#endif  // AMPC_TU_MAIN
-
-// x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
-template <typename T>
-int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
-  if (sur->has_sindy) {
-    const SindyDev<T> sd = sindy_of<T>(sur);
-    const size_t lb = (size_t)(2 * sur->nx + sur->nu + sur->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(sur);
-    HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
-    hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((B + 63) / 64), dim3(64), lb, h->stream, sd,
-                       (const T*)x, (const T*)u, (T*)x_next, B);
-    HIP_OK(hipGetLastError());
-    return 0;
-  }
-  const MlpDev<T>& sm = model_of<T>(sur);
-  const int SM = 16, stiles = (B + SM - 1) / SM;
-  TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
-  const size_t slds = (size_t)SL.extra * sizeof(T);
-  const RowMap rm{B, 0, 0, nullptr};
-  AMPC_DISPATCH(sur->nw, sur->nt, 1, {
-    auto k = mlp_forward_kernel<T, NT, MT, W, false>;
-    HIP_OK(allow_lds(k, slds));
-    hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)x,
-                       (const T*)u, (T*)x_next, (T*)nullptr, B, stiles * SM, rm);
-  });
-  HIP_OK(hipGetLastError());
-  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1492,7 +879,6 @@ static int score_device(ampc_handle* h, const void* d_obs, const void* d_ctl, in
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 template <typename T>
 static int score_host_impl(ampc_handle* h, int B, int T1, int nx, int nu, int no, const double* obs,
                            const double* ctrls, const ScoreSpec& sp, double* scores) {
@@ -1521,7 +907,6 @@ extern "C" int ampc_score_trajectories(ampc_handle* h, int n_traj, int n_rows, i
              ? score_host_impl<double>(h, n_traj, n_rows, state_dim, ctrl_dim, obs_dim, obs, ctrls, sp, scores)
              : score_host_impl<float>(h, n_traj, n_rows, state_dim, ctrl_dim, obs_dim, obs, ctrls, sp, scores);
 }
-#endif  // AMPC_TU_MAIN
 
 // ---------------------------------------------------------------------------------------------
 // Closed loop on a surrogate model, device resident (simulate(), utils/simulation.py:11-64)
@@ -1572,7 +957,6 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   return rc;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
                                      const double* init_obs, int n_steps, uint64_t seed,
                                      const double* eps_all, double* traj_obs, double* traj_ctrls) {
@@ -1588,9 +972,7 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
              : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls);
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surrogate,
                                             const double* init_obs, int n_steps, uint64_t seed,
                                             const double* eps_all, int n_terms, const int* kinds,
@@ -1613,15 +995,12 @@ extern "C" int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surr
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls, &sp, scores)
              : closed_loop_impl<float>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls, &sp, scores);
 }
-#endif  // AMPC_TU_MAIN
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out) {
   REQUIRE(p, "ampc_mppi_plan_set_outputs: NULL plan");
   p->keep_eps_out = keep_eps_out != 0;
   return 0;
 }
-#endif  // AMPC_TU_MAIN
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1657,7 +1036,6 @@ static int sindy_pred_impl(ampc_handle* h, const double* states, const double* c
   return 0;
 }
 
-#ifdef AMPC_TU_MAIN
 extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind,
                               const int* arg0, const int* arg1, const double* param,
                               const double* xi, int continuous, double dt, int strict_reference) {
@@ -1753,38 +1131,3 @@ extern "C" int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, 
   return h->precision == AMPC_F64 ? sindy_pred_impl<double>(h, states, ctrls, out, jx, ju, n)
                                   : sindy_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }
-#endif  // AMPC_TU_MAIN
-
-#if defined(AMPC_X_PHASETIME) && !defined(AMPC_TU_MAIN) && AMPC_TU_FAMILY == 2 && defined(AMPC_TU_F64)
-// experiment only (tools/phasetime.py): read back the phase marks of the f64 rollout kernel; lives
-// in the unit that owns that kernel because __device__ variables are per code object.
-extern "C" int ampc_x_phase_marks(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
-  return 0;
-}
-#endif
-
-#if defined(AMPC_X_PHASETIME) && !defined(AMPC_TU_MAIN) && AMPC_TU_FAMILY == 3 && defined(AMPC_TU_F64)
-// experiment only (tools/phasetime_ilqr.py): the f64 iLQR kernel's copy of the marks
-extern "C" int ampc_x_phase_marks_ilqr(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
-  return 0;
-}
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// explicit instantiations of the heavy launchers (one family, one precision per translation unit)
-// ---------------------------------------------------------------------------------------------
-#ifndef AMPC_TU_MAIN
-#if AMPC_TU_FAMILY == 1
-AMPC_HEAVY_MLP(, AMPC_TU_T)
-#elif AMPC_TU_FAMILY == 2
-AMPC_HEAVY_MPPI(, AMPC_TU_T)
-#elif AMPC_TU_FAMILY == 3
-AMPC_HEAVY_ILQR(, AMPC_TU_T)
-#else
-#error "define AMPC_TU_MAIN, or AMPC_TU_FAMILY (1..3) and AMPC_TU_T (double|float)"
-#endif
-#endif

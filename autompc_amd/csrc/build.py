@@ -1,7 +1,7 @@
 """Build libautompc_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-autompc_hip.cpp is compiled as seven translation units in parallel -- the C API plus one unit
-per (heavy kernel family, precision) -- and linked into one shared library.
+Seven translation units compiled in parallel and linked into one shared library: api.cpp (the C
+ABI and host logic) plus launch_{mlp,mppi,ilqr}.cpp once per precision (-DAMPC_T=double|float).
 """
 import concurrent.futures
 import os
@@ -13,13 +13,13 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libautompc_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCE = os.path.join(HERE, "autompc_hip.cpp")
-HEADERS = ["mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp",
+HEADERS = ["host_common.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp",
            "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
-UNITS = [("main", ["-DAMPC_TU_MAIN"])] + [
-    ("f%d_%s" % (fam, t), ["-DAMPC_TU_FAMILY=%d" % fam, "-DAMPC_TU_T=%s" % t] +
-     (["-DAMPC_TU_F64=1"] if t == "double" else []))
-    for fam in (1, 2, 3) for t in ("double", "float")]
+# (object name, source file, extra flags)
+UNITS = [("api", "api.cpp", [])] + [
+    ("%s_%s" % (fam, t), "launch_%s.cpp" % fam, ["-DAMPC_T=%s" % t] + (["-DAMPC_T_IS_F64=1"] if t == "double" else []))
+    for fam in ("mlp", "mppi", "ilqr") for t in ("double", "float")]
+SOURCES = sorted({u[1] for u in UNITS})
 
 
 def _hipcc():
@@ -33,7 +33,7 @@ def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [SOURCE, __file__] + [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+    deps = [os.path.join(HERE, f) for f in SOURCES] + [__file__] + [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -47,11 +47,11 @@ def build(force=False, verbose=True, extra_flags=(), out=None):
     tag = os.path.basename(out)
 
     def compile_unit(unit):
-        name, flags = unit
+        name, source, flags = unit
         obj = os.path.join(OBJ, "%s.%s.o" % (tag, name))
-        cmd = base + flags + ["-c", SOURCE, "-o", obj]
+        cmd = base + flags + ["-c", os.path.join(HERE, source), "-o", obj]
         if verbose:
-            print("[autompc_amd] hipcc %s -> %s" % (" ".join(flags), os.path.basename(obj)), flush=True)
+            print("[autompc_amd] hipcc %s %s -> %s" % (source, " ".join(flags), os.path.basename(obj)), flush=True)
         subprocess.run(cmd, check=True)
         return obj
 

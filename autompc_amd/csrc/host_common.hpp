@@ -1,0 +1,344 @@
+// host_common.hpp -- host-side declarations shared by the translation units of libautompc_hip.so:
+// the handle and plan structs, error plumbing, upload/download helpers, the (W, NT, MT) kernel
+// dispatch and the heavy launchers' declarations.
+//
+//   api.cpp                       the C ABI (include/autompc_hip.h), host logic, the small kernels
+//   launch_mlp.cpp   -DAMPC_T=..  MLP forward / Jacobian launchers         } one unit per precision:
+//   launch_mppi.cpp  -DAMPC_T=..  MPPI rollout / update launcher           } each holds the explicit
+//   launch_ilqr.cpp  -DAMPC_T=..  iLQR sweep / line-search launcher        } instantiation for AMPC_T
+#pragma once
+#include "autompc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mlp_kernels.hpp"
+#include "ilqr_kernels.hpp"
+#include "mppi_kernels.hpp"
+#include "rng_kernels.hpp"
+#include "sindy_kernels.hpp"
+#include "score_kernels.hpp"
+
+using namespace ampc;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+extern thread_local std::string g_err;     // defined in api.cpp
+inline int fail(const std::string& msg) {
+  g_err = msg;
+  return -1;
+}
+#define HIP_OK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+#define REQUIRE(cond, msg) \
+  do {                     \
+    if (!(cond)) return fail(msg); \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t reserve(size_t n) {
+    if (n <= bytes) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+// function-local device scratch: freed on every exit path (HIP_OK / REQUIRE return early)
+struct ScopedBuf : DevBuf {
+  ScopedBuf() = default;
+  ScopedBuf(const ScopedBuf&) = delete;
+  ScopedBuf& operator=(const ScopedBuf&) = delete;
+  ~ScopedBuf() { release(); }
+};
+
+static constexpr size_t kLdsLimit = 160 * 1024;
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : dflt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------------
+struct ampc_handle {
+  int device = 0;
+  int precision = AMPC_F64;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  size_t esz() const { return precision == AMPC_F64 ? 8 : 4; }
+  // Plans hold raw pointers to their handle.  Language bindings with garbage collection may
+  // destroy a handle before the plans built on it, so the handle is reference counted: it is
+  // actually freed when ampc_destroy has been called AND the last plan is gone.
+  int refs = 0;
+  bool dead = false;
+
+  // model (host copy, double) ---------------------------------------------------------------
+  bool has_mlp = false;
+  bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
+  bool has_model() const { return has_mlp || has_sindy; }
+  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0;
+  double s_dt = 0.0;
+  DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
+  int nx = 0, nu = 0, n_hidden = 0, act = 0;
+  int hidden[kMaxHidden] = {0, 0, 0, 0};
+  int hpad = 0, nt = 0, nw = 4, k1p = 0, nxp = 0;  // nw = waves per workgroup (4 or 8)
+  std::vector<std::vector<double>> W, b;
+  std::vector<double> norm;
+  DevBuf model_buf;   // all packed arrays, contiguous
+  const void* wout_plain = nullptr;  // [nx][hpad] view into model_buf (Jacobian chain)
+  MlpDev<double> md{};
+  MlpDev<float> mf{};
+
+  // cost blocks / bounds ----------------------------------------------------------------------
+  int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0;
+  DevBuf cost_buf;
+  bool has_bounds = false;
+  std::vector<double> lo, hi;
+  DevBuf bounds_buf;  // lo/scale, hi/scale, scale   (MPPI units)
+  DevBuf ubounds_buf; // lo, hi                     (iLQR clips in physical units)
+
+  // scratch for the batched model calls -----------------------------------------------------------
+  DevBuf s_states, s_ctrls, s_out, s_dz, s_jx, s_ju;
+};
+
+template <typename T> inline MlpDev<T>& model_of(ampc_handle* h);
+template <> inline MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }
+template <> inline MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
+
+// LDS bytes the kernels need on top of their own regions for the staged feature program
+template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
+  if (h->s_ntab == 0) return 0;
+  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, sizeof(T)) * sizeof(T);
+  return b <= (size_t)kSindyStageBytes ? b + 2 * sizeof(T) : 0;
+}
+
+template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
+  SindyDev<T> m;
+  m.nx = h->nx; m.nu = h->nu; m.n_feat = h->s_nfeat; m.continuous = h->s_continuous;
+  m.strict = h->s_strict; m.dt = (T)h->s_dt;
+  const int* ip = (const int*)h->sindy_int.p;
+  const int nf = h->s_nfeat;
+  m.kind = ip; m.a0 = ip + nf; m.a1 = ip + 2 * nf;
+  m.fx = ip + 3 * nf; m.fy = ip + 4 * nf; m.tvar = ip + 5 * nf; m.pvar = ip + 6 * nf;
+  const T* fp = (const T*)h->sindy_flt.p;
+  m.par = fp; m.xi = fp + nf;
+  m.tpar = fp + (size_t)nf * (h->nx + 1);
+  m.ppar = m.tpar + nf;
+  m.n_trig = h->s_ntrig; m.n_pow = h->s_npow; m.n_tab = h->s_ntab;
+  m.stage = sindy_stage_bytes<T>(h) > 0;
+  return m;
+}
+
+template <typename T>
+static hipError_t upload_converted(void* dst, const double* src, size_t n, hipStream_t s) {
+  if (sizeof(T) == 8) return hipMemcpyAsync(dst, src, n * 8, hipMemcpyHostToDevice, s);
+  std::vector<float> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), n * 4, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s);  // tmp goes out of scope
+}
+template <typename T>
+static hipError_t download_converted(double* dst, const void* src, size_t n, hipStream_t s) {
+  if (sizeof(T) == 8) {
+    hipError_t e = hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+  }
+  std::vector<float> tmp(n);
+  hipError_t e = hipMemcpyAsync(tmp.data(), src, n * 4, hipMemcpyDeviceToHost, s);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return e;
+  for (size_t i = 0; i < n; ++i) dst[i] = (double)tmp[i];
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel dispatch on (NT, MT)
+// ---------------------------------------------------------------------------------------------
+template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.
+#define AMPC_CASE(WV, NTV, MTV, ...) \
+  case (WV) * 100 + (NTV) * 10 + (MTV): { constexpr int W = WV, NT = NTV, MT = MTV; __VA_ARGS__; } break;
+#define AMPC_DISPATCH(WV, NTV, MTV, ...)                                     \
+  do {                                                                       \
+    switch ((WV) * 100 + (NTV) * 10 + (MTV)) {                               \
+      AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
+      AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
+      AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
+      AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
+      default: return fail("internal: unsupported (W, NT, MT) combination");  \
+    }                                                                        \
+  } while (0)
+
+// Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
+// LDS map for a tile: separate partials region when it fits the 160 KB, else aliased onto `act`.
+template <typename T>
+static TileLds tile_lds_for(const ampc_handle* h, const MlpDev<T>& m, int M, size_t extra_elems) {
+  // richest map first: ping-pong activations + separate partials, then drop one at a time
+  TileLds L = make_tile_lds(m, M, h->nw, true, env_int("AMPC_PINGPONG", 1) != 0);
+  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, true, false);
+  if (((size_t)L.extra + extra_elems) * sizeof(T) > kLdsLimit) L = make_tile_lds(m, M, h->nw, false, false);
+  return L;
+}
+
+template <typename T>
+static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_rows,
+                     size_t extra_elems) {
+  const int forced = env_int("AMPC_MT", 0);
+  int best = 1;
+  for (int mt : {1, 2, 4}) {
+    TileLds L = tile_lds_for<T>(h, m, 16 * mt, extra_elems);
+    const size_t bytes = ((size_t)L.extra + extra_elems) * sizeof(T);
+    if (bytes > kLdsLimit) break;
+    if (forced == mt) return mt;
+    if (mt == 4 && h->nt == 3 && sizeof(T) == 8) break;   // 12 f64 accumulator tiles per wave spill
+    if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MPPI plan
+// ---------------------------------------------------------------------------------------------
+struct ampc_mppi_plan {
+  ampc_handle* h = nullptr;
+  int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
+  int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
+  std::vector<int> N, H, cost_idx, a_off;
+  std::vector<double> sigma, lmda;
+  std::vector<long long> eps_off, epso_off, cost_off;
+  long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
+  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part;
+  int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
+  bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
+  int cur = 0;          // act[cur] is the input of the next solve
+  bool costs_final = true;
+  bool solved = false;
+  size_t lds_bytes = 0;
+  TileLds L{};
+  int lds_aseq = 0, lds_cost = 0;
+  // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // 3 per solve: before rollout, after rollout, after update
+  size_t ev_used = 0;
+};
+
+template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
+  ampc_handle* h = p->h;
+  MppiArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.mlp = model_of<T>(h);
+  a.lds = p->L;
+  a.lds_aseq = p->lds_aseq;
+  a.lds_cost = p->lds_cost;
+  a.obs_dim = h->obs_dim;
+  a.cost_stride = h->cost_stride;
+  a.term_mode = p->term_mode;
+  a.max_h = p->max_h;
+  a.cost_diag = h->cost_diag;
+  a.lds_eps = p->lds_eps;
+  a.lds_red = p->lds_red;
+  a.write_eps_out = (p->keep_eps_out || p->lds_eps < 0) ? 1 : 0;
+  a.hnu_stride = p->max_h * h->nu;
+  a.tile_stat = (T*)p->tile_stat.p;
+  a.tile_part = (T*)p->tile_part.p;
+  a.costs_par = (const T*)h->cost_buf.p;
+  a.bounds = (const T*)h->bounds_buf.p;
+  a.probs = (const MppiProblem<T>*)p->probs.p;
+  a.tile_prob = (const int*)p->tile_prob.p;
+  a.x0 = (const T*)p->x0.p;
+  a.act_in = (const T*)p->act[p->cur].p;
+  a.act_out = (T*)p->act[p->cur ^ 1].p;
+  a.eps = (const T*)p->eps.p;
+  a.eps_out = (T*)p->eps_out.p;
+  a.costs = (T*)p->costs.p;
+  a.term_last = (T*)p->term_last.p;
+  a.u_out = (T*)p->u_out.p;
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// iLQR plan
+// ---------------------------------------------------------------------------------------------
+struct ampc_ilqr_plan {
+  ampc_handle* h = nullptr;
+  int B = 0, H = 0, ls_n = 10, bounded = 0;
+  double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
+  std::vector<int> cost_idx;
+  DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
+  TileLds L{};
+  int lds_work = 0, lds_xn = 0;
+  size_t lds_bytes = 0;
+  int last_iterations = 0;
+};
+
+template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {
+  ampc_handle* h = p->h;
+  IlqrArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.mlp = model_of<T>(h);
+  if (h->has_sindy) a.sindy = sindy_of<T>(h);
+  a.lds_xn = p->lds_xn;
+  a.lds = p->L;
+  a.lds_work = p->lds_work;
+  a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
+  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag;
+  a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
+  for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
+  a.costs_par = (const T*)h->cost_buf.p;
+  a.cost_idx = (const int*)p->d_cost_idx.p;
+  a.ubounds = (const T*)h->ubounds_buf.p;
+  a.states = (T*)p->states.p; a.ctrls = (T*)p->ctrls.p;
+  a.jx = (const T*)p->jx.p; a.ju = (const T*)p->ju.p;
+  a.Ks = (T*)p->Ks.p; a.ks = (T*)p->ks.p;
+  a.ls_states = (T*)p->ls_states.p; a.ls_ctrls = (T*)p->ls_ctrls.p;
+  a.obj = (T*)p->obj.p;
+  int* f = (int*)p->flags.p;
+  a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
+  a.refresh = f + 4 * p->B;
+  a.ric = (T*)p->ric.p;
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// heavy launchers: defined in launch_*.cpp, explicitly instantiated there for double and float
+// ---------------------------------------------------------------------------------------------
+template <typename T> int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                                    double* jx, double* ju, int n);
+template <typename T> int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u,
+                                         void* x_next, int B);
+template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p);
+template <typename T> int mppi_solve_impl(ampc_mppi_plan* p);
+template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode);

@@ -1,0 +1,52 @@
+// launch_ilqr.cpp -- one iLQR iteration: backward Riccati sweep + batched line search
+// Compiled once per precision (-DAMPC_T=double|float, csrc/build.py); the explicit instantiations
+// at the end are what api.cpp links against.
+#include "host_common.hpp"
+
+#ifndef AMPC_T
+#error "compile with -DAMPC_T=double or -DAMPC_T=float"
+#endif
+
+template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
+  ampc_handle* h = p->h;
+  IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
+    const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
+    const size_t rb = (size_t)wk.total * sizeof(T);
+    if (h->nx > 32) {
+      auto rk = ilqr_riccati_kernel<T, true>;
+      HIP_OK(allow_lds(rk, rb));
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    } else {
+      auto rk = ilqr_riccati_kernel<T, false>;
+      HIP_OK(allow_lds(rk, rb));
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+    }
+    HIP_OK(hipGetLastError());
+  }
+  if (h->has_sindy) {
+    auto k = ilqr_iter_kernel<T, 1, 4, 1>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->B), dim3(256), p->lds_bytes, h->stream, a);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  AMPC_DISPATCH(h->nw, h->nt, 1, {
+    auto k = ilqr_iter_kernel<T, NT, W>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
+  });
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+#if defined(AMPC_X_PHASETIME) && defined(AMPC_T_IS_F64)
+// experiment only (tools/phasetime_ilqr.py): the f64 iLQR kernel's copy of the marks
+extern "C" int ampc_x_phase_marks_ilqr(long long* out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
+  return 0;
+}
+#endif
+
+template int ilqr_launch_iter<AMPC_T>(ampc_ilqr_plan*, int);

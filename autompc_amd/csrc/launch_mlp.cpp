@@ -1,0 +1,147 @@
+// launch_mlp.cpp -- Model.pred_batch / pred_diff_batch, the surrogate step and the iLQR Jacobian refresh
+// Compiled once per precision (-DAMPC_T=double|float, csrc/build.py); the explicit instantiations
+// at the end are what api.cpp links against.
+#include "host_common.hpp"
+
+#ifndef AMPC_T
+#error "compile with -DAMPC_T=double or -DAMPC_T=float"
+#endif
+
+// ---------------------------------------------------------------------------------------------
+// Model.pred_batch / pred_diff_batch
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                     double* jx, double* ju, int n) {
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nx = h->nx, nu = h->nu;
+  const bool deriv = jx != nullptr;
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const int mt = choose_mt<T>(h, m, n, 0);
+  const int M = 16 * mt;
+  const int tiles = (n + M - 1) / M;
+  const int n_pad = tiles * M;
+  TileLds L = tile_lds_for<T>(h, m, M, 0);
+  const size_t lds_bytes = (size_t)L.extra * sizeof(T);
+  if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
+  T* dz = (T*)h->s_dz.p;
+  const RowMap rm{n, 0, 0, nullptr};
+  AMPC_DISPATCH(h->nw, h->nt, mt, {
+    if (deriv) {
+      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+      HIP_OK(allow_lds(k, lds_bytes));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
+                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
+                         n_pad, rm);
+    } else {
+      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+      HIP_OK(allow_lds(k, lds_bytes));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
+                         (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
+                         (T*)nullptr, n, n_pad, rm);
+    }
+  });
+  HIP_OK(hipGetLastError());
+  if (deriv) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    const int jmt = 1;
+    const int JM = 16 * jmt;
+    const int jtiles = ((n + JM - 1) / JM) * nx;       // (sample block, output index) tiles
+    const int kinp = 16 * ((m.kin + 15) / 16);
+    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, jmt, {
+      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+      HIP_OK(allow_lds(k, jl));
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m,
+                         (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
+                         (T*)h->s_ju.p, rm);
+    });
+    HIP_OK(hipGetLastError());
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
+// Jacobians of every (problem, t) row of the nominal trajectories whose problem asked for it.
+template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
+  ampc_handle* h = p->h;
+  const MlpDev<T>& m = model_of<T>(h);
+  const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
+  const int n_pad = round_up(rows, 64);
+  const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
+  if (h->has_sindy) {
+    hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
+                       sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,
+                       (T*)p->ju.p, rows, rm);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  {
+    const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
+    TileLds L = tile_lds_for<T>(h, m, M, 0);
+    const size_t lb = (size_t)L.extra * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, mt, {
+      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+      HIP_OK(allow_lds(k, lb));
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
+                         (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
+    });
+  }
+  {
+    // 16-row tiles: their 33 KB of LDS lets four workgroups share a CU, so one tile's set-up
+    // (global loads of dz / W_out) and reduction overlap another's MFMAs; measured 4 % faster on
+    // c4 than 32- or 64-row tiles (AMPC_JMT overrides for experiments).
+    const int kinp = 16 * ((m.kin + 15) / 16);
+    int jmt = env_int("AMPC_JMT", 0);
+    if (jmt == 0) jmt = 1;
+    while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
+    const int JM = 16 * jmt, jtiles = ((rows + JM - 1) / JM) * nx;   // (sample block, output) tiles
+    const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
+    AMPC_DISPATCH(h->nw, h->nt, jmt, {
+      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+      HIP_OK(allow_lds(k, jl));
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
+                         (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
+    });
+  }
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
+template <typename T>
+int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
+  if (sur->has_sindy) {
+    const SindyDev<T> sd = sindy_of<T>(sur);
+    const size_t lb = (size_t)(2 * sur->nx + sur->nu + sur->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(sur);
+    HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
+    hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((B + 63) / 64), dim3(64), lb, h->stream, sd,
+                       (const T*)x, (const T*)u, (T*)x_next, B);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
+  const MlpDev<T>& sm = model_of<T>(sur);
+  const int SM = 16, stiles = (B + SM - 1) / SM;
+  TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
+  const size_t slds = (size_t)SL.extra * sizeof(T);
+  const RowMap rm{B, 0, 0, nullptr};
+  AMPC_DISPATCH(sur->nw, sur->nt, 1, {
+    auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+    HIP_OK(allow_lds(k, slds));
+    hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)x,
+                       (const T*)u, (T*)x_next, (T*)nullptr, B, stiles * SM, rm);
+  });
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
+template int pred_impl<AMPC_T>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
+template int surrogate_step<AMPC_T>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);
+template int ilqr_refresh_jacobians<AMPC_T>(ampc_ilqr_plan*);

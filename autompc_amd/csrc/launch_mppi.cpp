@@ -1,0 +1,69 @@
+// launch_mppi.cpp -- one MPPI solve: rollout kernel + softmin update
+// Compiled once per precision (-DAMPC_T=double|float, csrc/build.py); the explicit instantiations
+// at the end are what api.cpp links against.
+#include "host_common.hpp"
+
+#ifndef AMPC_T
+#error "compile with -DAMPC_T=double or -DAMPC_T=float"
+#endif
+
+template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
+  ampc_handle* h = p->h;
+  MppiArgs<T> a = make_args<T>(p);
+  hipEvent_t* e = nullptr;
+  if (p->timing) {
+    if (p->ev_used + 3 > p->ev.size()) {
+      for (int i = 0; i < 3; ++i) {
+        hipEvent_t x;
+        HIP_OK(hipEventCreate(&x));
+        p->ev.push_back(x);
+      }
+    }
+    e = &p->ev[p->ev_used];
+    p->ev_used += 3;
+    HIP_OK(hipEventRecord(e[0], h->stream));
+  }
+  if (h->has_sindy) {
+    const SindyDev<T> sm = sindy_of<T>(h);
+    const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
+                      sindy_stage_bytes<T>(h);
+    HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
+    hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
+  } else {
+    AMPC_DISPATCH(h->nw, h->nt, p->mt, {
+      auto k = mppi_rollout_kernel<T, NT, MT, W>;
+      HIP_OK(allow_lds(k, p->lds_bytes));
+      hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
+    });
+  }
+  if (e) HIP_OK(hipEventRecord(e[1], h->stream));
+  if (p->lds_eps >= 0) {
+    hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
+                       p->tile_m);
+  } else {
+    int maxn = 0;
+    for (int n : p->N) maxn = n > maxn ? n : maxn;
+    const size_t ub = ((size_t)(maxn <= kUpdateMaxN ? maxn : 0) + kWaves + kWG) * sizeof(T);
+    auto uk = mppi_update_kernel<T>;
+    HIP_OK(allow_lds(uk, ub));
+    hipLaunchKernelGGL(uk, dim3(p->max_h, p->B), dim3(kWG), ub, h->stream, a);
+  }
+  if (e) HIP_OK(hipEventRecord(e[2], h->stream));
+  HIP_OK(hipGetLastError());
+  p->cur ^= 1;
+  p->costs_final = false;
+  p->solved = true;
+  return 0;
+}
+
+#if defined(AMPC_X_PHASETIME) && defined(AMPC_T_IS_F64)
+// experiment only (tools/phasetime.py): read back the phase marks of the f64 rollout kernel; lives
+// in the unit that owns that kernel because __device__ variables are per code object.
+extern "C" int ampc_x_phase_marks(long long* out) {
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
+  return 0;
+}
+#endif
+
+template int mppi_solve_impl<AMPC_T>(ampc_mppi_plan*);

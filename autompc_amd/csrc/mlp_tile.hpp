@@ -323,7 +323,7 @@ struct TileNet {
   static constexpr int NOMAX = 2;             // nx <= 32
   // A wave's own output columns [16 NT w, 16 NT (w+1)) are one whole k-group of the next hidden
   // layer: that layer starts on them before the barrier (see run()).  Host packing must agree
-  // (own_first_packing() in autompc_hip.cpp).
+  // (own_first_packing() in api.cpp).
   static constexpr bool OWN = (16 * NT == 4 * GH) && (((KSH / GH) & (KSH / GH - 1)) == 0);
 
   // Layer 0's fragments requested ahead of time (prefetch0): the whole layer in f32 (its few
