@@ -7,7 +7,7 @@ import atexit
 import ctypes
 import os
 import weakref
-from ctypes import POINTER, c_char_p, c_double, c_int, c_uint64, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_int, c_uint32, c_uint64, c_void_p
 
 import numpy as np
 
@@ -52,6 +52,8 @@ SIGNATURES = {
     "ampc_mppi_plan_destroy": (c_int, [c_void_p]),
     "ampc_mppi_upload": (c_int, [c_void_p, _dp, _dp, _dp]),
     "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
+    "ampc_mppi_plan_set_noise_ids": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ampc_mppi_plan_set_geometry": (c_int, [c_void_p, c_int, c_int]),
     "ampc_mppi_solve": (c_int, [c_void_p]),
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
@@ -320,6 +322,19 @@ class MppiPlan:
 
     def generate_eps(self, seed, stream=0):
         check(self.lib.ampc_mppi_generate_eps(self._p, int(seed), int(stream)))
+
+    def set_geometry(self, tile_rows=0, horizon_cap=0):
+        """Fix the rollout tile height (0 = automatic, 16/32/64) and the horizon the LDS layout is
+        sized for, so results do not depend on what else shares the plan.  Call before upload()."""
+        check(self.lib.ampc_mppi_plan_set_geometry(self._p, int(tile_rows), int(horizon_cap)))
+
+    def set_noise_ids(self, ids):
+        """ids [B]: the key of every problem's device noise stream (default: its index in the
+        plan).  With a candidate's global index here its noise is independent of the sharding."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        if ids.shape != (self.B,):
+            raise ValueError("one noise id per problem expected")
+        check(self.lib.ampc_mppi_plan_set_noise_ids(self._p, ids.ctypes.data_as(POINTER(c_uint32))))
 
     def solve(self):
         check(self.lib.ampc_mppi_solve(self._p))

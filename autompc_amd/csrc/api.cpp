@@ -411,13 +411,13 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   if (h->has_sindy) {
     p->mt = 4;
   } else {
-    p->mt = choose_mt<T>(h, m, p->sum_n, extra);
+    p->mt = choose_mt<T>(h, m, p->sum_n, extra, p->forced_mt);
     // Problems of different horizons (tuning candidates): 64-row tiles are fewer, coarser work
     // items for the longest-first tile order to balance and leave no LDS for the fused update;
-    // 32-row tiles measured 3 % faster on c5.  (AMPC_MT still overrides.)
+    // 32-row tiles measured 3 % faster on c5.  (AMPC_MT / set_geometry still override.)
     bool mixed = false;
     for (int b = 1; b < p->B; ++b) mixed = mixed || p->H[b] != p->H[0];
-    if (mixed && p->mt > 2 && env_int("AMPC_MT", 0) == 0) p->mt = 2;
+    if (mixed && p->mt > 2 && env_int("AMPC_MT", 0) == 0 && p->forced_mt == 0) p->mt = 2;
   }
   const int M = 16 * p->mt;
   p->tile_m = M;
@@ -459,6 +459,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     q.sqrt_sigma = (T)std::sqrt(p->sigma[b]);
     q.eps_off = p->eps_off[b]; q.epso_off = p->epso_off[b]; q.cost_off = p->cost_off[b];
     q.a_off = p->a_off[b];
+    q.noise_id = p->noise_id[b];
     const int nt = (q.N + M - 1) / M;
     for (int t = 0; t < nt; ++t) tile_prob.push_back(b);
     tile += nt;
@@ -511,6 +512,7 @@ extern "C" int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path,
     p->N.push_back(num_path[b]); p->H.push_back(horizon[b]);
     p->sigma.push_back(sigma[b]); p->lmda.push_back(lmda[b]);
     p->cost_idx.push_back(cost_index ? cost_index[b] : 0);
+    p->noise_id.push_back((unsigned)b);
     p->a_off.push_back((int)p->sum_hnu);
     p->eps_off.push_back(p->sum_nhnu); p->epso_off.push_back(p->sum_nhnu);
     p->cost_off.push_back(p->sum_n);
@@ -569,18 +571,11 @@ template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t 
     const long long pairs = ((long long)p->N[b] * p->H[b] * nu + 1) / 2;
     max_pairs = pairs > max_pairs ? pairs : max_pairs;
   }
-  if (p->B <= 65535) {          // one launch for the whole plan (grid.y = problem)
-    hipLaunchKernelGGL(philox_normal_batch_kernel<T>, dim3((unsigned)((max_pairs + 255) / 256), p->B),
-                       dim3(256), 0, h->stream, (T*)p->eps.p, (const MppiProblem<T>*)p->probs.p, nu,
-                       seed, stream * 65536ull);
-  } else {
-    for (int b = 0; b < p->B; ++b) {
-      const long long count = (long long)p->N[b] * p->H[b] * nu;
-      hipLaunchKernelGGL(philox_normal_kernel<T>, dim3((unsigned)(((count + 1) / 2 + 255) / 256)),
-                         dim3(256), 0, h->stream, (T*)p->eps.p + p->eps_off[b], count,
-                         (T)std::sqrt(p->sigma[b]), seed, stream * 65536ull + (uint64_t)b);
-    }
-  }
+  // one launch for the whole plan: problems over grid.y (and grid.z beyond 65535 of them)
+  const unsigned gy = (unsigned)std::min(p->B, 65535), gz = (unsigned)((p->B + 65534) / 65535);
+  hipLaunchKernelGGL(philox_normal_batch_kernel<T>, dim3((unsigned)((max_pairs + 255) / 256), gy, gz),
+                     dim3(256), 0, h->stream, (T*)p->eps.p, (const MppiProblem<T>*)p->probs.p, p->B, nu,
+                     seed, stream);
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -591,6 +586,38 @@ extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t
   return p->h->precision == AMPC_F64 ? mppi_generate_impl<double>(p, seed, stream)
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
+extern "C" int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int horizon_cap) {
+  REQUIRE(p, "ampc_mppi_plan_set_geometry: NULL plan");
+  REQUIRE(tile_rows == 0 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64,
+          "ampc_mppi_plan_set_geometry: tile_rows must be 0 (automatic), 16, 32 or 64");
+  REQUIRE(horizon_cap >= 0, "ampc_mppi_plan_set_geometry: horizon_cap < 0");
+  HIP_OK(hipSetDevice(p->h->device));
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  p->forced_mt = tile_rows / 16;
+  for (int hb : p->H) p->max_h = hb > p->max_h ? hb : p->max_h;
+  if (horizon_cap > p->max_h) p->max_h = horizon_cap;
+  p->lds_eps = -1;
+  p->lds_red = 0;
+  return p->h->precision == AMPC_F64 ? plan_build<double>(p) : plan_build<float>(p);
+}
+
+template <typename T> static int mppi_set_noise_ids_impl(ampc_mppi_plan* p) {
+  std::vector<MppiProblem<T>> pr(p->B);
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  HIP_OK(hipMemcpy(pr.data(), p->probs.p, pr.size() * sizeof(MppiProblem<T>), hipMemcpyDeviceToHost));
+  for (int b = 0; b < p->B; ++b) pr[b].noise_id = p->noise_id[b];
+  HIP_OK(hipMemcpy(p->probs.p, pr.data(), pr.size() * sizeof(MppiProblem<T>), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_set_noise_ids(ampc_mppi_plan* p, const uint32_t* ids) {
+  REQUIRE(p && ids, "ampc_mppi_plan_set_noise_ids: NULL argument");
+  HIP_OK(hipSetDevice(p->h->device));
+  p->noise_id.assign(ids, ids + p->B);
+  return p->h->precision == AMPC_F64 ? mppi_set_noise_ids_impl<double>(p)
+                                     : mppi_set_noise_ids_impl<float>(p);
+}
+
 extern "C" int ampc_mppi_solve(ampc_mppi_plan* p) {
   REQUIRE(p, "ampc_mppi_solve: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));

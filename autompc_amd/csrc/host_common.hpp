@@ -214,8 +214,8 @@ static TileLds tile_lds_for(const ampc_handle* h, const MlpDev<T>& m, int M, siz
 
 template <typename T>
 static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_rows,
-                     size_t extra_elems) {
-  const int forced = env_int("AMPC_MT", 0);
+                     size_t extra_elems, int forced_mt = 0) {
+  const int forced = forced_mt ? forced_mt : env_int("AMPC_MT", 0);
   int best = 1;
   for (int mt : {1, 2, 4}) {
     TileLds L = tile_lds_for<T>(h, m, 16 * mt, extra_elems);
@@ -234,8 +234,10 @@ static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_r
 struct ampc_mppi_plan {
   ampc_handle* h = nullptr;
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
+  int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
   int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
   std::vector<int> N, H, cost_idx, a_off;
+  std::vector<unsigned> noise_id;   // per problem: key of its device noise stream (default: index)
   std::vector<double> sigma, lmda;
   std::vector<long long> eps_off, epso_off, cost_off;
   long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;

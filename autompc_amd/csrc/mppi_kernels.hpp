@@ -32,7 +32,9 @@ template <typename T> struct MppiProblem {
   long long epso_off;  // into eps_out  [H][N][nu]
   long long cost_off;  // into costs    [N]
   int a_off;           // into act_seq  [H][nu]
-  int pad_;
+  unsigned noise_id;   // keys the problem's device noise stream (default: index in the plan; the
+                       // candidate evaluator sets the candidate's GLOBAL index, so a candidate's
+                       // noise does not depend on how the batch is sharded over GPUs)
 };
 
 template <typename T> struct MppiArgs {

@@ -40,16 +40,20 @@ __host__ __device__ inline Philox4 philox4x32_10(Philox4 c, uint32_t k0, uint32_
 }
 
 // One Philox block -> two uniforms in (0,1) with 53 (f64) bits -> two standard normals.
+// Counter = (pair index [40 bits], stream [56 bits], noise id [32 bits]); key = seed.  `stream` is
+// the caller's step counter, `id` the problem's noise id: (seed, stream, id, element) names a value
+// independently of which plan / GPU / position in the batch the problem occupies.
 template <typename T>
 __device__ __forceinline__ void philox_normal_pair(T* __restrict__ out, long long count, T scale,
-                                                   uint64_t seed, uint64_t stream, long long pair) {
+                                                   uint64_t seed, uint64_t stream, uint32_t id,
+                                                   long long pair) {
   const long long e0 = 2 * pair;
   if (e0 >= count) return;
   Philox4 c;
   c.v[0] = (uint32_t)pair;
-  c.v[1] = (uint32_t)((uint64_t)pair >> 32);
+  c.v[1] = (uint32_t)(((uint64_t)pair >> 32) & 0xffu) | (uint32_t)((stream >> 32) << 8);
   c.v[2] = (uint32_t)stream;
-  c.v[3] = (uint32_t)(stream >> 32);
+  c.v[3] = id;
   const Philox4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   const uint64_t a = ((uint64_t)r.v[0] << 32) | r.v[1];
   const uint64_t b = ((uint64_t)r.v[2] << 32) | r.v[3];
@@ -62,23 +66,16 @@ __device__ __forceinline__ void philox_normal_pair(T* __restrict__ out, long lon
   if (e0 + 1 < count) out[e0 + 1] = (T)(rad * s) * scale;
 }
 
-template <typename T>
-__global__ void philox_normal_kernel(T* __restrict__ out, long long count, T scale, uint64_t seed,
-                                     uint64_t stream) {
-  philox_normal_pair<T>(out, count, scale, seed, stream,
-                        (long long)blockIdx.x * blockDim.x + threadIdx.x);
-}
-
-// The noise of every problem of a plan in one launch: blockIdx.y = problem; problem b draws
-// N_b*H_b*nu values of std sqrt(sigma_b) from stream stream_base + b -- the same values as B
-// separate philox_normal_kernel launches, without B launch latencies.
+// The noise of every problem of a plan in one launch: grid.y * grid.z covers the problems; problem
+// b draws N_b*H_b*nu values of std sqrt(sigma_b) keyed by (seed, stream, noise_id_b).
 template <typename T>
 __global__ void philox_normal_batch_kernel(T* __restrict__ eps, const MppiProblem<T>* __restrict__ probs,
-                                           int nu, uint64_t seed, uint64_t stream_base) {
-  const MppiProblem<T> pr = probs[blockIdx.y];
-  philox_normal_pair<T>(eps + pr.eps_off, (long long)pr.N * pr.H * nu, pr.sqrt_sigma, seed,
-                        stream_base + (uint64_t)blockIdx.y,
-                        (long long)blockIdx.x * blockDim.x + threadIdx.x);
+                                           int n_probs, int nu, uint64_t seed, uint64_t stream) {
+  const int b = blockIdx.z * gridDim.y + blockIdx.y;
+  if (b >= n_probs) return;
+  const MppiProblem<T> pr = probs[b];
+  philox_normal_pair<T>(eps + pr.eps_off, (long long)pr.N * pr.H * nu, pr.sqrt_sigma, seed, stream,
+                        pr.noise_id, (long long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 }  // namespace ampc

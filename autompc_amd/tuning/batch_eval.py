@@ -73,7 +73,12 @@ def _task_goal(cost, obs_dim):
 class CandidateEvaluator:
     """Evaluates MPPI + QuadCost candidates for one (system, task, model, surrogate) on one GPU."""
 
-    def __init__(self, system, task, model, surrogate=None, precision="f64", device=0):
+    def __init__(self, system, task, model, surrogate=None, precision="f64", device=0,
+                 tile_rows=32, horizon_cap=30):
+        """tile_rows / horizon_cap fix the rollout geometry (MppiPlan.set_geometry) so that a
+        candidate's score is bit-identical for any batch it is evaluated in; horizon_cap defaults
+        to the top of the reference's MPPI horizon range (mppi.py:52-55)."""
+        self.tile_rows, self.horizon_cap = int(tile_rows), int(horizon_cap)
         if not hasattr(model, "stage_into"):
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         self.system, self.task, self.model = system, task, model
@@ -84,16 +89,34 @@ class CandidateEvaluator:
         self.goal = _task_goal(task.get_cost(), system.obs_dim)
 
     def evaluate(self, candidates, n_steps=None, seed=0, init_obs=None, eps_all=None,
-                 act_init=None, return_trajectories=False):
+                 act_init=None, return_trajectories=False, index_offset=0):
         """Closed-loop score of every candidate (a list of dicts with keys horizon, sigma, lmda,
-        num_path, Q, R, F -- Q/R/F either diagonals or full matrices)."""
-        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        num_path, Q, R, F -- Q/R/F either diagonals or full matrices).
+
+        All randomness of candidate i is keyed by (seed, index_offset + i): its warm start comes
+        from ``default_rng([seed, index_offset + i])`` and its device noise from the Philox
+        stream of that global index.  A rank that evaluates the shard ``all[lo:hi]`` with
+        ``index_offset=lo`` therefore returns exactly the scores a single process returns for
+        those candidates (the per-candidate ``surr_cost`` of pipeline_tuner.py:213-258)."""
         B = len(candidates)
         if B == 0:
-            return np.zeros(0)
+            return (np.zeros(0), None, None) if return_trajectories else np.zeros(0)
+        opened = []                       # device objects, closed on every exit path
+        try:
+            return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
+                                  return_trajectories, int(index_offset), opened)
+        finally:
+            for obj in reversed(opened):
+                obj.close()
+
+    def _evaluate(self, candidates, n_steps, seed, init_obs, eps_all, act_init, return_trajectories,
+                  index_offset, opened):
+        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        B = len(candidates)
         n_steps = int(n_steps if n_steps is not None else self.task.get_num_steps())
         init_obs = self.task.get_init_obs() if init_obs is None else np.asarray(init_obs)
         h = _lib.Handle(self.device, self.precision)
+        opened.append(h)
         self.model.stage_into(h)
         Q = np.stack([_as_matrix(c["Q"], no) for c in candidates])
         R = np.stack([_as_matrix(c["R"], nu) for c in candidates])
@@ -103,17 +126,22 @@ class CandidateEvaluator:
         sur = None
         if self.surrogate is not self.model:
             sur = _lib.Handle(self.device, self.precision)
+            opened.append(sur)
             self.surrogate.stage_into(sur)
         Hs = [int(c["horizon"]) for c in candidates]
         plan = _lib.MppiPlan(h, [int(c["num_path"]) for c in candidates], Hs,
                              [float(c["sigma"]) for c in candidates],
                              [float(c["lmda"]) for c in candidates], cost_index=np.arange(B))
+        opened.append(plan)
+        plan.set_geometry(self.tile_rows, self.horizon_cap)
+        plan.set_noise_ids(index_offset + np.arange(B))
         if act_init is None:
             # MPPI.__init__ / reset() draw the warm start ~ N(0, sigma) (mppi.py:97-99); here from
-            # a seeded stream, one draw per candidate in candidate order
-            rng = np.random.default_rng(seed)
-            act_init = np.concatenate([rng.normal(scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
-                                       for i, c in enumerate(candidates)])
+            # a stream seeded by (seed, global candidate index)
+            act_init = np.concatenate([
+                np.random.default_rng([int(seed), index_offset + i]).normal(
+                    scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
+                for i, c in enumerate(candidates)])
         plan.upload(act_seq=act_init)
         try:
             terms = cost_terms(self.task.get_cost(), no, nu)
@@ -128,18 +156,21 @@ class CandidateEvaluator:
             obs, ctrls = plan.closed_loop(np.tile(init_obs, (B, 1)), n_steps, seed=seed,
                                           eps_all=eps_all, surrogate=sur)
             scores = score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
-        plan.close()
-        if sur is not None:
-            sur.close()
-        h.close()
         return (scores, obs, ctrls) if return_trajectories else scores
 
 
 def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None):
-    """Score ``candidates`` with ``local_eval(sub_list) -> scores`` on this rank's contiguous shard
-    and all-gather the scores so every rank returns the full vector (candidate order).
+    """Score ``candidates`` with ``local_eval(sub_list, lo) -> scores`` on this rank's contiguous
+    shard ``candidates[lo:hi]`` and all-gather the scores so every rank returns the full vector
+    (candidate order).  ``lo`` is the global index of the shard's first candidate: an evaluator that
+    keys its randomness by it (CandidateEvaluator.evaluate(..., index_offset=lo)) returns the same
+    score for a candidate whatever the world size.
     Uses the default torch.distributed process group when one is initialised; with none (or world
-    size 1) it is a plain local evaluation."""
+    size 1) it is a plain local evaluation.
+
+    A rank whose local evaluation raises still takes part in the all-gather (its slot carries a
+    failure marker), so the other ranks are not left waiting inside the collective; afterwards
+    every rank raises."""
     import torch
     import torch.distributed as dist
     if world is None:
@@ -148,18 +179,30 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None)
         rank = dist.get_rank() if world > 1 else 0
     n = len(candidates)
     lo, hi = shard_bounds(n, rank, world)
-    local = np.asarray(local_eval(candidates[lo:hi]), dtype=np.float64)
     if world == 1:
-        return local
+        return np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)
+    error = None
+    try:
+        local = np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)
+        if local.shape != (hi - lo,):
+            raise ValueError("local_eval returned %r scores for %d candidates" % (local.shape, hi - lo))
+    except Exception as e:           # noqa: BLE001 -- reported after the collective
+        error, local = e, np.zeros(hi - lo)
     per = (n + world - 1) // world                     # equal-sized slots for the all-gather
     dev = device if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
         else torch.device("cpu"))
-    slot = torch.full((per,), float("nan"), dtype=torch.float64, device=dev)
+    slot = torch.full((per + 1,), float("nan"), dtype=torch.float64, device=dev)
     slot[:hi - lo] = torch.from_numpy(local).to(dev)
-    gathered = torch.empty(world * per, dtype=torch.float64, device=dev)
+    slot[per] = 0.0 if error is None else 1.0          # failure marker of this rank
+    gathered = torch.empty(world * (per + 1), dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(gathered, slot)
-    g = gathered.cpu().numpy().reshape(world, per)
+    g = gathered.cpu().numpy().reshape(world, per + 1)
+    if error is not None:
+        raise error
+    failed = [r for r in range(world) if g[r, per] != 0.0]
+    if failed:
+        raise RuntimeError("candidate evaluation failed on rank(s) %s" % failed)
     out = np.empty(n)
     for r in range(world):
         a, b = shard_bounds(n, r, world)

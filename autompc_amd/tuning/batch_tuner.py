@@ -25,8 +25,8 @@ PipelineTuneResult = namedtuple("PipelineTuneResult", [
 
 
 class BatchPipelineTuner:
-    """``evaluator.evaluate(candidates, seed=...) -> scores`` is the only thing required of the
-    evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
+    """``evaluator.evaluate(candidates, seed=..., index_offset=...) -> scores`` is the only thing
+    required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
 
     def __init__(self, system, evaluator, batch_size=64, sampler=None):
         self.system, self.evaluator = system, evaluator
@@ -118,13 +118,16 @@ class BatchPipelineTuner:
         while done < n_iters:
             n = min(self.batch_size, n_iters - done)
             batch = self.ask(n, rng)
+            # randomness keyed by (seed, global evaluation index): scores do not depend on the
+            # world size or on the batch size
             scores = evaluate_sharded(
-                lambda shard, s=seed + done: self.evaluator.evaluate(shard, seed=s), batch)
+                lambda shard, lo, d=done: self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo),
+                batch)
             td = None
             if truedyn is not None:
                 td = evaluate_sharded(
-                    lambda shard, s=seed + done: [self.truedyn_score(c, truedyn, seed=s) for c in shard],
-                    batch)
+                    lambda shard, lo, d=done: [self.truedyn_score(c, truedyn, seed=seed + d + lo + i)
+                                               for i, c in enumerate(shard)], batch)
             self.tell(batch, scores, td)
             done += n
         return self._inc_cfg, self.result()

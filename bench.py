@@ -166,7 +166,8 @@ def secondary_workload(args, rank, local_rank, world):
         ev = CandidateEvaluator(system, task, model, precision=args.precision, device=local_rank)
 
         def step(i):
-            scores = evaluate_sharded(lambda shard: ev.evaluate(shard, n_steps=200, seed=i), cands)
+            scores = evaluate_sharded(
+                lambda shard, lo: ev.evaluate(shard, n_steps=200, seed=i, index_offset=lo), cands)
             if not np.all(np.isfinite(scores)) or scores.shape[0] != B * world:
                 raise RuntimeError("candidate scores incomplete")
         label = ("c5: %d tuning candidates (MPPI horizon/sigma/lmda/num_path + QuadCost weights from "
@@ -231,8 +232,28 @@ def secondary_workload(args, rank, local_rank, world):
         print(json.dumps(out))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here, one
+    process per GPU, exactly as the driver's own command line does
+    (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+           str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,6 +264,9 @@ def main():
     if "AMPC_BENCH_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["AMPC_BENCH_FORCE_DEVICE"])
     backend = os.environ.get("AMPC_BENCH_BACKEND", "nccl")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d device(s) are visible "
+                         "(--gpus %d)" % (rank, local_rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -117,6 +117,15 @@ int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path, const int*
                           const double* sigma, const double* lmda, const int* cost_index,
                           int term_mode, ampc_mppi_plan** out);
 int ampc_mppi_plan_destroy(ampc_mppi_plan* p);
+/* Fix the launch geometry instead of letting the library derive it from the batch: tile_rows
+ * (0 automatic, or 16 / 32 / 64 samples per rollout workgroup; a height that does not fit LDS
+ * falls back to the largest that does) and horizon_cap (the LDS / partial-sum layout is sized
+ * for max(horizon_cap, longest horizon in the plan)).  Summation orders inside a solve depend on
+ * the geometry; with both fixed, a problem's results are bit-identical whatever else shares the
+ * plan -- the candidate evaluator uses this so that a candidate's surrogate score
+ * (pipeline_tuner.py:213-258) is the same for any sharding of the batch.  Resets device buffers:
+ * call before ampc_mppi_upload. */
+int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int horizon_cap);
 /* Host -> device.  Any pointer may be NULL (left unchanged on the device).
  *   x0      [B][nx]                       model state each solve starts from
  *   act_seq [sum_p H_p*nu]                warm-start sequences, problem-major, units of umax
@@ -125,8 +134,14 @@ int ampc_mppi_plan_destroy(ampc_mppi_plan* p);
 int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
                      const double* eps);
 /* Fill the plan's noise buffer on the device: eps ~ N(0, sigma_p) from Philox4x32-10 keyed by
- * (seed, stream, sample, t, j).  Statistically equivalent to, not bit-identical with, numpy. */
+ * (seed, stream, noise id of the problem, element).  `stream` (< 2^56) is the caller's step
+ * counter.  Statistically equivalent to, not bit-identical with, numpy's draw (mppi.py:21-24). */
 int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
+/* ids[B]: the noise id of every problem (default: its index in the plan).  The candidate
+ * evaluator passes each candidate's GLOBAL index, so that the noise -- and therefore the
+ * surrogate score pipeline_tuner.py:213-258 returns for it -- does not depend on how a batch of
+ * candidates is sharded over GPUs or on the candidate's position in its shard. */
+int ampc_mppi_plan_set_noise_ids(ampc_mppi_plan* p, const uint32_t* ids);
 /* One MPPI solve per problem, enqueued on the handle's stream (MPPI.do_rollouts + update,
  * mppi.py:110-152): shift warm start, rollout all samples, softmin weights, update act_seq. */
 int ampc_mppi_solve(ampc_mppi_plan* p);
@@ -161,7 +176,7 @@ int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_
  * observation; obs <- surrogate.pred(obs, u) } with no host round trip per step.
  * surrogate: handle holding the simulation model (NULL = the plan's own model); it shares the
  * plan's device, precision and dimensions; its work is enqueued on the plan's stream.
- * eps_all: NULL -> device Philox noise keyed by (seed, step); else host noise for every step,
+ * eps_all: NULL -> device Philox noise keyed by (seed, step, noise id); else host noise for every step,
  *          [n_steps][sum_p N_p*H_p*nu], each step laid out as ampc_mppi_upload expects.
  * traj_obs [B][n_steps+1][nx], traj_ctrls [B][n_steps+1][nu] (last control row zero, as
  * simulate() returns them).  Scoring (Cost.__call__, cost.py:27-41) is left to the caller. */

@@ -16,8 +16,8 @@ class _FormulaEvaluator:
     def __init__(self):
         self.calls = []
 
-    def evaluate(self, candidates, seed=0):
-        self.calls.append((len(candidates), seed))
+    def evaluate(self, candidates, seed=0, index_offset=0):
+        self.calls.append((len(candidates), seed, index_offset))
         out = []
         for c in candidates:
             s = abs(c["sigma"] - 0.7) + 0.01 * c["horizon"] + float(np.sum(np.log10(c["Q"])) ** 2) * 1e-3
@@ -37,8 +37,10 @@ def _run(n_iters, batch):
 def test_result_fields_and_incumbent_trace():
     from autompc_amd.tuning import PipelineTuneResult
     ev, best, res = _run(50, 16)
-    assert [n for n, _ in ev.calls] == [16, 16, 16, 2]
-    assert [s for _, s in ev.calls] == [10, 26, 42, 58]
+    assert [c[0] for c in ev.calls] == [16, 16, 16, 2]
+    # one seed for the whole run; a candidate's randomness is keyed by its global evaluation index
+    assert [c[1] for c in ev.calls] == [10, 10, 10, 10]
+    assert [c[2] for c in ev.calls] == [0, 16, 32, 48]
     assert isinstance(res, PipelineTuneResult)
     assert res._fields == ("inc_cfg", "cfgs", "inc_cfgs", "costs", "inc_costs", "truedyn_costs",
                            "inc_truedyn_costs", "surr_trajs", "truedyn_trajs", "surr_tune_result")
@@ -83,7 +85,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ev, best, res = _run(21, 8)
-    q.put((rank, res.costs, [n for n, _ in ev.calls]))
+    q.put((rank, res.costs, [c[0] for c in ev.calls], [c[2] for c in ev.calls]))
     dist.destroy_process_group()
 
 
@@ -97,8 +99,8 @@ def test_two_ranks_agree_and_split_the_work():
         p.start()
     got = {}
     for _ in range(2):
-        rank, costs, sizes = q.get(timeout=120)
-        got[rank] = (costs, sizes)
+        rank, costs, sizes, offsets = q.get(timeout=120)
+        got[rank] = (costs, sizes, offsets)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -106,6 +108,7 @@ def test_two_ranks_agree_and_split_the_work():
     np.testing.assert_array_equal(got[0][0], single.costs)
     np.testing.assert_array_equal(got[1][0], single.costs)
     assert got[0][1] == [4, 4, 3] and got[1][1] == [4, 4, 2]    # shards of batches 8, 8, 5
+    assert got[0][2] == [0, 8, 16] and got[1][2] == [4, 12, 19]  # global index of each shard's first candidate
 
 
 def test_truedyn_scores_are_recorded_but_do_not_steer(monkeypatch):

@@ -1,0 +1,103 @@
+"""World-size invariance of the candidate evaluator on the device (SURVEY.md section 8 row e,
+BASELINE.json config 5): a candidate's surrogate score -- the per-candidate ``surr_cost`` of the
+reference's ``eval_cfg`` (autompc/tuning/pipeline_tuner.py:213-258) -- must not depend on how the
+batch is sharded over GPUs nor on the candidate's position in its shard.  Needs MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import make_system
+from oracle import mlp as omlp
+from test_sharded_eval import _free_port
+
+pytestmark = pytest.mark.gpu
+
+NX, NU = 17, 6
+
+
+def _setup(n_steps):
+    from autompc_amd import MLP, QuadCost, Task
+    system = make_system(NX, NU)
+    p = omlp.random_params(NX, NU, [256, 256], "relu", seed=7)
+    m = MLP(system, n_hidden_layers=2, hidden_size=256, nonlintype="relu")
+    m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(NX), 0.01 * np.eye(NU), np.eye(NX)))
+    task.set_ctrl_bounds(-np.ones(NU), np.ones(NU))
+    task.set_init_obs(np.random.default_rng(0).uniform(-0.1, 0.1, size=NX))
+    task.set_num_steps(n_steps)
+    return system, task, m
+
+
+def _evaluator(n_steps):
+    from autompc_amd.tuning import CandidateEvaluator
+    system, task, m = _setup(n_steps)
+    return system, CandidateEvaluator(system, task, m, device=0)
+
+
+def test_score_is_independent_of_batch_and_position():
+    from autompc_amd.tuning import random_candidates
+    system, ev = _evaluator(12)
+    cands = random_candidates(system, 6, seed=1)
+    full = ev.evaluate(cands, seed=5)
+    assert np.all(np.isfinite(full))
+    for i in (0, 3, 5):                                 # alone, under its global index
+        np.testing.assert_array_equal(ev.evaluate([cands[i]], seed=5, index_offset=i), full[i:i + 1])
+    np.testing.assert_array_equal(ev.evaluate(cands[2:5], seed=5, index_offset=2), full[2:5])
+    # the index is part of the key: the same candidate under another index sees other noise
+    assert ev.evaluate([cands[3]], seed=5, index_offset=4)[0] != full[3]
+
+
+def _worker(rank, world, port, n, n_steps, q):
+    import torch.distributed as dist
+    from autompc_amd.tuning import evaluate_sharded, random_candidates
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    system, ev = _evaluator(n_steps)                    # both ranks on device 0 (1-GPU box)
+    cands = random_candidates(system, n, seed=1)
+    scores = evaluate_sharded(lambda shard, lo: ev.evaluate(shard, seed=5, index_offset=lo), cands)
+    q.put((rank, scores))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7])
+def test_two_ranks_reproduce_the_single_process_scores(n):
+    """Two gloo ranks, both on device 0, the REAL CandidateEvaluator: identical scores to one
+    process evaluating the whole list (tolerance 1e-12; equality is expected)."""
+    import torch.multiprocessing as mp
+    from autompc_amd.tuning import random_candidates
+    n_steps = 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, n_steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    system, ev = _evaluator(n_steps)
+    ref = ev.evaluate(random_candidates(system, n, seed=1), seed=5)
+    assert np.all(np.isfinite(ref))
+    np.testing.assert_allclose(got[0], ref, rtol=1e-12)
+    np.testing.assert_allclose(got[1], ref, rtol=1e-12)
+
+
+def test_full_size_c5_batch():
+    """BASELINE config 5 at its per-GPU size: 64 candidates from the reference's full ranges (gains
+    1e-3 .. 1e4) x 200 control steps.  Finite, reproducible, and every probed candidate scores
+    the same when evaluated alone under its global index."""
+    from autompc_amd.tuning import random_candidates
+    system, ev = _evaluator(200)
+    cands = random_candidates(system, 64, seed=0)
+    s1 = ev.evaluate(cands, seed=0)
+    assert s1.shape == (64,) and np.all(np.isfinite(s1))
+    np.testing.assert_array_equal(s1, ev.evaluate(cands, seed=0))
+    for i in (0, 17, 63):
+        np.testing.assert_array_equal(ev.evaluate([cands[i]], seed=0, index_offset=i), s1[i:i + 1])
+    # second half as its own shard (what rank 1 of 2 would run)
+    np.testing.assert_array_equal(ev.evaluate(cands[32:], seed=0, index_offset=32), s1[32:])

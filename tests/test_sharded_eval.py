@@ -23,7 +23,7 @@ def _candidates(n):
                  F=rng.uniform(0.5, 2.0, size=2)) for _ in range(n)]
 
 
-def _oracle_eval(cands):
+def _oracle_eval(cands, lo=0):
     system = make_system(2, 1)
     p = omlp.random_params(2, 1, [16, 16], "tanh", seed=2)
     model = MLPOracle(system, p)
@@ -75,6 +75,52 @@ def test_two_rank_gloo_matches_single_process(n):
     ref = _oracle_eval(_candidates(n))
     np.testing.assert_allclose(got[0], ref, rtol=1e-12)
     np.testing.assert_allclose(got[1], ref, rtol=1e-12)
+
+
+def _failing_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from autompc_amd.tuning import evaluate_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local_eval(shard, lo):
+        if rank == 1:
+            raise ValueError("device error on rank 1")
+        return np.arange(lo, lo + len(shard), dtype=np.float64)
+    try:
+        evaluate_sharded(local_eval, list(range(5)))
+        q.put((rank, "no error"))
+    except Exception as e:           # noqa: BLE001
+        q.put((rank, type(e).__name__ + ": " + str(e)))
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_hang_the_collective():
+    """a rank that raises inside its local evaluation must still complete the
+    all-gather; every rank then raises instead of blocking forever."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[1] == "ValueError: device error on rank 1"
+    assert got[0].startswith("RuntimeError") and "rank(s) [1]" in got[0]
+
+
+def test_local_eval_receives_the_shard_offset():
+    from autompc_amd.tuning import evaluate_sharded, shard_bounds
+    seen = []
+    out = evaluate_sharded(lambda shard, lo: (seen.append((len(shard), lo)), np.zeros(len(shard)))[1],
+                           list(range(9)), rank=0, world=1)
+    assert seen == [(9, 0)] and out.shape == (9,)
+    assert shard_bounds(9, 1, 2) == (5, 9)
 
 
 def test_shard_bounds_cover_everything_once():
