@@ -7,11 +7,12 @@ interaction terms; powers up to ``poly_degree``), same ``time_mode`` semantics
 
     discrete:    x' = Theta([x,u]) Xi'          continuous:    x' = x + dt Theta([x,u]) Xi'
 
-The reference delegates fitting AND prediction to ``pysindy~=1.0``, which is not available in this
-environment, so this model is PARITY UNPINNED (see oracle/sindy.py): ``train`` is a numpy
-sequentially-thresholded least squares (what ``ps.STLSQ`` does: ridge alpha 0.05, 20 iterations),
-and inference is the feature program ``ampc_set_sindy`` describes.  Polynomial cross terms
-(``poly_cross_terms``) are not implemented.
+Inference (prediction, the name-lookup Jacobian with its two quirks, MPPI and iLQR on the model)
+is pinned by tests/golden/sindy_*.npz, generated from the reference's own code (see
+oracle/sindy.py); only the feature ORDER rests on the documented enumeration of the absent
+``pysindy~=1.0`` package.  ``train`` (out of the hot path) is a numpy sequentially-thresholded
+least squares (what ``ps.STLSQ`` does: ridge alpha 0.05, 20 iterations) and is not pinned.
+Polynomial cross terms (``poly_cross_terms``) are not implemented.
 """
 import itertools
 

@@ -88,9 +88,9 @@ int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double*
  * with a = arg0[k], b = arg1[k], p = param[k]; xi [nx][n_feat] are the coefficients.
  *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'        (nx <= 64)
  * strict_reference != 0 reproduces the reference Jacobian's quirks (interaction terms counted
- * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25).  PARITY
- * UNPINNED: pysindy is unavailable, see oracle/sindy.py.  MPPI plans, iLQR plans and the closed
- * loop all work on a handle holding a SINDy model. */
+ * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25), as pinned by
+ * tests/golden/sindy_*.npz (the reference's own pred_diff_batch outputs).  MPPI plans, iLQR
+ * plans and the closed loop all work on a handle holding a SINDy model. */
 int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind, const int* arg0,
                    const int* arg1, const double* param, const double* xi, int continuous,
                    double dt, int strict_reference);

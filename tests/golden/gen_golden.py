@@ -465,7 +465,158 @@ def gen_linear():
              ilqr_H=10, dt=system.dt, **out)
 
 
-GENERATORS = {"linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# ------------------------------------------------------------------------- SINDy
+class _StandInLibrary:
+    """What the reference hands to ``ps.CustomLibrary`` (sindy.py:146-150), kept as given."""
+
+    def __init__(self, library_functions, function_names):
+        self.functions, self.names = list(library_functions), list(function_names)
+
+
+class _StandInSINDy:
+    """Stand-in for ``pysindy.SINDy`` (pysindy~=1.0 is third-party and absent).  The ONLY pysindy
+    behaviour restated here is CustomLibrary's feature enumeration -- for every library function,
+    in list order, one feature per ``itertools.combinations(range(n_vars), n_args)`` -- and
+    ``predict = Theta(x, u) @ coefficients.T`` with the variables ordered [states, controls] and
+    named x0.., u0...  Feature VALUES come from the reference's own ``basis.func`` lambdas and
+    feature NAMES from its own ``basis.name_func`` (basis_funcs.py:8-126).  ``fit`` installs the
+    coefficients given in ``_StandInSINDy.next_coefficients`` instead of running STLSQ."""
+    next_coefficients = None
+
+    def __init__(self, feature_library, discrete_time, optimizer):
+        self.lib, self.discrete_time = feature_library, discrete_time
+
+    def fit(self, X, u=None, multiple_trajectories=False, t=None, x_dot=None):
+        import itertools
+        self.nx, self.nu = X[0].shape[1], u[0].shape[1]
+        n = self.nx + self.nu
+        self.combos = [(f, name, c) for f, name in zip(self.lib.functions, self.lib.names)
+                       for c in itertools.combinations(range(n), f.__code__.co_argcount)]
+        self.coef = np.array(_StandInSINDy.next_coefficients, dtype=np.float64)
+        assert self.coef.shape == (self.nx, len(self.combos)), (self.coef.shape, len(self.combos))
+
+    def get_feature_names(self):
+        var = ["x%d" % i for i in range(self.nx)] + ["u%d" % i for i in range(self.nu)]
+        return [name(*[var[j] for j in c]) for _, name, c in self.combos]
+
+    def coefficients(self):
+        return self.coef
+
+    def predict(self, states, ctrls):
+        V = np.concatenate([states, ctrls], axis=1)
+        theta = np.stack([np.broadcast_to(f(*[V[:, j] for j in c]), (V.shape[0],))
+                          for f, _, c in self.combos], axis=1)
+        return theta @ self.coef.T
+
+
+def ref_sindy(system, xi_fn, **hyper):
+    """The reference's SINDy with basis_funcs built by its OWN train() (sindy.py:130-171) on top
+    of the stand-in above; xi_fn(n_features) -> coefficients [nx, n_features]."""
+    import itertools
+    import autompc.sysid.sindy as ref_mod
+    from autompc.sysid.sindy import SINDy
+    ref_mod.ps.CustomLibrary = _StandInLibrary
+    ref_mod.ps.SINDy = _StandInSINDy
+    ref_mod.ps.STLSQ = lambda threshold: None
+    model = SINDy(system, "lstsq", **hyper)
+    nx, nu = system.obs_dim, system.ctrl_dim
+    # number of features = what the reference's own basis list enumerates to
+    probe = SINDy(system, "lstsq", **hyper)
+    _StandInSINDy.next_coefficients = None
+
+    class _Count(_StandInSINDy):
+        def fit(self, X, u=None, **kw):
+            n = X[0].shape[1] + u[0].shape[1]
+            probe.n_feat = sum(len(list(itertools.combinations(range(n), f.__code__.co_argcount)))
+                               for f in self.lib.functions)
+    ref_mod.ps.SINDy = _Count
+    dummy = ampc.zeros(system, 3)
+    probe.train([dummy])
+    ref_mod.ps.SINDy = _StandInSINDy
+    _StandInSINDy.next_coefficients = xi_fn(probe.n_feat)
+    model.train([dummy])
+    return model
+
+
+def sparse_xi(nx, n_feat, seed, identity=True, density=0.15, scale=0.05):
+    rng = np.random.default_rng(seed)
+    xi = (rng.random((nx, n_feat)) < density) * rng.normal(scale=scale, size=(nx, n_feat))
+    if identity:
+        xi[:, :nx] += np.eye(nx)
+    return xi
+
+
+SINDY_CASES = [
+    # tag, nx, nu, hyper-parameters, identity part, seed
+    ("c1_trig", 4, 1, dict(trig_basis="true", trig_freq=1, trig_interaction="true",
+                           time_mode="discrete"), True, 61),
+    ("poly3_trig2_cont", 3, 2, dict(poly_basis="true", poly_degree=3, trig_basis="true", trig_freq=2,
+                                    trig_interaction=True, time_mode="continuous"), False, 62),
+    ("poly4_disc", 2, 1, dict(poly_basis=True, poly_degree=4, time_mode="discrete"), True, 63),
+    ("identity_cont", 5, 2, dict(time_mode="continuous"), False, 64),
+]
+
+
+def gen_sindy():
+    """SINDy inference (sindy.py:173-244) incl. the name-lookup Jacobian; config 1 of BASELINE.json
+    (CartPole-shaped SINDy model, MPPI 256 x 20, the reference's CPU path) and the reference's own
+    SINDy + iLQR pairing (tests/test_pipeline.py:96-160)."""
+    for tag, nx, nu, hyper, ident, seed in SINDY_CASES:
+        system = make_system(nx, nu, dt=0.05)
+        model = ref_sindy(system, lambda nf: sparse_xi(nx, nf, seed, identity=ident), **hyper)
+        rng = np.random.default_rng(seed + 1000)
+        states, ctrls = rng.normal(scale=0.7, size=(24, nx)), rng.normal(scale=0.7, size=(24, nu))
+        pb = model.pred_batch(states, ctrls)
+        db, jx, ju = model.pred_diff_batch(states, ctrls)
+        d0 = model.pred_diff(states[0], ctrls[0])
+        out = dict(nx=nx, nu=nu, dt=0.05, time_mode=hyper["time_mode"],
+                   trig_freq=int(hyper.get("trig_freq", 0)) if hyper.get("trig_basis") else 0,
+                   trig_interaction=bool(hyper.get("trig_interaction")) and bool(hyper.get("trig_basis")),
+                   poly_degree=int(hyper.get("poly_degree", 1)) if hyper.get("poly_basis") else 1,
+                   Xi=model.model.coefficients(), feature_names=np.array(model.model.get_feature_names()),
+                   states=states, ctrls=ctrls, pred_batch=pb, diff_pred=db, diff_jx=jx, diff_ju=ju,
+                   pred0=model.pred(states[0], ctrls[0]), diff0_pred=d0[0], diff0_jx=d0[1], diff0_ju=d0[2])
+        if tag == "c1_trig":
+            # BASELINE config 1: MPPI 256 samples x 20 horizon on the SINDy model, reference CPU path
+            task = Task(system)
+            Q, R, F = np.diag([1.0, 10.0, 0.1, 0.1]), 0.01 * np.eye(1), np.eye(4)
+            cost = QuadCost(system, Q, R, F, goal=np.zeros(4))
+            task.set_cost(cost)
+            task.set_ctrl_bound("u0", -2.0, 2.0)
+            np.random.seed(8)
+            ctl = quiet(MPPI, system, task, model, horizon=20, num_path=256, sigma=1.0, lmda=1.0)
+            out["mppi_act0"] = ctl.act_sequence.copy()
+            obs = np.array([0.0, 0.2, 0.0, 0.0])
+            constate = np.concatenate([obs, np.zeros(1)])
+            for r in range(3):
+                cap = {}
+                orig_update = ctl.update
+
+                def spy(costs, eps, cap=cap, orig=orig_update):
+                    cap["costs"] = costs.copy()
+                    return orig(costs, eps)
+                ctl.update = spy
+                u, constate = ctl.run(constate, obs)
+                ctl.update = orig_update
+                out["mppi_x0_%d" % r] = obs.copy()
+                out["mppi_costs_%d" % r] = cap["costs"]
+                out["mppi_act_%d" % r] = ctl.act_sequence.copy()
+                out["mppi_u_%d" % r] = u.copy()
+                obs = model.pred(obs, u)
+            out.update(Q=Q, R=R, F=F, np_seed=8, N=256, H=20, sigma=1.0, lmda=1.0,
+                       bounds=np.array([-2.0, 2.0]))
+            # the reference's own pairing: iLQR on the SINDy model
+            task2 = Task(system)
+            task2.set_cost(cost)
+            ctl2 = IterativeLQR(system, task2, model, 15)
+            x0 = np.array([0.1, 0.3, -0.1, 0.05])
+            conv, st, ct, Ks, ks = quiet(ctl2.compute_ilqr_default, x0, np.zeros((15, 1)), silent=True)
+            out.update(ilqr_x0=x0, ilqr_H=15, ilqr_converged=conv, ilqr_states=st, ilqr_ctrls=ct,
+                       ilqr_Ks=Ks, ilqr_ks=ks)
+        save("sindy_" + tag, **out)
+
+
+GENERATORS = {"sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "cost_terms": gen_cost_terms}
 
 if __name__ == "__main__":

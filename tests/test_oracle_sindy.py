@@ -1,10 +1,14 @@
 """BASELINE config 1 (CartPole-swingup, SINDy model, MPPI 256 samples x 20 horizon) on the CPU
-path: plumbing only.  SINDy inference is PARITY UNPINNED (pysindy is absent everywhere, see
-oracle/sindy.py); these tests pin the restatement to itself: library layout, finite-difference
-agreement of the non-strict Jacobian, and an end-to-end MPPI / iLQR closed loop that runs."""
+path.  oracle/sindy.py is pinned by tests/golden/sindy_*.npz: outputs of the reference's own
+SINDy.pred_batch / pred_diff_batch / compute_gradient (sindy.py:173-244) with basis functions
+built by its own train() (sindy.py:134-152, basis_funcs.py:8-126) on a stand-in for the absent
+pysindy package (gen_golden.py: only CustomLibrary's feature enumeration is restated there),
+plus the reference's MPPI (config 1: 256 x 20) and iLQR on that model."""
 import numpy as np
+import pytest
 
-from helpers import make_system
+from conftest import golden
+from helpers import make_system, rel_err
 from oracle.closed_loop import simulate
 from oracle.costs import QuadCostOracle
 from oracle.ilqr import ILQROracle
@@ -83,3 +87,79 @@ def test_ilqr_on_sindy_model_reduces_cost():
     for i in range(15):
         xs[i + 1] = model.pred(xs[i], np.zeros(1))
     assert ctl.final_obj < zero._objective(xs, np.zeros((15, 1)))
+
+
+SINDY_GOLDENS = ["sindy_c1_trig", "sindy_poly3_trig2_cont", "sindy_poly4_disc", "sindy_identity_cont"]
+
+
+def oracle_from_golden(g, strict=True):
+    system = make_system(int(g["nx"]), int(g["nu"]), dt=float(g["dt"]))
+    return system, SINDyOracle(system, g["Xi"], trig_freq=int(g["trig_freq"]),
+                               trig_interaction=bool(g["trig_interaction"]),
+                               poly_degree=int(g["poly_degree"]), time_mode=str(g["time_mode"]),
+                               strict_reference=strict)
+
+
+@pytest.mark.parametrize("name", SINDY_GOLDENS)
+def test_sindy_oracle_matches_reference(name):
+    """Prediction and the name-lookup Jacobian incl. its two quirks (polynomial gradient without
+    the exponent factor, interaction gradients counted twice) against the reference's outputs."""
+    g = golden(name)
+    _, m = oracle_from_golden(g)
+    assert m.Xi.shape[1] == len(g["feature_names"])
+    assert rel_err(m.pred_batch(g["states"], g["ctrls"]), g["pred_batch"]) < 1e-14
+    o, jx, ju = m.pred_diff_batch(g["states"], g["ctrls"])
+    assert rel_err(o, g["diff_pred"]) < 1e-14
+    assert rel_err(jx, g["diff_jx"]) < 1e-13 and rel_err(ju, g["diff_ju"]) < 1e-13
+    assert rel_err(m.pred(g["states"][0], g["ctrls"][0]), g["pred0"]) < 1e-14
+    o0, jx0, ju0 = m.pred_diff(g["states"][0], g["ctrls"][0])
+    assert rel_err(jx0, g["diff0_jx"]) < 1e-13 and rel_err(ju0, g["diff0_ju"]) < 1e-13
+    if int(g["poly_degree"]) > 1 or bool(g["trig_interaction"]):
+        # the quirks are real: the true derivative differs from what the reference returns
+        _, mt = oracle_from_golden(g, strict=False)
+        assert rel_err(mt.pred_diff_batch(g["states"], g["ctrls"])[1], g["diff_jx"]) > 1e-3
+
+
+def test_feature_order_matches_reference_names():
+    g = golden("sindy_poly3_trig2_cont")
+    feats = build_library(5, trig_freq=2, trig_interaction=True, poly_degree=3)
+    var = ["x0", "x1", "x2", "u0", "u1"]
+    fmt = {"id": lambda c, p: var[c[0]], "sin": lambda c, p: "sin(%d %s)" % (p, var[c[0]]),
+           "cos": lambda c, p: "cos(%d %s)" % (p, var[c[0]]),
+           "xsin": lambda c, p: "%s sin(%d %s)" % (var[c[0]], p, var[c[1]]),
+           "xsin2": lambda c, p: "%s sin(%d %s)" % (var[c[1]], p, var[c[0]]),
+           "xcos": lambda c, p: "%s cos(%d %s)" % (var[c[0]], p, var[c[1]]),
+           "xcos2": lambda c, p: "%s cos(%d %s)" % (var[c[1]], p, var[c[0]]),
+           "pow": lambda c, p: "%s**%d" % (var[c[0]], p)}
+    assert [fmt[k](c, p) for k, c, p in feats] == [str(n) for n in g["feature_names"]]
+
+
+def test_config1_mppi_matches_reference():
+    """BASELINE config 1: the reference's MPPI (256 samples x 20 horizon) on the SINDy model."""
+    g = golden("sindy_c1_trig")
+    _, model = oracle_from_golden(g)
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPIOracle(model, QuadCostOracle(g["Q"], g["R"], g["F"], np.zeros(4)), np.array([g["bounds"]]),
+                     horizon=int(g["H"]), num_path=int(g["N"]), sigma=float(g["sigma"]),
+                     lmda=float(g["lmda"]))
+    np.testing.assert_array_equal(ctl.act_sequence, g["mppi_act0"])
+    obs = np.array([0.0, 0.2, 0.0, 0.0])
+    cs = np.concatenate([obs, np.zeros(1)])
+    for r in range(3):
+        np.testing.assert_allclose(obs, g["mppi_x0_%d" % r], rtol=1e-10, atol=1e-13)
+        u, cs = ctl.run(cs, obs)
+        assert rel_err(ctl.last_costs, g["mppi_costs_%d" % r]) < 1e-10
+        assert rel_err(ctl.act_sequence, g["mppi_act_%d" % r]) < 1e-9
+        assert rel_err(u, g["mppi_u_%d" % r]) < 1e-9
+        obs = model.pred(obs, u)
+
+
+def test_ilqr_on_sindy_matches_reference():
+    g = golden("sindy_c1_trig")
+    _, model = oracle_from_golden(g)
+    H = int(g["ilqr_H"])
+    orc = ILQROracle(model, QuadCostOracle(g["Q"], g["R"], g["F"], np.zeros(4)), 0.05, H)
+    conv, st, ct, Ks, ks = orc.solve(g["ilqr_x0"], np.zeros((H, 1)))
+    assert conv == bool(g["ilqr_converged"])
+    assert rel_err(st, g["ilqr_states"]) < 1e-7 and rel_err(ct, g["ilqr_ctrls"]) < 1e-7
+    assert rel_err(Ks, g["ilqr_Ks"]) < 1e-6
