@@ -69,6 +69,7 @@ SIGNATURES = {
     "ampc_ilqr_plan_create": (c_int, [c_void_p, c_int, c_int, c_double, _ip, c_int,
                                       POINTER(c_void_p)]),
     "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
+    "ampc_ilqr_plan_set_terminal_goal": (c_int, [c_void_p, c_int]),
     "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
 }
 
@@ -406,7 +407,8 @@ class MppiPlan:
 class IlqrPlan:
     """Device buffers for a batch of B independent iLQR problems of horizon H."""
 
-    def __init__(self, handle, B, horizon, dt, cost_index=None, clip_to_bounds=False):
+    def __init__(self, handle, B, horizon, dt, cost_index=None, clip_to_bounds=False,
+                 terminal_goal=False):
         self.handle = handle
         self.lib = handle.lib
         self.B, self.H = int(B), int(horizon)
@@ -417,6 +419,8 @@ class IlqrPlan:
                                              int(bool(clip_to_bounds)), ctypes.byref(self._p)))
         _live_plans.add(self)
         handle._plans.add(self)
+        if terminal_goal:      # QuadCost(strict_reference=False): terminal gradient about the goal
+            check(self.lib.ampc_ilqr_plan_set_terminal_goal(self._p, 1))
 
     def close(self):
         if getattr(self, "_p", None) is not None and self._p:

@@ -71,7 +71,11 @@ class IterativeLQR(Controller):
                 h.set_ctrl_bounds(np.asarray(self.ubounds[0], dtype=float),
                                   np.asarray(self.ubounds[1], dtype=float))
             self._handle = h
-            self._plan = _lib.IlqrPlan(h, 1, self.horizon, self.dt, clip_to_bounds=bounded)
+            # QuadCost(strict_reference=False) opts out of the reference's goal-less terminal
+            # gradient (cost.py:195): the device sweep then seeds v_N = (F+F')(x_N - goal) too
+            tg = not getattr(self.task.get_cost(), "strict_reference", True)
+            self._plan = _lib.IlqrPlan(h, 1, self.horizon, self.dt, clip_to_bounds=bounded,
+                                       terminal_goal=tg)
         return self._plan
 
     def __getstate__(self):

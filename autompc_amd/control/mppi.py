@@ -91,10 +91,16 @@ class MPPI(Controller):
 
     @property
     def act_sequence(self):
+        """The warm-start sequence (H, nu) in units of umax.  The array handed out is READ-ONLY:
+        after a solve the live copy is on the device, so an in-place edit of the host copy
+        (``ctl.act_sequence[0] += d`` works on the reference's plain attribute) would be silently
+        lost.  Assign through the setter instead: ``ctl.act_sequence = new_array``."""
         if self._plan is not None and not self._act_dirty:
             a, _, _, _ = self._plan.download(act_seq=True, u=False)
             self._act_host = a.reshape(self.H, self.dim_ctrl)
-        return self._act_host
+        view = self._act_host.view()
+        view.setflags(write=False)
+        return view
 
     @act_sequence.setter
     def act_sequence(self, value):

@@ -789,6 +789,12 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   return 0;
 }
 
+extern "C" int ampc_ilqr_plan_set_terminal_goal(ampc_ilqr_plan* p, int use_goal) {
+  REQUIRE(p, "ampc_ilqr_plan_set_terminal_goal: NULL plan");
+  p->term_goal = use_goal ? 1 : 0;
+  return 0;
+}
+
 extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);

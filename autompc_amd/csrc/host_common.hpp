@@ -295,7 +295,7 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
 // ---------------------------------------------------------------------------------------------
 struct ampc_ilqr_plan {
   ampc_handle* h = nullptr;
-  int B = 0, H = 0, ls_n = 10, bounded = 0;
+  int B = 0, H = 0, ls_n = 10, bounded = 0, term_goal = 0;
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
@@ -316,7 +316,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.lds = p->L;
   a.lds_work = p->lds_work;
   a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
-  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag;
+  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag; a.term_goal = p->term_goal;
   a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
   for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
   a.costs_par = (const T*)h->cost_buf.p;

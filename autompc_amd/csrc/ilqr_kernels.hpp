@@ -38,6 +38,8 @@ template <typename T> struct IlqrArgs {
   int lds_work;                  // start of the Riccati / line-search scratch (elements)
   int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
   int cost_diag;                 // 1: Q, R, F of every cost block are diagonal -> O(n) objective
+  int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it
+                                 //    (cost.py:195, goal ignored); 1: (F+F')(x_N - goal)
   T dt, u_threshold, ls_cost_threshold;
   T alphas[kIlqrMaxLs];          // step sizes discount**j, computed on the host like the reference
   const T* costs_par;            // [n_costs][cost_stride]: Q R F goal
@@ -213,8 +215,9 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   for (int a = tid; a < nx; a += NTHR) {
     T s = T(0);
     if (a < no)
-      for (int b = 0; b < no; ++b) s += (Fm[a * no + b] + Fm[b * no + a]) * st[(size_t)H * nx + b];
-    v[a] = s;     // NOTE: no goal subtraction -- the reference's terminal gradient quirk
+      for (int b = 0; b < no; ++b)
+        s += (Fm[a * no + b] + Fm[b * no + a]) * (st[(size_t)H * nx + b] - (args.term_goal ? goal[b] : T(0)));
+    v[a] = s;     // term_goal == 0: no goal subtraction -- the reference's terminal gradient quirk
   }
   if (tid == 0) scal[8] = T(0);
   __syncthreads();

@@ -223,7 +223,13 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   __syncthreads();
   T mw = cred[0];
   for (int i = 1; i < M; ++i) mw = cred[i] < mw ? cred[i] : mw;
-  if (tid < M) sred[tid] = (first + tid < N) ? exp(pr.neg_inv_lambda * (cred[tid] - mw)) : T(0);
+  // A tile whose every sample has cost +inf (a diverged rollout: the cost overflows before the
+  // state does) has mw = inf and would form exp(-(inf - inf)/lmda) = NaN.  Such samples carry
+  // weight 0 in the reference's softmin (mppi.py:113-116) as long as one finite cost exists
+  // anywhere: the tile publishes zero sums and the combine kernel skips it.
+  const bool dead_tile = !(mw < T(INFINITY));
+  if (tid < M)
+    sred[tid] = (first + tid < N && !dead_tile) ? exp(pr.neg_inv_lambda * (cred[tid] - mw)) : T(0);
   __syncthreads();
   const T* el = lds + args.lds_eps;
   T* tp = args.tile_part + (size_t)blockIdx.x * args.hnu_stride;
@@ -266,6 +272,7 @@ __global__ __launch_bounds__(kWG) void mppi_combine_kernel(const MppiArgs<T> arg
 #pragma unroll
   for (int j = 0; j < kMaxNu; ++j) acc[j] = T(0);
   for (int i = tid; i < tiles; i += kWG) {
+    if (!(st[2 * i] < T(INFINITY))) continue;      // all-inf tile: weight 0 (its sums are zero too)
     const T sc = exp(pr.neg_inv_lambda * (st[2 * i] - vmin));
     ssum += sc * st[2 * i + 1];
     const T* row = tp + (size_t)i * args.hnu_stride;

@@ -222,6 +222,11 @@ int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surrogate, cons
 int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt, const int* cost_index,
                           int clip_to_bounds, ampc_ilqr_plan** out);
 int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
+/* use_goal = 0 (default): the backward sweep is seeded with the terminal gradient exactly as the
+ * reference computes it, (F + F') x_N -- Cost.eval_term_obs_cost_diff ignores the goal
+ * (cost.py:195, 208-211).  use_goal != 0: (F + F') (x_N - goal), the derivative of the terminal
+ * cost actually charged; what QuadCost(strict_reference=False) asks for. */
+int ampc_ilqr_plan_set_terminal_goal(ampc_ilqr_plan* p, int use_goal);
 int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess, int max_iter,
                     double* states, double* ctrls, double* Ks, double* ks, int* converged,
                     int* iters, int* status, double* objective);

@@ -97,3 +97,52 @@ def test_ilqr_singular_quu_raises_linalgerror():
     ctl = _hip_ilqr(p, nx, nu, np.eye(nx), np.zeros((nu, nu)), np.eye(nx), np.zeros(nx), H, 0.05, None)
     with pytest.raises(np.linalg.LinAlgError):
         ctl.compute_ilqr_default(np.array([0.1, -0.2]), np.zeros((H, nu)))
+
+
+def test_closed_loop_ilqr_matches_reference_simulate():
+    """loop_ilqr.npz: the reference's simulate() -> IterativeLQR.run() (utils/simulation.py:52-63,
+    ilqr.py:267-295; a full re-solve from a zero guess every control step) replayed through the
+    drop-in classes on the device, 15 steps."""
+    from autompc_amd import simulate
+    g = golden("loop_ilqr")
+    nx = int(g["nx"])
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], True)
+    check_weights(p, g)
+    ctl = _hip_ilqr(p, nx, 1, g["Q"], g["R"], g["F"], g["goal"], int(g["H"]), float(g["dt"]), None)
+    traj = simulate(ctl, g["init"], sim_model=ctl.model, max_steps=15)
+    assert rel_err(traj.obs, g["obs"]) < 1e-6 and rel_err(traj.ctrls, g["ctrls"]) < 1e-6
+    score = ctl.task.get_cost()(traj)
+    assert abs(score - g["score"]) < 1e-6 * abs(g["score"])
+
+
+def test_nonstrict_quadcost_seeds_the_sweep_about_the_goal():
+    """QuadCost(strict_reference=False) must reach the device sweep: terminal gradient
+    (F+F')(x_N - goal) instead of the reference's goal-less (F+F')x_N (cost.py:195)."""
+    from autompc_amd import MLP, IterativeLQR, QuadCost, Task
+    nx, nu, H = 3, 1, 12
+    p = omlp.random_params(nx, nu, [64, 64], "tanh", seed=9)
+    goal = np.array([0.4, -0.3, 0.2])
+    Q, R, F = np.eye(nx), 0.1 * np.eye(nu), 20.0 * np.eye(nx)
+    system = make_system(nx, nu)
+    omodel = MLPOracle(system, p)
+    x0 = np.array([0.1, 0.0, -0.1])
+
+    class GoalAwareTerminal(QuadCostOracle):
+        def eval_term_obs_cost_hess(self, obs):
+            d, S = obs - self.goal, self.F + self.F.T
+            return d.T @ self.F @ d, S @ d, S
+    res = {}
+    for strict in (True, False):
+        m = MLP(system, n_hidden_layers=2, hidden_size=64, nonlintype="tanh")
+        m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+        task = Task(system)
+        task.set_cost(QuadCost(system, Q, R, F, goal=goal, strict_reference=strict))
+        ctl = IterativeLQR(system, task, m, H)
+        conv, st, ct, Ks, ks = ctl.compute_ilqr_default(x0, np.zeros((H, nu)))
+        orc = ILQROracle(omodel, (QuadCostOracle if strict else GoalAwareTerminal)(Q, R, F, goal), 0.05, H)
+        oc, ost, oct_, oKs, oks = orc.solve(x0, np.zeros((H, nu)))
+        assert conv == oc
+        assert rel_err(st, ost) < 1e-6 and rel_err(ct, oct_) < 1e-6
+        res[strict] = ct
+    assert rel_err(res[True], res[False]) > 1e-3        # the flag changes the solve

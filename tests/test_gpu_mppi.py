@@ -189,3 +189,87 @@ def test_device_noise_is_standard_normal():
     _, _, _, e3 = plan.download(eps_out=True)
     # counter-based: same (seed, stream) -> same noise (up to the (eps + a) - a round trip)
     np.testing.assert_allclose(e, e3, rtol=0, atol=1e-12)
+
+
+def test_three_identical_controls_reduce_to_the_nu1_golden_on_device():
+    """the nu > 1 path with identical per-dimension noise / weights / bounds / cost
+    reproduces the reference's nu = 1 golden (construction: tests/test_nu_reduction.py)."""
+    from autompc_amd import _lib
+    from test_nu_reduction import reduction_problem
+    g, nx, N, H, p3, act0, eps = reduction_problem()
+    system, model, task = _hip_stack(p3, nx, 3, g["Q"], g["R"][0, 0] / 3.0 * np.eye(3), g["F"], g["goal"],
+                                     g["bounds"])
+    h = _lib.Handle(0, "f64")
+    model.stage_into(h)
+    h.set_quad_costs(g["Q"], g["R"][0, 0] / 3.0 * np.eye(3), g["F"], g["goal"])
+    h.set_ctrl_bounds(np.full(3, g["bounds"][0]), np.full(3, g["bounds"][1]))
+    plan = _lib.MppiPlan(h, [N], [H], [3.0 * float(g["sigma"])], [float(g["lmda"])])
+    plan.upload(act_seq=act0)
+    ref = MLPOracle(system, p3)
+    obs = g["x0_0"].copy()
+    for r in range(3):
+        plan.upload(x0=obs, eps=eps[r])
+        plan.solve()
+        a, u, costs, _ = plan.download(costs=True)
+        assert rel_err(costs, g["costs_%d" % r]) < 1e-9
+        a = a.reshape(H, 3)
+        for j in range(3):
+            assert rel_err(a[:, j:j + 1], g["act_%d" % r]) < 1e-8
+            assert rel_err(u[0, j:j + 1], g["u_%d" % r]) < 1e-8
+        obs = ref.pred(obs, u[0])
+    plan.close()
+    h.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_fused_update_with_an_all_inf_tile_matches_the_plain_update(precision, monkeypatch):
+    """a rollout tile whose every sample has cost +inf (diverged, overflowing cost) must
+    get weight 0 -- as in the reference's softmin (mppi.py:113-116) and in the non-fused update
+    kernel -- instead of poisoning the sequence with exp(-(inf - inf)/lmda) = NaN."""
+    from autompc_amd import _lib
+    nx, nu, N, H = 17, 6, 96, 6
+    p = omlp.random_params(nx, nu, [256, 256], "relu", seed=3)
+    big = 1e300 if precision == "f64" else 1e34
+    Q, R, F = big * np.eye(nx), 0.01 * np.eye(nu), np.eye(nx)
+    system, model, task = _hip_stack(p, nx, nu, Q, R, F, np.zeros(nx), (-1e6, 1e6), precision)
+    rng = np.random.default_rng(0)
+    eps = rng.normal(size=(N, H, nu))
+    eps[32:48] *= 1e6                  # samples of the third 16-row tile diverge: cost overflows to inf
+    act0 = rng.normal(size=(H, nu))
+    x0 = rng.uniform(-0.1, 0.1, size=nx)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("AMPC_FUSED_UPDATE", fused)
+        monkeypatch.setenv("AMPC_MT", "1")
+        h = _lib.Handle(0, precision)
+        model.stage_into(h)
+        h.set_quad_costs(Q, R, F, np.zeros(nx))
+        h.set_ctrl_bounds(np.full(nu, -1e6), np.full(nu, 1e6))
+        plan = _lib.MppiPlan(h, [N], [H], [1.0], [1.0])
+        plan.upload(x0=x0, act_seq=act0, eps=eps)
+        plan.solve()
+        a, u, costs, _ = plan.download(costs=True)
+        out[fused] = (a, u, costs)
+        plan.close()
+        h.close()
+    costs = out["1"][2]
+    assert np.all(np.isinf(costs[32:48])) and np.all(np.isfinite(np.delete(costs, np.s_[32:48])))
+    for fused in ("1", "0"):
+        assert np.all(np.isfinite(out[fused][0])) and np.all(np.isfinite(out[fused][1]))
+    tol = 1e-12 if precision == "f64" else 1e-5
+    assert rel_err(out["1"][0], out["0"][0]) < tol and rel_err(out["1"][1], out["0"][1]) < tol
+
+
+def test_act_sequence_getter_is_read_only():
+    """in-place edits of the host copy would be lost after a solve -- they must fail."""
+    from autompc_amd import MPPI
+    nx = 2
+    p = omlp.random_params(nx, 1, [64, 64], "relu", seed=2)
+    system, model, task = _hip_stack(p, nx, 1, np.eye(nx), 0.01 * np.eye(1), np.eye(nx), np.zeros(nx), (-1, 1))
+    ctl = MPPI(system, task, model, horizon=5, num_path=64)
+    ctl.run(np.zeros(3), np.zeros(2))
+    with pytest.raises(ValueError):
+        ctl.act_sequence[0] = 0.0
+    new = np.zeros((5, 1))
+    ctl.act_sequence = new                      # the setter is the supported path
+    np.testing.assert_array_equal(ctl.act_sequence, new)
