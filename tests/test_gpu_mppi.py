@@ -233,9 +233,12 @@ def test_fused_update_with_an_all_inf_tile_matches_the_plain_update(precision, m
     Q, R, F = big * np.eye(nx), 0.01 * np.eye(nu), np.eye(nx)
     system, model, task = _hip_stack(p, nx, nu, Q, R, F, np.zeros(nx), (-1e6, 1e6), precision)
     rng = np.random.default_rng(0)
-    eps = rng.normal(size=(N, H, nu))
-    eps[32:48] *= 1e6                  # samples of the third 16-row tile diverge: cost overflows to inf
-    act0 = rng.normal(size=(H, nu))
+    # noise and warm start are in units of umax = 1e6 and clipped to [-1, 1]: ordinary samples apply
+    # controls of order 1, the samples of the third 16-row tile saturate at +-1e6, their states
+    # reach ~1e5 and the stage cost big * x^2 overflows to +inf
+    eps = 1e-6 * rng.normal(size=(N, H, nu))
+    eps[32:48] = np.sign(rng.normal(size=(16, H, nu)))
+    act0 = 1e-6 * rng.normal(size=(H, nu))
     x0 = rng.uniform(-0.1, 0.1, size=nx)
     out = {}
     for fused in ("1", "0"):
