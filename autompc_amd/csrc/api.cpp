@@ -222,6 +222,7 @@ template <typename T> static int build_model(ampc_handle* h) {
   m.nx = nx; m.nu = nu; m.kin = kin; m.k1p = k1p; m.n_hidden = L; m.hpad = hpad; m.nxp = nxp;
   m.act = h->act;
   const T* base = (const T*)h->model_buf.p;
+  m.wbase = base;
   size_t idx = 0;
   for (int l = 0; l <= L; ++l) m.w[l] = base + off[idx++];
   m.wt = base + off[idx++];

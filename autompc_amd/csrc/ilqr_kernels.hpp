@@ -27,6 +27,15 @@
 
 namespace ampc {
 
+// phase marks of the iLQR kernels (tools/phasetime_ilqr.py): only in the AMPC_X_PHASETIME build
+#if defined(AMPC_X_PHASETIME) && !defined(AMPC_X_WAVETIME)
+#define AMPC_IMARK(idx) AMPC_MARK(idx)
+#define AMPC_IMARK_ALWAYS(idx) AMPC_MARK_ALWAYS(idx)
+#else
+#define AMPC_IMARK(idx) do { } while (0)
+#define AMPC_IMARK_ALWAYS(idx) do { } while (0)
+#endif
+
 constexpr int kRicThreads = 512;  // workgroup of the backward-sweep kernel
 constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows of one MFMA tile
 
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   T* kg = args.ks + (size_t)p * H * nu;
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
   const T dt = args.dt;
-  AMPC_MARK_ALWAYS(30);
+  AMPC_IMARK_ALWAYS(30);
   for (int idx = tid; idx < nx * nx; idx += NTHR) {
     const int a = idx / nx, b = idx - a * nx;
     V[idx] = (a < no && b < no) ? Fm[a * no + b] + Fm[b * no + a] : T(0);
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
 #ifdef AMPC_X_PHASETIME
     if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
 #endif
-    AMPC_MARK(20);
+    AMPC_IMARK(20);
     if (t > 0) fetch_step(t - 1);
     for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
       const int a = idx / n, c = idx - a * n;
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
       VJ[idx] = s;
     }
     lds_barrier();
-    AMPC_MARK(21);
+    AMPC_IMARK(21);
     // Qt = Ct + J' V J is symmetric (V is, up to rounding): only the upper triangle is computed
     // and mirrored.  Rows r and n-1-r are folded into one row of n+1 tasks, so the triangle is
     // ceil(n/2) x (n+1) tasks -- one round for n <= 30 (for odd n the middle row is done twice,
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
       qt[c] = cc * dt + s;
     }
     lds_barrier();
-    AMPC_MARK(22);
+    AMPC_IMARK(22);
     // ---- Quu [K | k] = -[Qux | qu]: Gauss-Jordan with partial pivoting (the pivot sequence of
     // numpy.linalg.solve / LAPACK gesv) on the augmented matrix [Quu | Qux | qu], by wave 0,
     // entirely in registers: lane j owns column j (nc = nu + nx + 1 <= 49 columns), its nu
@@ -319,9 +328,9 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
       }
       if (sing && tid == 0) { args.status[p] = 1; scal[8] = T(1); }
     }
-    AMPC_MARK(23);
+    AMPC_IMARK(23);
     lds_barrier();
-    AMPC_MARK(24);
+    AMPC_IMARK(24);
     // three independent pieces on disjoint waves: sums on wave 0, wq on wave 1, Wk on waves 2..
     for (int idx = tid - 128; idx < nu * nx; idx += NTHR - 128) {   // Wk = Quu K ; store K
       if (idx < 0) break;
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
       if (tid == 0) { lin += l; quad += qd; ksn2 += k2; }
     }
     lds_barrier();
-    AMPC_MARK(25);
+    AMPC_IMARK(25);
     for (int idx = tid; idx < nx * nx; idx += NTHR) {      // V <- Qxx + Qxu K + K'Qux + K'Quu K
       const int a = idx / nx, b = idx - a * nx;
       T s = Qt[a * n + b];
@@ -373,9 +382,9 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     }
     if (t > 0) commit_step();                              // J, xbar, ubar are not read in this phase
     lds_barrier();
-    AMPC_MARK(26);
+    AMPC_IMARK(26);
   }
-  AMPC_MARK_ALWAYS(33);
+  AMPC_IMARK_ALWAYS(33);
   if (tid == 0) {
     T* out = args.ric + (size_t)p * 4;
     out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = scal[8];
@@ -444,7 +453,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
 
   // =========================== forward rollout(s) (ilqr.py:141-149, 196-205) ===================
-  AMPC_MARK_ALWAYS(31);
+  AMPC_IMARK_ALWAYS(31);
   if constexpr (DYN == 0) net.init(mlp);
   const int rows = args.mode == 0 ? 1 : args.ls_n;
   const int m = tid / TPS, r = tid % TPS;        // row-in-tile, helper index (same wave)
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
 #ifdef AMPC_X_PHASETIME
     if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (args.mode == 1 && t == H / 2) ? 1 : 0;
 #endif
-    AMPC_MARK(40);
+    AMPC_IMARK(40);
     if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
     // controls for this step
     for (int a = r; a < nu; a += TPS) {
@@ -521,16 +530,16 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     }
     if (args.mode == 1 && m < rows)
       for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
-    AMPC_MARK(41);
+    AMPC_IMARK(41);
     lds_barrier();
-    AMPC_MARK(42);
+    AMPC_IMARK(42);
     // objective: dt * (stage costs)
     obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, cdiag) +
                            quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, cdiag));
-    AMPC_MARK(43);
+    AMPC_IMARK(43);
     if constexpr (DYN == 0) {
       net.run(mlp, L, lds);
-      AMPC_MARK(44);
+      AMPC_IMARK(44);
       for (int a = r; a < nx; a += TPS) {
         const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
         xu[m * xs_ + a] = xn;
@@ -549,12 +558,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
     }
     // every thread passed the barrier above after its last read of K, k, ubar, xbar
-    AMPC_MARK(45);
+    AMPC_IMARK(45);
     if (args.mode == 1 && t + 1 < H) commit_ls();
     lds_barrier();
-    AMPC_MARK(46);
+    AMPC_IMARK(46);
   }
-  AMPC_MARK_ALWAYS(32);
+  AMPC_IMARK_ALWAYS(32);
   if (args.mode == 1 && m < rows)
     for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
   obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, cdiag);

@@ -130,10 +130,11 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-    const T* wl = mlp.wj[l] + ((size_t)w * KSH * 64 + lane) * NT;
+    const rsrc_t wr = weight_rsrc(mlp.wbase);
+    const unsigned wl = (unsigned)(mlp.wj[l] - mlp.wbase) + (unsigned)w * KSH * 64u * NT;   // uniform
     T first_group[GH][NT];
-    load_group<T, NT, GH>(wl, 0, first_group);
-    layer_mma_static<T, NT, MT, KSH, GH>(G, gs, wl, lane, first_group, acc);
+    load_group<T, NT, GH>(wr, wl, (unsigned)lane * NT, 0, first_group);
+    layer_mma_static<T, NT, MT, KSH, GH>(G, gs, wr, wl, lane, first_group, acc);
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)

@@ -56,6 +56,28 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
 }
+// timing experiments: the MFMAs of one layer class replaced by a single FMA (dependencies kept)
+template <bool REAL, typename T, typename A>
+__device__ __forceinline__ A mfma16_x(T a, T b, A c) {
+  if constexpr (REAL) return mfma16(a, b, c);
+  else { c[0] += a * b; return c; }
+}
+#ifdef AMPC_X_NOHID
+constexpr bool kRealHid = false;
+#else
+constexpr bool kRealHid = true;
+#endif
+#ifdef AMPC_X_NOL0
+constexpr bool kRealL0 = false;
+#else
+constexpr bool kRealL0 = true;
+#endif
+#ifdef AMPC_X_NOOUT
+constexpr bool kRealOut = false;
+#else
+constexpr bool kRealOut = true;
+#endif
+
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products (blocks); 16 cycles against the 64 of
 // the 16x16x4.  Lane layout (probed on gfx950, tools/mfma44_probe.cpp), block = (lane/4)%4:
 //   A[i][k]: i = lane%4, k = lane/16      B[k][j]: k = lane/16, j = lane%4
@@ -120,6 +142,7 @@ template <typename T> struct MlpDev {
   int hpad;             // 16*NT*W
   int nxp;              // nx rounded up to a multiple of 16
   int act;              // activation kind
+  const T* wbase;               // start of the packed model buffer (every array below lies in it)
   const T* w[kMaxHidden + 1];   // packed fragments, layer 0..n_hidden (last = output layer)
   const T* b[kMaxHidden + 1];   // padded biases (normalisers folded in)
   const T* wj[kMaxHidden + 1];  // packed fragments for the Jacobian chain (transposed use)
@@ -198,31 +221,68 @@ __device__ __forceinline__ void tile_load_constants(const MlpDev<T>& m, const Ti
 // A lane's NT consecutive fragment values for one k-step, as the widest aligned vector load.
 template <typename T, int N> using vec_t = T __attribute__((ext_vector_type(N)));
 
+// Weight fragments are fetched with BUFFER loads: one resource descriptor for the whole packed
+// model (MlpDev::wbase), the stream position as a wave-uniform element offset `so` (SGPR soffset +
+// immediate) and the lane's 32-bit element offset `lo` (VGPR voffset):
+//   buffer_load_dwordx4 v, v_lo, s[rsrc:rsrc+3], s_so offen offset:imm
+// All of a stream's address arithmetic then runs on the scalar unit.  This matters because VALU
+// instructions are NOT hidden behind MFMAs on gfx950: each costs ~8 cycles of matrix-pipe time
+// (calibrated by padding the hidden layer with dummy v_add_u32 / v_add_f64), and the per-lane 64-bit
+// pointer form cost ~5 VALU instructions per 8 MFMAs.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ rsrc_t weight_rsrc(const T* base) {
+  // raw buffer (stride 0), no bounds clamp, gfx9 untyped-dword format word
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, -1, 0x00020000);
+}
+
 template <typename T, int NT>
-__device__ __forceinline__ void load_frag(const T* __restrict__ p, T (&b)[NT]) {
+__device__ __forceinline__ void load_frag(rsrc_t r, unsigned so, unsigned lo, T (&b)[NT]) {
 #ifdef AMPC_X_NOLOAD
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) b[nt] = T((threadIdx.x + nt) & 7) * T(1e-3);
   return;
 #endif
-  if constexpr (NT == 4) {
-    const vec_t<T, 4> v = *reinterpret_cast<const vec_t<T, 4>*>(p);
-    b[0] = v[0]; b[1] = v[1]; b[2] = v[2]; b[3] = v[3];
-  } else if constexpr (NT == 2) {
-    const vec_t<T, 2> v = *reinterpret_cast<const vec_t<T, 2>*>(p);
-    b[0] = v[0]; b[1] = v[1];
-  } else {
+  const unsigned vo = lo * (unsigned)sizeof(T), sb = so * (unsigned)sizeof(T);
+  constexpr int BYTES = NT * (int)sizeof(T);
+  if constexpr (BYTES == 16) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, vo, sb, 0);
+    struct P { T e[NT]; };
+    const P p = __builtin_bit_cast(P, v);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = p[nt];
+    for (int nt = 0; nt < NT; ++nt) b[nt] = p.e[nt];
+  } else if constexpr (BYTES == 8) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, vo, sb, 0);
+    struct P { T e[NT]; };
+    const P p = __builtin_bit_cast(P, v);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = p.e[nt];
+  } else if constexpr (BYTES == 12) {
+    const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, vo, sb, 0);   // (a 3-vector occupies 16 bytes)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = __builtin_bit_cast(T, (unsigned int)v[nt]);
+  } else if constexpr (BYTES == 4) {
+    b[0] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, vo, sb, 0));
+  } else {                       // e.g. NT = 3 in f64: one element per load
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if constexpr (sizeof(T) == 8)
+        b[nt] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, vo + nt * 8u, sb, 0));
+      else
+        b[nt] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, vo + nt * 4u, sb, 0));
+    }
   }
 }
 
-// Fetch group `g` (G k-steps) of a wave's N-split fragment stream.  wl = layer base + this
-// wave's slice + lane*NT.
+// Fetch group `g` (G k-steps) of a wave's N-split fragment stream.  so = element offset of the
+// wave's slice from MlpDev::wbase (uniform); lo = lane*NT.
 template <typename T, int NT, int G>
-__device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&b)[G][NT]) {
+__device__ __forceinline__ void load_group(rsrc_t r, unsigned so, unsigned lo, int g, T (&b)[G][NT]) {
 #pragma unroll
-  for (int kk = 0; kk < G; ++kk) load_frag<T, NT>(wl + (size_t)(g * G + kk) * 64 * NT, b[kk]);
+  for (int kk = 0; kk < G; ++kk) load_frag<T, NT>(r, so + (unsigned)(g * G + kk) * 64u * NT, lo, b[kk]);
 }
 
 // One N-split layer with compile-time k extent KS: acc[mt][nt] += A[16mt.., :] * Wpacked.
@@ -234,11 +294,18 @@ __device__ __forceinline__ void load_group(const T* __restrict__ wl, int g, T (&
 // SG: streaming granularity after the pre-loaded first group.  The double buffer holds two
 // sub-groups of SG k-steps; tall f64 tiles (MT >= 2) have enough MFMA work per k-step to cover an
 // L2 round trip with SG = 4, which halves the buffer's registers (64 VGPRs).
-template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false, int SG = G>
+struct NoSide { __device__ __forceinline__ void operator()() const {} };
+
+// `mid` is invoked once, right after the barrier an OWN layer takes behind its first group (never
+// for !OWN): caller work placed there issues between this layer's MFMAs instead of on the serial
+// chain at the end of a step.
+template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false, int SG = G,
+          typename Mid = NoSide>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
-                                                 const T* __restrict__ wl, int lane,
+                                                 rsrc_t wr, unsigned wl, int lane,
                                                  const T (&first)[G][NT],
-                                                 typename Acc<T>::type (&acc)[MT][NT], int rot = 0) {
+                                                 typename Acc<T>::type (&acc)[MT][NT], int rot = 0,
+                                                 Mid&& mid = Mid()) {
   static_assert(KS % G == 0 && G % SG == 0, "group sizes must divide the k extent");
   constexpr int NG = KS / G;       // groups (the unit of the rotated k order)
   constexpr int NS = KS / SG;      // sub-groups (the unit of the weight stream)
@@ -255,7 +322,7 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
   }
 #pragma unroll
   for (int sgi = 0; sgi < NS; ++sgi) {
-    if (sgi + 1 >= FS && sgi + 1 < NS) load_group<T, NT, SG>(wl, sgi + 1, b[(sgi + 1) & 1]);
+    if (sgi + 1 >= FS && sgi + 1 < NS) load_group<T, NT, SG>(wr, wl, (unsigned)lane * NT, sgi + 1, b[(sgi + 1) & 1]);
     const int g = sgi / FS;
     const T* ag = (OWN ? arow + 4 * G * ((g + rot) & (NG - 1)) : arow + 4 * G * g) + 4 * SG * (sgi % FS);
 #pragma unroll
@@ -268,7 +335,7 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const T bv = (FS > 1 && sgi < FS) ? first[sgi * SG + kk][nt] : b[sgi & 1][kk][nt];
-          acc[mt][nt] = mfma16(a[mt], bv, acc[mt][nt]);
+          acc[mt][nt] = mfma16_x<(KS < 16 ? kRealL0 : kRealHid)>(a[mt], bv, acc[mt][nt]);
         }
     }
 #ifndef AMPC_X_NOSCHED
@@ -277,6 +344,16 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
     // that consume them, weight loads for the next sub-group are spread between MFMA clusters.
     //   masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read
     if (PIPE && KS >= 8) {
+#ifdef AMPC_X_VMEMFIRST
+      // all of the next sub-group's weight loads up front: the full sub-group of MFMAs covers them
+      __builtin_amdgcn_sched_group_barrier(0x020, SG, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+#pragma unroll
+      for (int i = 0; i < SG / 2; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+      }
+#else
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll
       for (int i = 0; i < SG / 2; ++i) {
@@ -284,13 +361,39 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
         __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
       }
+#endif
     }
 #endif
-    if (OWN && sgi == FS - 1) lds_barrier();
+    if (OWN && sgi == FS - 1) {
+      lds_barrier();
+      mid();
+    }
+#ifdef AMPC_X_VALUPAD      // calibration: 64 extra int32 VALU instructions per layer call, spread over 8 sub-groups
+    if (KS >= 16 && sgi >= 2 && sgi < 10) {
+      int padv = lane;
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+      asm volatile("" :: "v"(padv));
+    }
+#endif
+#ifdef AMPC_X_VALUPAD64    // calibration: 64 extra f64 VALU instructions per layer call
+    if (KS >= 16 && sgi >= 2 && sgi < 10) {
+      double padd = (double)lane;
+#pragma unroll
+      for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_f64 %0, %0, 1.0" : "+v"(padd));
+      asm volatile("" :: "v"(padd));
+    }
+#endif
   }
 }
 
-#ifdef AMPC_X_PHASETIME
+#ifdef AMPC_X_WAVETIME
+// Low-perturbation timeline (tools/wavetime.py): every wave of workgroup 7 keeps its own
+// s_memtime marks of ONE time step in registers (TileNet::xm) and dumps them at kernel end.
+__device__ long long g_wave_marks[8 * 16];
+#define AMPC_MARK(idx) do { if (_xon) _xm[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define AMPC_MARK_ALWAYS(idx) do { } while (0)
+#elif defined(AMPC_X_PHASETIME)
 __device__ long long g_phase_marks[64];
 #define AMPC_MARK(idx)                                                              \
   do {                                                                              \
@@ -326,18 +429,33 @@ struct TileNet {
   // (own_first_packing() in api.cpp).
   static constexpr bool OWN = (16 * NT == 4 * GH) && (((KSH / GH) & (KSH / GH - 1)) == 0);
 
-  // Layer 0's fragments requested ahead of time (prefetch0): the whole layer in f32 (its few
-  // MFMAs cannot cover an in-loop L2 round trip; measured +3 %), only the first two k-steps in
-  // f64, where the extra 40 live VGPRs cost more than the latency they hide (measured -4 %).
-  static constexpr bool FULL0 = sizeof(T) == 4;
-  T pf0[FULL0 ? KS0MAX : 2][NT];
+  // Layer 0's fragments are RESIDENT in registers for the kernel's lifetime whenever the layer is
+  // at most KS0RES k-steps (all widths in f32; k1p <= 24, i.e. nx + nu <= 24, in f64 -- HalfCheetah
+  // is 23): layer 0 has only 2..12 MFMAs per tile to cover an L2 round trip with, and its loads sat
+  // on the serial chain of a time step (state update -> layer 0 -> layer 1) behind in-order vmcnt
+  // waits.  Wider f64 first layers keep the streamed scheme (first two k-steps prefetched, the
+  // rest double-buffered in the loop): 12 k-steps would cost 48 VGPRs.
+  static constexpr int KS0RES = sizeof(T) == 4 ? KS0MAX : 6;
+  T pf0[KS0RES][NT];
+  // layer 0 resident?  (wave-uniform; a function of the model only)
+  __device__ __forceinline__ static bool resident0(const MlpDev<T>& m) {
+#ifdef AMPC_X_NORES0
+    return false;
+#else
+    // (f64 tiles of 32 / 64 rows have no registers to spare: they keep the streamed scheme)
+    return LEAN < 2 && (sizeof(T) == 4 || MT == 1) && m.k1p <= 4 * KS0RES;
+#endif
+  }
 
-  __device__ __forceinline__ static const T* slice0(const MlpDev<T>& m, int w, int lane) {
-    return m.w[0] + ((size_t)w * (m.k1p / 4) * 64 + lane) * NT;
+  // wave-uniform element offsets (from MlpDev::wbase) of this wave's fragment streams; the lane's
+  // own offset is lane*NT elements
+  __device__ __forceinline__ static unsigned slice0(const MlpDev<T>& m, int w) {
+    return (unsigned)(m.w[0] - m.wbase) + (unsigned)w * (unsigned)(m.k1p / 4) * 64u * NT;
   }
-  __device__ __forceinline__ static const T* slice_h(const MlpDev<T>& m, int l, int w, int lane) {
-    return m.w[l] + ((size_t)w * KSH * 64 + lane) * NT;
+  __device__ __forceinline__ static unsigned slice_h(const MlpDev<T>& m, int l, int w) {
+    return (unsigned)(m.w[l] - m.wbase) + (unsigned)w * (unsigned)KSH * 64u * NT;
   }
+  rsrc_t wr;                      // buffer resource of the packed model (set by init())
   template <int KS> __device__ __forceinline__ const T (&first0() const)[KS][NT] {
     return reinterpret_cast<const T(&)[KS][NT]>(pf0);
   }
@@ -362,7 +480,7 @@ struct TileNet {
     } else {
       const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
-      for (int ks = 0; ks < KSW; ++ks) load_frag<T, 2>(wl + ks * 128, dst[ks]);
+      for (int ks = 0; ks < KSW; ++ks) { const vec_t<T, 2> v = *reinterpret_cast<const vec_t<T, 2>*>(wl + ks * 128); dst[ks][0] = v[0]; dst[ks][1] = v[1]; }
       if (m.tail4) {          // second slot: the 4x4x4 tail fragment instead of tile 1
         const T* wt = m.wt + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
@@ -375,45 +493,82 @@ struct TileNet {
   // epilogue has neither an LDS read nor an add between the last MFMA and the activation.
   // (16-row tiles only: the taller tiles are register-bound and keep reading the bias from LDS.)
   static constexpr bool RESIDENT_BIAS = LEAN < 1 && (MT == 1);
-  T bias_r[kMaxHidden][NT];
+  // (the first kResBias hidden layers -- the reference's default network has two; deeper layers'
+  // accumulators are seeded from the LDS copy of the bias instead, one read per column tile)
+  static constexpr int kResBias = 2;
+  T bias_r[kResBias][NT];
   // Prefetch buffer: the first group of the next hidden layer (and, when they are not resident,
   // the output-layer fragments).  A member, not a local of run(): the first group of hidden layer 1
   // for the NEXT call is requested at the end of a call, together with layer 0's fragments, so it
   // has the caller's whole inter-call phase to arrive (measured +1 % f64, +3 % f32 on c3).
   T pfn[GH][NT];
   bool pfn_ready = false;
+#ifdef AMPC_X_WAVETIME
+  long long xm[16];
+  bool xon = false;
+#endif
 
   // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
   __device__ __forceinline__ void init(const MlpDev<T>& m) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-    for (int l = 0; l < kMaxHidden; ++l)
+    for (int l = 0; l < kResBias; ++l)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         bias_r[l][nt] = (RESIDENT_BIAS && l < m.n_hidden) ? m.b[l][16 * (NT * w + nt) + (lane & 15)] : T(0);
+    wr = weight_rsrc(m.wbase);
     if constexpr (RESIDENT_OUT) load_out(m, w, lane, wout);
-    prefetch0(m);
+    load0_all(m);
+  }
+
+  // layer 0's fragments into pf0, once per kernel (init()).  Written as a fully unrolled, predicated
+  // loop: a switch over the k extent gets merged by the compiler into a loop with a run-time
+  // index, which forces the whole TileNet object into scratch memory.
+  __device__ __forceinline__ void load0_all(const MlpDev<T>& m) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned wl = slice0(m, w);
+    // resident: the whole layer; streamed: its first two k-steps (what prefetch0 requests) -- ONE
+    // code path for both, so that no two branches store to different elements of pf0
+    const int ks0 = resident0(m) ? m.k1p / 4 : 2;
+#pragma unroll
+    for (int ks = 0; ks < KS0RES; ++ks) {
+      T tmp[NT];                  // (values, not references, cross the branch: a store through a
+#pragma unroll                    //  phi of two pf0 addresses would pin pf0 to the stack)
+      for (int nt = 0; nt < NT; ++nt) tmp[nt] = T(0);
+      if (ks < ks0) load_frag<T, NT>(wr, wl + (unsigned)ks * 64u * NT, (unsigned)lane * NT, tmp);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pf0[ks][nt] = tmp[nt];
+    }
+  }
+
+  // Layer 0 from the resident fragments: KS k-steps, operands straight from pf0 (static indices:
+  // no reinterpreted views of the member array, which the compiler answers with a stack copy).
+  template <int KS>
+  __device__ __forceinline__ void layer0_resident(const T* __restrict__ A, int a_stride, int lane,
+                                                  acc_t (&acc)[MT][NT]) const {
+    static_assert(KS <= KS0RES, "layer 0 wider than the resident buffer");
+    const T* arow = A + (lane & 15) * a_stride + (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      T a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = arow[mt * 16 * a_stride + 4 * ks];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16_x<kRealL0>(a[mt], pf0[ks][nt], acc[mt][nt]);
+    }
   }
 
   // Request layer 0's weights.  Call before the barrier/phase that precedes run(); the loads
   // complete while other work proceeds.
   __device__ __forceinline__ void prefetch0(const MlpDev<T>& m) {
+    if (resident0(m)) return;     // resident: nothing to request
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const T* wl = slice0(m, w, lane);
-    if constexpr (!FULL0) {
-      load_group<T, NT, 2>(wl, 0, first0<2>());
-      return;
-    }
-    switch (m.k1p) {
-      case 8: load_group<T, NT, 2>(wl, 0, first0<2>()); break;
-      case 16: load_group<T, NT, 4>(wl, 0, first0<4>()); break;
-      case 24: load_group<T, NT, 6>(wl, 0, first0<6>()); break;
-      case 32: load_group<T, NT, 8>(wl, 0, first0<8>()); break;
-      case 40: load_group<T, NT, 10>(wl, 0, first0<10>()); break;
-      default: load_group<T, NT, 12>(wl, 0, first0<12>()); break;
-    }
+    load_group<T, NT, 2>(wr, slice0(m, w), (unsigned)lane * NT, 0, first0<2>());
   }
 
   // On entry lds[L.xu] holds [x | u | 0] for the tile's M rows, init() has been called and every
@@ -426,16 +581,25 @@ struct TileNet {
     run_side(m, L, lds, [] {}, dz, dz_layer_stride);
   }
 
-  // As run(); `side()` is executed by every thread after the output layer's MFMAs have been
-  // issued and before their results are read: work placed there (the caller's bookkeeping for the
-  // next step -- anything that does not depend on this call's output and does not touch the
-  // activation / partials buffers) runs while the matrix pipe drains instead of after it.
+  // As run(); `side()` is executed once by every thread at a point where it costs least: work
+  // placed there is the caller's bookkeeping for the next step -- anything that does not depend
+  // on this call's output, does not touch the activation / partials buffers, and may overwrite
+  // the CONTROL columns of lds[L.xu] (layer 0 has consumed them).  With two or more hidden
+  // layers in the own-group-first scheme it runs right after the barrier inside the second
+  // hidden layer, i.e. between that layer's MFMAs (every wave has finished reading lds[L.xu]
+  // by then); otherwise after the output layer's MFMAs have been issued, while the pipe drains.
+  // (Measured on c3 f64, one 16-row tile per CU: at the end of the step the same work sat on
+  // the serial chain for ~1.3 k cycles with the matrix pipe idle.)
   template <typename Side>
   __device__ __forceinline__ void run_side(const MlpDev<T>& m, const TileLds& L, T* lds, Side&& side,
                                            T* __restrict__ dz = nullptr, size_t dz_layer_stride = 0) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
+#ifdef AMPC_X_WAVETIME
+    auto& _xm = xm;
+    const bool _xon = xon;
+#endif
     T* act = lds + L.act;            // buffer the next layer reads
     T* act_other = lds + L.act2;     // buffer the next epilogue may write (== act if single-buffered)
     const bool pingpong = L.act2 != L.act;
@@ -444,7 +608,7 @@ struct TileNet {
     static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");   // pfn holds either
     auto prefetch_next = [&](int l_next) {
       if (l_next < m.n_hidden) {
-        load_group<T, NT, GH>(slice_h(m, l_next, w, lane), 0, pfn);
+        load_group<T, NT, GH>(wr, slice_h(m, l_next, w), (unsigned)lane * NT, 0, pfn);
       } else if constexpr (!RESIDENT_OUT) {
         // not resident: the output fragments ([KSW][2]) reuse the hidden prefetch buffer
         // ([GH][NT], the same 8*NT values) -- one register range for whatever comes next
@@ -458,7 +622,8 @@ struct TileNet {
 #pragma unroll
           for (int ks = 0; ks < KSW; ++ks) {
             T two[2];
-            load_frag<T, 2>(wl + ks * 128, two);
+            const vec_t<T, 2> v2 = *reinterpret_cast<const vec_t<T, 2>*>(wl + ks * 128);
+            two[0] = v2[0]; two[1] = v2[1];
             flat[2 * ks] = two[0];
             flat[2 * ks + 1] = two[1];
           }
@@ -504,6 +669,7 @@ struct TileNet {
       }
     };
 
+    bool side_done = false;
     // ---- layer 0: K = k1p (8, 16, .. 48), A = [x | u] ----------------------------------------
     {
       acc_t acc[MT][NT];
@@ -511,28 +677,34 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{bias_r[0][nt], bias_r[0][nt], bias_r[0][nt], bias_r[0][nt]};
-      const T* wl = slice0(m, w, lane);
+      const unsigned wl = slice0(m, w);
       const T* A = lds + L.xu;
       // first group of hidden layer 1: in flight under layer 0's MFMAs (64-row tiles have no
       // registers to spare for that and fetch it after the MFMAs instead)
       if (!pfn_ready) prefetch_next(1);   // first call only; later calls were served at the previous call's end
-      if constexpr (FULL0) {
-        switch (m.k1p) {   // one fully unrolled variant per padded input width
-          case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          case 16: layer_mma_static<T, NT, MT, 4, 4>(A, L.xu_stride, wl, lane, first0<4>(), acc); break;
-          case 24: layer_mma_static<T, NT, MT, 6, 6>(A, L.xu_stride, wl, lane, first0<6>(), acc); break;
-          case 32: layer_mma_static<T, NT, MT, 8, 8>(A, L.xu_stride, wl, lane, first0<8>(), acc); break;
-          case 40: layer_mma_static<T, NT, MT, 10, 10>(A, L.xu_stride, wl, lane, first0<10>(), acc); break;
-          default: layer_mma_static<T, NT, MT, 12, 12>(A, L.xu_stride, wl, lane, first0<12>(), acc); break;
+      if (resident0(m)) {
+        switch (m.k1p) {   // one fully unrolled variant per padded input width, no loads
+          case 8: layer0_resident<2>(A, L.xu_stride, lane, acc); break;
+          case 16: layer0_resident<4>(A, L.xu_stride, lane, acc); break;
+          case 24: layer0_resident<6>(A, L.xu_stride, lane, acc); break;
+          default:
+            if constexpr (KS0RES >= 12) {
+              switch (m.k1p) {
+                case 32: layer0_resident<8>(A, L.xu_stride, lane, acc); break;
+                case 40: layer0_resident<10>(A, L.xu_stride, lane, acc); break;
+                default: layer0_resident<12>(A, L.xu_stride, lane, acc); break;
+              }
+            }
+            break;
         }
       } else {
         switch (m.k1p) {
-          case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          case 16: layer_mma_static<T, NT, MT, 4, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          case 24: layer_mma_static<T, NT, MT, 6, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          case 32: layer_mma_static<T, NT, MT, 8, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          case 40: layer_mma_static<T, NT, MT, 10, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
-          default: layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wl, lane, first0<2>(), acc); break;
+          case 8: layer_mma_static<T, NT, MT, 2, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          case 16: layer_mma_static<T, NT, MT, 4, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          case 24: layer_mma_static<T, NT, MT, 6, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          case 32: layer_mma_static<T, NT, MT, 8, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          case 40: layer_mma_static<T, NT, MT, 10, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          default: layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
         }
       }
       AMPC_MARK(2);
@@ -552,16 +724,28 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          T b = bias_r[0][nt];                  // bias_r[l][nt] with l a loop variable: selected
-#pragma unroll                                  // by compares so the array stays in registers
-          for (int k = 1; k < kMaxHidden; ++k) b = (l == k) ? bias_r[k][nt] : b;
+          T b = bias_r[kResBias - 1][nt];       // l == 1: resident (static index keeps the array in
+          if (RESIDENT_BIAS && l >= kResBias)   // registers); deeper layers: the LDS copy
+            b = lds[L.bias + l * m.hpad + 16 * (NT * w + nt) + i];
           acc[mt][nt] = acc_t{b, b, b, b};
         }
       // f64 streams the weights in half-groups (32-64 VGPRs less: the 64-row tile stops spilling,
       // +2 %, and the 16-row tile has room for the early prefetch); f32 keeps whole groups
       // (half-groups measured -4 % there)
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, (sizeof(T) == 8 ? GH / 2 : GH)>(
-          act, as, slice_h(m, l, w, lane), lane, pfn, acc, w);
+#ifdef AMPC_X_SG8
+      constexpr int SGH = GH;
+#else
+      constexpr int SGH = sizeof(T) == 8 ? GH / 2 : GH;
+#endif
+#ifdef AMPC_X_SIDELATE
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH>(
+          act, as, wr, slice_h(m, l, w), lane, pfn, acc, w);
+#else
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH>(
+          act, as, wr, slice_h(m, l, w), lane, pfn, acc, w, [&] {
+            if (l == 1) { side(); side_done = true; }
+          });
+#endif
       AMPC_MARK(4);
       prefetch_next(l + 1);
       // single buffer: every wave must finish reading act before it is overwritten;
@@ -590,15 +774,15 @@ struct TileNet {
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            oacc[mt][0] = mfma16(arow[mt * 16 * as + 4 * ks], wo(ks, 0), oacc[mt][0]);
+            oacc[mt][0] = mfma16_x<kRealOut>(arow[mt * 16 * as + 4 * ks], wo(ks, 0), oacc[mt][0]);
       } else if (m.tail4) {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const T a = arow[mt * 16 * as + 4 * ks];
-            oacc[mt][0] = mfma16(a, wo(ks, 0), oacc[mt][0]);
-            tacc[mt] = mfma4(a, wo(ks, 1), tacc[mt]);
+            oacc[mt][0] = mfma16_x<kRealOut>(a, wo(ks, 0), oacc[mt][0]);
+            tacc[mt] = kRealOut ? mfma4(a, wo(ks, 1), tacc[mt]) : tacc[mt] + a * wo(ks, 1);
           }
       } else {
 #pragma unroll
@@ -606,15 +790,15 @@ struct TileNet {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const T a = arow[mt * 16 * as + 4 * ks];
-            oacc[mt][0] = mfma16(a, wo(ks, 0), oacc[mt][0]);
-            oacc[mt][1] = mfma16(a, wo(ks, 1), oacc[mt][1]);
+            oacc[mt][0] = mfma16_x<kRealOut>(a, wo(ks, 0), oacc[mt][0]);
+            oacc[mt][1] = mfma16_x<kRealOut>(a, wo(ks, 1), oacc[mt][1]);
           }
       }
     }
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
     if (m.n_hidden > 1) { prefetch_next(1); pfn_ready = true; }
-    side();
+    if (!side_done) side();
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
     T* part = lds + L.part + w * M * m.nxp;

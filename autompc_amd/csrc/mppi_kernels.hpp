@@ -167,8 +167,16 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   // the time loop has no separate cost phase; the stage cost of x_0 is added here.
   if (diag) c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, true);
 
+#ifdef AMPC_X_WAVETIME
+  auto& _xm = net.xm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) _xm[i] = 0;
+#endif
   for (int t = 0; t < H; ++t) {
-#ifdef AMPC_X_PHASETIME
+#ifdef AMPC_X_WAVETIME
+    net.xon = (blockIdx.x == 7 && t == 5);
+    const bool _xon = net.xon;
+#elif defined(AMPC_X_PHASETIME)
     if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == 5) ? 1 : 0;
 #endif
     AMPC_MARK(0);
@@ -199,6 +207,12 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     AMPC_MARK(11);
   }
 
+#ifdef AMPC_X_WAVETIME
+  if (blockIdx.x == 7 && (threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g_wave_marks[(threadIdx.x >> 6) * 16 + i] = _xm[i];
+  }
+#endif
   // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------
   T term = quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, diag);
   T c = c_part + pr.lam_over_sigma * ca_part;
