@@ -428,17 +428,29 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   } else {
     p->L = tile_lds_for<T>(h, m, M, extra);
   }
-  p->lds_aseq = p->L.extra;
-  p->lds_cost = round_up(p->lds_aseq + p->max_h * nu, 4);
-  p->lds_bytes = ((size_t)p->lds_cost + h->cost_stride + 3 * nu) * sizeof(T);
+  // behind the tile map, fixed-size regions first (their offsets are compile-time constants of a
+  // shape-specialised kernel): cost block + bounds, then the shifted sequence [max_h][nu]
+  p->lds_cost = p->L.extra;
+  p->lds_aseq = round_up(p->lds_cost + h->cost_stride + 3 * nu, 4);
+  p->lds_bytes = ((size_t)p->lds_aseq + (size_t)p->max_h * nu) * sizeof(T);
   REQUIRE(p->lds_bytes <= kLdsLimit, "mppi plan: model + horizon do not fit the 160 KB LDS");
   {  // fused update: keep the tile's clipped noise [max_h][M][nu] (+ 2M reduction slots) in LDS
-    const int e0 = round_up(p->lds_cost + h->cost_stride + 3 * nu, 4);
+    const int e0 = round_up(p->lds_aseq + p->max_h * nu, 4);
     const size_t bytes = ((size_t)e0 + (size_t)p->max_h * M * nu + 2 * M) * sizeof(T);
     if (!h->has_sindy && bytes <= kLdsLimit && env_int("AMPC_FUSED_UPDATE", 1) != 0) {
       p->lds_eps = e0;
       p->lds_red = e0 + p->max_h * M * nu;
       p->lds_bytes = bytes;
+    }
+  }
+  // shape-specialised kernel: registered shape, 16- or 32-row tile, and the LDS map the shape
+  // implies (ping-pong activations + separate partials -- tile_lds_for picked it iff it fits)
+  p->static_shape = -1;
+  if (!h->has_sindy && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
+    const int sid = static_shape_of<T>(h, m);
+    if (sid >= 0) {
+      const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, M, h->nw, true, true);
+      if (std::memcmp(&S, &p->L, sizeof(TileLds)) == 0) p->static_shape = sid;
     }
   }
   std::vector<MppiProblem<T>> pr(p->B);

@@ -25,6 +25,7 @@
 #include "rng_kernels.hpp"
 #include "sindy_kernels.hpp"
 #include "score_kernels.hpp"
+#include "shapes.hpp"
 
 using namespace ampc;
 
@@ -235,6 +236,7 @@ struct ampc_mppi_plan {
   ampc_handle* h = nullptr;
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
+  int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
   int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
   std::vector<int> N, H, cost_idx, a_off;
   std::vector<unsigned> noise_id;   // per problem: key of its device noise stream (default: index)
@@ -332,6 +334,18 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.refresh = f + 4 * p->B;
   a.ric = (T*)p->ric.p;
   return a;
+}
+
+// id of the registered static shape (shapes.hpp) the staged MLP matches, or -1
+template <typename T> inline int static_shape_of(const ampc_handle* h, const MlpDev<T>& m) {
+  if (!h->has_mlp) return -1;
+#define AMPC_SHAPE_MATCH(ID, NX, NU, NO, NH, HPAD)                                                  \
+  if (m.nx == NX && m.nu == NU && h->obs_dim == NO && m.n_hidden == NH && m.hpad == HPAD &&         \
+      m.tail4 == (StaticShape<NX, NU, NO, NH, HPAD>::template tail4<T> ? 1 : 0))                    \
+    return ID;
+  AMPC_STATIC_SHAPES(AMPC_SHAPE_MATCH)
+#undef AMPC_SHAPE_MATCH
+  return -1;
 }
 
 // ---------------------------------------------------------------------------------------------

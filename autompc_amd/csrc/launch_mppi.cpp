@@ -29,6 +29,30 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
                       sindy_stage_bytes<T>(h);
     HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
     hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
+  } else if (p->static_shape >= 0) {
+    // shape-specialised instantiation (dimensions, strides and LDS offsets are immediates)
+    // (relu -- the reference's default, mlp.py:126-128 -- gets its own instantiation; the other
+    // activations share one with a run-time switch)
+    switch ((p->static_shape * 4 + p->mt) * 2 + (h->act == 0 ? 1 : 0)) {
+#define AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, RELU)                                     \
+      case (ID * 4 + MTV) * 2 + RELU: {                                                               \
+        constexpr int W = (HPAD % 128 == 0) ? 8 : 4, NT = HPAD / (16 * W);                             \
+        auto k = mppi_rollout_kernel<T, NT, MTV, W, StaticShape<NX, NU, NO, NH, HPAD, RELU ? 0 : -1>>; \
+        HIP_OK(allow_lds(k, p->lds_bytes));                                                           \
+        hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);             \
+      } break;
+#define AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, MTV)   \
+      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, 0)  \
+      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, 1)
+#define AMPC_SHAPE_LAUNCH(ID, NX, NU, NO, NH, HPAD)       \
+      AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, 1)   \
+      AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, 2)
+      AMPC_STATIC_SHAPES(AMPC_SHAPE_LAUNCH)
+#undef AMPC_SHAPE_LAUNCH
+#undef AMPC_SHAPE_LAUNCH_MT
+#undef AMPC_SHAPE_LAUNCH_ONE
+      default: return fail("internal: unknown static shape");
+    }
   } else {
     AMPC_DISPATCH(h->nw, h->nt, p->mt, {
       auto k = mppi_rollout_kernel<T, NT, MT, W>;

