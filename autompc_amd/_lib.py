@@ -70,6 +70,8 @@ SIGNATURES = {
                                       POINTER(c_void_p)]),
     "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
     "ampc_ilqr_plan_set_terminal_goal": (c_int, [c_void_p, c_int]),
+    "ampc_ilqr_plan_set_timing": (c_int, [c_void_p, c_int]),
+    "ampc_ilqr_plan_timing": (c_int, [c_void_p, _dp, _ip]),
     "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
 }
 
@@ -432,6 +434,16 @@ class IlqrPlan:
             self.close()
         except Exception:
             pass
+
+    def set_timing(self, enable=True):
+        check(self.lib.ampc_ilqr_plan_set_timing(self._p, int(bool(enable))))
+
+    def timing(self):
+        ms = np.zeros(4)
+        n = c_int()
+        check(self.lib.ampc_ilqr_plan_timing(self._p, dptr(ms), ctypes.byref(n)))
+        return {"riccati_ms": ms[0], "iter_ms": ms[1], "forward_ms": ms[2], "jacobian_ms": ms[3],
+                "launches": n.value}
 
     def solve(self, x0, uguess, max_iter=50):
         nx, nu, B, H = self.handle.nx, self.handle.nu, self.B, self.H

@@ -802,6 +802,31 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   return 0;
 }
 
+extern "C" int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable) {
+  REQUIRE(p, "ampc_ilqr_plan_set_timing: NULL plan");
+  p->timing = enable != 0;
+  p->ev_used = 0;
+  return 0;
+}
+
+extern "C" int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations) {
+  REQUIRE(p && kernel_ms, "ampc_ilqr_plan_timing: NULL argument");
+  HIP_OK(hipSetDevice(p->h->device));
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  double acc[4] = {0, 0, 0, 0};
+  const size_t n = p->ev_used / 5;
+  for (size_t i = 0; i < n; ++i)
+    for (int k = 0; k < 4; ++k) {
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, p->ev[5 * i + k], p->ev[5 * i + k + 1]));
+      acc[k] += ms;
+    }
+  for (int k = 0; k < 4; ++k) kernel_ms[k] = n ? acc[k] / n : 0.0;
+  if (iterations) *iterations = (int)n;
+  p->ev_used = 0;
+  return 0;
+}
+
 extern "C" int ampc_ilqr_plan_set_terminal_goal(ampc_ilqr_plan* p, int use_goal) {
   REQUIRE(p, "ampc_ilqr_plan_set_terminal_goal: NULL plan");
   p->term_goal = use_goal ? 1 : 0;
@@ -815,6 +840,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
                     &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric};
   for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
   delete p;
   handle_release(h);
@@ -838,8 +864,19 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   std::vector<int> flags(5 * B);
   int it = 0;
   for (; it < max_iter; ++it) {
+    if (p->timing) {
+      if (p->ev_used + 5 > p->ev.size())
+        for (int i = 0; i < 5; ++i) {
+          hipEvent_t x;
+          HIP_OK(hipEventCreate(&x));
+          p->ev.push_back(x);
+        }
+      p->ev_cur = &p->ev[p->ev_used];
+      p->ev_used += 5;
+    }
     if (int rc = ilqr_launch_iter<T>(p, 1)) return rc;      // backward sweep + line search + accept
     if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
+    p->ev_cur = nullptr;
     if ((it & 3) == 3 || it + 1 == max_iter) {              // poll the active flags every 4 iterations
       HIP_OK(hipMemcpyAsync(flags.data(), p->flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_OK(hipStreamSynchronize(h->stream));

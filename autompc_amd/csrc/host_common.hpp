@@ -306,6 +306,12 @@ struct ampc_ilqr_plan {
   int lds_work = 0, lds_xn = 0;
   size_t lds_bytes = 0;
   int last_iterations = 0;
+  // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg):
+  // events bracket the four launches of an iteration: sweep | line search | forward | Jacobians
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // 5 per timed iteration
+  size_t ev_used = 0;
+  hipEvent_t* ev_cur = nullptr; // the running iteration's five events (null: not timed)
 };
 
 template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {

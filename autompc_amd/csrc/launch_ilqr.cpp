@@ -10,6 +10,8 @@
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  hipEvent_t* e = mode == 1 ? p->ev_cur : nullptr;
+  if (e) HIP_OK(hipEventRecord(e[0], h->stream));
   if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
     const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
     const size_t rb = (size_t)wk.total * sizeof(T);
@@ -24,11 +26,13 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     }
     HIP_OK(hipGetLastError());
   }
+  if (e) HIP_OK(hipEventRecord(e[1], h->stream));
   if (h->has_sindy) {
     auto k = ilqr_iter_kernel<T, 1, 4, 1>;
     HIP_OK(allow_lds(k, p->lds_bytes));
     hipLaunchKernelGGL(k, dim3(p->B), dim3(256), p->lds_bytes, h->stream, a);
     HIP_OK(hipGetLastError());
+    if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
   }
   AMPC_DISPATCH(h->nw, h->nt, 1, {
@@ -37,6 +41,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
   });
   HIP_OK(hipGetLastError());
+  if (e) HIP_OK(hipEventRecord(e[2], h->stream));
   return 0;
 }
 

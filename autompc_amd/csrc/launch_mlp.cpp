@@ -81,6 +81,7 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
                        sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,
                        (T*)p->ju.p, rows, rm);
     HIP_OK(hipGetLastError());
+    if (p->ev_cur) { HIP_OK(hipEventRecord(p->ev_cur[3], h->stream)); HIP_OK(hipEventRecord(p->ev_cur[4], h->stream)); }
     return 0;
   }
   {
@@ -94,6 +95,7 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
                          (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
     });
   }
+  if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[3], h->stream));
   {
     // 16-row tiles: their 33 KB of LDS lets four workgroups share a CU, so one tile's set-up
     // (global loads of dz / W_out) and reduction overlap another's MFMAs; measured 4 % faster on
@@ -112,6 +114,7 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     });
   }
   HIP_OK(hipGetLastError());
+  if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[4], h->stream));
   return 0;
 }
 

@@ -89,7 +89,7 @@ class CandidateEvaluator:
         self.goal = _task_goal(task.get_cost(), system.obs_dim)
 
     def evaluate(self, candidates, n_steps=None, seed=0, init_obs=None, eps_all=None,
-                 act_init=None, return_trajectories=False, index_offset=0):
+                 act_init=None, return_trajectories=False, index_offset=0, timing=None):
         """Closed-loop score of every candidate (a list of dicts with keys horizon, sigma, lmda,
         num_path, Q, R, F -- Q/R/F either diagonals or full matrices).
 
@@ -97,20 +97,23 @@ class CandidateEvaluator:
         from ``default_rng([seed, index_offset + i])`` and its device noise from the Philox
         stream of that global index.  A rank that evaluates the shard ``all[lo:hi]`` with
         ``index_offset=lo`` therefore returns exactly the scores a single process returns for
-        those candidates (the per-candidate ``surr_cost`` of pipeline_tuner.py:213-258)."""
+        those candidates (the per-candidate ``surr_cost`` of pipeline_tuner.py:213-258).
+
+        timing: an optional dict; on return timing["timing"] holds the average HIP-event duration of
+        the rollout / update kernels over the closed loop's control steps (bench.py roofline leg)."""
         B = len(candidates)
         if B == 0:
             return (np.zeros(0), None, None) if return_trajectories else np.zeros(0)
         opened = []                       # device objects, closed on every exit path
         try:
             return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
-                                  return_trajectories, int(index_offset), opened)
+                                  return_trajectories, int(index_offset), opened, timing)
         finally:
             for obj in reversed(opened):
                 obj.close()
 
     def _evaluate(self, candidates, n_steps, seed, init_obs, eps_all, act_init, return_trajectories,
-                  index_offset, opened):
+                  index_offset, opened, timing=None):
         nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
         B = len(candidates)
         n_steps = int(n_steps if n_steps is not None else self.task.get_num_steps())
@@ -143,6 +146,8 @@ class CandidateEvaluator:
                     scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
                 for i, c in enumerate(candidates)])
         plan.upload(act_seq=act_init)
+        if timing is not None:
+            plan.set_timing(True)
         try:
             terms = cost_terms(self.task.get_cost(), no, nu)
         except TypeError:
@@ -156,6 +161,8 @@ class CandidateEvaluator:
             obs, ctrls = plan.closed_loop(np.tile(init_obs, (B, 1)), n_steps, seed=seed,
                                           eps_all=eps_all, surrogate=sur)
             scores = score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
+        if timing is not None:
+            timing["timing"] = plan.timing()
         return (scores, obs, ctrls) if return_trajectories else scores
 
 

@@ -222,6 +222,14 @@ int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surrogate, cons
 int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double dt, const int* cost_index,
                           int clip_to_bounds, ampc_ilqr_plan** out);
 int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
+/* Per-kernel timing for the roofline report: when enabled, every iteration of ampc_ilqr_solve
+ * brackets its four launches with HIP events on the handle's stream.  ampc_ilqr_plan_timing
+ * synchronises and returns the AVERAGE duration (ms) per iteration of
+ *   kernel_ms[0] backward sweep   [1] line search + acceptance   [2] forward pass (activation
+ *   derivatives of the accepted trajectory)   [3] Jacobian chain
+ * over the iterations since the last call, and their number; then resets the counters. */
+int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable);
+int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations);
 /* use_goal = 0 (default): the backward sweep is seeded with the terminal gradient exactly as the
  * reference computes it, (F + F') x_N -- Cost.eval_term_obs_cost_diff ignores the goal
  * (cost.py:195, 208-211).  use_goal != 0: (F + F') (x_N - goal), the derivative of the terminal
