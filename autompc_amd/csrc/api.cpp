@@ -752,6 +752,14 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   }
   p->lds_work = p->L.extra;
   p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
+  p->static_shape = -1;
+  if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
+    const int sid = static_shape_of<T>(h, m);
+    if (sid >= 0) {
+      const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, 16, h->nw, true, true);
+      if (std::memcmp(&S, &p->L, sizeof(TileLds)) == 0) p->static_shape = sid;
+    }
+  }
   REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
   REQUIRE((size_t)wk.total * sizeof(T) <= kLdsLimit,
           "ilqr plan: the Riccati workspace for this state dimension does not fit the 160 KB LDS");

@@ -298,6 +298,7 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
 struct ampc_ilqr_plan {
   ampc_handle* h = nullptr;
   int B = 0, H = 0, ls_n = 10, bounded = 0, term_goal = 0;
+  int static_shape = -1;     // >= 0: registered shape whose specialised kernels run (shapes.hpp)
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
@@ -353,6 +354,26 @@ template <typename T> inline int static_shape_of(const ampc_handle* h, const Mlp
 #undef AMPC_SHAPE_MATCH
   return -1;
 }
+
+// Run AMPC_SD_BODY (a macro the caller defines; it sees `SH`, `W`, `NT`) for the registered shape
+// `SID`, with the activation folded when RELU:
+//   #define AMPC_SD_BODY  { auto k = kernel<T, NT, .., W, SH>; launch(k); }
+//   AMPC_STATIC_DISPATCH(sid, relu);
+//   #undef AMPC_SD_BODY
+#define AMPC_SD_CASE(ID, NX, NU, NO, NH, HPAD, RELU)                              \
+  case (ID) * 2 + (RELU): {                                                       \
+    using SH = StaticShape<NX, NU, NO, NH, HPAD, (RELU) ? 0 : -1>;                 \
+    constexpr int W = (HPAD % 128 == 0) ? 8 : 4, NT = HPAD / (16 * W);            \
+    (void)W; (void)NT;                                                            \
+    AMPC_SD_BODY                                                                  \
+  } break;
+#define AMPC_SD_ONE(ID, NX, NU, NO, NH, HPAD) \
+  AMPC_SD_CASE(ID, NX, NU, NO, NH, HPAD, 0) AMPC_SD_CASE(ID, NX, NU, NO, NH, HPAD, 1)
+#define AMPC_STATIC_DISPATCH(SID, RELU)                                  \
+  switch ((SID) * 2 + ((RELU) ? 1 : 0)) {                                \
+    AMPC_STATIC_SHAPES(AMPC_SD_ONE)                                      \
+    default: return fail("internal: unknown static shape");              \
+  }
 
 // ---------------------------------------------------------------------------------------------
 // heavy launchers: defined in launch_*.cpp, explicitly instantiated there for double and float

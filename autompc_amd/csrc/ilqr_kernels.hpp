@@ -191,24 +191,25 @@ __device__ __attribute__((noinline)) int quu_solve(const T* __restrict__ Qt, con
 // it needs none of the MLP tile's registers or LDS, so it is compiled once per precision, keeps
 // the Quu solve in registers without spilling, and leaves K_t, k_t (global) and the expected-
 // reduction sums `ric[p] = {lin, quad, |k|, singular}` for the line-search kernel.
-template <typename T, bool WIDE = false>     // WIDE: model states above 32 (longer register staging)
+template <typename T, bool WIDE = false, typename SH = DynShape>   // WIDE: model states above 32 (longer register staging)
 __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Wr = reinterpret_cast<T*>(smem_raw);
   constexpr int NTHR = kRicThreads;
-  const MlpDev<T>& mlp = args.mlp;
+  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, p = blockIdx.x;
-  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = args.obs_dim, H = args.H;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   if (args.active[p] == 0) return;
-  const IlqrWork wk = make_ilqr_work(nx, nu, args.cost_stride);
+  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
   T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
   T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
   T* Wk = Wr + wk.Wk; T* wq = Wr + wk.wq;
   T* xbar = Wr + wk.xbar; T* ubar = Wr + wk.ubar; T* cpar = Wr + wk.cpar; T* scal = Wr + wk.scal;
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
-  for (int i = tid; i < args.cost_stride; i += NTHR)
-    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * args.cost_stride + i];
+  for (int i = tid; i < cost_stride; i += NTHR)
+    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * cost_stride + i];
   __syncthreads();
   const T* st = args.states + (size_t)p * (H + 1) * nx;
   const T* ct = args.ctrls + (size_t)p * H * nu;
@@ -396,19 +397,22 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
 
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
-template <typename T, int NT, int W, int DYN = 0>
+template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  using Net = TileNet<T, NT, 1, W, false, 2>;   // nothing resident: measured equal to level 1, 44 VGPRs less
+  // nothing resident: the kernel is launched once per iteration and runs only H steps, so filling
+  // resident fragments does not pay (measured with a static shape: 0.74 ms resident vs 0.58 ms)
+  using Net = TileNet<T, NT, 1, W, false, 2, SH>;
   constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
-  const MlpDev<T>& mlp = args.mlp;
-  const TileLds& L = args.lds;
+  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x, p = blockIdx.x;
-  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = args.obs_dim, H = args.H;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   const int xs_ = L.xu_stride;
-  const IlqrWork wk = make_ilqr_work(nx, nu, args.cost_stride);
-  T* Wr = lds + args.lds_work;
+  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
+  T* Wr = lds + (SH::kStatic ? L.extra : args.lds_work);
   T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
   T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
   T* Wk = Wr + wk.Wk; T* wq = Wr + wk.wq; T* lu = Wr + wk.lu; T* rhs = Wr + wk.rhs;
@@ -430,8 +434,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   } else {                                       //  wants the registers for itself)
     for (int i = tid; i < M * L.xu_stride; i += NTHR) lds[L.xu + i] = T(0);
   }
-  for (int i = tid; i < args.cost_stride; i += NTHR)
-    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * args.cost_stride + i];
+  for (int i = tid; i < cost_stride; i += NTHR)
+    cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * cost_stride + i];
   for (int i = tid; i < nu; i += NTHR) {
     blo[i] = args.bounded ? args.ubounds[i] : T(0);
     bhi[i] = args.bounded ? args.ubounds[nu + i] : T(0);

@@ -15,7 +15,12 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
     const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
     const size_t rb = (size_t)wk.total * sizeof(T);
-    if (h->nx > 32) {
+    if (p->static_shape >= 0) {
+#define AMPC_SD_BODY { auto rk = ilqr_riccati_kernel<T, false, SH>; HIP_OK(allow_lds(rk, rb));   \
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a); }
+      AMPC_STATIC_DISPATCH(p->static_shape, 0);      // (the sweep never evaluates the activation)
+#undef AMPC_SD_BODY
+    } else if (h->nx > 32) {
       auto rk = ilqr_riccati_kernel<T, true>;
       HIP_OK(allow_lds(rk, rb));
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
@@ -35,11 +40,18 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
   }
-  AMPC_DISPATCH(h->nw, h->nt, 1, {
-    auto k = ilqr_iter_kernel<T, NT, W>;
-    HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
-  });
+  if (p->static_shape >= 0) {
+#define AMPC_SD_BODY { auto k = ilqr_iter_kernel<T, NT, W, 0, SH>; HIP_OK(allow_lds(k, p->lds_bytes));   \
+      hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a); }
+    AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
+#undef AMPC_SD_BODY
+  } else {
+    AMPC_DISPATCH(h->nw, h->nt, 1, {
+      auto k = ilqr_iter_kernel<T, NT, W>;
+      HIP_OK(allow_lds(k, p->lds_bytes));
+      hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
+    });
+  }
   HIP_OK(hipGetLastError());
   if (e) HIP_OK(hipEventRecord(e[2], h->stream));
   return 0;

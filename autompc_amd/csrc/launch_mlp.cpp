@@ -88,12 +88,21 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
     TileLds L = tile_lds_for<T>(h, m, M, 0);
     const size_t lb = (size_t)L.extra * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, mt, {
-      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
-      HIP_OK(allow_lds(k, lb));
-      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
-                         (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
-    });
+    const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, M, h->nw, true, true);
+    if (p->static_shape >= 0 && std::memcmp(&S, &L, sizeof(TileLds)) == 0) {
+#define AMPC_SD_BODY { auto k = mlp_forward_kernel<T, NT, 1, W, true, SH>; HIP_OK(allow_lds(k, lb));          \
+      hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,       \
+                         (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm); }
+      AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
+#undef AMPC_SD_BODY
+    } else {
+      AMPC_DISPATCH(h->nw, h->nt, mt, {
+        auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+        HIP_OK(allow_lds(k, lb));
+        hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
+                           (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
+      });
+    }
   }
   if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[3], h->stream));
   {
@@ -106,12 +115,20 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
     const int JM = 16 * jmt, jtiles = ((rows + JM - 1) / JM) * nx;   // (sample block, output) tiles
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, jmt, {
-      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
-      HIP_OK(allow_lds(k, jl));
-      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
-                         (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
-    });
+    if (p->static_shape >= 0 && jmt == 1) {
+#define AMPC_SD_BODY { auto k = mlp_jacobian_kernel<T, NT, 1, W, SH>; HIP_OK(allow_lds(k, jl));               \
+      hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,       \
+                         (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm); }
+      AMPC_STATIC_DISPATCH(p->static_shape, 0);       // (the chain multiplies stored derivatives)
+#undef AMPC_SD_BODY
+    } else {
+      AMPC_DISPATCH(h->nw, h->nt, jmt, {
+        auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+        HIP_OK(allow_lds(k, jl));
+        hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
+                           (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
+      });
+    }
   }
   HIP_OK(hipGetLastError());
   if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[4], h->stream));

@@ -24,8 +24,8 @@ struct RowMap {
   const int* mask;
 };
 
-template <typename T, int NT, int MT, int W, bool DERIV>
-__global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp, const TileLds L,
+template <typename T, int NT, int MT, int W, bool DERIV, typename SH = DynShape>
+__global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp_in, const TileLds L_in,
                                                              const T* __restrict__ states,
                                                              const T* __restrict__ ctrls,
                                                              T* __restrict__ out,
@@ -33,8 +33,10 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
                                                              const RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  using Net = TileNet<T, NT, MT, W, DERIV>;
+  using Net = TileNet<T, NT, MT, W, DERIV, 0, SH>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
+  const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
+  const TileLds L = SH::template fold_lds<T, M, W>(L_in);
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   const int first = blockIdx.x * M;
   T* xu = lds + L.xu;
@@ -90,8 +92,8 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
 // mlp_forward_kernel<DERIV>.  jx[n][nx][nx], ju[n][nx][nu].
 // (16-row, 8-wave tiles ask for >= 6 waves per SIMD, i.e. <= 80 VGPRs: three workgroups per CU
 // overlap one tile's global loads with the others' MFMAs; measured +4 % on c4 over the default 88)
-template <typename T, int NT, int MT, int W>
-__global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacobian_kernel(const MlpDev<T> mlp,
+template <typename T, int NT, int MT, int W, typename SH = DynShape>
+__global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacobian_kernel(const MlpDev<T> mlp_in,
                                                               const T* __restrict__ wout_plain,
                                                               const T* __restrict__ dz, int n,
                                                               int n_pad, T* __restrict__ jx,
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   using Net = TileNet<T, NT, MT, W, false>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int NIMAX = 3;  // kin <= 48
+  const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
   constexpr int KSH = Net::KSH, KSW = Net::KSW, GH = Net::GH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
