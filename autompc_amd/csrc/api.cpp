@@ -448,10 +448,9 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   p->static_shape = -1;
   if (!h->has_sindy && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
     const int sid = static_shape_of<T>(h, m);
-    if (sid >= 0) {
-      const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, M, h->nw, true, true);
-      if (std::memcmp(&S, &p->L, sizeof(TileLds)) == 0) p->static_shape = sid;
-    }
+    const int lv = sid >= 0 ? lds_variant_of<T>(m, p->L, M, h->nw) : -1;
+    // instantiated: 16-row tiles with the richest map, 32-row tiles with any of the three
+    if (lv == 0 || (lv > 0 && p->mt == 2)) { p->static_shape = sid; p->static_lv = lv; }
   }
   std::vector<MppiProblem<T>> pr(p->B);
   std::vector<int> tile_prob;

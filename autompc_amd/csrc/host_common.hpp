@@ -237,6 +237,7 @@ struct ampc_mppi_plan {
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
   int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
+  int static_lv = 0;      // which LDS map variant (StaticShape LV) the plan's tile uses
   int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
   std::vector<int> N, H, cost_idx, a_off;
   std::vector<unsigned> noise_id;   // per problem: key of its device noise stream (default: index)
@@ -374,6 +375,16 @@ template <typename T> inline int static_shape_of(const ampc_handle* h, const Mlp
     AMPC_STATIC_SHAPES(AMPC_SD_ONE)                                      \
     default: return fail("internal: unknown static shape");              \
   }
+
+// LDS map variant (StaticShape LV) of a tile map produced by tile_lds_for, or -1 if it is none of
+// the three maps the shape implies
+template <typename T> inline int lds_variant_of(const MlpDev<T>& m, const TileLds& L, int M, int W) {
+  for (int lv = 0; lv < 3; ++lv) {
+    const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, M, W, lv < 2, lv == 0);
+    if (std::memcmp(&S, &L, sizeof(TileLds)) == 0) return lv;
+  }
+  return -1;
+}
 
 // ---------------------------------------------------------------------------------------------
 // heavy launchers: defined in launch_*.cpp, explicitly instantiated there for double and float

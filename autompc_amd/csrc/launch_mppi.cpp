@@ -32,24 +32,27 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   } else if (p->static_shape >= 0) {
     // shape-specialised instantiation (dimensions, strides and LDS offsets are immediates)
     // (relu -- the reference's default, mlp.py:126-128 -- gets its own instantiation; the other
-    // activations share one with a run-time switch)
-    switch ((p->static_shape * 4 + p->mt) * 2 + (h->act == 0 ? 1 : 0)) {
-#define AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, RELU)                                     \
-      case (ID * 4 + MTV) * 2 + RELU: {                                                               \
+    // activations share one with a run-time switch.  (tile rows, LDS map): (16, 0) (32, 0) (32, 1) (32, 2))
+    const int geo = p->mt == 1 ? 0 : 1 + p->static_lv;
+    switch ((p->static_shape * 4 + geo) * 2 + (h->act == 0 ? 1 : 0)) {
+#define AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, GEO, MTV, LVV, RELU)                            \
+      case (ID * 4 + GEO) * 2 + RELU: {                                                               \
         constexpr int W = (HPAD % 128 == 0) ? 8 : 4, NT = HPAD / (16 * W);                             \
-        auto k = mppi_rollout_kernel<T, NT, MTV, W, StaticShape<NX, NU, NO, NH, HPAD, RELU ? 0 : -1>>; \
+        auto k = mppi_rollout_kernel<T, NT, MTV, W, StaticShape<NX, NU, NO, NH, HPAD, RELU ? 0 : -1, LVV>>; \
         HIP_OK(allow_lds(k, p->lds_bytes));                                                           \
         hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);             \
       } break;
-#define AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, MTV)   \
-      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, 0)  \
-      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, MTV, 1)
-#define AMPC_SHAPE_LAUNCH(ID, NX, NU, NO, NH, HPAD)       \
-      AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, 1)   \
-      AMPC_SHAPE_LAUNCH_MT(ID, NX, NU, NO, NH, HPAD, 2)
+#define AMPC_SHAPE_LAUNCH_GEO(ID, NX, NU, NO, NH, HPAD, GEO, MTV, LVV)   \
+      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, GEO, MTV, LVV, 0)  \
+      AMPC_SHAPE_LAUNCH_ONE(ID, NX, NU, NO, NH, HPAD, GEO, MTV, LVV, 1)
+#define AMPC_SHAPE_LAUNCH(ID, NX, NU, NO, NH, HPAD)             \
+      AMPC_SHAPE_LAUNCH_GEO(ID, NX, NU, NO, NH, HPAD, 0, 1, 0)  \
+      AMPC_SHAPE_LAUNCH_GEO(ID, NX, NU, NO, NH, HPAD, 1, 2, 0)  \
+      AMPC_SHAPE_LAUNCH_GEO(ID, NX, NU, NO, NH, HPAD, 2, 2, 1)  \
+      AMPC_SHAPE_LAUNCH_GEO(ID, NX, NU, NO, NH, HPAD, 3, 2, 2)
       AMPC_STATIC_SHAPES(AMPC_SHAPE_LAUNCH)
 #undef AMPC_SHAPE_LAUNCH
-#undef AMPC_SHAPE_LAUNCH_MT
+#undef AMPC_SHAPE_LAUNCH_GEO
 #undef AMPC_SHAPE_LAUNCH_ONE
       default: return fail("internal: unknown static shape");
     }

@@ -234,7 +234,10 @@ struct DynShape {
 
 // ACT >= 0 also fixes the activation (the run-time switch keeps all five epilogues in the loop
 // body: ~4x the code of the relu-only loop); ACT = -1 leaves it a run-time value.
-template <int NX, int NU, int NO, int NH, int HPAD, int ACT = -1> struct StaticShape {
+// LV selects the LDS map the tile uses (tile_lds_for picks the richest that fits the 160 KB):
+//   0 ping-pong activations + separate partials, 1 one activation buffer + separate partials,
+//   2 one buffer shared by activations and partials.
+template <int NX, int NU, int NO, int NH, int HPAD, int ACT = -1, int LV = 0> struct StaticShape {
   static constexpr bool kStatic = true;
   static constexpr int nx = NX, nu = NU, no = NO, n_hidden = NH, hpad = HPAD;
   static constexpr int k1p = (NX + NU + 7) / 8 * 8;
@@ -248,7 +251,7 @@ template <int NX, int NU, int NO, int NH, int HPAD, int ACT = -1> struct StaticS
     return m;
   }
   template <typename T, int M, int W> static constexpr TileLds lds_map() {
-    return tile_lds_dims((int)sizeof(T), HPAD, k1p, nxp, NH, M, W, true, true);
+    return tile_lds_dims((int)sizeof(T), HPAD, k1p, nxp, NH, M, W, LV < 2, LV == 0);
   }
   template <typename T, int M, int W>
   __device__ __forceinline__ static TileLds fold_lds(const TileLds&) { return lds_map<T, M, W>(); }
