@@ -53,6 +53,8 @@ SIGNATURES = {
     "ampc_mppi_upload": (c_int, [c_void_p, _dp, _dp, _dp]),
     "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
     "ampc_mppi_plan_set_noise_ids": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ampc_mppi_legacy_normal": (c_int, [c_void_p, POINTER(c_uint32), c_int, c_int, c_double,
+                                        POINTER(c_uint32), _ip, _ip, _dp]),
     "ampc_mppi_plan_set_geometry": (c_int, [c_void_p, c_int, c_int]),
     "ampc_mppi_solve": (c_int, [c_void_p]),
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
@@ -325,6 +327,22 @@ class MppiPlan:
 
     def generate_eps(self, seed, stream=0):
         check(self.lib.ampc_mppi_generate_eps(self._p, int(seed), int(stream)))
+
+    def legacy_normal(self, state):
+        """Fill the noise buffer with numpy's legacy normal draw for the generator state `state`
+        (the tuple np.random.get_state() returns); returns the state to install afterwards."""
+        name, key, pos, has_gauss, cached = state
+        if name != "MT19937":
+            raise ValueError("numpy's legacy global generator (MT19937) expected")
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        key_out = np.empty(624, dtype=np.uint32)
+        pos_out, hg_out, cached_out = c_int(), c_int(), c_double()
+        u32p = POINTER(c_uint32)
+        check(self.lib.ampc_mppi_legacy_normal(self._p, key.ctypes.data_as(u32p), int(pos), int(has_gauss),
+                                               float(cached), key_out.ctypes.data_as(u32p),
+                                               ctypes.byref(pos_out), ctypes.byref(hg_out),
+                                               ctypes.byref(cached_out)))
+        return ("MT19937", key_out, pos_out.value, hg_out.value, cached_out.value)
 
     def set_geometry(self, tile_rows=0, horizon_cap=0):
         """Fix the rollout tile height (0 = automatic, 16/32/64) and the horizon the LDS layout is

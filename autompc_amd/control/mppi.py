@@ -50,8 +50,9 @@ class MPPI(Controller):
         self.precision = kwargs.get("precision", getattr(model, "precision", "f64"))
         self.device = kwargs.get("device", getattr(model, "device", 0))
         self.per_particle_terminal = bool(kwargs.get("per_particle_terminal", False))
-        if self.noise not in ("numpy", "device"):
-            raise ValueError("noise must be 'numpy' (parity) or 'device' (fast)")
+        if self.noise not in ("numpy", "numpy_device", "device"):
+            raise ValueError("noise must be 'numpy' (parity, host draw), 'numpy_device' (numpy's "
+                             "legacy stream generated on the device) or 'device' (Philox, fast)")
         bounds = task.get_ctrl_bounds()
         self.umin = bounds[:, 0].copy()
         self.umax = bounds[:, 1].copy()
@@ -119,6 +120,11 @@ class MPPI(Controller):
         if self.noise == "numpy":
             eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
             plan.upload(x0=x0, act_seq=act, eps=eps)
+        elif self.noise == "numpy_device":
+            # the same draw from the same global generator state, made on the device; the host
+            # generator is then put into the state the draw would have left it in
+            plan.upload(x0=x0, act_seq=act)
+            np.random.set_state(plan.legacy_normal(np.random.get_state()))
         else:
             plan.upload(x0=x0, act_seq=act)
             plan.generate_eps(self.seed, self.cur_step)

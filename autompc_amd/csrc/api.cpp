@@ -3,6 +3,7 @@
 // families are launched through the templates declared in host_common.hpp (launch_*.cpp).
 // Built with hipcc for gfx950 only.
 #include "host_common.hpp"
+#include "legacy_rng_kernels.hpp"      // (non-template kernels: this translation unit only)
 
 thread_local std::string g_err;
 
@@ -547,7 +548,11 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
-                    &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part};
+                    &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
+                    &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
+                    &p->lg_scale};
+  if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
+  if (p->lg_ev) (void)hipEventDestroy(p->lg_ev);
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
@@ -598,6 +603,133 @@ extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t
   return p->h->precision == AMPC_F64 ? mppi_generate_impl<double>(p, seed, stream)
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
+// numpy's legacy normal stream generated on the device (legacy_rng_kernels.hpp)
+static uint32_t mt_untemper(uint32_t y) {
+  y ^= y >> 18;
+  y ^= (y << 15) & 0xefc60000u;
+  uint32_t t = y;                                   // invert y ^= (y << 7) & 0x9d2c5680
+  for (int i = 0; i < 4; ++i) t = y ^ ((t << 7) & 0x9d2c5680u);
+  y = t;
+  t = y;                                            // invert y ^= y >> 11
+  for (int i = 0; i < 2; ++i) t = y ^ (t >> 11);
+  return t;
+}
+
+template <typename T>
+static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
+                              uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out) {
+  ampc_handle* h = p->h;
+  const long long n = p->sum_nhnu;
+  const int shift = has_gauss ? 1 : 0;
+  const long long n_pairs = (n - shift + 1) / 2;
+  if (n_pairs == 0) {          // the single value asked for is the cached one
+    HIP_OK(p->lg_scale.reserve(sizeof(double)));
+    const double sc = std::sqrt(p->sigma[0]);
+    HIP_OK(hipMemcpyAsync(p->lg_scale.p, &sc, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(legacy_first_value_kernel<T>, dim3(1), dim3(64), 0, h->stream, cached,
+                       (const double*)p->lg_scale.p, (T*)p->eps.p);
+    HIP_OK(hipStreamSynchronize(h->stream));
+    std::memcpy(key_out, key, kMtN * sizeof(uint32_t));
+    *pos_out = pos; *has_gauss_out = 0; *cached_out = 0.0;
+    return 0;
+  }
+  // attempts to evaluate: acceptance probability pi/4, 2 % + 4096 slack (the count is checked)
+  const long long n_att = (long long)((double)n_pairs / 0.7853981633974483 * 1.02) + 4096;
+  auto blocks_for = [&](int start_pos) { return (int)(((long long)start_pos + 4 * n_att) / kMtN) + 2; };
+  const int nblocks = blocks_for(pos);
+  const int n_wg = (int)((n_att + kPolarPerWg - 1) / kPolarPerWg);
+  REQUIRE(n_wg <= 65536 * 16, "legacy normal: too many values for one call");
+  if (!p->lg_side) {
+    HIP_OK(hipStreamCreateWithFlags(&p->lg_side, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&p->lg_ev, hipEventDisableTiming));
+  }
+  HIP_OK(p->lg_cnt.reserve(((size_t)n_wg + 1) * sizeof(int)));
+  HIP_OK(p->lg_fin.reserve(2 * sizeof(long long)));
+  HIP_OK(p->lg_scale.reserve((size_t)p->B * sizeof(double)));
+  std::vector<double> sc(p->B);
+  for (int b = 0; b < p->B; ++b) sc[b] = std::sqrt(p->sigma[b]);
+  const long long fin0[2] = {-1, 0};
+  HIP_OK(hipMemcpyAsync(p->lg_scale.p, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(p->lg_fin.p, fin0, sizeof(fin0), hipMemcpyHostToDevice, h->stream));
+  // the raw stream: the speculation of the previous call if this call starts where that one ended
+  const bool hit = p->lg_spec && p->lg_spec_pos == pos && p->lg_spec_blocks >= nblocks &&
+                   std::memcmp(p->lg_spec_key.data(), key, kMtN * sizeof(uint32_t)) == 0;
+  int buf = p->lg_cur;
+  if (hit) {
+    HIP_OK(hipStreamWaitEvent(h->stream, p->lg_ev, 0));
+  } else {
+    if (p->lg_spec) HIP_OK(hipStreamSynchronize(p->lg_side));       // (a stale speculation still running)
+    buf = p->lg_cur = 0;
+    HIP_OK(p->lg_key[0].reserve(kMtN * sizeof(uint32_t)));
+    HIP_OK(p->lg_stream[0].reserve((size_t)nblocks * kMtN * sizeof(uint32_t)));
+    HIP_OK(hipMemcpyAsync(p->lg_key[0].p, key, kMtN * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));          // (sources are stack / caller memory)
+    hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, h->stream,
+                       (const uint32_t*)p->lg_key[0].p, nblocks, (uint32_t*)p->lg_stream[0].p);
+  }
+  p->lg_spec = false;
+  uint32_t* stream = (uint32_t*)p->lg_stream[buf].p;
+  const uint32_t* u = stream + pos;                 // the generator's next output
+  int* cnt = (int*)p->lg_cnt.p;
+  hipLaunchKernelGGL(polar_count_kernel, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, cnt);
+  hipLaunchKernelGGL(polar_scan_kernel, dim3(1), dim3(256), 0, h->stream, cnt, n_wg, cnt + n_wg);
+  if (shift)
+    hipLaunchKernelGGL(legacy_first_value_kernel<T>, dim3(1), dim3(64), 0, h->stream, cached,
+                       (const double*)p->lg_scale.p, (T*)p->eps.p);
+  hipLaunchKernelGGL(polar_scatter_kernel<T>, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att,
+                     (const int*)cnt, n, shift, (const MppiProblem<T>*)p->probs.p,
+                     (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, (long long*)p->lg_fin.p);
+  HIP_OK(hipGetLastError());
+  long long fin[2];
+  int total = 0;
+  HIP_OK(hipMemcpyAsync(fin, p->lg_fin.p, sizeof(fin), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipMemcpyAsync(&total, cnt + n_wg, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  REQUIRE(total >= n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
+  // generator state after the last consumed word
+  long long idx = (long long)pos + 4 * (fin[0] + 1);
+  long long blk = idx / kMtN;
+  int po = (int)(idx % kMtN);
+  if (po == 0 && idx > 0) { blk -= 1; po = kMtN; }  // randomkit regenerates lazily: pos == 624
+  std::vector<uint32_t> last(kMtN);
+  HIP_OK(hipMemcpy(last.data(), stream + (size_t)blk * kMtN, kMtN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (int i = 0; i < kMtN; ++i) key_out[i] = mt_untemper(last[i]);
+  *pos_out = po;
+  const bool odd = ((n - shift) & 1) != 0;
+  *has_gauss_out = odd ? 1 : 0;
+  double cg = 0.0;
+  if (odd) std::memcpy(&cg, &fin[1], sizeof(double));
+  *cached_out = cg;
+  // speculate: the next call most likely starts from the state this one leaves behind (nothing else
+  // drew from the generator in between) and consumes about as many words.  Its stream is generated
+  // on the side stream into the other buffer while the caller's solve runs on the main stream.
+  if (env_int("AMPC_LEGACY_SPECULATE", 1) != 0) {
+    const int nb = 1 - buf;
+    const int sb = blocks_for(po);
+    HIP_OK(p->lg_key[nb].reserve(kMtN * sizeof(uint32_t)));
+    HIP_OK(p->lg_stream[nb].reserve((size_t)sb * kMtN * sizeof(uint32_t)));
+    p->lg_spec_key.assign(key_out, key_out + kMtN);
+    HIP_OK(hipMemcpyAsync(p->lg_key[nb].p, p->lg_spec_key.data(), kMtN * sizeof(uint32_t),
+                          hipMemcpyHostToDevice, p->lg_side));
+    hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, p->lg_side,
+                       (const uint32_t*)p->lg_key[nb].p, sb, (uint32_t*)p->lg_stream[nb].p);
+    HIP_OK(hipEventRecord(p->lg_ev, p->lg_side));
+    p->lg_spec = true; p->lg_spec_pos = po; p->lg_spec_blocks = sb; p->lg_cur = nb;
+  }
+  return 0;
+}
+
+extern "C" int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
+                                       double cached, uint32_t* key_out, int* pos_out,
+                                       int* has_gauss_out, double* cached_out) {
+  REQUIRE(p && key && key_out && pos_out && has_gauss_out && cached_out, "ampc_mppi_legacy_normal: NULL argument");
+  REQUIRE(pos >= 0 && pos <= kMtN, "ampc_mppi_legacy_normal: generator position must be in 0..624");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? legacy_normal_impl<double>(p, key, pos, has_gauss, cached, key_out, pos_out, has_gauss_out, cached_out)
+             : legacy_normal_impl<float>(p, key, pos, has_gauss, cached, key_out, pos_out, has_gauss_out, cached_out);
+}
+
 extern "C" int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int horizon_cap) {
   REQUIRE(p, "ampc_mppi_plan_set_geometry: NULL plan");
   REQUIRE(tile_rows == 0 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64,

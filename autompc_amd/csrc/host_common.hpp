@@ -245,6 +245,16 @@ struct ampc_mppi_plan {
   std::vector<long long> eps_off, epso_off, cost_off;
   long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
   DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part;
+  // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
+  // call is generated speculatively on a side stream (it only depends on the generator state this
+  // call leaves behind) and used if the next call indeed starts from that state.
+  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale;
+  hipStream_t lg_side = nullptr;
+  hipEvent_t lg_ev = nullptr;
+  int lg_cur = 0;                 // buffer the speculation (if any) was written to
+  bool lg_spec = false;
+  int lg_spec_pos = 0, lg_spec_blocks = 0;
+  std::vector<uint32_t> lg_spec_key;
   int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
   bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
   int cur = 0;          // act[cur] is the input of the next solve

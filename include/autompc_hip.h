@@ -137,6 +137,17 @@ int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
  * (seed, stream, noise id of the problem, element).  `stream` (< 2^56) is the caller's step
  * counter.  Statistically equivalent to, not bit-identical with, numpy's draw (mppi.py:21-24). */
 int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
+/* The reference's noise draw itself, on the device: fills the plan's noise buffer with what
+ *   np.random.normal(scale=sqrt(sigma_p), size=(N_p, H_p, nu))          (mppi.py:16-24, :126)
+ * returns for every problem in turn when numpy's global LEGACY generator (MT19937 + polar method
+ * with its cached second value) is in the state (key[624], pos, has_gauss, cached) -- the tuple
+ * np.random.get_state() returns -- and hands back the state the generator is left in, to be
+ * installed with np.random.set_state().  The raw MT19937 stream, the uniform doubles and every
+ * accept / reject decision are bit-identical to numpy's; the normals are identical except where
+ * the device's log() rounds differently from the host libm's (last bit).  Synchronises. */
+int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
+                            double cached, uint32_t* key_out, int* pos_out, int* has_gauss_out,
+                            double* cached_out);
 /* ids[B]: the noise id of every problem (default: its index in the plan).  The candidate
  * evaluator passes each candidate's GLOBAL index, so that the noise -- and therefore the
  * surrogate score pipeline_tuner.py:213-258 returns for it -- does not depend on how a batch of

@@ -1,0 +1,146 @@
+"""numpy's legacy normal stream generated on the device (ampc_mppi_legacy_normal) against numpy
+itself: the reference draws MPPI's noise with np.random.normal(scale=sqrt(sigma), size=(N, H, nu))
+from the global legacy generator (autompc/control/mppi.py:16-24, :126).  Needs MI355X."""
+import numpy as np
+import pytest
+
+from helpers import check_weights, golden_params, make_system, rel_err
+from conftest import golden
+from oracle import mlp as omlp
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(N, H, sigma, nx=2, nu=1, precision="f64", B=1):
+    from autompc_amd import MLP, _lib
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [64, 64], "relu", seed=1)
+    m = MLP(system, n_hidden_layers=2, hidden_size=64, nonlintype="relu", precision=precision)
+    m.weights, m.biases = p["weights"], p["biases"]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    h = _lib.Handle(0, precision)
+    m.stage_into(h)
+    h.set_quad_costs(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))     # (tests use sigma << 1: nothing reaches the clip at +-1)
+    N, H, sigma = np.atleast_1d(N), np.atleast_1d(H), np.atleast_1d(sigma)
+    plan = _lib.MppiPlan(h, N, H, sigma, np.ones(len(N)))
+    return h, plan
+
+
+def _device_draw(plan):
+    """legacy_normal + read the noise back through a solve with a zero warm start and noise far
+    inside the bounds (eps_out == eps, laid out [H][N][nu] per problem)."""
+    new_state = plan.legacy_normal(np.random.get_state())
+    plan.upload(x0=np.zeros((plan.B, plan.handle.nx)), act_seq=np.zeros(plan.sum_hnu))
+    plan.solve()
+    _, _, _, e = plan.download(act_seq=False, u=False, eps_out=True)
+    return new_state, e
+
+
+@pytest.mark.parametrize("N,H,nu,seed,pre", [(1000, 20, 1, 0, 0), (333, 7, 3, 5, 0), (64, 5, 1, 11, 1),
+                                             (4096, 30, 6, 3, 0), (50, 3, 1, 2, 3)])
+def test_stream_and_state_match_numpy(N, H, nu, seed, pre):
+    """Same draw, same generator state afterwards.  `pre` normals are drawn on the host first so
+    that the call starts with a value in numpy's cache (odd counts) / mid-block positions."""
+    sigma = 0.0049            # std 0.07: 14 sigma to the clip
+    h, plan = _plan(N, H, sigma, nx=2, nu=nu)
+    np.random.seed(seed)
+    np.random.normal(size=pre)
+    st0 = np.random.get_state()
+    ref = np.random.normal(scale=np.sqrt(sigma), size=(N, H, nu))
+    st_ref = np.random.get_state()
+    np.random.set_state(st0)
+    st_dev, e = _device_draw(plan)
+    got = e.reshape(H, N, nu).transpose(1, 0, 2)
+    # every accept / reject decision and the MT19937 state are exact ...
+    assert st_dev[2] == st_ref[2] and st_dev[3] == st_ref[3]
+    np.testing.assert_array_equal(st_dev[1], st_ref[1])
+    if st_ref[3]:
+        assert abs(st_dev[4] - st_ref[4]) <= 2 * np.spacing(abs(st_ref[4]))
+    # ... the normals agree to the last bit or two (device log vs host libm)
+    ulp = np.spacing(np.abs(ref))
+    assert np.max(np.abs(got - ref) / ulp) <= 4.0
+    assert np.mean(got == ref) > 0.95
+    # the host generator continues exactly where numpy's own draw would have left it
+    np.random.set_state(st_dev)
+    a = np.random.random_sample(5)
+    np.random.set_state(st_ref)
+    np.testing.assert_array_equal(a, np.random.random_sample(5))
+    plan.close()
+    h.close()
+
+
+def test_two_problems_draw_in_turn_with_their_own_scale():
+    h, plan = _plan([40, 25], [6, 4], [0.005, 0.02], nx=2, nu=1)
+    np.random.seed(9)
+    st0 = np.random.get_state()
+    r0 = np.random.normal(scale=np.sqrt(0.005), size=(40, 6, 1))
+    r1 = np.random.normal(scale=np.sqrt(0.02), size=(25, 4, 1))
+    np.random.set_state(st0)
+    _, e = _device_draw(plan)
+    g0 = e[:240].reshape(6, 40, 1).transpose(1, 0, 2)
+    g1 = e[240:].reshape(4, 25, 1).transpose(1, 0, 2)
+    assert rel_err(g0, r0) < 1e-15 and rel_err(g1, r1) < 1e-15
+    plan.close()
+    h.close()
+
+
+@pytest.mark.parametrize("name", ["mppi_c2_pendulum", "mppi_clip_asym"])
+def test_mppi_golden_with_device_drawn_numpy_noise(name):
+    """The reference's golden MPPI runs reproduced with noise='numpy_device': same seeds, the draw
+    made on the device; the warm start (drawn on the host at construction) is bit-identical."""
+    from autompc_amd import MLP, MPPI, QuadCost, Task
+    from oracle.mlp import MLPOracle
+    g = golden(name)
+    nx = int(g["nx"])
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    check_weights(p, g)
+    system = make_system(nx, 1)
+    m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
+            **{"hidden_size_%d" % (i + 1): w.shape[0] for i, w in enumerate(p["weights"][:-1])})
+    m.weights, m.biases = p["weights"], p["biases"]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    task.set_ctrl_bounds([g["bounds"][0]], [g["bounds"][1]])
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPI(system, task, m, horizon=int(g["H"]), num_path=int(g["N"]), sigma=float(g["sigma"]),
+               lmda=float(g["lmda"]), noise="numpy_device")
+    np.testing.assert_array_equal(ctl.act_sequence, g["act0"])
+    obs = np.random.default_rng(int(g["np_seed"]) + 99).uniform(-0.1, 0.1, size=nx)
+    constate = np.concatenate([obs, np.zeros(1)])
+    ref_model = MLPOracle(system, p)
+    for r in range(int(g["n_runs"])):
+        if r == 3:
+            ctl.reset()
+            np.testing.assert_array_equal(ctl.act_sequence, g["act_reset"])   # host stream stayed in step
+        u, constate = ctl.run(constate, obs, return_details=True)
+        assert rel_err(ctl.last_costs, g["costs_%d" % r]) < 1e-9
+        assert rel_err(ctl.last_eps[:, ::16, :], g["eps_sub_%d" % r]) < 1e-12
+        assert rel_err(ctl.act_sequence, g["act_%d" % r]) < 1e-8
+        assert rel_err(u, g["u_%d" % r]) < 1e-8
+        obs = ref_model.pred(obs, g["u_%d" % r])
+
+
+def test_consecutive_calls_and_interleaved_host_draws():
+    """The next call's raw stream is generated speculatively from the state a call leaves behind:
+    consecutive calls take that path, a host draw in between invalidates it -- both must continue
+    numpy's stream exactly."""
+    N, H, nu, sigma = 500, 10, 2, 0.0049
+    h, plan = _plan(N, H, sigma, nx=2, nu=nu)
+    np.random.seed(21)
+    for call in range(6):
+        if call in (3, 5):
+            np.random.normal(size=3 + call)          # someone else draws: speculation misses
+        st0 = np.random.get_state()
+        ref = np.random.normal(scale=np.sqrt(sigma), size=(N, H, nu))
+        st_ref = np.random.get_state()
+        np.random.set_state(st0)
+        st_dev, e = _device_draw(plan)
+        got = e.reshape(H, N, nu).transpose(1, 0, 2)
+        assert st_dev[2] == st_ref[2] and st_dev[3] == st_ref[3]
+        np.testing.assert_array_equal(st_dev[1], st_ref[1])
+        assert np.max(np.abs(got - ref) / np.spacing(np.abs(ref))) <= 4.0
+        np.random.set_state(st_dev)
+    plan.close()
+    h.close()

@@ -9,7 +9,7 @@ from autompc_amd.synthetic import make_workload
 
 for name in ("c3", "c2", "arx"):
     system, task, model, spec = make_workload(name)
-    for noise in ("device", "numpy"):
+    for noise in ("device", "numpy_device", "numpy"):
         np.random.seed(0)
         ctl = MPPI(system, task, model, horizon=spec["horizon"], num_path=spec["num_path"], sigma=1.0,
                    lmda=1.0, noise=noise)
@@ -18,14 +18,14 @@ for name in ("c3", "c2", "arx"):
         one = zeros(system, 1)
         one.obs[0, :] = obs
         cs = ctl.traj_to_state(one)
-        n = 200 if noise == "device" else 20
+        n = 20 if noise == "numpy" else 200
         for _ in range(5):
             u, cs = ctl.run(cs, obs)
         t0 = time.perf_counter()
         for _ in range(n):
             u, cs = ctl.run(cs, obs)
         dt = time.perf_counter() - t0
-        print("%-4s MPPI.run noise=%-6s %8.1f calls/s  (%.3f ms per call)" % (name, noise, n / dt, 1e3 * dt / n))
+        print("%-4s MPPI.run noise=%-12s %8.1f calls/s  (%.3f ms per call)" % (name, noise, n / dt, 1e3 * dt / n))
 system, task, model, spec = make_workload("c3")
 from autompc_amd import QuadCost, Task
 t2 = Task(system)
