@@ -53,6 +53,7 @@ SIGNATURES = {
     "ampc_mppi_upload": (c_int, [c_void_p, _dp, _dp, _dp]),
     "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
     "ampc_mppi_plan_set_noise_ids": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ampc_set_mt_jump_table": (c_int, [POINTER(c_uint32), c_int, c_int]),
     "ampc_mppi_legacy_normal": (c_int, [c_void_p, POINTER(c_uint32), c_int, c_int, c_double,
                                         POINTER(c_uint32), _ip, _ip, _dp]),
     "ampc_mppi_plan_set_geometry": (c_int, [c_void_p, c_int, c_int]),
@@ -328,9 +329,26 @@ class MppiPlan:
     def generate_eps(self, seed, stream=0):
         check(self.lib.ampc_mppi_generate_eps(self._p, int(seed), int(stream)))
 
+    _jump_table_set = False
+
+    @classmethod
+    def _install_jump_table(cls, lib):
+        """MT19937 jump polynomials for the block-parallel stream generator (once per process);
+        without the data file the library generates the stream sequentially."""
+        if cls._jump_table_set:
+            return
+        cls._jump_table_set = True
+        path = os.path.join(_HERE, "data", "mt19937_jump.npz")
+        if os.path.exists(path):
+            d = np.load(path)
+            polys = np.ascontiguousarray(d["polys"], dtype=np.uint32)
+            check(lib.ampc_set_mt_jump_table(polys.ctypes.data_as(POINTER(c_uint32)), polys.shape[0],
+                                             int(d["jump_blocks"])))
+
     def legacy_normal(self, state):
         """Fill the noise buffer with numpy's legacy normal draw for the generator state `state`
         (the tuple np.random.get_state() returns); returns the state to install afterwards."""
+        self._install_jump_table(self.lib)
         name, key, pos, has_gauss, cached = state
         if name != "MT19937":
             raise ValueError("numpy's legacy global generator (MT19937) expected")

@@ -550,7 +550,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
-                    &p->lg_scale};
+                    &p->lg_scale, &p->lg_xraw, &p->lg_poly, &p->lg_win};
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   if (p->lg_ev) (void)hipEventDestroy(p->lg_ev);
   for (DevBuf* b : bufs) b->release();
@@ -604,6 +604,44 @@ extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
 // numpy's legacy normal stream generated on the device (legacy_rng_kernels.hpp)
+static std::vector<uint32_t> g_mt_polys;      // [n][624] jump polynomials (tools/mt_jump.py), host copy
+static int g_mt_jump_blocks = 0;
+static constexpr int kMtHead = 34;            // blocks 0..33 come from the sequential head kernel
+
+extern "C" int ampc_set_mt_jump_table(const uint32_t* polys, int n_polys, int jump_blocks) {
+  REQUIRE(polys && n_polys >= 1 && jump_blocks >= kMtHead, "ampc_set_mt_jump_table: bad table");
+  g_mt_polys.assign(polys, polys + (size_t)n_polys * kMtN);
+  g_mt_jump_blocks = jump_blocks;
+  return 0;
+}
+
+// raw MT19937 stream of `nblocks` blocks from `key` into `stream` (enqueued on `st`): the head
+// sequentially, the rest block-parallel when the jump table covers it
+static int launch_mt_stream(ampc_mppi_plan* p, hipStream_t st, const uint32_t* d_key, int nblocks,
+                            uint32_t* stream) {
+  const int nseg = g_mt_jump_blocks > 0 ? (nblocks - 1 + g_mt_jump_blocks - 1) / g_mt_jump_blocks : 0;
+  const bool par = nseg >= 1 && nblocks > kMtHead && (size_t)(nseg - 1) * kMtN <= g_mt_polys.size();
+  if (!par) {
+    hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, st, d_key, nblocks, stream, (uint32_t*)nullptr);
+    return 0;
+  }
+  HIP_OK(p->lg_xraw.reserve((size_t)(kMtHead - 1) * kMtN * sizeof(uint32_t)));
+  if (p->lg_poly.bytes == 0) {
+    HIP_OK(p->lg_poly.reserve(g_mt_polys.size() * sizeof(uint32_t)));
+    HIP_OK(hipMemcpy(p->lg_poly.p, g_mt_polys.data(), g_mt_polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, st, d_key, kMtHead, stream, (uint32_t*)p->lg_xraw.p);
+  if (nseg > 1) {
+    HIP_OK(p->lg_win.reserve((size_t)(nseg - 1) * kMtN * sizeof(uint32_t)));
+    HIP_OK(hipMemsetAsync(p->lg_win.p, 0, (size_t)(nseg - 1) * kMtN * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(mt19937_jump_kernel, dim3(nseg - 1, kMtSlices), dim3(256), 0, st,
+                       (const uint32_t*)p->lg_xraw.p, (const uint32_t*)p->lg_poly.p, (uint32_t*)p->lg_win.p);
+  }
+  hipLaunchKernelGGL(mt19937_segment_kernel, dim3(nseg), dim3(256), 0, st, (const uint32_t*)p->lg_xraw.p,
+                     (const uint32_t*)p->lg_win.p, kMtHead, g_mt_jump_blocks, nblocks, stream);
+  return 0;
+}
+
 static uint32_t mt_untemper(uint32_t y) {
   y ^= y >> 18;
   y ^= (y << 15) & 0xefc60000u;
@@ -664,8 +702,8 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
     HIP_OK(p->lg_stream[0].reserve((size_t)nblocks * kMtN * sizeof(uint32_t)));
     HIP_OK(hipMemcpyAsync(p->lg_key[0].p, key, kMtN * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));          // (sources are stack / caller memory)
-    hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, h->stream,
-                       (const uint32_t*)p->lg_key[0].p, nblocks, (uint32_t*)p->lg_stream[0].p);
+    if (int rc = launch_mt_stream(p, h->stream, (const uint32_t*)p->lg_key[0].p, nblocks,
+                                  (uint32_t*)p->lg_stream[0].p)) return rc;
   }
   p->lg_spec = false;
   uint32_t* stream = (uint32_t*)p->lg_stream[buf].p;
@@ -711,8 +749,8 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
     p->lg_spec_key.assign(key_out, key_out + kMtN);
     HIP_OK(hipMemcpyAsync(p->lg_key[nb].p, p->lg_spec_key.data(), kMtN * sizeof(uint32_t),
                           hipMemcpyHostToDevice, p->lg_side));
-    hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, p->lg_side,
-                       (const uint32_t*)p->lg_key[nb].p, sb, (uint32_t*)p->lg_stream[nb].p);
+    if (int rc = launch_mt_stream(p, p->lg_side, (const uint32_t*)p->lg_key[nb].p, sb,
+                                  (uint32_t*)p->lg_stream[nb].p)) return rc;
     HIP_OK(hipEventRecord(p->lg_ev, p->lg_side));
     p->lg_spec = true; p->lg_spec_pos = po; p->lg_spec_blocks = sb; p->lg_cur = nb;
   }

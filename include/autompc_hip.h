@@ -148,6 +148,11 @@ int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
 int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
                             double cached, uint32_t* key_out, int* pos_out, int* has_gauss_out,
                             double* cached_out);
+/* Jump polynomials of MT19937 (autompc_amd/data/mt19937_jump.npz, computed by tools/mt_jump.py):
+ * polys[n_polys][624] = bits of t^(s * jump_blocks * 624) mod phi for s = 1 .. n_polys.  With the
+ * table installed (process-wide) ampc_mppi_legacy_normal generates the raw stream block-parallel
+ * (one workgroup per jump_blocks blocks) instead of sequentially; results are identical. */
+int ampc_set_mt_jump_table(const uint32_t* polys, int n_polys, int jump_blocks);
 /* ids[B]: the noise id of every problem (default: its index in the plan).  The candidate
  * evaluator passes each candidate's GLOBAL index, so that the noise -- and therefore the
  * surrogate score pipeline_tuner.py:213-258 returns for it -- does not depend on how a batch of
