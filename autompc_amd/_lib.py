@@ -198,7 +198,7 @@ class Handle:
             raise ValueError("A must be [nx, nx] and B [nx, nu]")
         check(self.lib.ampc_set_linear(self._h, nx, B.shape[1], dptr(A), dptr(B)))
         self.nx, self.nu = nx, B.shape[1]
-        self._sindy = nx > 32          # wide states are staged as a feature-library model
+        self._sindy = False
 
     def set_sindy(self, nx, nu, kind, arg0, arg1, param, xi, continuous, dt, strict_reference=True):
         kind = np.ascontiguousarray(kind, dtype=np.int32)

@@ -239,7 +239,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
                             const double* const* biases, const double* xu_mean,
                             const double* xu_std, const double* dy_mean, const double* dy_std) {
   REQUIRE(h, "ampc_set_mlp: NULL handle");
-  REQUIRE(nx >= 1 && nx <= 32, "ampc_set_mlp: state dim must be in 1..32");
+  REQUIRE(nx >= 1 && nx <= 64, "ampc_set_mlp: state dim must be in 1..64");
   REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_mlp: ctrl dim must be in 1..16");
   REQUIRE(n_hidden >= 1 && n_hidden <= kMaxHidden, "ampc_set_mlp: 1..4 hidden layers");
   REQUIRE(activation >= 0 && activation <= 4, "ampc_set_mlp: unknown activation");
@@ -251,6 +251,9 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
     REQUIRE(hidden_sizes[l] >= 1 && hidden_sizes[l] <= 256, "ampc_set_mlp: hidden size 1..256");
     hmax = hidden_sizes[l] > hmax ? hidden_sizes[l] : hmax;
   }
+  // more than 32 states: four output column tiles, built for the 64-wide tile only (the linear models
+  // that need it are staged with a hidden width equal to their state dimension)
+  REQUIRE(nx <= 32 || hmax <= 64, "ampc_set_mlp: state dims 33..64 need hidden layers of at most 64 units");
   h->nx = nx; h->nu = nu; h->n_hidden = n_hidden; h->act = activation;
   for (int l = 0; l < kMaxHidden; ++l) h->hidden[l] = l < n_hidden ? hidden_sizes[l] : 0;
   // Workgroup shape: 8 waves (two per SIMD) whenever the padded width allows whole 16-column
@@ -290,21 +293,6 @@ extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, 
   REQUIRE(nx >= 1 && nx <= 64, "ampc_set_linear: state dim must be in 1..64");
   REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_linear: ctrl dim must be in 1..16");
   const int kin = nx + nu;
-  if (nx > 32) {
-    // Wider than the MFMA tile's output (long-history ARX, large Koopman lifts): staged as a
-    // feature-library model with the nx + nu identity features and Xi = [A | B], i.e. the scalar
-    // one-thread-per-sample path of sindy_kernels.hpp (MPPI, prediction, Jacobians, closed loop;
-    // the iLQR plan is limited to 32 states).
-    std::vector<int> kind(kin, 0), a0(kin), a1(kin, 0);
-    std::vector<double> par(kin, 1.0), xi((size_t)nx * kin);
-    for (int k = 0; k < kin; ++k) a0[k] = k;
-    for (int i = 0; i < nx; ++i) {
-      for (int j = 0; j < nx; ++j) xi[(size_t)i * kin + j] = A[(size_t)i * nx + j];
-      for (int j = 0; j < nu; ++j) xi[(size_t)i * kin + nx + j] = B[(size_t)i * nu + j];
-    }
-    return ampc_set_sindy(h, nx, nu, kin, kind.data(), a0.data(), a1.data(), par.data(), xi.data(), 0,
-                          1.0, 0);
-  }
   std::vector<double> w0((size_t)nx * kin), w1((size_t)nx * nx, 0.0), b0(nx, 0.0);
   for (int i = 0; i < nx; ++i) {
     for (int j = 0; j < nx; ++j) w0[(size_t)i * kin + j] = A[(size_t)i * nx + j] - (i == j ? 1.0 : 0.0);

@@ -188,19 +188,23 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.
-#define AMPC_CASE(WV, NTV, MTV, ...) \
-  case (WV) * 100 + (NTV) * 10 + (MTV): { constexpr int W = WV, NT = NTV, MT = MTV; __VA_ARGS__; } break;
-#define AMPC_DISPATCH(WV, NTV, MTV, ...)                                     \
+// (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.  The body sees W, NT, MT and WD
+// (wide outputs: model states 33..64, the 64-wide tile only).
+#define AMPC_CASE(WV, NTV, MTV, WDV, ...) \
+  case ((WV) * 100 + (NTV) * 10 + (MTV)) * 2 + (WDV): { constexpr int W = WV, NT = NTV, MT = MTV; constexpr bool WD = WDV != 0; (void)WD; __VA_ARGS__; } break;
+#define AMPC_DISPATCH_W(WIDEV, WV, NTV, MTV, ...)                            \
   do {                                                                       \
-    switch ((WV) * 100 + (NTV) * 10 + (MTV)) {                               \
-      AMPC_CASE(4, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, __VA_ARGS__) AMPC_CASE(4, 1, 4, __VA_ARGS__) \
-      AMPC_CASE(8, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, __VA_ARGS__) AMPC_CASE(8, 1, 4, __VA_ARGS__) \
-      AMPC_CASE(4, 3, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, __VA_ARGS__) AMPC_CASE(4, 3, 4, __VA_ARGS__) \
-      AMPC_CASE(8, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, __VA_ARGS__) AMPC_CASE(8, 2, 4, __VA_ARGS__) \
-      default: return fail("internal: unsupported (W, NT, MT) combination");  \
+    switch (((WV) * 100 + (NTV) * 10 + (MTV)) * 2 + ((WIDEV) ? 1 : 0)) {     \
+      AMPC_CASE(4, 1, 1, 0, __VA_ARGS__) AMPC_CASE(4, 1, 2, 0, __VA_ARGS__) AMPC_CASE(4, 1, 4, 0, __VA_ARGS__) \
+      AMPC_CASE(8, 1, 1, 0, __VA_ARGS__) AMPC_CASE(8, 1, 2, 0, __VA_ARGS__) AMPC_CASE(8, 1, 4, 0, __VA_ARGS__) \
+      AMPC_CASE(4, 3, 1, 0, __VA_ARGS__) AMPC_CASE(4, 3, 2, 0, __VA_ARGS__) AMPC_CASE(4, 3, 4, 0, __VA_ARGS__) \
+      AMPC_CASE(8, 2, 1, 0, __VA_ARGS__) AMPC_CASE(8, 2, 2, 0, __VA_ARGS__) AMPC_CASE(8, 2, 4, 0, __VA_ARGS__) \
+      AMPC_CASE(4, 1, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, 1, __VA_ARGS__) AMPC_CASE(4, 1, 4, 1, __VA_ARGS__) \
+      default: return fail("internal: unsupported (W, NT, MT, wide) combination");  \
     }                                                                        \
   } while (0)
+// wide <=> the staged model has more than two 16-column output tiles
+#define AMPC_DISPATCH(H, MTV, ...) AMPC_DISPATCH_W((H)->nxp > 32, (H)->nw, (H)->nt, MTV, __VA_ARGS__)
 
 // Largest tile (MT) that fits LDS, preferring enough workgroups to cover the 256 CUs twice.
 // LDS map for a tile: separate partials region when it fits the 160 KB, else aliased onto `act`.

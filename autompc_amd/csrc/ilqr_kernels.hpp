@@ -397,13 +397,13 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
 
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
-template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape>
+template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   // nothing resident: the kernel is launched once per iteration and runs only H steps, so filling
   // resident fragments does not pay (measured with a static shape: 0.74 ms resident vs 0.58 ms)
-  using Net = TileNet<T, NT, 1, W, false, 2, SH>;
+  using Net = TileNet<T, NT, 1, W, false, 2, SH, WIDE>;
   constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // barriers inside the loop are LDS-only, so neither these loads nor the line-search stores
   // (lss / lsc) stall a step.
   // nu <= 16; nx <= 32 with the MLP tile, <= 64 on the feature-library path (predicated on nu * nx)
-  constexpr int KR = (16 * (DYN == 1 ? 64 : 32) + NTHR - 1) / NTHR;
+  constexpr int KR = (16 * ((DYN == 1 || WIDE) ? 64 : 32) + NTHR - 1) / NTHR;
   T kreg[KR];
   T kvr = T(0), ubr = T(0), xbr = T(0);
   auto fetch_ls = [&](int t) {

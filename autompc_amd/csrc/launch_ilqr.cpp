@@ -46,8 +46,8 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
   } else {
-    AMPC_DISPATCH(h->nw, h->nt, 1, {
-      auto k = ilqr_iter_kernel<T, NT, W>;
+    AMPC_DISPATCH(h, 1, {
+      auto k = ilqr_iter_kernel<T, NT, W, 0, DynShape, WD>;
       HIP_OK(allow_lds(k, p->lds_bytes));
       hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
     });

@@ -30,15 +30,15 @@ int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double*
   if (deriv) HIP_OK(h->s_dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
   T* dz = (T*)h->s_dz.p;
   const RowMap rm{n, 0, 0, nullptr};
-  AMPC_DISPATCH(h->nw, h->nt, mt, {
+  AMPC_DISPATCH(h, mt, {
     if (deriv) {
-      auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+      auto k = mlp_forward_kernel<T, NT, MT, W, true, DynShape, WD>;
       HIP_OK(allow_lds(k, lds_bytes));
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, dz, n,
                          n_pad, rm);
     } else {
-      auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+      auto k = mlp_forward_kernel<T, NT, MT, W, false, DynShape, WD>;
       HIP_OK(allow_lds(k, lds_bytes));
       hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lds_bytes, h->stream, m, L,
                          (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p,
@@ -54,8 +54,8 @@ int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double*
     const int jtiles = ((n + JM - 1) / JM) * nx;       // (sample block, output index) tiles
     const int kinp = 16 * ((m.kin + 15) / 16);
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);
-    AMPC_DISPATCH(h->nw, h->nt, jmt, {
-      auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+    AMPC_DISPATCH(h, jmt, {
+      auto k = mlp_jacobian_kernel<T, NT, MT, W, DynShape, WD>;
       HIP_OK(allow_lds(k, jl));
       hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m,
                          (const T*)h->wout_plain, (const T*)dz, n, n_pad, (T*)h->s_jx.p,
@@ -96,8 +96,8 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
       AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
     } else {
-      AMPC_DISPATCH(h->nw, h->nt, mt, {
-        auto k = mlp_forward_kernel<T, NT, MT, W, true>;
+      AMPC_DISPATCH(h, mt, {
+        auto k = mlp_forward_kernel<T, NT, MT, W, true, DynShape, WD>;
         HIP_OK(allow_lds(k, lb));
         hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
                            (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
@@ -122,8 +122,8 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
       AMPC_STATIC_DISPATCH(p->static_shape, 0);       // (the chain multiplies stored derivatives)
 #undef AMPC_SD_BODY
     } else {
-      AMPC_DISPATCH(h->nw, h->nt, jmt, {
-        auto k = mlp_jacobian_kernel<T, NT, MT, W>;
+      AMPC_DISPATCH(h, jmt, {
+        auto k = mlp_jacobian_kernel<T, NT, MT, W, DynShape, WD>;
         HIP_OK(allow_lds(k, jl));
         hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
                            (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
@@ -152,8 +152,8 @@ int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* 
   TileLds SL = tile_lds_for<T>(sur, sm, SM, 0);
   const size_t slds = (size_t)SL.extra * sizeof(T);
   const RowMap rm{B, 0, 0, nullptr};
-  AMPC_DISPATCH(sur->nw, sur->nt, 1, {
-    auto k = mlp_forward_kernel<T, NT, MT, W, false>;
+  AMPC_DISPATCH(sur, 1, {
+    auto k = mlp_forward_kernel<T, NT, MT, W, false, DynShape, WD>;
     HIP_OK(allow_lds(k, slds));
     hipLaunchKernelGGL(k, dim3(stiles), dim3(64 * W), slds, h->stream, sm, SL, (const T*)x,
                        (const T*)u, (T*)x_next, (T*)nullptr, B, stiles * SM, rm);

@@ -57,8 +57,8 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
       default: return fail("internal: unknown static shape");
     }
   } else {
-    AMPC_DISPATCH(h->nw, h->nt, p->mt, {
-      auto k = mppi_rollout_kernel<T, NT, MT, W>;
+    AMPC_DISPATCH(h, p->mt, {
+      auto k = mppi_rollout_kernel<T, NT, MT, W, DynShape, WD>;
       HIP_OK(allow_lds(k, p->lds_bytes));
       hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
     });

@@ -24,7 +24,7 @@ struct RowMap {
   const int* mask;
 };
 
-template <typename T, int NT, int MT, int W, bool DERIV, typename SH = DynShape>
+template <typename T, int NT, int MT, int W, bool DERIV, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp_in, const TileLds L_in,
                                                              const T* __restrict__ states,
                                                              const T* __restrict__ ctrls,
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
                                                              const RowMap rm) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  using Net = TileNet<T, NT, MT, W, DERIV, 0, SH>;
+  using Net = TileNet<T, NT, MT, W, DERIV, 0, SH, WIDE>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
   const TileLds L = SH::template fold_lds<T, M, W>(L_in);
@@ -92,7 +92,7 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
 // mlp_forward_kernel<DERIV>.  jx[n][nx][nx], ju[n][nx][nu].
 // (16-row, 8-wave tiles ask for >= 6 waves per SIMD, i.e. <= 80 VGPRs: three workgroups per CU
 // overlap one tile's global loads with the others' MFMAs; measured +4 % on c4 over the default 88)
-template <typename T, int NT, int MT, int W, typename SH = DynShape>
+template <typename T, int NT, int MT, int W, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacobian_kernel(const MlpDev<T> mlp_in,
                                                               const T* __restrict__ wout_plain,
                                                               const T* __restrict__ dz, int n,
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   using acc_t = typename Acc<T>::type;
   using Net = TileNet<T, NT, MT, W, false>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
-  constexpr int NIMAX = 3;  // kin <= 48
+  constexpr int NIMAX = WIDE ? 5 : 3;  // kin <= 48 (80 when WIDE)
   const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
   constexpr int KSH = Net::KSH, KSW = Net::KSW, GH = Net::GH;
   const int tid = threadIdx.x, lane = tid & 63;

@@ -465,7 +465,12 @@ __device__ long long g_phase_marks[64];
 // ---- the fused network on one tile -------------------------------------------------------------
 // LEAN: what stays resident in registers between calls, for callers that need registers
 // themselves: 0 output fragments + hidden biases, 1 output fragments only, 2 nothing.
-template <typename T, int NT, int MT, int W, bool DERIV = false, int LEAN = 0, typename SH = DynShape>
+// WIDE: up to four 16-column output tiles (model states 33..64: long-history ARX, large Koopman
+// lifts -- arx.py:146-162, koopman.py:166-181) and first layers of up to 20 k-steps (nx + nu <= 80).
+// Instantiated for the 64-wide tile only (W = 4, NT = 1: such models are linear, staged with a hidden
+// width equal to the state dimension); the output fragments are always resident there.
+template <typename T, int NT, int MT, int W, bool DERIV = false, int LEAN = 0, typename SH = DynShape,
+          bool WIDE = false>
 struct TileNet {
   using acc_t = typename Acc<T>::type;
   static constexpr int M = 16 * MT;
@@ -474,7 +479,7 @@ struct TileNet {
   static constexpr int KSW = KSH / W;         // output-layer k-steps per wave (= 4*NT)
   static constexpr int KS0MAX = 12;           // first-layer k-steps (k1p/4 is 2, 4, .. 12)
   static constexpr int GH = 8;                // hidden-layer group
-  static constexpr int NOMAX = 2;             // nx <= 32
+  static constexpr int NOMAX = WIDE ? 4 : 2;  // nx <= 32 (64 when WIDE)
   // A wave's own output columns [16 NT w, 16 NT (w+1)) are one whole k-group of the next hidden
   // layer: that layer starts on them before the barrier (see run()).  Host packing must agree
   // (own_first_packing() in api.cpp).
@@ -519,12 +524,19 @@ struct TileNet {
   // lifetime: fetching them per call put a 64 KB-per-CU burst on L2 right before the output
   // MFMAs needed them (measured ~1 us exposed per rollout step).
   // (Not in the 64-row f64 tile: its accumulators leave no room, the copy would spill.)
-  static constexpr bool RESIDENT_OUT = LEAN < 2 && !(MT == 4 && sizeof(T) == 8);
+  static constexpr bool RESIDENT_OUT = WIDE || (LEAN < 2 && !(MT == 4 && sizeof(T) == 8));
   T wout[KSW][NOMAX];            // dead (never written or read) when not resident
 
   __device__ __forceinline__ static void load_out(const MlpDev<T>& m, int w, int lane,
                                                   T (&dst)[KSW][NOMAX]) {
-    if (m.nxp == 16) {
+    if constexpr (WIDE) {              // packed [w][ks][lane][tile], tiles = nxp / 16 (1..4)
+      const int tiles = m.nxp / 16;
+      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * tiles;
+#pragma unroll
+      for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+        for (int n = 0; n < NOMAX; ++n) dst[ks][n] = n < tiles ? wl[(size_t)ks * 64 * tiles + n] : T(0);
+    } else if (m.nxp == 16) {
       const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) { dst[ks][0] = wl[ks * 64]; dst[ks][1] = T(0); }
@@ -663,7 +675,7 @@ struct TileNet {
     const bool pingpong = L.act2 != L.act;
     const int as = L.act_stride;
     const int no = m.nxp / 16;
-    static_assert(GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");   // pfn holds either
+    static_assert(WIDE || GH * NT == KSW * NOMAX, "prefetch buffer shapes must coincide");   // pfn holds either
     auto prefetch_next = [&](int l_next) {
       if (l_next < m.n_hidden) {
         load_group<T, NT, GH>(wr, slice_h(m, l_next, w), (unsigned)lane * NT, 0, pfn);
@@ -774,7 +786,19 @@ struct TileNet {
           case 24: layer_mma_static<T, NT, MT, 6, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
           case 32: layer_mma_static<T, NT, MT, 8, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
           case 40: layer_mma_static<T, NT, MT, 10, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
-          default: layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          case 48: layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+          default:
+            if constexpr (WIDE) {
+              switch (m.k1p) {
+                case 56: layer_mma_static<T, NT, MT, 14, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+                case 64: layer_mma_static<T, NT, MT, 16, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+                case 72: layer_mma_static<T, NT, MT, 18, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+                default: layer_mma_static<T, NT, MT, 20, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc); break;
+              }
+            } else {
+              layer_mma_static<T, NT, MT, 12, 2>(A, L.xu_stride, wr, wl, lane, first0<2>(), acc);
+            }
+            break;
         }
       }
       AMPC_MARK(2);
@@ -836,7 +860,17 @@ struct TileNet {
     }
     {
       const T* arow = act + i * as + q + 4 * w * KSW;
-      if (no == 1) {
+      if constexpr (WIDE) {
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const T a = arow[mt * 16 * as + 4 * ks];
+#pragma unroll
+            for (int n = 0; n < NOMAX; ++n)
+              if (n < no) oacc[mt][n] = mfma16_x<kRealOut>(a, wo(ks, n), oacc[mt][n]);
+          }
+      } else if (no == 1) {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll

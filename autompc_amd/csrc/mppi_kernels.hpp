@@ -71,11 +71,11 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v);
 
 // SH: DynShape (everything read from `args` at run time) or a StaticShape (shapes.hpp) whose
 // dimensions, strides and LDS offsets are compile-time constants -- see mlp_tile.hpp.
-template <typename T, int NT, int MT, int W, typename SH = DynShape>
+template <typename T, int NT, int MT, int W, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  using Net = TileNet<T, NT, MT, W, false, 0, SH>;
+  using Net = TileNet<T, NT, MT, W, false, 0, SH, WIDE>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int TPS = NTHR / M;                 // threads per sample (32..4), all in one wave
   constexpr int EPT = (16 + TPS - 1) / TPS;     // noise elements per thread (nu <= 16)
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   for (int i = 0; i < 16; ++i) _xm[i] = 0;
 #endif
   // the (at most ceil(nx / TPS)) state columns this thread updates: goal and diagonal Q weight
-  constexpr int XPT = (32 + TPS - 1) / TPS;
+  constexpr int XPT = ((WIDE ? 64 : 32) + TPS - 1) / TPS;
   T qd_r[XPT], gl_r[XPT];
 #pragma unroll
   for (int e = 0; e < XPT; ++e) {

@@ -11,9 +11,9 @@ through basis functions (koopman.py:112-122).  Fitting (least squares / lasso) i
 host computation; ``pred`` / ``pred_batch`` / ``pred_diff`` / ``pred_diff_batch`` and every MPPI /
 iLQR solve built on them go through the C ABI (``ampc_set_linear``), where the pair (A, B) is
 staged as a one-hidden-layer identity-activation network so that the MFMA rollout, Jacobian and
-iLQR kernels serve it unchanged.  That path takes model states of up to 32 entries; 33..64
-entries (long histories, large lifts) are staged as a feature-library model and served by the
-scalar kernels instead (prediction, Jacobians, MPPI, closed loop, and iLQR while nx + nu <= 63).
+iLQR kernels serve it unchanged.  Model states of up to 32 entries use two 16-column output tiles;
+33..64 entries (long histories, large lifts) use the four-tile variant of the same kernels (hidden
+width -- here the padded model state -- of at most 64).
 """
 import numpy as np
 

@@ -51,6 +51,7 @@ int ampc_precision(const ampc_handle* h);
 /* ---- model: MLP surrogate dynamics --------------------------------------------------------
  * Replaces the state held by autompc.sysid.MLP (mlp.py:137-165 net, :308-321 parameters).
  * weights[l] is torch.nn.Linear layout [out_l][in_l]; l = 0..n_hidden (last = output layer).
+ * nx <= 32 for hidden widths up to 256; nx <= 64 when every hidden layer has at most 64 units.
  * x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)          (mlp.py:219-236)
  * activation: 0 relu, 1 tanh, 2 sigmoid, 3 selu (mlp.py:44-51); 4 identity (ampc_set_linear). */
 int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
@@ -66,11 +67,9 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
  * points below (ampc_mlp_pred_batch / _pred_diff_batch, whose Jacobians are then A and B) and
  * every solver serve it unchanged.  Costs see the first obs_dim state entries
  * (mppi.py:73-82, ilqr.py:124-128).
- * nx <= 32: MFMA path as described.  32 < nx <= 64 (long-history ARX, large Koopman lifts): the
- * model is staged as a feature-library model (nx + nu identity features, Xi = [A | B]; see
- * ampc_set_sindy) and served by the scalar kernels -- prediction, Jacobians, MPPI plans and the
- * closed loop work; iLQR plans work while the Riccati workspace fits LDS and nx + nu <= 63
- * (e.g. 41 states + 6 controls in f64). */
+ * nx <= 64.  Above 32 states (long-history ARX, large Koopman lifts; e.g. ARX with history 2 on
+ * HalfCheetah: 41) the MFMA tile carries three or four output column tiles; iLQR plans need
+ * nx + nu <= 63 (the augmented Quu system lives in one wave). */
 int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B);
 
 /* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */

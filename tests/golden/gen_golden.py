@@ -616,7 +616,41 @@ def gen_sindy():
         save("sindy_" + tag, **out)
 
 
-GENERATORS = {"sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# ------------------------------------------------------- wide linear model (41 states)
+def gen_linear_wide():
+    """ARX with history 2 on a HalfCheetah-sized system (17 observations, 6 controls): model state
+    2*17 + 6 + 1 = 41 entries -- the reference's arx.py:42-187 fit and prediction, and one
+    compute_ilqr_default on it (ilqr.py:100-265).  (The reference's MPPI cannot run with 6
+    controls, mppi.py:21-24.)"""
+    from autompc.sysid.arx import ARX
+    system = make_system(17, 6)
+    trajs = linear_train_trajs(system, n_traj=8, T=60, seed=321)
+    model = quiet(ARX, system, history=2)
+    quiet(model.train, trajs)
+    assert model.state_dim == 41
+    rng = np.random.default_rng(19)
+    states = model.traj_to_states(trajs[1])[5:29].copy()
+    ctrls = rng.uniform(-1, 1, size=(24, 6))
+    d0 = model.pred_diff(states[0], ctrls[0])
+    cost = make_cost(system, "dense", 900)
+    Q, R, F = cost.get_cost_matrices()
+    task = Task(system)
+    task.set_cost(cost)
+    ctl = IterativeLQR(system, task, model, 12)
+    one = ampc.zeros(system, 1)
+    init = np.random.default_rng(4).uniform(-0.4, 0.4, size=17)
+    one[0].obs[:] = init
+    x0 = model.traj_to_state(one)
+    conv, st, ct, Ks, ks = quiet(ctl.compute_ilqr_default, x0, np.zeros((12, 6)), silent=True)
+    save("linear_arx2_wide", train_obs=np.stack([t.obs for t in trajs]),
+         train_ctrls=np.stack([t.ctrls for t in trajs]), A=model.A, B=model.B, state_dim=41,
+         pb_states=states, pb_ctrls=ctrls, pred_batch=model.pred_batch(states, ctrls),
+         pred0=model.pred(states[0], ctrls[0]), diff0_pred=d0[0], diff0_jx=d0[1], diff0_ju=d0[2],
+         Q=Q, R=R, F=F, goal=cost.get_goal(), init=init, ilqr_H=12, dt=system.dt, ilqr_x0=x0,
+         ilqr_converged=conv, ilqr_states=st, ilqr_ctrls=ct, ilqr_Ks=Ks, ilqr_ks=ks)
+
+
+GENERATORS = {"linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "cost_terms": gen_cost_terms}
 
 if __name__ == "__main__":

@@ -134,7 +134,7 @@ def test_ilqr_on_linear_dynamics_recovers_finite_horizon_lqr():
 
 def test_ilqr_on_a_wide_linear_model_recovers_lqr_too():
     """41 states + 6 controls (ARX history 2 on a HalfCheetah-sized system): the model runs on the
-    scalar feature-library path, the Riccati sweep holds 47 x 47 matrices in LDS and the Quu solve
+    four-output-tile MFMA path, the Riccati sweep holds 47 x 47 matrices in LDS and the Quu solve
     uses 48 lanes; the gains must still be the closed-form finite-horizon LQR gains."""
     from autompc_amd import _lib
     rng = np.random.default_rng(9)

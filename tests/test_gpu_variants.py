@@ -103,12 +103,49 @@ def test_mppi_dimension_extremes(nx, nu, H):
 
 def test_unsupported_shapes_fail_loudly():
     from autompc_amd import _lib
-    p = omlp.random_params(33, 1, [64], "relu", seed=0)
     h = _lib.Handle(0, "f64")
-    with pytest.raises(_lib.AmpcError):
-        h.set_mlp(33, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
-                  p["dy_std"])
-    p = omlp.random_params(4, 1, [300], "relu", seed=0)
-    with pytest.raises(_lib.AmpcError):
-        h.set_mlp(4, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
-                  p["dy_std"])
+    for nx, hidden in ((33, [128]), (65, [64]), (4, [300])):   # wide states need hidden <= 64
+        p = omlp.random_params(nx, 1, hidden, "relu", seed=0)
+        with pytest.raises(_lib.AmpcError):
+            h.set_mlp(nx, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
+                      p["dy_std"])
+    h.close()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("nx,nu,hidden,act", [(33, 1, [64], "relu"), (40, 3, [64, 64], "tanh"),
+                                              (64, 2, [48, 64], "relu"), (50, 6, [32], "selu")])
+def test_wide_state_networks_match_the_oracle(nx, nu, hidden, act, precision):
+    """33..64 model states (four output tiles): prediction, Jacobians and an MPPI solve."""
+    from autompc_amd import _lib
+    p = omlp.random_params(nx, nu, hidden, act, seed=nx)
+    h = _handle(p, nx, nu, act, precision)
+    rng = np.random.default_rng(nx)
+    n = 77
+    X, U = rng.normal(size=(n, nx)), rng.normal(size=(n, nu))
+    ref = omlp.pred_batch(p, X, U)
+    tol = 1e-12 if precision == "f64" else 2e-5
+    assert rel_err(h.pred_batch(X, U), ref) < tol
+    o, jx, ju = h.pred_diff_batch(X, U)
+    _, rjx, rju = omlp.pred_diff_batch(p, X, U)[:3]
+    assert rel_err(o, ref) < tol and rel_err(jx, rjx) < 10 * tol and rel_err(ju, rju) < 10 * tol
+    if precision == "f32":
+        h.close()
+        return
+    N, H = 100, 7
+    Q, R, F = np.eye(nx), 0.1 * np.eye(nu), 2 * np.eye(nx)
+    h.set_quad_costs(Q, R, F, np.zeros(nx))
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    plan = _lib.MppiPlan(h, [N], [H], [1.0], [1.0])
+    x0 = rng.normal(size=nx)
+    eps = rng.normal(size=(N, H, nu))
+    act0 = rng.uniform(-0.3, 0.3, size=(H, nu))
+    plan.upload(x0, act0, eps)
+    plan.solve()
+    a, u, c, _ = plan.download(costs=True)
+    orc = MPPIOracle(MLPOracle(make_system(nx, nu), p), QuadCostOracle(Q, R, F, np.zeros(nx)),
+                     np.tile([-1.0, 1.0], (nu, 1)), horizon=H, num_path=N)
+    orc.act_sequence = act0.copy()
+    uo, _ = orc.run(np.concatenate([x0, np.zeros(nu)]), x0, eps_nhu=eps)
+    assert rel_err(c, orc.last_costs) < 1e-9 and rel_err(u[0], uo) < 1e-8
+    plan.close(); h.close()

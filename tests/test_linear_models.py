@@ -345,3 +345,89 @@ def test_arx_history_two_on_a_halfcheetah_sized_system_closed_loop():
         ctl.act_sequence = orc.act_sequence          # lock-step: per-solve error only
         cs_h = cs_o.copy()
         obs = M @ obs + G @ uo
+
+
+# ------------------------------------------------------------ model states above 32 (MFMA path)
+def _wide_models(precision="f64"):
+    """ARX with history 2 on a HalfCheetah-sized system: 41 model states (linear_arx2_wide.npz)."""
+    from autompc_amd import ARX
+    g = golden("linear_arx2_wide")
+    system = make_system(17, 6, dt=float(g["dt"]))
+    m = ARX(system, history=2, precision=precision)
+    m.set_parameters({"coeffs": np.concatenate([g["A"][:17], g["B"][:17]], axis=1)})
+    orc = ARXOracle(system, 2, g["A"], g["B"])
+    return g, system, m, orc
+
+
+def test_wide_oracle_fit_matches_reference():
+    g = golden("linear_arx2_wide")
+    system = make_system(17, 6, dt=float(g["dt"]))
+    m = ARXOracle(system, 2)
+    m.train(list(g["train_obs"]), list(g["train_ctrls"]))
+    assert m.state_dim == 41
+    assert rel_err(m.A, g["A"]) < 1e-7 and rel_err(m.B, g["B"]) < 1e-7
+    m.A, m.B = g["A"], g["B"]
+    assert rel_err(m.pred_batch(g["pb_states"], g["pb_ctrls"]), g["pred_batch"]) < 1e-13
+    orc = ILQROracle(m, QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"]), float(g["dt"]), int(g["ilqr_H"]))
+    conv, st, ct, Ks, ks = orc.solve(g["ilqr_x0"], np.zeros((int(g["ilqr_H"]), 6)))
+    assert conv == bool(g["ilqr_converged"])
+    assert rel_err(st, g["ilqr_states"]) < 1e-6 and rel_err(ct, g["ilqr_ctrls"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_wide_device_prediction_and_jacobians(precision):
+    g, system, m, _ = _wide_models(precision)
+    assert m.A.shape == (41, 41)
+    tol = 1e-13 if precision == "f64" else 3e-6
+    assert rel_err(m.pred_batch(g["pb_states"], g["pb_ctrls"]), g["pred_batch"]) < tol
+    o, jx, ju = m.pred_diff_batch(g["pb_states"], g["pb_ctrls"])
+    assert rel_err(o, g["pred_batch"]) < tol
+    for i in range(jx.shape[0]):
+        assert rel_err(jx[i], g["A"]) < tol and rel_err(ju[i], g["B"]) < tol
+    o0, a0, b0 = m.pred_diff(g["pb_states"][0], g["pb_ctrls"][0])
+    assert rel_err(o0, g["diff0_pred"]) < tol and rel_err(a0, g["diff0_jx"]) < tol and rel_err(b0, g["diff0_ju"]) < tol
+
+
+@pytest.mark.gpu
+def test_wide_device_ilqr_matches_reference():
+    from autompc_amd import IterativeLQR
+    g, system, m, _ = _wide_models()
+    H = int(g["ilqr_H"])
+    ctl = IterativeLQR(system, _task(system, g, False), m, H)
+    conv, st, ct, Ks, ks = ctl.compute_ilqr_default(g["ilqr_x0"], np.zeros((H, 6)))
+    assert conv == bool(g["ilqr_converged"])
+    assert rel_err(st, g["ilqr_states"]) < 1e-6 and rel_err(ct, g["ilqr_ctrls"]) < 1e-6
+    assert rel_err(Ks, g["ilqr_Ks"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tile_rows", [16, 32, 64])
+def test_wide_device_mppi_matches_oracle(tile_rows, monkeypatch):
+    """MPPI with 6 controls on the 41-state model (the reference's MPPI cannot run nu > 1) vs the
+    oracle, for every tile height of the wide MFMA path."""
+    from autompc_amd import MPPI
+    monkeypatch.setenv("AMPC_MT", str(tile_rows // 16))
+    g, system, m, orc_model = _wide_models()
+    from autompc_amd import QuadCost, Task
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    task.set_ctrl_bounds(-np.ones(6), np.ones(6))
+    N, H = 200, 9
+    np.random.seed(3)
+    ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=0.5, lmda=0.8)
+    np.random.seed(3)
+    orc = MPPIOracle(orc_model, QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"]), np.tile([-1.0, 1.0], (6, 1)),
+                     horizon=H, num_path=N, sigma=0.5, lmda=0.8)
+    x = g["ilqr_x0"]
+    cs_h = cs_o = np.concatenate([x, np.zeros(6)])
+    obs = g["init"]
+    for _ in range(2):
+        st = np.random.get_state()
+        uo, cs_o = orc.run(cs_o, obs)
+        np.random.set_state(st)
+        uh, cs_h = ctl.run(cs_h, obs, return_details=True)
+        assert rel_err(ctl.last_costs, orc.last_costs) < 1e-9
+        assert rel_err(ctl.act_sequence, orc.act_sequence) < 1e-8 and rel_err(uh, uo) < 1e-8
+        ctl.act_sequence = orc.act_sequence
+        obs = orc_model.pred(cs_o[:41], uo)[:17]
