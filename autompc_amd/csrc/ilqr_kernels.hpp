@@ -395,6 +395,442 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward sweep, latency-optimised variant (model states <= 32, nu in {1, 2, 3, 4, 6, 8}).
+//
+// The sweep is a chain of H dependent steps, each a chain of three small matrix products and one
+// nu x nu solve: what bounds it is the latency of that chain, not arithmetic.  Here the products
+// run on MFMA 16x16x4 tiles straight from LDS (one ds_read per operand per MFMA instead of two per
+// scalar FMA), and the solve is done by every lane on a private register copy of Quu with its own
+// right-hand-side column, so that the factorisation has no cross-lane traffic at all.
+//
+//   A  VJ  = V J                                   (nx x n;  column n of VJ holds v)
+//   B  Qt  = Ct + J' [VJ | v]                      (n x (n+1); column n is qt)
+//   C  LU with partial pivoting of Quu in every lane (the pivot sequence of LAPACK gesv);
+//      lane b solves Quu x = Qux[:, b], lane nx solves Quu x = qu;  K = -x, k = -x;
+//      Z = Qux + Quu K, z = qu + Quu k                      -> SB = [K k ; Z z]
+//   D  V   = Qxx + [Qxu | K'] [K ; Z],  v = qx + [Qxu | K'] [k ; z]
+//
+// (D is the reference's Qxx + Qxu K + K'Qux + K'Quu K with the last two terms factored.)
+// LDS matrices are zero padded to MFMA tile multiples once; only valid entries are ever rewritten.
+struct RicLds {
+  int V, J, VJ, Qt, SB, CQ, CR, cq, xbar, ubar, goal, Fm, scal, total;
+  int ldV, ldJ, ldQ, ldB, nxp4, nxp16, nr16, np16, nb16, nu4;
+};
+__host__ __device__ constexpr int ric_ld(int cols16) { return cols16 % 32 == 0 ? cols16 + 16 : cols16; }
+__host__ __device__ constexpr RicLds make_ric_lds(int nx, int nu, int no) {
+  const int n = nx + nu;
+  RicLds r{};
+  r.nxp4 = (nx + 3) / 4 * 4; r.nxp16 = (nx + 15) / 16 * 16; r.nr16 = (n + 15) / 16 * 16;
+  r.np16 = (n + 1 + 15) / 16 * 16; r.nb16 = (nx + 1 + 15) / 16 * 16; r.nu4 = (nu + 3) / 4 * 4;
+  r.ldV = r.nxp4 | 1; r.ldJ = ric_ld(r.np16); r.ldQ = r.np16 + 1; r.ldB = ric_ld(r.nb16);
+  int o = 0;
+  r.V = o; o += r.nxp16 * r.ldV + 4;
+  r.J = o; o += r.nxp4 * r.ldJ;
+  r.VJ = o; o += r.nxp4 * r.ldJ;
+  r.Qt = o; o += r.nr16 * r.ldQ + 8;
+  r.SB = o; o += 2 * r.nu4 * r.ldB;
+  r.CQ = o; o += no * no;
+  r.CR = o; o += nu * nu;
+  r.Fm = o; o += no * no;
+  r.cq = o; o += 2 * n;
+  r.xbar = o; o += nx;
+  r.ubar = o; o += nu;
+  r.goal = o; o += no;
+  r.scal = o; o += 4;
+  r.total = (o + 3) / 4 * 4;
+  return r;
+}
+
+// 1 / d to within an ulp or two: hardware estimate + Newton steps (the full IEEE division sequence
+// is twice as long, and every pivot's reciprocal sits on the sweep's critical path).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+__device__ __forceinline__ float fast_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+
+// Quu x = rhs on a private register copy, for symmetric positive definite Quu (the usual case):
+// LDL' on the lower triangle, no pivot search.  Returns 0 when some pivot is not safely positive;
+// the caller then repeats the solve with lu_solve_lane.  x: rhs in, solution out.
+template <typename T, int NU>
+__device__ __forceinline__ int ldl_solve_lane(const T (&A0)[NU][NU], T (&x)[NU]) {
+  T L[NU][NU], rd[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) L[i][j] = A0[i][j];
+  T dmax = T(0), dmin = L[0][0];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) dmax = fmax(dmax, fabs(A0[i][i]));
+#pragma unroll
+  for (int c = 0; c < NU; ++c) {
+    const T d = L[c][c];
+    dmin = fmin(dmin, d);
+    rd[c] = fast_rcp(d);
+    T lc[NU];                                       // column c of the unit lower factor
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i) lc[i] = L[i][c] * rd[c];
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i) {
+#pragma unroll
+      for (int j = c + 1; j <= i; ++j) L[i][j] -= lc[i] * L[j][c];   // L[j][c] is still d_c * l_jc
+      x[i] -= lc[i] * x[c];
+    }
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i) L[i][c] = lc[i];
+  }
+#pragma unroll
+  for (int c = NU - 1; c >= 0; --c) {
+    T s = x[c] * rd[c];
+#pragma unroll
+    for (int j = c + 1; j < NU; ++j) s -= L[j][c] * x[j];
+    x[c] = s;
+  }
+  return dmin > dmax * T(sizeof(T) == 8 ? 1e-10 : 1e-4);
+}
+
+// General case: LU with partial pivoting (the pivot sequence of numpy.linalg.solve / LAPACK gesv).
+// Every lane holds the same matrix, so the pivot row is wave-uniform.  Returns 1 on a zero pivot.
+template <typename T, int NU>
+__device__ __forceinline__ int lu_solve_lane(const T (&A0)[NU][NU], T (&x)[NU]) {
+  T A[NU][NU], rd[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i)
+#pragma unroll
+    for (int j = 0; j < NU; ++j) A[i][j] = A0[i][j];
+  int sing = 0;
+#pragma unroll
+  for (int c = 0; c < NU; ++c) {
+    T best = fabs(A[c][c]);
+    int pr = c;
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i) {
+      const T a = fabs(A[i][c]);
+      if (a > best) { best = a; pr = i; }
+    }
+    pr = __builtin_amdgcn_readfirstlane(pr);
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i)
+      if (pr == i) {
+#pragma unroll
+        for (int j = c; j < NU; ++j) { const T tmp = A[c][j]; A[c][j] = A[i][j]; A[i][j] = tmp; }
+        const T tmp = x[c]; x[c] = x[i]; x[i] = tmp;
+      }
+    const T d = A[c][c];
+    if (d == T(0)) sing = 1;
+    rd[c] = T(1) / d;
+#pragma unroll
+    for (int i = c + 1; i < NU; ++i) {
+      const T f = A[i][c] * rd[c];
+#pragma unroll
+      for (int j = c + 1; j < NU; ++j) A[i][j] -= f * A[c][j];
+      x[i] -= f * x[c];
+    }
+  }
+#pragma unroll
+  for (int c = NU - 1; c >= 0; --c) {
+    T s = x[c];
+#pragma unroll
+    for (int j = c + 1; j < NU; ++j) s -= A[c][j] * x[j];
+    x[c] = s * rd[c];
+  }
+  return sing;
+}
+
+template <typename T, int NU, typename SH = DynShape>
+__global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const IlqrArgs<T> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* Wr = reinterpret_cast<T*>(smem_raw);
+  using acc_t = typename Acc<T>::type;
+  constexpr int NTHR = kRicThreads, NW = NTHR / 64, SIDE0 = NTHR / 2;   // side work: threads >= SIDE0
+  constexpr int TPW = 2;                                // tiles per wave: n + 1 <= 48 -> at most 9 tiles
+  constexpr int KX = 8, KD = 2 * ((NU + 3) / 4);        // k-steps over the state / the stacked controls
+  constexpr int nu = NU, nu4 = (NU + 3) / 4 * 4;
+  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int nx = mlp.nx, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
+  if (args.active[p] == 0) return;
+  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const RicLds R = make_ric_lds(nx, nu, no);
+  T* V = Wr + R.V; T* Jm = Wr + R.J; T* VJ = Wr + R.VJ; T* Qt = Wr + R.Qt; T* SB = Wr + R.SB;
+  T* CQ = Wr + R.CQ; T* CR = Wr + R.CR; T* Fs = Wr + R.Fm; T* cq = Wr + R.cq;
+  T* xbar = Wr + R.xbar; T* ubar = Wr + R.ubar; T* goal = Wr + R.goal; T* scal = Wr + R.scal;
+  const int ldV = R.ldV, ldJ = R.ldJ, ldQ = R.ldQ, ldB = R.ldB;
+  const T* cpar = args.costs_par + (size_t)args.cost_idx[p] * cost_stride;   // Q R F goal
+  const T* st = args.states + (size_t)p * (H + 1) * nx;
+  const T* ct = args.ctrls + (size_t)p * H * nu;
+  T* Kg = args.Ks + (size_t)p * H * nu * nx;
+  T* kg = args.ks + (size_t)p * H * nu;
+  const T dt = args.dt;
+  for (int i = tid; i < R.total; i += NTHR) Wr[i] = T(0);
+  __syncthreads();
+  for (int i = tid; i < no * no; i += NTHR) {           // symmetrised cost Hessians (cost.py:181-211)
+    const int a = i / no, b = i - a * no;
+    CQ[i] = cpar[a * no + b] + cpar[b * no + a];
+    Fs[i] = cpar[no * no + nu * nu + a * no + b] + cpar[no * no + nu * nu + b * no + a];
+  }
+  for (int i = tid; i < nu * nu; i += NTHR) {
+    const int a = i / nu, b = i - a * nu;
+    CR[i] = cpar[no * no + a * nu + b] + cpar[no * no + b * nu + a];
+  }
+  for (int i = tid; i < no; i += NTHR) goal[i] = cpar[2 * no * no + nu * nu + i];
+  __syncthreads();
+  for (int i = tid; i < no * no; i += NTHR) {           // V_H = F + F' on the observed block
+    const int a = i / no, b = i - a * no;
+    V[a * ldV + b] = Fs[i];
+  }
+  for (int a = tid; a < no; a += NTHR) {                // v_H (term_goal == 0: the reference's quirk)
+    T s = T(0);
+    for (int b = 0; b < no; ++b) s += Fs[a * no + b] * (st[(size_t)H * nx + b] - (args.term_goal ? goal[b] : T(0)));
+    VJ[a * ldJ + n] = s;
+  }
+  // J_t = [jx | ju], xbar_t, ubar_t: loaded one step ahead into registers by the side threads
+  constexpr int SIDE = NTHR - SIDE0;
+  constexpr int JR = (32 * 40 + SIDE - 1) / SIDE;
+  const int sid = tid - SIDE0;
+  T jreg[JR];
+  T xreg = T(0), ureg = T(0);
+  auto fetch_step = [&](int t) {
+    const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
+    const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
+#pragma unroll
+    for (int k = 0; k < JR; ++k) {
+      const int idx = sid + k * SIDE;
+      if (idx < nx * n) {
+        const int a = idx / n, c = idx - a * n;
+        jreg[k] = c < nx ? jxp[a * nx + c] : jup[a * nu + (c - nx)];
+      }
+    }
+    if (sid < nx) xreg = st[(size_t)t * nx + sid];
+    if (sid < nu) ureg = ct[(size_t)t * nu + sid];
+  };
+  auto commit_step = [&]() {
+#pragma unroll
+    for (int k = 0; k < JR; ++k) {
+      const int idx = sid + k * SIDE;
+      if (idx < nx * n) {
+        const int a = idx / n, c = idx - a * n;
+        Jm[a * ldJ + c] = jreg[k];
+      }
+    }
+    if (sid < nx) xbar[sid] = xreg;
+    if (sid < nu) ubar[sid] = ureg;
+  };
+  // gradient of the stage cost about (xbar, ubar), times dt: eight threads per entry, into cq[buf]
+  auto stage_gradient = [&](int buf) {
+    for (int base = 0; base < 8 * n; base += SIDE) {
+      const int idx = base + sid, c = idx >> 3, part = idx & 7;
+      T cc = T(0);
+      if (c < no) {
+        for (int b = part; b < no; b += 8) cc += CQ[c * no + b] * (xbar[b] - goal[b]);
+      } else if (c >= nx && c < n) {
+        for (int j = part; j < nu; j += 8) cc += CR[(c - nx) * nu + j] * ubar[j];
+      }
+      cc += __shfl_xor(cc, 1);
+      cc += __shfl_xor(cc, 2);
+      cc += __shfl_xor(cc, 4);
+      if (part == 0 && c < n) cq[buf * n + c] = cc * dt;
+    }
+  };
+  if (sid >= 0) { fetch_step(H - 1); commit_step(); }
+  __syncthreads();
+  if (sid >= 0) stage_gradient((H - 1) & 1);
+  const int kx = R.nxp4 / 4;                            // k-steps over the state dimension
+  const int mtx = R.nxp16 / 16, mtn = R.nr16 / 16, ntn = R.np16 / 16, ntb = R.nb16 / 16;
+  // loop-invariant part of phase B's epilogue: the Hessian of the stage cost at this lane's entries
+  T ccB[TPW][4];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tile = w + ti * NW, mt = tile / ntn, nt = tile - mt * ntn, d = 16 * nt + i16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * mt + acc_row<T>(q, r);
+      T cc = T(0);
+      if (tile < mtn * ntn) {
+        if (c < no && d < no) cc = CQ[c * no + d] * dt;
+        else if (c >= nx && c < n && d >= nx && d < n) cc = CR[(c - nx) * nu + (d - nx)] * dt;
+      }
+      ccB[ti][r] = cc;
+    }
+  }
+  __syncthreads();
+  T lin = T(0), quad = T(0), ksn2 = T(0);               // meaningful in thread nx only
+  int sing_any = 0;
+  AMPC_IMARK_ALWAYS(30);
+  for (int t = H - 1; t >= 0; --t) {
+#ifdef AMPC_X_PHASETIME
+    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
+#endif
+    AMPC_IMARK(20);
+    // ---- A: VJ = V J on the tile waves; side threads issue the next step's loads
+    if (sid >= 0 && t > 0) fetch_step(t - 1);
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int tile = w + ti * NW;
+      if (tile < mtx * ntn) {
+        const int mt = tile / ntn, nt = tile - mt * ntn;
+        const T* a = V + (16 * mt + i16) * ldV + q;
+        const T* b = Jm + q * ldJ + 16 * nt + i16;
+        T av[KX], bv[KX];
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks)
+          if (ks < kx) { av[ks] = a[4 * ks]; bv[ks] = b[4 * ks * ldJ]; }
+        __builtin_amdgcn_sched_barrier(0);
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks)
+          if (ks < kx) acc = mfma16(av[ks], bv[ks], acc);
+        const int col = 16 * nt + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + acc_row<T>(q, r);
+          if (row < R.nxp4 && col < n) VJ[row * ldJ + col] = acc[r];
+        }
+      }
+    }
+    AMPC_IMARK(10);
+    lds_barrier();
+    AMPC_IMARK(21);
+    // ---- B: Qt = Ct + J' [VJ | v]
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int tile = w + ti * NW;
+      if (tile < mtn * ntn) {
+        const int mt = tile / ntn, nt = tile - mt * ntn;
+        const T* a = Jm + q * ldJ + 16 * mt + i16;
+        const T* b = VJ + q * ldJ + 16 * nt + i16;
+        const int d = 16 * nt + i16;
+        T av[KX], bv[KX], cqv[4];
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks)
+          if (ks < kx) { av[ks] = a[4 * ks * ldJ]; bv[ks] = b[4 * ks * ldJ]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + acc_row<T>(q, r);
+          cqv[r] = cq[(t & 1) * n + (c < n ? c : 0)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KX; ++ks)
+          if (ks < kx) acc = mfma16(av[ks], bv[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mt + acc_row<T>(q, r);
+          if (c < n && d <= n) Qt[c * ldQ + d] = (d == n ? cqv[r] : ccB[ti][r]) + acc[r];
+        }
+      }
+    }
+    AMPC_IMARK(11);
+    lds_barrier();
+    AMPC_IMARK(22);
+    // ---- C: the nu x nu solves, one right-hand side per lane; side threads commit step t-1
+    if (sid >= 0 && t > 0) commit_step();
+    if (tid < 64) {
+      const int colr = tid < nx ? tid : n;             // this lane's right-hand-side column of Qt
+      const bool valid = tid <= nx;
+      T A0[NU][NU], x[NU], x0[NU];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) A0[i][j] = Qt[(nx + i) * ldQ + nx + j];
+        x0[i] = Qt[(nx + i) * ldQ + colr];
+        x[i] = x0[i];
+      }
+      int ok = ldl_solve_lane<T, NU>(A0, x);
+      ok = __builtin_amdgcn_readfirstlane(ok);         // identical in every lane
+      if (!ok) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) x[i] = x0[i];
+        sing_any |= lu_solve_lane<T, NU>(A0, x);
+      }
+      T l = T(0), qd = T(0), k2 = T(0);
+#pragma unroll
+      for (int i = 0; i < NU; ++i) x[i] = -x[i];
+#pragma unroll
+      for (int i = 0; i < NU; ++i) {
+        T s = T(0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) s += A0[i][j] * x[j];
+        l += x0[i] * x[i];
+        qd += x[i] * s;
+        k2 += x[i] * x[i];
+        if (valid) {
+          SB[i * ldB + tid] = x[i];
+          SB[(nu4 + i) * ldB + tid] = x0[i] + s;
+        }
+      }
+      if (tid == nx) { lin += l; quad += qd; ksn2 += k2; }
+    }
+    AMPC_IMARK(23);
+    lds_barrier();
+    AMPC_IMARK(24);
+    // ---- D: V = Qxx + [Qxu | K'] [K ; Z] (column nx: v); side threads store K_t, k_t and
+    //         prepare the next step's stage-cost gradient
+    if (sid >= 0) {
+      for (int i = sid; i < nu * nx; i += SIDE) {
+        const int j = i / nx, b = i - j * nx;
+        Kg[(size_t)t * nu * nx + i] = SB[j * ldB + b];
+      }
+      if (sid < nu) kg[(size_t)t * nu + sid] = SB[sid * ldB + nx];
+      if (t > 0) stage_gradient((t - 1) & 1);
+    }
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int tile = w + ti * NW;
+      if (tile < mtx * ntb) {
+        const int mt = tile / ntb, nt = tile - mt * ntb;
+        const int b = 16 * nt + i16;
+        T av[KD], bv[KD], q0[4];
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) {
+          av[ks] = ks < KD / 2 ? Qt[(16 * mt + i16) * ldQ + nx + 4 * ks + q]
+                               : SB[(4 * ks - nu4 + q) * ldB + 16 * mt + i16];
+          bv[ks] = SB[(4 * ks + q) * ldB + 16 * nt + i16];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * mt + acc_row<T>(q, r);
+          q0[r] = Qt[a * ldQ + (b < nx ? b : n)];       // rows >= nx: finite padding, discarded
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < KD; ++ks) acc = mfma16(av[ks], bv[ks], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * mt + acc_row<T>(q, r);
+          if (a < nx) {
+            if (b < nx) V[a * ldV + b] = q0[r] + acc[r];
+            else if (b == nx) VJ[a * ldJ + n] = q0[r] + acc[r];
+          }
+        }
+      }
+    }
+    AMPC_IMARK(25);
+    lds_barrier();
+    AMPC_IMARK(26);
+  }
+  AMPC_IMARK_ALWAYS(33);
+  if (tid < 64 && sing_any) scal[0] = T(1);
+  __syncthreads();
+  if (tid == nx) {
+    T* out = args.ric + (size_t)p * 4;
+    const T sg = scal[0];
+    out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = sg;
+    if (sg != T(0)) {             // singular Quu: the reference raises LinAlgError here
+      args.status[p] = 1; args.active[p] = 0; args.refresh[p] = 0;
+    }
+  }
+}
+
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
 template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape, bool WIDE = false>

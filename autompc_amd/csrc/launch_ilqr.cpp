@@ -15,10 +15,34 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
     const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
     const size_t rb = (size_t)wk.total * sizeof(T);
-    if (p->static_shape >= 0) {
+    // latency-optimised sweep (MFMA products, per-lane LU): model states <= 32 and the control
+    // dimensions it is instantiated for; everything else takes the general kernel
+    const size_t mb = (size_t)make_ric_lds(h->nx, h->nu, h->obs_dim).total * sizeof(T);
+    static const bool mfma_sweep = !(getenv("AMPC_RICCATI") && atoi(getenv("AMPC_RICCATI")) == 0);
+#define AMPC_RIC_NU(NUV, SHT)                                                                        \
+    case NUV: { auto rk = ilqr_riccati_mfma_kernel<T, NUV, SHT>; HIP_OK(allow_lds(rk, mb));          \
+      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; break; }
+    bool done = false;
+    if (mfma_sweep && h->nx <= 32) {
+      if (p->static_shape >= 0) {
+#define AMPC_SD_BODY { auto rk = ilqr_riccati_mfma_kernel<T, SH::nu, SH>; HIP_OK(allow_lds(rk, mb));   \
+        hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; }
+        AMPC_STATIC_DISPATCH(p->static_shape, 0);    // (the sweep never evaluates the activation)
+#undef AMPC_SD_BODY
+      } else {
+        switch (h->nu) {
+          AMPC_RIC_NU(1, DynShape) AMPC_RIC_NU(2, DynShape) AMPC_RIC_NU(3, DynShape)
+          AMPC_RIC_NU(4, DynShape) AMPC_RIC_NU(6, DynShape) AMPC_RIC_NU(8, DynShape)
+          default: break;
+        }
+      }
+    }
+#undef AMPC_RIC_NU
+    if (done) {
+    } else if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto rk = ilqr_riccati_kernel<T, false, SH>; HIP_OK(allow_lds(rk, rb));   \
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a); }
-      AMPC_STATIC_DISPATCH(p->static_shape, 0);      // (the sweep never evaluates the activation)
+      AMPC_STATIC_DISPATCH(p->static_shape, 0);
 #undef AMPC_SD_BODY
     } else if (h->nx > 32) {
       auto rk = ilqr_riccati_kernel<T, true>;

@@ -228,9 +228,9 @@ def test_device_ilqr_matches_reference(tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ns,nu,no", [(41, 6, 17), (64, 16, 5), (33, 1, 33)])
-def test_wide_linear_states_run_on_the_scalar_path(ns, nu, no):
-    """33..64 model states (ARX history 2 on a 17-observation / 6-control system is 41): staged as
-    a feature-library model; prediction, Jacobians and an MPPI solve against the oracle."""
+def test_wide_linear_states(ns, nu, no):
+    """33..64 model states (ARX history 2 on a 17-observation / 6-control system is 41): the four-output-tile
+    MFMA path; prediction, Jacobians and an MPPI solve against the oracle."""
     from autompc_amd import MPPI, QuadCost, Task, _lib
     from oracle.linear import LinearOracle
     rng = np.random.default_rng(ns)

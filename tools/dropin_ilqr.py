@@ -1,0 +1,39 @@
+"""Drop-in IterativeLQR.run() on the reference's H = 50 golden problems (one problem per call, host
+buffers in / host control out): ms per call, iterations taken, per-iteration kernel times."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import golden_params, make_system
+from autompc_amd import MLP, IterativeLQR, QuadCost, Task
+
+for name in ("ilqr_hc6_relu_free", "ilqr_hc6_relu_bounded", "ilqr_hc6_tanh_free"):
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=True)
+    nx, nu, H = int(g["nx"]), int(g["nu"]), int(g["H"])
+    p = golden_params(nx, nu, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    system = make_system(nx, nu, dt=float(g["dt"]))
+    m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
+            **{"hidden_size_%d" % (i + 1): w.shape[0] for i, w in enumerate(p["weights"][:-1])})
+    m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    if bool(g["bounded"]):
+        task.set_ctrl_bounds(np.full(nu, g["bounds"][0]), np.full(nu, g["bounds"][1]))
+    ctl = IterativeLQR(system, task, m, H)
+    cs0 = np.concatenate([g["x0"], np.zeros(nu)])
+    ts = []
+    for i in range(8):
+        ctl.reset()
+        t0 = time.perf_counter()
+        u, cs = ctl.run(cs0, g["x0"])
+        ts.append(time.perf_counter() - t0)
+    err = float(np.max(np.abs(u - g["u"])) / max(1e-300, np.max(np.abs(g["u"]))))
+    plan = ctl._device()
+    plan.set_timing(True)
+    ctl.reset(); ctl.run(cs0, g["x0"])
+    kt = plan.timing()
+    plan.set_timing(False)
+    print("%-24s IterativeLQR.run  %.2f ms per call (min %.2f)  iterations %d  converged %s  u rel err %.1e"
+          % (name, 1e3 * np.median(ts[2:]), 1e3 * min(ts[2:]), ctl.last_iters, bool(g["converged"]), err))
+    print("    per-iteration kernel ms:", {k: round(v, 4) for k, v in kt.items() if k.endswith("_ms")}, "launches", kt.get("launches"))

@@ -22,11 +22,17 @@ lib = _lib.load()
 lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks_ilqr(marks)
 m = np.array(marks[:50], dtype=np.int64)
-names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
-         24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
-print("Riccati step, cycles:", m[26] - m[20], "(each line includes ~440 of mark overhead)")
-for a in range(21, 27):
-    print("  %-32s %6d" % (names[a], m[a] - m[a - 1]))
+if os.environ.get("AMPC_RICCATI") == "0":
+    names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
+             24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
+    seq = [20, 21, 22, 23, 24, 25, 26]
+else:
+    names = {10: "A: VJ = V J (wave 0's tile)", 21: "barrier", 11: "B: Qt = Ct + J'[VJ|v]", 22: "barrier",
+             23: "C: per-lane LU solve, K, Z", 24: "barrier", 25: "D: V, v update", 26: "barrier"}
+    seq = [20, 10, 21, 11, 22, 23, 24, 25, 26]
+print("Riccati step, cycles:", m[26] - m[20], "(each line includes the mark's own s_memtime wait)")
+for a, b in zip(seq[:-1], seq[1:]):
+    print("  %-32s %6d" % (names[b], m[b] - m[a]))
 print("problem 7, last iteration: Riccati sweep %d cycles (ilqr_riccati_kernel), line-search rollout %d cycles (ilqr_iter_kernel)" % (m[33] - m[30], m[32] - m[31]))
 ls = {41: "fetch issue + controls + lss stores", 42: "barrier", 43: "objective", 44: "network (net.run)",
       45: "reduce + state update", 46: "commit + barrier"}
