@@ -13,7 +13,7 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libautompc_hip.so")
 OBJ = os.path.join(HERE, "build")
-HEADERS = ["host_common.hpp", "shapes.hpp", "legacy_rng_kernels.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp",
+HEADERS = ["host_common.hpp", "shapes.hpp", "legacy_rng_kernels.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp", "ilqr_ls4.hpp",
            "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
 # (object name, source file, extra flags)
 UNITS = [("api", "api.cpp", [])] + [

@@ -21,6 +21,7 @@
 
 #include "mlp_kernels.hpp"
 #include "ilqr_kernels.hpp"
+#include "ilqr_ls4.hpp"
 #include "mppi_kernels.hpp"
 #include "rng_kernels.hpp"
 #include "sindy_kernels.hpp"

@@ -64,6 +64,29 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
   }
+  // f64 MLP models with <= 32 states: candidates four at a time on 4x4x4 MFMA tiles (ilqr_ls4.hpp)
+  if constexpr (sizeof(T) == 8) {
+    static const bool ls4 = !(getenv("AMPC_LS4") && atoi(getenv("AMPC_LS4")) == 0);
+    if (ls4 && h->nx <= 32) {
+      const size_t lb = (size_t)make_ls4_lds(h->nx, h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, h->nw,
+                                             h->cost_stride).total * sizeof(T);
+      if (p->static_shape >= 0) {
+#define AMPC_SD_BODY { auto k = ilqr_ls4_kernel<NT, W, SH>; HIP_OK(allow_lds(k, lb));   \
+        hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), lb, h->stream, a); }
+        AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
+#undef AMPC_SD_BODY
+      } else {
+        AMPC_DISPATCH(h, 1, {
+          auto k = ilqr_ls4_kernel<NT, W, DynShape>;
+          HIP_OK(allow_lds(k, lb));
+          hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), lb, h->stream, a);
+        });
+      }
+      HIP_OK(hipGetLastError());
+      if (e) HIP_OK(hipEventRecord(e[2], h->stream));
+      return 0;
+    }
+  }
   if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto k = ilqr_iter_kernel<T, NT, W, 0, SH>; HIP_OK(allow_lds(k, p->lds_bytes));   \
       hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a); }

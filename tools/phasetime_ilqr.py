@@ -21,7 +21,7 @@ marks = (ctypes.c_longlong * 64)()
 lib = _lib.load()
 lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks_ilqr(marks)
-m = np.array(marks[:50], dtype=np.int64)
+m = np.array(marks[:56], dtype=np.int64)
 if os.environ.get("AMPC_RICCATI") == "0":
     names = {21: "fetch issue + VJ = V J (+bar)", 22: "Qt, qt (+bar)", 23: "Gauss-Jordan (wave 0)",
              24: "barrier", 25: "Wk, wq, sums (+bar)", 26: "V, v update, commit (+bar)"}
@@ -34,8 +34,16 @@ print("Riccati step, cycles:", m[26] - m[20], "(each line includes the mark's ow
 for a, b in zip(seq[:-1], seq[1:]):
     print("  %-32s %6d" % (names[b], m[b] - m[a]))
 print("problem 7, last iteration: Riccati sweep %d cycles (ilqr_riccati_kernel), line-search rollout %d cycles (ilqr_iter_kernel)" % (m[33] - m[30], m[32] - m[31]))
-ls = {41: "fetch issue + controls + lss stores", 42: "barrier", 43: "objective", 44: "network (net.run)",
-      45: "reduce + state update", 46: "commit + barrier"}
-print("line-search step, cycles:", m[46] - m[40], "(each line includes ~440 of mark overhead; net.run has its own marks inside)")
-for a in range(41, 47):
-    print("  %-36s %6d" % (ls[a], m[a] - m[a - 1]))
+if os.environ.get("AMPC_LS4") == "0":
+    ls = {41: "fetch issue + controls + lss stores", 42: "barrier", 43: "objective", 44: "network (net.run)",
+          45: "reduce + state update", 46: "commit + barrier"}
+    seq = [40, 41, 42, 43, 44, 45, 46]
+else:
+    ls = {41: "fetch issue + controls + stores", 42: "barrier", 43: "objective", 44: "layer 0", 45: "barrier",
+          46: "hidden layer(s) incl. barrier", 47: "output layer partials", 48: "barrier", 49: "state update + commit",
+          50: "barrier"}
+    seq = list(range(40, 51))
+m = np.array(marks[:56], dtype=np.int64)
+print("line-search step, cycles:", m[seq[-1]] - m[40], "(each line includes the mark's own s_memtime wait)")
+for a, b in zip(seq[:-1], seq[1:]):
+    print("  %-36s %6d" % (ls[b], m[b] - m[a]))
