@@ -75,6 +75,7 @@ SIGNATURES = {
     "ampc_ilqr_plan_set_terminal_goal": (c_int, [c_void_p, c_int]),
     "ampc_ilqr_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_ilqr_plan_timing": (c_int, [c_void_p, _dp, _ip]),
+    "ampc_ilqr_plan_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
 }
 
@@ -480,6 +481,13 @@ class IlqrPlan:
         check(self.lib.ampc_ilqr_plan_timing(self._p, dptr(ms), ctypes.byref(n)))
         return {"riccati_ms": ms[0], "iter_ms": ms[1], "forward_ms": ms[2], "jacobian_ms": ms[3],
                 "launches": n.value}
+
+    def stats(self):
+        """Work of the last solve: iterations launched and line-search candidate rows rolled out
+        (summed over the plan's problems)."""
+        it, rows = ctypes.c_longlong(), ctypes.c_longlong()
+        check(self.lib.ampc_ilqr_plan_stats(self._p, ctypes.byref(it), ctypes.byref(rows)))
+        return {"iterations": it.value, "candidate_rows": rows.value}
 
     def solve(self, x0, uguess, max_iter=50):
         nx, nu, B, H = self.handle.nx, self.handle.nu, self.B, self.H

@@ -207,6 +207,35 @@ template <typename T> static int build_model(ampc_handle* h) {
       for (int k = 0; k < in; ++k) wp[(size_t)i * hpad + k] = Wf[L][(size_t)i * in + k];
     push(std::move(wp));
   }
+  // four-wave packing of the forward weights (MlpDev::w4, ilqr_ls4.hpp): N-split layers as
+  // [wave][k-step][chunk][lane][cw] with cw = 2 values per lane for even NT4, else 1 -- every fragment
+  // load is then one fully coalesced 16- or 8-byte-per-lane access -- and a K-split output layer
+  {
+    const int NT4 = hpad / 64;
+    const int cw = NT4 % 2 == 0 ? 2 : 1, chunks = NT4 / cw;
+    for (int l = 0; l <= L; ++l) {
+      const std::vector<double>& Wl = Wf[l];
+      const int in = width_in(l), out = width_out(l);
+      std::vector<double> pk;
+      auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
+      if (l < L) {
+        const int KS = (l == 0 ? k1p : hpad) / 4;
+        pk.assign((size_t)KS * 4 * hpad, 0.0);
+        for (int w = 0; w < 4; ++w)
+          for (int pos = 0; pos < KS; ++pos)
+            for (int c = 0; c < chunks; ++c)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < cw; ++e) {
+                  const int nt = c * cw + e;
+                  pk[((((size_t)w * KS + pos) * chunks + c) * 64 + lane) * cw + e] =
+                      Bt(4 * pos + (lane >> 4), 16 * (NT4 * w + nt) + (lane & 15));
+                }
+      } else {
+        pack_ksplit(pk, hpad, nxp / 16, 4, Bt);
+      }
+      push(std::move(pk));
+    }
+  }
   size_t total = 0;
   for (auto& v : parts) {
     off.push_back(total);
@@ -231,6 +260,7 @@ template <typename T> static int build_model(ampc_handle* h) {
   for (int l = 0; l <= L; ++l) m.b[l] = base + off[idx++];
   for (int l = 0; l < L; ++l) m.wj[l] = base + off[idx++];
   h->wout_plain = (const void*)(base + off[idx++]);
+  for (int l = 0; l <= L; ++l) m.w4[l] = base + off[idx++];
   return 0;
 }
 
@@ -909,6 +939,8 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   }
   p->lds_work = p->L.extra;
   p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
+  p->use_ls4 = env_int("AMPC_LS4", 1) != 0;
+  p->use_mfma_sweep = env_int("AMPC_RICCATI", 1) != 0;
   p->static_shape = -1;
   if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
     const int sid = static_shape_of<T>(h, m);
@@ -934,8 +966,8 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(p->ls_states.reserve((size_t)B * p->ls_n * (H + 1) * nx * e));
   HIP_OK(p->ls_ctrls.reserve((size_t)B * p->ls_n * H * nu * e));
   HIP_OK(p->obj.reserve((size_t)B * e));
-  HIP_OK(p->flags.reserve((size_t)5 * B * sizeof(int)));
-  HIP_OK(hipMemset(p->flags.p, 0, (size_t)5 * B * sizeof(int)));
+  HIP_OK(p->flags.reserve((size_t)6 * B * sizeof(int)));
+  HIP_OK(hipMemset(p->flags.p, 0, (size_t)6 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
   if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
@@ -992,6 +1024,13 @@ extern "C" int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* 
   return 0;
 }
 
+extern "C" int ampc_ilqr_plan_stats(ampc_ilqr_plan* p, long long* iterations, long long* candidate_rows) {
+  REQUIRE(p, "ampc_ilqr_plan_stats: NULL plan");
+  if (iterations) *iterations = p->last_iterations;
+  if (candidate_rows) *candidate_rows = p->last_ls_rows;
+  return 0;
+}
+
 extern "C" int ampc_ilqr_plan_set_terminal_goal(ampc_ilqr_plan* p, int use_goal) {
   REQUIRE(p, "ampc_ilqr_plan_set_terminal_goal: NULL plan");
   p->term_goal = use_goal ? 1 : 0;
@@ -1026,7 +1065,8 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   HIP_OK(hipStreamSynchronize(h->stream));
   if (int rc = ilqr_launch_iter<T>(p, 0)) return rc;        // rollout of the guess + objective
   if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
-  std::vector<int> flags(5 * B);
+  std::vector<int> flags(6 * B);
+  HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)B * sizeof(int), h->stream));
   int it = 0;
   for (; it < max_iter; ++it) {
     if (p->timing) {
@@ -1056,6 +1096,8 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   if (converged) std::memcpy(converged, flags.data(), B * sizeof(int));
   if (iters) std::memcpy(iters, flags.data() + 2 * B, B * sizeof(int));
   if (status) std::memcpy(status, flags.data() + 3 * B, B * sizeof(int));
+  p->last_ls_rows = 0;
+  for (int b = 0; b < B; ++b) p->last_ls_rows += flags[5 * B + b];
   if (states) HIP_OK(download_converted<T>(states, p->states.p, (size_t)B * (H + 1) * nx, h->stream));
   if (ctrls) HIP_OK(download_converted<T>(ctrls, p->ctrls.p, (size_t)B * H * nu, h->stream));
   if (Ks) HIP_OK(download_converted<T>(Ks, p->Ks.p, (size_t)B * H * nu * nx, h->stream));

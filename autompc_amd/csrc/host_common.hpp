@@ -318,11 +318,13 @@ struct ampc_ilqr_plan {
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
-  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B]
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B]
+  int use_ls4 = 1, use_mfma_sweep = 1;   // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
   TileLds L{};
   int lds_work = 0, lds_xn = 0;
   size_t lds_bytes = 0;
   int last_iterations = 0;
+  long long last_ls_rows = 0;   // candidate rows the line searches of the last solve rolled out (all problems)
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg):
   // events bracket the four launches of an iteration: sweep | line search | forward | Jacobians
   bool timing = false;
@@ -354,7 +356,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.obj = (T*)p->obj.p;
   int* f = (int*)p->flags.p;
   a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
-  a.refresh = f + 4 * p->B;
+  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B;
   a.ric = (T*)p->ric.p;
   return a;
 }

@@ -68,6 +68,7 @@ template <typename T> struct IlqrArgs {
   int* iters;                    // [B]
   int* status;                   // [B] 0 ok, 1 singular Quu, 2 no line-search candidate
   int* refresh;                  // [B] Jacobians must be recomputed for this problem
+  int* ls_rows;                  // [B] candidate rows rolled out by the line search since the solve began
   T* ric;                        // [B][4] sweep -> line search: lin, quad, |k|, singular flag
 };
 
@@ -1046,6 +1047,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     piv[0] = sel; piv[1] = fail; piv[2] = success ? 1 : 0;
     scal[3] = new_obj;
     args.iters[p] += 1;
+    args.ls_rows[p] += M;
   }
   __syncthreads();
   const int sel = piv[0], fail = piv[1], success = piv[2];

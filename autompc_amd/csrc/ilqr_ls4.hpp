@@ -15,19 +15,81 @@
 // fragment the 16x16x4 MFMA takes, so the packed weights of mlp_tile.hpp are used unchanged -- and
 // D = out[row l/16][col 16g + l%16], one value per lane.
 //
-// First-layer and output-layer fragments stay in registers for the kernel's lifetime; hidden ->
-// hidden layers are streamed from L2 through a ring of NB groups of G k-steps that runs NB-1 groups
-// ahead of the MFMAs, across layer and time-step boundaries.
+// Weights.  A CU can fetch 64 B per clock from L2: streaming the 512 KB of a 256 x 256 f64 layer
+// costs 8 k cycles per step, twice the matrix-pipe time of four rows.  The kernel runs H steps on
+// the same weights, so it keeps what fits on chip.  The workgroup is FOUR waves, one per SIMD (its
+// own N-split packing, MlpDev::w4: wave w owns hidden columns [16 NT w, 16 NT (w+1)), NT = hpad/64):
+// a wave then has the SIMD's whole 512-entry register file, and the per-wave working set is paid
+// once per SIMD instead of twice.  Output-layer fragments stay in registers, first-layer fragments
+// in registers or (NT >= 3) LDS, and with RES (networks with one hidden -> hidden layer) that layer
+// is split, per round of KSH/8 k-steps, into RPR register-resident, LPR LDS-resident and SPR
+// streamed k-steps.  Streamed k-steps go through a ring of NB groups that runs NB-1 rounds ahead of
+// the MFMAs, across time-step boundaries.  Without RES every hidden -> hidden layer is streamed.
 #pragma once
 #include "ilqr_kernels.hpp"
 
 namespace ampc {
 
+constexpr int kLs4W = 4;   // waves per workgroup
+
+// Sum over aligned groups of 4 or 8 consecutive lanes with DPP moves (no LDS round trips, unlike the
+// ds_bpermute a generic shuffle lowers to): row_half_mirror pairs lane i with 7-i, the two
+// quad_perm steps finish the sum inside each quad.  Every lane ends up with its group's total.
+template <int CTRL> __device__ __forceinline__ double dpp_add(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double group_sum(double v, bool eight) {
+  if (eight) v = dpp_add<0x141>(v);              // row_half_mirror
+  v = dpp_add<0xb1>(v);                          // quad_perm [1,0,3,2]
+  return dpp_add<0x4e>(v);                       // quad_perm [2,3,0,1]
+}
+
+// One k-step of a wave's MlpDev::w4 stream: NT values per lane, stored [chunk][lane][CW] (CW = 2 for
+// even NT, else 1).  so = element offset of the k-step from MlpDev::wbase (wave-uniform).
+template <int NT>
+__device__ __forceinline__ void load_frag4(rsrc_t r, unsigned so, int lane, double (&b)[NT]) {
+  constexpr int CW = NT % 2 == 0 ? 2 : 1, CH = NT / CW;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    double t[CW];
+    load_frag<double, CW>(r, so + (unsigned)c * 64u * CW, (unsigned)lane * CW, t);
+#pragma unroll
+    for (int e = 0; e < CW; ++e) b[c * CW + e] = t[e];
+  }
+}
+// the same fragment from / to an LDS copy with the same [chunk][lane][CW] layout (p = start of the k-step)
+template <int NT>
+__device__ __forceinline__ void lds_frag4(const double* p, int lane, double (&b)[NT]) {
+  constexpr int CW = NT % 2 == 0 ? 2 : 1, CH = NT / CW;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const vec_t<double, CW> v = *reinterpret_cast<const vec_t<double, CW>*>(p + (c * 64 + lane) * CW);
+#pragma unroll
+    for (int e = 0; e < CW; ++e) b[c * CW + e] = v[e];
+  }
+}
+template <int NT>
+__device__ __forceinline__ void lds_put4(double* p, int lane, const double (&b)[NT]) {
+  constexpr int CW = NT % 2 == 0 ? 2 : 1, CH = NT / CW;
+#pragma unroll
+  for (int c = 0; c < CH; ++c)
+#pragma unroll
+    for (int e = 0; e < CW; ++e) p[(c * 64 + lane) * CW + e] = b[c * CW + e];
+}
+
 struct Ls4Lds {
-  int xu, xs, act0, act1, as, part, bias, Km, kv, ubar, xbar, cpar, blo, bhi, scal, lsobj, piv, total;
+  int xu, xs, act0, act1, as, part, bias, cpar, blo, bhi, scal, lsobj, piv, hres, w0, total;
 };
-__host__ __device__ constexpr Ls4Lds make_ls4_lds(int nx, int nu, int k1p, int nxp, int hpad, int n_hidden,
-                                                  int W, int cost_stride) {
+// hidden-layer residency split (k-steps per round of KSH/8 = 2 NT): registers, LDS, streamed
+__host__ __device__ constexpr int ls4_rpr(int NT) { return NT <= 2 ? 2 * NT : (NT == 4 ? 3 : 4); }
+__host__ __device__ constexpr int ls4_lpr(int NT) { return NT == 4 ? 1 : 0; }
+// first-layer fragments in LDS instead of registers
+__host__ __device__ constexpr bool ls4_w0_lds(int NT) { return NT >= 3; }
+__host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int hpad, int n_hidden, bool res,
+                                                  int cost_stride) {
+  const int NT = hpad / 64, W = kLs4W;
   Ls4Lds L{};
   int o = 0;
   L.xs = k1p + 1; L.as = hpad + 1;
@@ -36,42 +98,45 @@ __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nx, int nu, int k1p, int n
   L.act1 = o; o += 4 * L.as;
   L.part = o; o += W * 4 * nxp;
   L.bias = o; o += n_hidden * hpad + nxp;
-  L.Km = o; o += nu * nx;
-  L.kv = o; o += nu;
-  L.ubar = o; o += nu;
-  L.xbar = o; o += nx;
   L.cpar = o; o += cost_stride;
   L.blo = o; o += nu;
   L.bhi = o; o += nu;
   L.scal = o; o += 8;
   L.lsobj = o; o += 2 * kIlqrMaxLs;
   L.piv = o; o += 8;
+  o = (o + 3) / 4 * 4;                               // 32-byte aligned fragment reads
+  L.hres = o; o += res ? W * 8 * ls4_lpr(NT) * 64 * NT : 0;
+  L.w0 = o; o += ls4_w0_lds(NT) ? W * (k1p / 4) * 64 * NT : 0;
   L.total = (o + 3) / 4 * 4;
   return L;
 }
 
-template <int NT, int W, typename SH = DynShape>
-__global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double> args) {
+template <int NT, bool RES, typename SH = DynShape>
+__global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<double> args) {
   using T = double;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
-  constexpr int NTHR = 64 * W, ROWS = 4, TPS = NTHR / ROWS;
+  constexpr int W = kLs4W, NTHR = 64 * W, ROWS = 4;
+  static_assert(W == ROWS, "wave w owns candidate row w");
   constexpr int HP = 16 * NT * W, KSH = HP / 4, KSW = KSH / W, KS0MAX = 12;
-  constexpr int G = (KSH % 32 == 0) ? 8 : 4, NB = 4, NGH = KSH / G, D = NB - 1;
+  // RES: the layer in rounds of PPR k-steps -- SPR streamed, RPR in registers, LPR in LDS
+  constexpr int ROUNDS = 8, PPR = KSH / ROUNDS;
+  constexpr int RPR = RES ? ls4_rpr(NT) : 0, LPR = RES ? ls4_lpr(NT) : 0, SPR = RES ? PPR - RPR - LPR : 0;
+  static_assert(SPR >= 0, "residency split");
+  // streamed groups: RES: SPR k-steps per round; otherwise G k-steps, KSH / G groups per layer
+  constexpr int G = RES ? (SPR > 0 ? SPR : 1) : (NT <= 2 && KSH % 32 == 0 ? 8 : 4);
+  constexpr int NGH = RES ? ROUNDS : KSH / G, NB = 4, D = NB - 1;
   static_assert(NGH % NB == 0 && D < NGH, "ring phase must repeat per layer");
-  static_assert(W <= 8 && TPS % 64 == 0, "objective partials: one slot per wave");
-  constexpr int NG8 = KSH / 8;
-  constexpr bool OWNPACK = (NT == 2) && ((NG8 & (NG8 - 1)) == 0);   // api.cpp: own_first_packing()
-  static_assert(!OWNPACK || G == 8, "rotated streams rotate by whole groups of 8 k-steps");
+  constexpr bool STREAM = !RES || SPR > 0;
+  constexpr bool W0LDS = ls4_w0_lds(NT);
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
-  const int Lh = mlp.n_hidden, nxp = mlp.nxp, tiles = nxp / 16, ks0 = mlp.k1p / 4;
+  const int Lh = RES ? 2 : mlp.n_hidden, nxp = mlp.nxp, tiles = nxp / 16, ks0 = mlp.k1p / 4;
   const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
-  const Ls4Lds L = make_ls4_lds(nx, nu, mlp.k1p, nxp, HP, Lh, W, cost_stride);
+  const Ls4Lds L = make_ls4_lds(nu, mlp.k1p, nxp, HP, Lh, RES, cost_stride);
   T* xu = lds + L.xu; T* part = lds + L.part; T* bias = lds + L.bias;
-  T* Km = lds + L.Km; T* kv = lds + L.kv; T* ubar = lds + L.ubar; T* xbar = lds + L.xbar;
   T* cpar = lds + L.cpar; T* blo = lds + L.blo; T* bhi = lds + L.bhi; T* scal = lds + L.scal;
   T* lsobj = lds + L.lsobj; int* piv = reinterpret_cast<int*>(lds + L.piv);
   const int xs = L.xs, as = L.as;
@@ -101,40 +166,66 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
 
   // ---- resident fragments + the hidden-layer ring ------------------------------------------------
   const rsrc_t wr = weight_rsrc(mlp.wbase);
-  const unsigned lo = (unsigned)lane * NT;
-  T w0[KS0MAX][NT];
+  T w0[W0LDS ? 1 : KS0MAX][NT];
+  T* w0l = lds + L.w0 + (size_t)w * ks0 * 64 * NT;               // this wave's fragments, k-step stride 64 * NT
   {
-    const unsigned s0 = (unsigned)(mlp.w[0] - mlp.wbase) + (unsigned)w * (unsigned)ks0 * 64u * NT;
+    const unsigned s0 = (unsigned)(mlp.w4[0] - mlp.wbase) + (unsigned)w * (unsigned)ks0 * 64u * NT;
 #pragma unroll
     for (int ks = 0; ks < KS0MAX; ++ks) {
-      if (ks < ks0) load_frag<T, NT>(wr, s0 + (unsigned)ks * 64u * NT, lo, w0[ks]);
-      else {
+      if constexpr (W0LDS) {
+        if (ks < ks0) {
+          T tmp[NT];
+          load_frag4<NT>(wr, s0 + (unsigned)ks * 64u * NT, lane, tmp);
+          lds_put4<NT>(w0l + ks * 64 * NT, lane, tmp);
+        }
+      } else {
+        if (ks < ks0) load_frag4<NT>(wr, s0 + (unsigned)ks * 64u * NT, lane, w0[ks]);
+        else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w0[ks][nt] = T(0);
+          for (int nt = 0; nt < NT; ++nt) w0[ks][nt] = T(0);
+        }
       }
     }
   }
   T wout[KSW][2];
   {
-    const T* wl = mlp.w[Lh] + ((size_t)w * KSW * 64 + lane) * tiles;
+    const T* wl = mlp.w4[Lh] + ((size_t)w * KSW * 64 + lane) * tiles;
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks) {
       wout[ks][0] = wl[(size_t)ks * 64 * tiles];
       wout[ks][1] = tiles > 1 ? wl[(size_t)ks * 64 * tiles + 1] : T(0);
     }
   }
-  T ring[NB][G][NT];
   auto slice_h = [&](int l) {
-    return (unsigned)(mlp.w[l] - mlp.wbase) + (unsigned)w * (unsigned)KSH * 64u * NT;
+    return (unsigned)(mlp.w4[l] - mlp.wbase) + (unsigned)w * (unsigned)KSH * 64u * NT;
   };
+  // position (k-step index in this wave's packed stream) of streamed k-step kk of group g
+  auto spos = [&](int g, int kk) { return RES ? g * PPR + kk : g * G + kk; };
+  T ring[STREAM ? NB : 1][G][NT];
+  T res[RES ? ROUNDS : 1][RPR > 0 ? RPR : 1][NT];
+  T* hres = lds + L.hres + (size_t)w * ROUNDS * (LPR > 0 ? LPR : 1) * 64 * NT;
   if (Lh > 1) {
     const unsigned s1 = slice_h(1);
+    if constexpr (STREAM) {
 #pragma unroll
-    for (int g = 0; g < D; ++g)
+      for (int g = 0; g < D; ++g)
 #pragma unroll
-      for (int kk = 0; kk < G; ++kk) load_frag<T, NT>(wr, s1 + (unsigned)(g * G + kk) * 64u * NT, lo, ring[g][kk]);
+        for (int kk = 0; kk < G; ++kk) load_frag4<NT>(wr, s1 + (unsigned)spos(g, kk) * 64u * NT, lane, ring[g][kk]);
+    }
+    if constexpr (RES) {
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; ++rd) {
+#pragma unroll
+        for (int i = 0; i < RPR; ++i) load_frag4<NT>(wr, s1 + (unsigned)(rd * PPR + SPR + i) * 64u * NT, lane, res[rd][i]);
+#pragma unroll
+        for (int i = 0; i < LPR; ++i) {
+          T tmp[NT];
+          load_frag4<NT>(wr, s1 + (unsigned)(rd * PPR + SPR + RPR + i) * 64u * NT, lane, tmp);
+          lds_put4<NT>(hres + (rd * LPR + i) * 64 * NT, lane, tmp);
+        }
+      }
+    }
   }
-  // this lane's hidden biases live in LDS; its A-operand row / k offsets
   const int arow = lane & 3, ak = lane >> 4, drow = lane >> 4, dcol = lane & 15;
 
   const T* st = args.states + (size_t)p * (H + 1) * nx;
@@ -145,32 +236,26 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
   T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
   T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
   const int rows = args.mode == 0 ? 1 : args.ls_n;
-  const int m = tid / TPS, r = tid % TPS;          // candidate row of this thread, helper index
   const bool cdiag = args.cost_diag != 0;
-  // control law: `parts` threads per (row, control), interleaved over the state index
-  const int parts = (8 * nu <= TPS) ? 8 : 4;
-  const int ca = r / parts, cpart = r - ca * parts;
-
-  constexpr int KR = (16 * 32 + NTHR - 1) / NTHR;
-  T kreg[KR];
-  T kvr = T(0), ubr = T(0), xbr = T(0);
-  auto fetch_ls = [&](int t) {
+  // Wave w owns row w of the tile between time steps: it adds the network output to its state,
+  // evaluates the control law (ilqr.py:196-205) -- no workgroup barrier in between -- and
+  // accumulates the row's stage cost.  Control law: `parts` lanes per control, interleaved over
+  // the state index; each lane keeps its entries of K_t, xbar_t (and k_t, ubar_t) in registers,
+  // loaded one step ahead.
+  const int parts = nu <= 8 ? 8 : 4;
+  const int ca = lane / parts, cpart = lane - ca * parts;
+  constexpr int KPL = 8;                             // entries per lane: nx <= 32 = 4 * 8
+  T kreg[KPL], xbreg[KPL], kvr = T(0), ubr = T(0);
+  auto fetch_law = [&](int t) {
+    if (args.mode == 1) {
 #pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const int idx = tid + k * NTHR;
-      if (idx < nu * nx) kreg[k] = Kg[(size_t)t * nu * nx + idx];
+      for (int i = 0; i < KPL; ++i) {
+        const int b = cpart + parts * i;
+        if (ca < nu && b < nx) { kreg[i] = Kg[((size_t)t * nu + ca) * nx + b]; xbreg[i] = st[(size_t)t * nx + b]; }
+      }
+      if (ca < nu) kvr = kg[(size_t)t * nu + ca];
     }
-    if (tid < nu) { kvr = kg[(size_t)t * nu + tid]; ubr = ctw[(size_t)t * nu + tid]; }
-    if (tid < nx) xbr = st[(size_t)t * nx + tid];
-  };
-  auto commit_ls = [&]() {
-#pragma unroll
-    for (int k = 0; k < KR; ++k) {
-      const int idx = tid + k * NTHR;
-      if (idx < nu * nx) Km[idx] = kreg[k];
-    }
-    if (tid < nu) { kv[tid] = kvr; ubar[tid] = ubr; }
-    if (tid < nx) xbar[tid] = xbr;
+    if (ca < nu) ubr = ctw[(size_t)t * nu + ca];    // mode 0: the control itself
   };
 
   // acceptance state of the reference's sequential loop (thread 0)
@@ -180,48 +265,52 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
 
   const int npass = (rows + ROWS - 1) / ROWS;
   for (int pass = 0; pass < npass; ++pass) {
-    const int j = ROWS * pass + m;                 // this thread's candidate
-    const bool live = j < rows;
-    const T alpha = args.alphas[j < kIlqrMaxLs ? j : 0];
+    const int jw = ROWS * pass + w;                  // the candidate this wave's row carries
+    const bool livew = jw < rows;
+    const T alpha = args.alphas[jw < kIlqrMaxLs ? jw : 0];
     T obj_part = T(0);
-    for (int i = tid; i < ROWS * nx; i += NTHR) {
-      const int row = i / nx, col = i - row * nx;
-      xu[row * xs + col] = st[col];
-    }
-    if (args.mode == 1) { fetch_ls(0); commit_ls(); }
-    __syncthreads();
-    for (int t = 0; t < H; ++t) {
+    if (lane < nx) xu[w * xs + lane] = st[lane];
+    fetch_law(0);
+    for (int t = 0; t <= H; ++t) {
 #ifdef AMPC_X_PHASETIME
       if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (args.mode == 1 && pass == 0 && t == H / 2) ? 1 : 0;
 #endif
       AMPC_IMARK(40);
-      if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
-      // ---- controls of this step (ilqr.py:196-205)
-      if (args.mode == 0) {
-        for (int a = r; a < nu; a += TPS) xu[m * xs + nx + a] = ctw[(size_t)t * nu + a];
-      } else {
-        T f = T(0);
-        if (ca < nu)
-          for (int b = cpart; b < nx; b += parts) f += Km[ca * nx + b] * (xu[m * xs + b] - xbar[b]);
-        f += __shfl_xor(f, 1);
-        f += __shfl_xor(f, 2);
-        if (parts == 8) f += __shfl_xor(f, 4);
-        if (ca < nu && cpart == 0) {
-          T u = alpha * kv[ca] + ubar[ca] + f;
-          if (args.bounded) { u = u < blo[ca] ? blo[ca] : u; u = u > bhi[ca] ? bhi[ca] : u; }
-          if (live) lsc[((size_t)j * H + t) * nu + ca] = u;
-          xu[m * xs + nx + ca] = u;
+      // ---- between steps, on row w: x_t = x_{t-1} + net output, then u_t
+      if (t > 0 && lane < nx) {
+        T s = bias[Lh * HP + lane];
+#pragma unroll
+        for (int ww = 0; ww < W; ++ww) s += part[(ww * ROWS + w) * nxp + lane];
+        const T xn = xu[w * xs + lane] + s;
+        xu[w * xs + lane] = xn;
+        if (args.mode == 0 && w == 0) stw[(size_t)t * nx + lane] = xn;
+      }
+      if (args.mode == 1 && livew && lane < nx) lss[((size_t)jw * (H + 1) + t) * nx + lane] = xu[w * xs + lane];
+      if (t == H) break;
+      {
+        T u;
+        if (args.mode == 0) {
+          u = ubr;
+        } else {
+          T f = T(0);
+#pragma unroll
+          for (int i = 0; i < KPL; ++i) {
+            const int b = cpart + parts * i;
+            if (ca < nu && b < nx) f += kreg[i] * (xu[w * xs + b] - xbreg[i]);
+          }
+          f = group_sum(f, parts == 8);
+          u = alpha * kvr + ubr + f;
+          if (args.bounded && ca < nu) { u = u < blo[ca] ? blo[ca] : u; u = u > bhi[ca] ? bhi[ca] : u; }
         }
-        if (live)
-          for (int a = r; a < nx; a += TPS) lss[((size_t)j * (H + 1) + t) * nx + a] = xu[m * xs + a];
+        if (ca < nu && cpart == 0) {
+          if (args.mode == 1 && livew) lsc[((size_t)jw * H + t) * nu + ca] = u;
+          xu[w * xs + nx + ca] = u;
+        }
+        if (t + 1 < H) fetch_law(t + 1);
       }
       AMPC_IMARK(41);
       lds_barrier();
       AMPC_IMARK(42);
-      // ---- objective: dt * (stage costs)
-      obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs, goal, no, r, TPS, cdiag) +
-                             quad_rows<T>(Rm, xu + m * xs + nx, nullptr, nu, r, TPS, cdiag));
-      AMPC_IMARK(43);
       // ---- layer 0
       T* ain = lds + L.act0;
       {
@@ -229,12 +318,24 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = T(0);
         const T* ap = xu + arow * xs + ak;
+        T av0[KS0MAX];
+#pragma unroll
+        for (int ks = 0; ks < KS0MAX; ++ks)
+          if (ks < ks0) av0[ks] = ap[4 * ks];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KS0MAX; ++ks)
           if (ks < ks0) {
-            const T a = ap[4 * ks];
+            const T a = av0[ks];
+            T bv[NT];
+            if constexpr (W0LDS) {
+              lds_frag4<NT>(w0l + ks * 64 * NT, lane, bv);
+            } else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(a, w0[ks][nt], acc[nt]);
+              for (int nt = 0; nt < NT; ++nt) bv[nt] = w0[ks][nt];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(a, bv[nt], acc[nt]);
           }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -245,7 +346,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
       AMPC_IMARK(44);
       lds_barrier();
       AMPC_IMARK(45);
-      // ---- hidden -> hidden layers, streamed
+      // ---- hidden -> hidden layers
       for (int l = 1; l < Lh; ++l) {
         T* aout = lds + ((l & 1) ? L.act1 : L.act0);
         const unsigned sl = slice_h(l), sn = slice_h(l + 1 < Lh ? l + 1 : 1);
@@ -253,20 +354,49 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = T(0);
         const T* ap = ain + arow * as + ak;
+        constexpr int APG = RES ? PPR : G;            // A operands (k-steps) per group
+        T av[2][APG];                                 // one group ahead of the MFMAs
+#pragma unroll
+        for (int kk = 0; kk < APG; ++kk) av[0][kk] = ap[4 * kk];
 #pragma unroll
         for (int g = 0; g < NGH; ++g) {
-          const int gn = g + D;                     // the group fetched now: D ahead, into the slot group g-1 left
+          if (g + 1 < NGH) {
 #pragma unroll
-          for (int kk = 0; kk < G; ++kk) {
-            if (gn < NGH) load_frag<T, NT>(wr, sl + (unsigned)(gn * G + kk) * 64u * NT, lo, ring[gn % NB][kk]);
-            else load_frag<T, NT>(wr, sn + (unsigned)((gn - NGH) * G + kk) * 64u * NT, lo, ring[gn % NB][kk]);
+            for (int kk = 0; kk < APG; ++kk) av[(g + 1) & 1][kk] = ap[4 * (APG * (g + 1) + kk)];
           }
-          const int kg0 = OWNPACK ? 8 * ((g + w) & (NG8 - 1)) : G * g;   // first k-step of this group
+          const int gn = g + D;                       // the streamed group fetched now: D ahead
+          if constexpr (STREAM) {
 #pragma unroll
-          for (int kk = 0; kk < G; ++kk) {
-            const T a = ap[4 * (kg0 + kk)];
+            for (int kk = 0; kk < G; ++kk) {
+              if (gn < NGH) load_frag4<NT>(wr, sl + (unsigned)spos(gn, kk) * 64u * NT, lane, ring[gn % NB][kk]);
+              else load_frag4<NT>(wr, sn + (unsigned)spos(gn - NGH, kk) * 64u * NT, lane, ring[gn % NB][kk]);
+            }
+          }
+          if constexpr (RES) {
+            // round g = k-steps [PPR g, PPR (g+1)): streamed, then register-resident, then LDS-resident
+            T lv[LPR > 0 ? LPR : 1][NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(a, ring[g % NB][kk][nt], acc[nt]);
+            for (int i = 0; i < LPR; ++i) lds_frag4<NT>(hres + (g * LPR + i) * 64 * NT, lane, lv[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < PPR; ++kk) {
+              const T a = av[g & 1][kk];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const T bv = kk < SPR ? ring[g % NB][kk < SPR ? kk : 0][nt]
+                           : kk < SPR + RPR ? res[g][kk - SPR < RPR && kk >= SPR ? kk - SPR : 0][nt]
+                                            : lv[kk >= SPR + RPR ? kk - SPR - RPR : 0][nt];
+                acc[nt] = mfma4(a, bv, acc[nt]);
+              }
+            }
+          } else {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < G; ++kk) {
+              const T a = av[g & 1][kk];
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma4(a, ring[g % NB][kk][nt], acc[nt]);
+            }
           }
         }
 #pragma unroll
@@ -282,9 +412,13 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
       {
         T o0 = T(0), o1 = T(0);
         const T* ap = ain + arow * as + 4 * (w * KSW) + ak;
+        T avo[KSW];
+#pragma unroll
+        for (int ks = 0; ks < KSW; ++ks) avo[ks] = ap[4 * ks];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks) {
-          const T a = ap[4 * ks];
+          const T a = avo[ks];
           o0 = mfma4(a, wout[ks][0], o0);
           if (tiles > 1) o1 = mfma4(a, wout[ks][1], o1);
         }
@@ -294,31 +428,24 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
       AMPC_IMARK(47);
       lds_barrier();
       AMPC_IMARK(48);
-      for (int a = r; a < nx; a += TPS) {
-        T s = bias[Lh * HP + a];
-#pragma unroll
-        for (int ww = 0; ww < W; ++ww) s += part[(ww * ROWS + m) * nxp + a];
-        const T xn = xu[m * xs + a] + s;
-        xu[m * xs + a] = xn;
-        if (args.mode == 0 && m == 0) stw[(size_t)(t + 1) * nx + a] = xn;
-      }
-      if (args.mode == 1 && t + 1 < H) commit_ls();
-      AMPC_IMARK(49);
-      lds_barrier();
-      AMPC_IMARK(50);
     }
-    if (args.mode == 1 && live)
-      for (int a = r; a < nx; a += TPS) lss[((size_t)j * (H + 1) + H) * nx + a] = xu[m * xs + a];
-    obj_part += quad_rows<T>(Fm, xu + m * xs, goal, no, r, TPS, cdiag);
+    // ---- objective of row w (ilqr.py:141-149, 206): dt * stage costs + terminal cost, from the stored
+    // trajectory, one time step per lane -- kept off the serial chain of the rollout above
+    __syncthreads();                                 // (orders this workgroup's trajectory stores)
+    {
+      const T* xsrc = args.mode == 0 ? stw : lss + (size_t)jw * (H + 1) * nx;
+      const T* usrc = args.mode == 0 ? ctw : lsc + (size_t)jw * H * nu;
+      if (livew)
+        for (int t = lane; t <= H; t += 64) {
+          const T* xt = xsrc + (size_t)t * nx;
+          if (t < H) obj_part += args.dt * (quad_rows<T>(Qm, xt, goal, no, 0, 1, cdiag) +
+                                            quad_rows<T>(Rm, usrc + (size_t)t * nu, nullptr, nu, 0, 1, cdiag));
+          else obj_part += quad_rows<T>(Fm, xt, goal, no, 0, 1, cdiag);
+        }
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) obj_part += __shfl_xor(obj_part, off);
-    if (lane == 0) lsobj[kIlqrMaxLs + w] = obj_part;      // one partial per wave; TPS / 64 waves per row
-    __syncthreads();
-    if (tid < ROWS) {
-      T s = T(0);
-      for (int ww = 0; ww < TPS / 64; ++ww) s += lsobj[kIlqrMaxLs + tid * (TPS / 64) + ww];
-      lsobj[ROWS * pass + tid] = s;
-    }
+    if (lane == 0) lsobj[ROWS * pass + w] = obj_part;
     __syncthreads();
 
     if (args.mode == 0) {
@@ -362,6 +489,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_ls4_kernel(const IlqrArgs<double>
     piv[0] = sel; piv[1] = fail; piv[2] = success ? 1 : 0;
     scal[3] = new_obj;
     args.iters[p] += 1;
+    args.ls_rows[p] += ROWS * (last / ROWS + 1);
   }
   __syncthreads();
   const int sel = piv[0], fail = piv[1], success = piv[2];

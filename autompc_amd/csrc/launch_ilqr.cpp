@@ -18,7 +18,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     // latency-optimised sweep (MFMA products, per-lane LU): model states <= 32 and the control
     // dimensions it is instantiated for; everything else takes the general kernel
     const size_t mb = (size_t)make_ric_lds(h->nx, h->nu, h->obs_dim).total * sizeof(T);
-    static const bool mfma_sweep = !(getenv("AMPC_RICCATI") && atoi(getenv("AMPC_RICCATI")) == 0);
+    const bool mfma_sweep = p->use_mfma_sweep != 0;
 #define AMPC_RIC_NU(NUV, SHT)                                                                        \
     case NUV: { auto rk = ilqr_riccati_mfma_kernel<T, NUV, SHT>; HIP_OK(allow_lds(rk, mb));          \
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; break; }
@@ -66,21 +66,28 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   }
   // f64 MLP models with <= 32 states: candidates four at a time on 4x4x4 MFMA tiles (ilqr_ls4.hpp)
   if constexpr (sizeof(T) == 8) {
-    static const bool ls4 = !(getenv("AMPC_LS4") && atoi(getenv("AMPC_LS4")) == 0);
-    if (ls4 && h->nx <= 32) {
-      const size_t lb = (size_t)make_ls4_lds(h->nx, h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, h->nw,
+    if (p->use_ls4 && !h->has_sindy && h->nx <= 32) {
+      // one hidden -> hidden layer: that layer partly resident on chip (registers + LDS)
+      const bool res = h->n_hidden == 2;
+      const size_t lb = (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res,
                                              h->cost_stride).total * sizeof(T);
+      REQUIRE(lb <= kLdsLimit, "ilqr: line-search workspace does not fit the 160 KB LDS");
       if (p->static_shape >= 0) {
-#define AMPC_SD_BODY { auto k = ilqr_ls4_kernel<NT, W, SH>; HIP_OK(allow_lds(k, lb));   \
-        hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), lb, h->stream, a); }
+#define AMPC_SD_BODY { auto k = ilqr_ls4_kernel<SH::hpad / 64, SH::n_hidden == 2, SH>; HIP_OK(allow_lds(k, lb));   \
+        hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * kLs4W), lb, h->stream, a); }
         AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
       } else {
-        AMPC_DISPATCH(h, 1, {
-          auto k = ilqr_ls4_kernel<NT, W, DynShape>;
-          HIP_OK(allow_lds(k, lb));
-          hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), lb, h->stream, a);
-        });
+#define AMPC_LS4_CASE(NTV, RESV)                                                               \
+        case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
+          HIP_OK(allow_lds(k, lb));                                                            \
+          hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * kLs4W), lb, h->stream, a); } break;
+        switch ((h->hpad / 64) * 2 + (res ? 1 : 0)) {
+          AMPC_LS4_CASE(1, 0) AMPC_LS4_CASE(1, 1) AMPC_LS4_CASE(2, 0) AMPC_LS4_CASE(2, 1)
+          AMPC_LS4_CASE(3, 0) AMPC_LS4_CASE(3, 1) AMPC_LS4_CASE(4, 0) AMPC_LS4_CASE(4, 1)
+          default: return fail("internal: unsupported hidden width for the four-row line search");
+        }
+#undef AMPC_LS4_CASE
       }
       HIP_OK(hipGetLastError());
       if (e) HIP_OK(hipEventRecord(e[2], h->stream));

@@ -151,6 +151,11 @@ template <typename T> struct MlpDev {
   // W_out'[k = 4 ks + l/16][col = 16 + l%4].
   const T* wt;
   int tail4;
+  // the forward weights once more, packed for a FOUR-wave workgroup whatever (W, NT) the tile uses
+  // (N-split hidden layers with hpad/64 column tiles per wave, no rotation, chunked so that every
+  // fragment load is coalesced -- see build_model; K-split output layer): the four-row line-search
+  // kernel (ilqr_ls4.hpp).
+  const T* w4[kMaxHidden + 1];
 };
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).

@@ -339,10 +339,13 @@ def secondary_workload(args, R):
         ug = np.zeros((B, 50, nu))
         iters = []
 
+        rows = []
+
         def step(i):
             out = plan.solve(x0, ug, max_iter=50)
             if i >= warm:
                 iters.append(float(out["iters"].mean()))
+                rows.append(plan.stats()["candidate_rows"] / float(B))
         label = "c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU" % B
         unit_per_step = B
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
@@ -350,19 +353,25 @@ def secondary_workload(args, R):
                                     before_timed=lambda: plan.set_timing(True))
         kt = plan.timing()
         if rank == 0:
-            # algorithmic work of one iteration of one problem: Jacobian chain over H
-            # rows + the 10-candidate line-search rollout + the accepted-trajectory forward pass
+            # work of one solve of one problem: per iteration the Jacobian chain over H rows
+            # and the forward pass of the accepted trajectory; the line search as EXECUTED -- candidate
+            # rows rolled out (four per pass; the reference rolls out all ten step sizes every
+            # iteration, ilqr.py:196-205, the same arithmetic per row)
             it = float(np.mean(iters))
+            ls_rows = float(np.mean(rows))
             hid = sum(a * b for a, b in zip(spec["hidden"], spec["hidden"][1:]))
             jac = 50 * 2 * nx * (hid + spec["hidden"][0] * (nx + nu))
-            ls = 10 * 50 * 2 * mlp_macs
-            per_iter = jac + ls + 50 * 2 * mlp_macs
+            row = 50 * 2 * mlp_macs
+            per_solve = it * (jac + row) + ls_rows * row
+            ls = ls_rows / it * row                      # line-search flops of one problem-iteration
             extra["mean_iterations_per_solve"] = it
-            extra["algorithmic_tflops"] = world * steps * B * it * per_iter / elapsed / 1e12
+            extra["mean_line_search_rows_per_iteration"] = ls_rows / it
+            extra["algorithmic_tflops"] = world * steps * B * per_solve / elapsed / 1e12
+            extra["reference_work_tflops"] = world * steps * B * it * (jac + 11 * row) / elapsed / 1e12
             if kt and kt.get("launches"):
                 n = nx + nu
-                cand = {"jacobian": (B * jac, "mlp_jacobian_kernel"), "iter": (B * ls, "ilqr_iter_kernel"),
-                        "riccati": (B * 50 * 2.0 * (2 * nx * nx * n + nx * n * n), "ilqr_riccati_kernel")}
+                cand = {"jacobian": (B * jac, "mlp_jacobian_kernel"), "iter": (B * ls, "ilqr_ls4_kernel"),
+                        "riccati": (B * 50 * 2.0 * (2 * nx * nx * n + nx * n * n), "ilqr_riccati_mfma_kernel")}
                 dom = max(cand, key=lambda k: kt.get(k + "_ms", 0.0))
                 fl, kname = cand[dom]
                 ach = fl / (kt[dom + "_ms"] * 1e-3) / 1e12

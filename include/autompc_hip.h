@@ -245,6 +245,12 @@ int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
  * over the iterations since the last call, and their number; then resets the counters. */
 int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable);
 int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations);
+/* Work of the last ampc_ilqr_solve: iterations launched, and candidate rows the line searches
+ * rolled out, summed over the plan's problems.  The reference rolls out all ls_max_iter = 10 step
+ * sizes in every iteration (ilqr.py:196-205) and then accepts the first that passes its test; the
+ * f64 MLP path rolls them out four at a time and stops at the first accepted one (same decisions,
+ * same results), so its row count is a multiple of 4 per iteration.  Either pointer may be NULL. */
+int ampc_ilqr_plan_stats(ampc_ilqr_plan* p, long long* iterations, long long* candidate_rows);
 /* use_goal = 0 (default): the backward sweep is seeded with the terminal gradient exactly as the
  * reference computes it, (F + F') x_N -- Cost.eval_term_obs_cost_diff ignores the goal
  * (cost.py:195, 208-211).  use_goal != 0: (F + F') (x_N - goal), the derivative of the terminal

@@ -146,3 +146,59 @@ def test_nonstrict_quadcost_seeds_the_sweep_about_the_goal():
         assert rel_err(st, ost) < 1e-6 and rel_err(ct, oct_) < 1e-6
         res[strict] = ct
     assert rel_err(res[True], res[False]) > 1e-3        # the flag changes the solve
+
+
+@pytest.mark.parametrize("nx,nu,hidden,act,bounded", [
+    (17, 6, [256, 256], "relu", False),      # resident hidden layer (registers + LDS + streamed)
+    (17, 6, [200, 256], "tanh", True),
+    (5, 2, [128, 100], "sigmoid", True),     # hidden layer fully register-resident
+    (3, 1, [64, 64], "selu", False),
+    (9, 3, [192, 150], "relu", True),        # 192-wide: registers + streamed
+    (17, 6, [256], "relu", True),            # no hidden -> hidden layer
+    (8, 8, [256, 256, 256], "tanh", False),  # every hidden layer streamed
+    (32, 16, [128, 128, 128, 128], "relu", True),
+    (12, 4, [64], "tanh", False),
+])
+def test_four_row_line_search_and_mfma_sweep_match_the_general_kernels(monkeypatch, nx, nu, hidden, act, bounded):
+    """The latency-optimised f64 iLQR kernels -- the four-row line search (candidates four at a
+    time, stops at the first accepted one) and the MFMA backward sweep -- against the general
+    16-row / scalar kernels on the same problems, and against the oracle: same decisions (iteration
+    counts, convergence flags), same trajectories."""
+    from autompc_amd import _lib
+    H, B, dt = 15, 5, 0.05
+    p = omlp.random_params(nx, nu, hidden, act, seed=nx * 7 + nu)
+    rng = np.random.default_rng(nx + len(hidden))
+    Q = np.stack([rng.uniform(0.5, 2.0) * np.eye(nx) + 0.1 * np.diag(rng.uniform(size=nx)) for _ in range(B)])
+    if nx == 17 and not bounded:                     # a dense cost block as well
+        S = rng.normal(size=(B, nx, nx))
+        Q = Q + 0.05 * (S + S.transpose(0, 2, 1)) + 0.3 * np.eye(nx)
+    R = np.stack([np.diag(rng.uniform(0.05, 0.2, size=nu)) for _ in range(B)])
+    F = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(B)])
+    goal = rng.normal(scale=0.05, size=(B, nx))
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx))
+    outs = {}
+    for name, ls4, sweep in (("fast", "1", "1"), ("general", "0", "0")):
+        monkeypatch.setenv("AMPC_LS4", ls4)
+        monkeypatch.setenv("AMPC_RICCATI", sweep)
+        h = _lib.Handle(0, "f64")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], act, p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        h.set_quad_costs(Q, R, F, goal)
+        if bounded:
+            h.set_ctrl_bounds(-0.4 * np.ones(nu), 0.5 * np.ones(nu))
+        plan = _lib.IlqrPlan(h, B, H, dt, cost_index=np.arange(B), clip_to_bounds=bounded)
+        outs[name] = plan.solve(x0, np.zeros((B, H, nu)), max_iter=30)
+        outs[name]["rows"] = plan.stats()["candidate_rows"]
+        plan.close(); h.close()
+    f, g = outs["fast"], outs["general"]
+    assert np.array_equal(f["converged"], g["converged"]) and np.array_equal(f["iters"], g["iters"])
+    assert np.array_equal(f["status"], g["status"])
+    assert rel_err(f["states"], g["states"]) < 1e-7 and rel_err(f["ctrls"], g["ctrls"]) < 1e-7
+    assert rel_err(f["objective"], g["objective"]) < 1e-9
+    assert f["rows"] % 4 == 0 and 0 < f["rows"] <= g["rows"]        # never more candidates than the full tile
+    system = make_system(nx, nu, dt=dt)
+    b = 0
+    orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q[b], R[b], F[b], goal[b]), dt, H,
+                     ubounds=(np.full(nu, -0.4), np.full(nu, 0.5)) if bounded else None, max_iter=30)
+    conv, st, ct, Ks, ks = orc.solve(x0[b], np.zeros((H, nu)))
+    assert int(f["iters"][b]) == orc.n_iter and bool(f["converged"][b]) == conv
+    assert rel_err(f["states"][b], st) < 1e-6 and rel_err(f["ctrls"][b], ct) < 1e-6

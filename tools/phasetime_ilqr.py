@@ -39,10 +39,9 @@ if os.environ.get("AMPC_LS4") == "0":
           45: "reduce + state update", 46: "commit + barrier"}
     seq = [40, 41, 42, 43, 44, 45, 46]
 else:
-    ls = {41: "fetch issue + controls + stores", 42: "barrier", 43: "objective", 44: "layer 0", 45: "barrier",
-          46: "hidden layer(s) incl. barrier", 47: "output layer partials", 48: "barrier", 49: "state update + commit",
-          50: "barrier"}
-    seq = list(range(40, 51))
+    ls = {41: "state update + controls + objective", 42: "barrier", 44: "layer 0", 45: "barrier",
+          46: "hidden layer(s) incl. barrier", 47: "output layer partials", 48: "barrier"}
+    seq = [40, 41, 42, 44, 45, 46, 47, 48]
 m = np.array(marks[:56], dtype=np.int64)
 print("line-search step, cycles:", m[seq[-1]] - m[40], "(each line includes the mark's own s_memtime wait)")
 for a, b in zip(seq[:-1], seq[1:]):
