@@ -36,6 +36,10 @@ extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle*
   ampc_handle* h = new ampc_handle();
   h->device = device;
   h->precision = precision;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+  }
   if (stream) {
     h->stream = (hipStream_t)stream;
   } else {
@@ -941,6 +945,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   p->lds_bytes = ((size_t)p->lds_work + wk.total) * sizeof(T);
   p->use_ls4 = env_int("AMPC_LS4", 1) != 0;
   p->use_mfma_sweep = env_int("AMPC_RICCATI", 1) != 0;
+  p->par_passes = env_int("AMPC_LS4_PAR", 1) != 0;
   p->static_shape = -1;
   if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
     const int sid = static_shape_of<T>(h, m);
@@ -966,12 +971,12 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(p->ls_states.reserve((size_t)B * p->ls_n * (H + 1) * nx * e));
   HIP_OK(p->ls_ctrls.reserve((size_t)B * p->ls_n * H * nu * e));
   HIP_OK(p->obj.reserve((size_t)B * e));
-  HIP_OK(p->flags.reserve((size_t)6 * B * sizeof(int)));
-  HIP_OK(hipMemset(p->flags.p, 0, (size_t)6 * B * sizeof(int)));
+  HIP_OK(p->flags.reserve((size_t)7 * B * sizeof(int)));
+  HIP_OK(hipMemset(p->flags.p, 0, (size_t)7 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
   if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
-  HIP_OK(p->ric.reserve((size_t)4 * p->B * e));
+  HIP_OK(p->ric.reserve((size_t)kRicStride * p->B * e));
   return 0;
 }
 

@@ -88,6 +88,7 @@ inline int env_int(const char* name, int dflt) {
 // ---------------------------------------------------------------------------------------------
 struct ampc_handle {
   int device = 0;
+  int n_cus = 256;      // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int precision = AMPC_F64;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -318,8 +319,9 @@ struct ampc_ilqr_plan {
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
-  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B]
-  int use_ls4 = 1, use_mfma_sweep = 1;   // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B] ls_count[B]
+  int use_ls4 = 1, use_mfma_sweep = 1, par_passes = 1;   // (AMPC_LS4_PAR = 0: passes one after the other)
+  int unused_ = 0;   // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
   TileLds L{};
   int lds_work = 0, lds_xn = 0;
   size_t lds_bytes = 0;
@@ -356,7 +358,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.obj = (T*)p->obj.p;
   int* f = (int*)p->flags.p;
   a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
-  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B;
+  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B; a.ls_count = f + 6 * p->B;
   a.ric = (T*)p->ric.p;
   return a;
 }

@@ -38,6 +38,7 @@ namespace ampc {
 
 constexpr int kRicThreads = 512;  // workgroup of the backward-sweep kernel
 constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows of one MFMA tile
+constexpr int kRicStride = 4 + kIlqrMaxLs;   // per problem: sweep sums [4], candidate objectives [16]
 
 template <typename T> struct IlqrArgs {
   MlpDev<T> mlp;
@@ -69,7 +70,10 @@ template <typename T> struct IlqrArgs {
   int* status;                   // [B] 0 ok, 1 singular Quu, 2 no line-search candidate
   int* refresh;                  // [B] Jacobians must be recomputed for this problem
   int* ls_rows;                  // [B] candidate rows rolled out by the line search since the solve began
-  T* ric;                        // [B][4] sweep -> line search: lin, quad, |k|, singular flag
+  T* ric;                        // [B][kRicStride] sweep -> line search: lin, quad, |k|, singular flag;
+                                 //    then the candidates' objectives when their passes run in parallel
+  int* ls_count;                 // [B] passes of the running line search that have finished (parallel passes)
+  int par_passes;                // line-search passes of one problem on separate workgroups (grid.y)
 };
 
 // Scratch map inside the work region (offsets in elements of T), nx/nu/n known at run time.
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   }
   AMPC_IMARK_ALWAYS(33);
   if (tid == 0) {
-    T* out = args.ric + (size_t)p * 4;
+    T* out = args.ric + (size_t)p * kRicStride;
     out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = scal[8];
     if (scal[8] != T(0)) {        // singular Quu: the reference raises LinAlgError here
       args.active[p] = 0; args.refresh[p] = 0;
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   if (tid < 64 && sing_any) scal[0] = T(1);
   __syncthreads();
   if (tid == nx) {
-    T* out = args.ric + (size_t)p * 4;
+    T* out = args.ric + (size_t)p * kRicStride;
     const T sg = scal[0];
     out[0] = lin; out[1] = quad; out[2] = sqrt(ksn2); out[3] = sg;
     if (sg != T(0)) {             // singular Quu: the reference raises LinAlgError here
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
 
   // (backward Riccati sweep: ilqr_riccati_kernel above, launched just before this kernel)
   if (args.mode == 1) {
-    const T* rin = args.ric + (size_t)p * 4;
+    const T* rin = args.ric + (size_t)p * kRicStride;
     if (rin[3] != T(0)) return;     // singular Quu: the sweep already retired this problem
     if (tid == 0) { scal[0] = rin[0]; scal[1] = rin[1]; scal[2] = rin[2]; }
     __syncthreads();

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     if (tid == 0) args.refresh[p] = 0;
     return;
   }
-  if (args.mode == 1 && args.ric[(size_t)p * 4 + 3] != T(0)) return;   // singular Quu: retired by the sweep
+  if (args.mode == 1 && args.ric[(size_t)p * kRicStride + 3] != T(0)) return;   // singular Quu: retired by the sweep
 
   for (int l = 0; l < Lh; ++l)
     for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.b[l][i];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     bhi[i] = args.bounded ? args.ubounds[nu + i] : T(0);
   }
   if (tid == 0 && args.mode == 1) {
-    const T* rin = args.ric + (size_t)p * 4;
+    const T* rin = args.ric + (size_t)p * kRicStride;
     scal[0] = rin[0]; scal[1] = rin[1]; scal[2] = rin[2];
   }
 
@@ -263,8 +263,13 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   int best = -1, last = 0, decided = 0;
   __syncthreads();
 
+  // Passes: one after the other in this workgroup (stopping at the first accepted candidate), or --
+  // small batches, idle CUs -- each pass on its own workgroup (blockIdx.y), all at once; the last
+  // workgroup to finish then runs the reference's acceptance loop over all of them.
   const int npass = (rows + ROWS - 1) / ROWS;
-  for (int pass = 0; pass < npass; ++pass) {
+  const bool par = args.mode == 1 && args.par_passes != 0;
+  const int pass0 = par ? (int)blockIdx.y : 0, pass1 = par ? (int)blockIdx.y + 1 : npass;
+  for (int pass = pass0; pass < pass1; ++pass) {
     const int jw = ROWS * pass + w;                  // the candidate this wave's row carries
     const bool livew = jw < rows;
     const T alpha = args.alphas[jw < kIlqrMaxLs ? jw : 0];
@@ -456,11 +461,25 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
       }
       return;
     }
+    if (par) {
+      // publish this pass's objectives; the last pass to arrive takes over
+      T* gobj = args.ric + (size_t)p * kRicStride + 4;
+      if (tid < ROWS) gobj[ROWS * pass + tid] = lsobj[ROWS * pass + tid];
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) piv[4] = atomicAdd(&args.ls_count[p], 1);
+      __syncthreads();
+      if (piv[4] != npass - 1) return;
+      __threadfence();
+      if (tid == 0) args.ls_count[p] = 0;
+      if (tid < kIlqrMaxLs) lsobj[tid] = tid < rows ? __builtin_nontemporal_load(gobj + tid) : T(0);
+      __syncthreads();
+    }
     // ---- the reference's acceptance loop over the candidates rolled out so far (ilqr.py:207-233)
     if (tid == 0) {
       const T obj = args.obj[p];
       const T lin_ = scal[0], quad_ = scal[1], ksn = scal[2];
-      for (int jj = ROWS * pass; jj < rows && jj < ROWS * (pass + 1); ++jj) {
+      for (int jj = par ? 0 : ROWS * pass; jj < rows && (par || jj < ROWS * (pass + 1)); ++jj) {
         last = jj;
         const T a = args.alphas[jj];
         const T new_obj = lsobj[jj];
@@ -489,7 +508,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     piv[0] = sel; piv[1] = fail; piv[2] = success ? 1 : 0;
     scal[3] = new_obj;
     args.iters[p] += 1;
-    args.ls_rows[p] += ROWS * (last / ROWS + 1);
+    args.ls_rows[p] += par ? ROWS * npass : ROWS * (last / ROWS + 1);
   }
   __syncthreads();
   const int sel = piv[0], fail = piv[1], success = piv[2];

@@ -72,16 +72,20 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       const size_t lb = (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res,
                                              h->cost_stride).total * sizeof(T);
       REQUIRE(lb <= kLdsLimit, "ilqr: line-search workspace does not fit the 160 KB LDS");
+      // few problems: the passes of a line search side by side on otherwise idle CUs
+      const int npass = (p->ls_n + 3) / 4;
+      a.par_passes = (mode == 1 && p->par_passes && p->B * npass <= h->n_cus) ? 1 : 0;
+      const dim3 grid(p->B, a.par_passes ? npass : 1);
       if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto k = ilqr_ls4_kernel<SH::hpad / 64, SH::n_hidden == 2, SH>; HIP_OK(allow_lds(k, lb));   \
-        hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * kLs4W), lb, h->stream, a); }
+        hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); }
         AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
       } else {
 #define AMPC_LS4_CASE(NTV, RESV)                                                               \
         case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
           HIP_OK(allow_lds(k, lb));                                                            \
-          hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * kLs4W), lb, h->stream, a); } break;
+          hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
         switch ((h->hpad / 64) * 2 + (res ? 1 : 0)) {
           AMPC_LS4_CASE(1, 0) AMPC_LS4_CASE(1, 1) AMPC_LS4_CASE(2, 0) AMPC_LS4_CASE(2, 1)
           AMPC_LS4_CASE(3, 0) AMPC_LS4_CASE(3, 1) AMPC_LS4_CASE(4, 0) AMPC_LS4_CASE(4, 1)

@@ -23,6 +23,7 @@ b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_2rank_plumbing.json 2> $OUT/bench_2rank_plumbing.err
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
+timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f64_b1 --steps 100 --warmup 10 > $OUT/profile_c3.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f32_b1 --precision f32 --steps 100 --warmup 10 > $OUT/profile_c3f32.log 2>&1
 bash tools/gpu_profile.sh $TAG c4_f64_b256 --workload c4 --steps 2 --warmup 1 > $OUT/profile_c4.log 2>&1
