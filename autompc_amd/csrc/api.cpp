@@ -1050,6 +1050,8 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
                     &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
+  if (p->poll_host) (void)hipHostFree(p->poll_host);
+  for (hipEvent_t e : p->poll_ev) if (e) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
   delete p;
   handle_release(h);
@@ -1070,30 +1072,48 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   HIP_OK(hipStreamSynchronize(h->stream));
   if (int rc = ilqr_launch_iter<T>(p, 0)) return rc;        // rollout of the guess + objective
   if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
-  std::vector<int> flags(6 * B);
+  std::vector<int> flags(7 * B);
   HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)B * sizeof(int), h->stream));
-  int it = 0;
-  for (; it < max_iter; ++it) {
-    if (p->timing) {
-      if (p->ev_used + 5 > p->ev.size())
-        for (int i = 0; i < 5; ++i) {
-          hipEvent_t x;
-          HIP_OK(hipEventCreate(&x));
-          p->ev.push_back(x);
-        }
-      p->ev_cur = &p->ev[p->ev_used];
-      p->ev_used += 5;
+  if (!p->poll_host) {
+    HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * B * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
+  }
+  // Iterations are queued in batches of kPoll; the `active` flags of a batch are copied out behind
+  // it and inspected only after the NEXT batch has been queued, so the stream never drains while the
+  // host decides.  Iterations queued past convergence are no-ops (retired problems exit at once).
+  constexpr int kPoll = 4;
+  int it = 0, batch = 0, pending = -1;     // pending: batch whose flags are in flight
+  bool done = false;
+  while (it < max_iter && !done) {
+    const int n = std::min(kPoll, max_iter - it);
+    for (int k = 0; k < n; ++k) {
+      if (p->timing) {
+        if (p->ev_used + 5 > p->ev.size())
+          for (int i = 0; i < 5; ++i) {
+            hipEvent_t x;
+            HIP_OK(hipEventCreate(&x));
+            p->ev.push_back(x);
+          }
+        p->ev_cur = &p->ev[p->ev_used];
+        p->ev_used += 5;
+      }
+      if (int rc = ilqr_launch_iter<T>(p, 1)) return rc;      // backward sweep + line search + accept
+      if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
+      p->ev_cur = nullptr;
     }
-    if (int rc = ilqr_launch_iter<T>(p, 1)) return rc;      // backward sweep + line search + accept
-    if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
-    p->ev_cur = nullptr;
-    if ((it & 3) == 3 || it + 1 == max_iter) {              // poll the active flags every 4 iterations
-      HIP_OK(hipMemcpyAsync(flags.data(), p->flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIP_OK(hipStreamSynchronize(h->stream));
+    it += n;
+    const int slot = batch & 1;
+    HIP_OK(hipMemcpyAsync(p->poll_host + (size_t)slot * B, (const int*)p->flags.p + B, (size_t)B * sizeof(int),
+                          hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
+    if (pending >= 0) {
+      const int ps = pending & 1;
+      HIP_OK(hipEventSynchronize(p->poll_ev[ps]));
       bool any = false;
-      for (int b = 0; b < B; ++b) any |= flags[B + b] != 0;
-      if (!any) { ++it; break; }
+      for (int b = 0; b < B; ++b) any |= p->poll_host[(size_t)ps * B + b] != 0;
+      if (!any) done = true;
     }
+    pending = batch++;
   }
   p->last_iterations = it;
   HIP_OK(hipMemcpyAsync(flags.data(), p->flags.p, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -333,6 +333,10 @@ struct ampc_ilqr_plan {
   std::vector<hipEvent_t> ev;   // 5 per timed iteration
   size_t ev_used = 0;
   hipEvent_t* ev_cur = nullptr; // the running iteration's five events (null: not timed)
+  // convergence polling: the `active` flags of one batch of iterations are copied to pinned host
+  // memory behind that batch and read while the NEXT batch is already queued
+  int* poll_host = nullptr;     // [2][B] pinned
+  hipEvent_t poll_ev[2] = {nullptr, nullptr};
 };
 
 template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {

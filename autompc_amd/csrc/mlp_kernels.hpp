@@ -40,6 +40,12 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   const int first = blockIdx.x * M;
   T* xu = lds + L.xu;
+  if (rm.mask != nullptr && first < n) {   // (iLQR refresh) every group of this tile is masked out
+    const int last = (first + M - 1 < n ? first + M - 1 : n - 1) / rm.grp;
+    bool any = false;
+    for (int g = first / rm.grp; g <= last; ++g) any |= rm.mask[g] != 0;
+    if (!any) return;
+  }
   Net net;
   net.init(mlp);
   tile_load_constants<T, W>(mlp, L, lds, M);
@@ -115,6 +121,12 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   const int i_out = blockIdx.x % nx;               // the output index of this tile
   const int s0 = (blockIdx.x / nx) * M;            // its first sample
   const size_t lstride = (size_t)n_pad * hpad;
+  if (rm.mask != nullptr) {            // every group this tile touches is masked out: nothing to refresh
+    const int last = (s0 + M - 1 < n ? s0 + M - 1 : n - 1) / rm.grp;
+    bool any = false;
+    for (int g = s0 / rm.grp; g <= last; ++g) any |= rm.mask[g] != 0;
+    if (!any) return;
+  }
 
   // G_L[s][k] = W_out'[i][k] * d_L[s][k]
   for (int e = tid; e < M * HP; e += NTHR) {
