@@ -36,4 +36,4 @@ for name in ("ilqr_hc6_relu_free", "ilqr_hc6_relu_bounded", "ilqr_hc6_tanh_free"
     plan.set_timing(False)
     print("%-24s IterativeLQR.run  %.2f ms per call (min %.2f)  iterations %d  converged %s  u rel err %.1e"
           % (name, 1e3 * np.median(ts[2:]), 1e3 * min(ts[2:]), ctl.last_iters, bool(g["converged"]), err))
-    print("    per-iteration kernel ms:", {k: round(v, 4) for k, v in kt.items() if k.endswith("_ms")}, "launches", kt.get("launches"))
+    print("    per-iteration kernel ms:", {k: round(float(v), 4) for k, v in kt.items() if k.endswith("_ms")}, "launches", kt.get("launches"))
