@@ -202,3 +202,31 @@ def test_four_row_line_search_and_mfma_sweep_match_the_general_kernels(monkeypat
     conv, st, ct, Ks, ks = orc.solve(x0[b], np.zeros((H, nu)))
     assert int(f["iters"][b]) == orc.n_iter and bool(f["converged"][b]) == conv
     assert rel_err(f["states"][b], st) < 1e-6 and rel_err(f["ctrls"][b], ct) < 1e-6
+
+
+def test_line_search_passes_side_by_side_equal_passes_in_sequence(monkeypatch):
+    """Few problems: the three four-row passes of a line search run on separate workgroups and the
+    last one to finish decides; many problems: one workgroup runs them one after the other and stops
+    at the first accepted candidate.  Same arithmetic, same decisions: identical results."""
+    from autompc_amd import _lib
+    nx, nu, H, B, dt = 17, 6, 25, 4, 0.05
+    p = omlp.random_params(nx, nu, [256, 256], "relu", seed=5)
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx))
+    outs = []
+    for par in ("1", "0"):
+        monkeypatch.setenv("AMPC_LS4_PAR", par)
+        h = _lib.Handle(0, "f64")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        h.set_quad_costs(np.eye(nx), 0.05 * np.eye(nu), 2 * np.eye(nx), np.zeros(nx))
+        plan = _lib.IlqrPlan(h, B, H, dt)
+        out = plan.solve(x0, np.zeros((B, H, nu)), max_iter=40)
+        out["stats"] = plan.stats()
+        outs.append(out)
+        plan.close(); h.close()
+    a, b = outs
+    for k in ("states", "ctrls", "Ks", "ks", "objective", "iters", "converged", "status"):
+        assert np.array_equal(a[k], b[k]), k
+    total_iters = int(a["iters"].sum())
+    assert a["stats"]["candidate_rows"] == 12 * total_iters          # side by side: all three passes, always
+    assert 4 * total_iters <= b["stats"]["candidate_rows"] <= 12 * total_iters
