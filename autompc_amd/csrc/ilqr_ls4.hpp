@@ -11,8 +11,8 @@
 // decisions, and therefore the results, are those of the reference's sequential loop.
 //
 // Operand layout (lane l of a wave; probed, see mfma4 in mlp_tile.hpp): A = act[row l%4][k = 4ks +
-// l/16] (the same for the four blocks), B = W[k = 4ks + l/16][col 16g + l%16] -- exactly the
-// fragment the 16x16x4 MFMA takes, so the packed weights of mlp_tile.hpp are used unchanged -- and
+// l/16] (the same for the four blocks), B = W[k = 4ks + l/16][col 16g + l%16] -- the lane <-> (k, col)
+// map of the fragment the 16x16x4 MFMA takes, so the packers of api.cpp serve both -- and
 // D = out[row l/16][col 16g + l%16], one value per lane.
 //
 // Weights.  A CU can fetch 64 B per clock from L2: streaming the 512 KB of a 256 x 256 f64 layer
