@@ -92,7 +92,7 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
   }
 }
 
-// Tile = 16*MT samples x ONE output index i: blockIdx.x = sample_block * nx + i.  Every row of a
+// Tile = 16*MT samples x ONE output index i (blockIdx -> tile: see the XCD-aware map below).  Every row of a
 // tile then shares the W_out row (a broadcast) and maps to its sample without a division.
 // wout_plain: folded output weights [nx][hpad] (zero padded); dz: [layer][n_pad][hpad] from
 // mlp_forward_kernel<DERIV>.  jx[n][nx][nx], ju[n][nx][nu].
@@ -118,8 +118,25 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   const int nx = mlp.nx, nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
   constexpr int HP = Net::HP;                      // == hpad for this instantiation
   const int gs = hpad + (sizeof(T) == 8 ? 1 : 2);  // same padding rule as TileLds::act_stride
-  const int i_out = blockIdx.x % nx;               // the output index of this tile
-  const int s0 = (blockIdx.x / nx) * M;            // its first sample
+  // blockIdx -> (sample block, output index), XCD-aware: workgroups are dealt round-robin to the 8
+  // XCDs (blockIdx % 8), each with its own L2.  The nx tiles of one sample block read the same
+  // stored activation derivatives, so they are given block indices of one residue mod 8 -- one
+  // XCD, one HBM fetch of that data instead of up to eight.  (Sample blocks beyond the last
+  // multiple of 8 keep the plain order.)
+  int i_out, sblk;
+  {
+    const int nblk = gridDim.x / nx, full = nblk / 8 * 8, b = blockIdx.x;
+    if (b < full * nx) {
+      const int xcd = b & 7, q8 = b >> 3;          // q8 counts this XCD's tiles
+      i_out = q8 % nx;
+      sblk = (q8 / nx) * 8 + xcd;
+    } else {
+      const int r = b - full * nx;
+      i_out = r % nx;
+      sblk = full + r / nx;
+    }
+  }
+  const int s0 = sblk * M;                         // the tile's first sample
   const size_t lstride = (size_t)n_pad * hpad;
   if (rm.mask != nullptr) {            // every group this tile touches is masked out: nothing to refresh
     const int last = (s0 + M - 1 < n ? s0 + M - 1 : n - 1) / rm.grp;
