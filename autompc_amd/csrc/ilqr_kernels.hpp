@@ -447,18 +447,6 @@ __host__ __device__ constexpr RicLds make_ric_lds(int nx, int nu, int no) {
   return r;
 }
 
-// 1 / d to within an ulp or two: hardware estimate + Newton steps (the full IEEE division sequence
-// is twice as long, and every pivot's reciprocal sits on the sweep's critical path).
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  return fma(fma(-d, r, 1.0), r, r);
-}
-__device__ __forceinline__ float fast_rcp(float d) {
-  float r = __builtin_amdgcn_rcpf(d);
-  return fmaf(fmaf(-d, r, 1.0f), r, r);
-}
-
 // Quu x = rhs on a private register copy, for symmetric positive definite Quu (the usual case):
 // LDL' on the lower triangle, no pivot search.  Returns 0 when some pivot is not safely positive;
 // the caller then repeats the solve with lu_solve_lane.  x: rhs in, solution out.

@@ -77,10 +77,23 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       a.par_passes = (mode == 1 && p->par_passes && p->B * npass <= h->n_cus) ? 1 : 0;
       const dim3 grid(p->B, a.par_passes ? npass : 1);
       if (p->static_shape >= 0) {
-#define AMPC_SD_BODY { auto k = ilqr_ls4_kernel<SH::hpad / 64, SH::n_hidden == 2, SH>; HIP_OK(allow_lds(k, lb));   \
-        hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); }
-        AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
-#undef AMPC_SD_BODY
+        // (the activation is a compile-time constant for relu AND tanh here: with the run-time
+        //  switch the epilogue keeps all five activations' temporaries alive and the kernel falls
+        //  off its register budget -- spills inside the time loop, 2x slower)
+#define AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, ACTV)                                            \
+        case (ID) * 8 + ((ACTV) < 0 ? 7 : (ACTV)): {                                               \
+          using SH = StaticShape<NX, NU, NO, NH, HPAD, ACTV>;                                      \
+          auto k = ilqr_ls4_kernel<HPAD / 64, NH == 2, SH>; HIP_OK(allow_lds(k, lb));              \
+          hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
+#define AMPC_LS4_ONE(ID, NX, NU, NO, NH, HPAD)                                                    \
+        AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 0) AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 1)    \
+        AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, -1)
+        switch (p->static_shape * 8 + ((h->act == 0 || h->act == 1) ? h->act : 7)) {
+          AMPC_STATIC_SHAPES(AMPC_LS4_ONE)
+          default: return fail("internal: unknown static shape");
+        }
+#undef AMPC_LS4_ONE
+#undef AMPC_LS4_SHAPE
       } else {
 #define AMPC_LS4_CASE(NTV, RESV)                                                               \
         case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
