@@ -115,16 +115,15 @@ __device__ __forceinline__ float fast_rcp(float d) {
   return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
 
-// tanh in f64, <= 3 ulp (checked against a long-double reference over 4.7 M points, incl. subnormal
-// and saturating arguments), ~35 instructions against the ~130 of the library routine -- which made a
-// tanh network cost twice a relu one in every kernel that evaluates the activation in its time loop.
-//   tanh|x| = M / (M + 2),  M = expm1(2|x|) = 2^n E + (2^n - 1),  2|x| = n ln2 + r,  E = expm1(r):
-// one formula for all magnitudes, no cancellation (M >= 0), E from a degree-14 polynomial on
-// |r| <= 0.347.
-__device__ __forceinline__ double fast_tanh(double x) {
-  const double a = fmin(fabs(x), 20.0), y = a + a;                 // tanh(20) rounds to 1
+// expm1(y) in f64 for |y| <= 700, ~25 instructions: y = n ln2 + r (Cody-Waite), E = expm1(r) from a
+// degree-14 polynomial on |r| <= 0.347, expm1(y) = 2^n E + (2^n - 1).  The three smooth activations
+// are built on it -- a few ulp each (checked against long-double references over millions of
+// points, incl. subnormal and saturating arguments) at a quarter of the library routines'
+// instruction count, and with few enough temporaries that the run-time activation switch no longer
+// decides a kernel's register budget.
+__device__ __forceinline__ double expm1_core(double y) {
   const double n = __builtin_rint(y * 1.4426950408889634074);
-  double r = fma(-n, 6.93147180369123816490e-01, y);               // Cody-Waite, ln2 = hi + lo
+  double r = fma(-n, 6.93147180369123816490e-01, y);               // ln2 = hi + lo
   r = fma(-n, 1.90821492927058770002e-10, r);
   double q = 1.1470745597729725e-11;                               // 1/14!
   q = fma(q, r, 1.6059043836821613e-10);                           // 1/13!
@@ -141,14 +140,35 @@ __device__ __forceinline__ double fast_tanh(double x) {
   q = fma(q, r, 0.5);                                              // 1/2!
   const double E = fma(r * r, q, r);
   const double s = ldexp(1.0, (int)n);
-  const double M = fma(s, E, s - 1.0);
-  const double d = M + 2.0, rc = fast_rcp(d);
-  double t = M * rc;
-  t = fma(fma(-d, t, M), rc, t);
+  return fma(s, E, s - 1.0);
+}
+// num / den with one correction step (den > 0, no overflow at the call sites)
+__device__ __forceinline__ double fast_div(double num, double den) {
+  const double rc = fast_rcp(den);
+  const double t = num * rc;
+  return fma(fma(-den, t, num), rc, t);
+}
+// tanh|x| = M / (M + 2), M = expm1(2|x|): one formula for all magnitudes, no cancellation (M >= 0)
+__device__ __forceinline__ double fast_tanh(double x) {
+  const double a = fmin(fabs(x), 20.0);                            // tanh(20) rounds to 1
+  const double M = expm1_core(a + a);
+  const double t = fast_div(M, M + 2.0);
   return x != x ? x : copysign(t, x);
 }
+// sigmoid(x) = 1 / (1 + e^-x) = 1 / (2 + expm1(-x))
+__device__ __forceinline__ double fast_sigmoid(double x) {
+  const double M = expm1_core(-fmax(fmin(x, 700.0), -700.0));
+  const double t = fast_div(1.0, M + 2.0);
+  return x != x ? x : t;
+}
+// expm1 for the negative branch of SELU (saturates at -1 below -40)
+__device__ __forceinline__ double fast_expm1_neg(double x) { return expm1_core(fmax(x, -40.0)); }
 __device__ __forceinline__ double tanh_t(double x) { return fast_tanh(x); }
 __device__ __forceinline__ float tanh_t(float x) { return tanhf(x); }
+__device__ __forceinline__ double sigmoid_t(double x) { return fast_sigmoid(x); }
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ double expm1n_t(double x) { return fast_expm1_neg(x); }
+__device__ __forceinline__ float expm1n_t(float x) { return expm1f(x); }
 
 // ---- activations (torch semantics: ReLU, Tanh, Sigmoid, SELU; mlp.py:44-51) -------------
 // kind 4 = identity: a linear model x' = A x + B u (ARX arx.py:151-154, Koopman
@@ -157,12 +177,12 @@ template <typename T> __device__ __forceinline__ T act_apply(int kind, T z) {
   switch (kind) {
     case 0: return z > T(0) ? z : T(0);
     case 1: return tanh_t(z);
-    case 2: return T(1) / (T(1) + exp(-z));
+    case 2: return sigmoid_t(z);
     case 4: return z;
     default: {
       const T alpha = T(1.6732632423543772848170429916717);
       const T scale = T(1.0507009873554804934193349852946);
-      return scale * (z > T(0) ? z : alpha * expm1(z));
+      return scale * (z > T(0) ? z : alpha * expm1n_t(z));
     }
   }
 }
@@ -171,12 +191,12 @@ template <typename T> __device__ __forceinline__ T act_deriv(int kind, T z) {
   switch (kind) {
     case 0: return z > T(0) ? T(1) : T(0);
     case 1: { T t = tanh_t(z); return T(1) - t * t; }
-    case 2: { T s = T(1) / (T(1) + exp(-z)); return s * (T(1) - s); }
+    case 2: { T s = sigmoid_t(z); return s * (T(1) - s); }
     case 4: return T(1);
     default: {
       const T alpha = T(1.6732632423543772848170429916717);
       const T scale = T(1.0507009873554804934193349852946);
-      return z > T(0) ? scale : scale * alpha * exp(z);
+      return z > T(0) ? scale : scale * alpha * (expm1n_t(z) + T(1));
     }
   }
 }
