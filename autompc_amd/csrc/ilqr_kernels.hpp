@@ -11,9 +11,12 @@
 //     accept the first alpha with (obj-new)/(-(alpha lin + alpha^2 quad/2)) > 0.3, else best-so-far;
 //     refresh Jacobians of the accepted trajectory; stop on ||du|| < 1e-3 or line-search failure
 //
-// Decomposition.  ilqr_iter_kernel (this file) does the backward sweep, the batched line-search
-// rollout (the MLP tile of mlp_tile.hpp, rows = step sizes) and the acceptance logic for one
-// problem per workgroup, entirely from LDS.  Between iterations the host launches
+// Decomposition.  One iteration is four launches.  The backward sweep: ilqr_riccati_mfma_kernel
+// (model states <= 32 and the usual control dimensions: MFMA products from LDS, per-lane LDL' / LU
+// solve) or ilqr_riccati_kernel (everything else).  The line search + acceptance: ilqr_ls4_kernel
+// (ilqr_ls4.hpp: f64 MLP models, candidates four at a time on 4x4x4 MFMA tiles, weights resident
+// on chip) or ilqr_iter_kernel (this file: all step sizes as the rows of one 16-row tile of
+// mlp_tile.hpp; f32, SINDy, wide states).  One problem per workgroup, entirely from LDS.  Then
 // mlp_forward_kernel<DERIV> + mlp_jacobian_kernel over all (problem, t) rows at once -- the
 // Jacobian refresh is the only phase with H-fold parallelism, so it gets the whole chip.
 // Problems that have converged / failed keep their workgroup slot but exit immediately.
