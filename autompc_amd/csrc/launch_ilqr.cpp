@@ -66,12 +66,14 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   }
   // f64 MLP models with <= 32 states: candidates four at a time on 4x4x4 MFMA tiles (ilqr_ls4.hpp)
   if constexpr (sizeof(T) == 8) {
-    if (p->use_ls4 && !h->has_sindy && h->nx <= 32) {
-      // one hidden -> hidden layer: that layer partly resident on chip (registers + LDS)
-      const bool res = h->n_hidden == 2;
-      const size_t lb = (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res,
-                                             h->cost_stride).total * sizeof(T);
-      REQUIRE(lb <= kLdsLimit, "ilqr: line-search workspace does not fit the 160 KB LDS");
+    // one hidden -> hidden layer: that layer partly resident on chip (registers + LDS)
+    const bool res = h->n_hidden == 2;
+    const size_t lb = (p->use_ls4 && !h->has_sindy && h->nx <= 32)
+        ? (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res, h->cost_stride).total * sizeof(T)
+        : 0;
+    // (a wide first layer with many controls can push the resident LDS copies past 160 KB: those
+    //  shapes take the general kernel below)
+    if (lb > 0 && lb <= kLdsLimit) {
       // few problems: the passes of a line search side by side on otherwise idle CUs
       const int npass = (p->ls_n + 3) / 4;
       a.par_passes = (mode == 1 && p->par_passes && p->B * npass <= h->n_cus) ? 1 : 0;

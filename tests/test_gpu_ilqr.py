@@ -158,6 +158,7 @@ def test_nonstrict_quadcost_seeds_the_sweep_about_the_goal():
     (8, 8, [256, 256, 256], "tanh", False),  # every hidden layer streamed
     (32, 16, [128, 128, 128, 128], "relu", True),
     (12, 4, [64], "tanh", False),
+    (17, 16, [192, 256], "relu", False),     # resident LDS copies would not fit: the general kernel serves it
 ])
 def test_four_row_line_search_and_mfma_sweep_match_the_general_kernels(monkeypatch, nx, nu, hidden, act, bounded):
     """The latency-optimised f64 iLQR kernels -- the four-row line search (candidates four at a
