@@ -93,8 +93,9 @@ def main():
                 t2 = Task(system)
                 t2.set_cost(QuadCost(system, Q, R, F, goal=goal))
                 il = IterativeLQR(system, t2, m, Hh)
-                oil = ILQROracle(omodel, QuadCostOracle(Q, R, F, goal), system.dt, Hh, max_iter=2)
-                r1 = il._device().solve(obs[None, :], np.zeros((1, Hh, nu)), 2)
+                n_it = int(rng.integers(1, 7))
+                oil = ILQROracle(omodel, QuadCostOracle(Q, R, F, goal), system.dt, Hh, max_iter=n_it)
+                r1 = il._device().solve(obs[None, :], np.zeros((1, Hh, nu)), n_it)
                 co, so, uo2, Ko, ko = oil.solve(obs, np.zeros((Hh, nu)))
                 ei = max(rel(r1["states"][0], so), rel(r1["Ks"][0], Ko))
                 worst["ilqr"] = max(worst["ilqr"], ei / 1e-6)
@@ -111,8 +112,8 @@ def main():
     worst.update({"lin_pred": 0.0, "lin_mppi": 0.0, "loop_score": 0.0})
     os.environ["AMPC_MT"] = "0"
     for case in range(max(4, n_cases // 10)):
-        ns, nu = int(rng.integers(1, 33)), int(rng.integers(1, 9))
-        if ns + nu > 48:
+        ns, nu = int(rng.integers(1, 65)), int(rng.integers(1, 9))     # 33..64: the four-output-tile path
+        if ns <= 32 and ns + nu > 48:
             nu = 48 - ns
         no = int(rng.integers(1, ns + 1))
         system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
