@@ -231,3 +231,33 @@ def test_line_search_passes_side_by_side_equal_passes_in_sequence(monkeypatch):
     total_iters = int(a["iters"].sum())
     assert a["stats"]["candidate_rows"] == 12 * total_iters          # side by side: all three passes, always
     assert 4 * total_iters <= b["stats"]["candidate_rows"] <= 12 * total_iters
+
+
+@pytest.mark.parametrize("H", [1, 2, 3, 8, 9, 17])
+def test_fast_kernels_on_short_and_odd_horizons(monkeypatch, H):
+    """Horizons around the kernels' internal strides (one step, fewer steps than a ring look-ahead,
+    not a multiple of anything): fast vs general kernels, and the oracle."""
+    from autompc_amd import _lib
+    nx, nu, B, dt = 17, 6, 3, 0.05
+    p = omlp.random_params(nx, nu, [256, 256], "relu", seed=H)
+    rng = np.random.default_rng(H)
+    Q, R, F = np.eye(nx), 0.05 * np.eye(nu), 2 * np.eye(nx)
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx))
+    outs = {}
+    for name, flag in (("fast", "1"), ("general", "0")):
+        monkeypatch.setenv("AMPC_LS4", flag)
+        monkeypatch.setenv("AMPC_RICCATI", flag)
+        h = _lib.Handle(0, "f64")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        h.set_quad_costs(Q, R, F, np.zeros(nx))
+        plan = _lib.IlqrPlan(h, B, H, dt)
+        outs[name] = plan.solve(x0, np.zeros((B, H, nu)), max_iter=20)
+        plan.close(); h.close()
+    f, g = outs["fast"], outs["general"]
+    assert np.array_equal(f["iters"], g["iters"]) and np.array_equal(f["converged"], g["converged"])
+    assert rel_err(f["states"], g["states"]) < 1e-8 and rel_err(f["ctrls"], g["ctrls"]) < 1e-8
+    system = make_system(nx, nu, dt=dt)
+    orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q, R, F, np.zeros(nx)), dt, H, max_iter=20)
+    conv, st, ct, Ks, ks = orc.solve(x0[0], np.zeros((H, nu)))
+    assert int(f["iters"][0]) == orc.n_iter and bool(f["converged"][0]) == conv
+    assert rel_err(f["states"][0], st) < 1e-6 and rel_err(f["ctrls"][0], ct) < 1e-6
