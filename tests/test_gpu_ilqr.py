@@ -261,3 +261,31 @@ def test_fast_kernels_on_short_and_odd_horizons(monkeypatch, H):
     conv, st, ct, Ks, ks = orc.solve(x0[0], np.zeros((H, nu)))
     assert int(f["iters"][0]) == orc.n_iter and bool(f["converged"][0]) == conv
     assert rel_err(f["states"][0], st) < 1e-6 and rel_err(f["ctrls"][0], ct) < 1e-6
+
+
+@pytest.mark.parametrize("nx,nu,hidden", [(17, 6, [256, 256]), (5, 2, [64, 64]), (12, 3, [128])])
+def test_f32_ilqr_sweep_kernels_agree_and_track_f64(monkeypatch, nx, nu, hidden):
+    """f32 mode (north_star's 1e-4 fast mode): the MFMA backward sweep in float against the general
+    float sweep (same first iterations), and against the f64 oracle within f32 accuracy."""
+    from autompc_amd import _lib
+    H, B, dt = 12, 3, 0.05
+    p = omlp.random_params(nx, nu, hidden, "tanh", seed=nx)
+    rng = np.random.default_rng(nx)
+    Q, R, F = np.eye(nx), 0.1 * np.eye(nu), 2 * np.eye(nx)
+    x0 = rng.uniform(-0.2, 0.2, size=(B, nx))
+    outs = {}
+    for name, flag in (("mfma", "1"), ("general", "0")):
+        monkeypatch.setenv("AMPC_RICCATI", flag)
+        h = _lib.Handle(0, "f32")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], "tanh", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        h.set_quad_costs(Q, R, F, np.zeros(nx))
+        plan = _lib.IlqrPlan(h, B, H, dt)
+        outs[name] = plan.solve(x0, np.zeros((B, H, nu)), max_iter=1)     # one iteration: no decision flips yet
+        plan.close(); h.close()
+    a, b = outs["mfma"], outs["general"]
+    assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
+    assert rel_err(a["Ks"], b["Ks"]) < 2e-3 and rel_err(a["states"], b["states"]) < 1e-3
+    system = make_system(nx, nu, dt=dt)
+    orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q, R, F, np.zeros(nx)), dt, H, max_iter=1)
+    conv, st, ct, Ks, ks = orc.solve(x0[0], np.zeros((H, nu)))
+    assert rel_err(a["states"][0], st) < 2e-3 and rel_err(a["Ks"][0], Ks) < 5e-3
