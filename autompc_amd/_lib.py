@@ -54,9 +54,11 @@ SIGNATURES = {
     "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
     "ampc_mppi_plan_set_noise_ids": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ampc_set_mt_jump_table": (c_int, [POINTER(c_uint32), c_int, c_int]),
+    "ampc_legacy_log_mode": (c_int, []),
     "ampc_mppi_legacy_normal": (c_int, [c_void_p, POINTER(c_uint32), c_int, c_int, c_double,
                                         POINTER(c_uint32), _ip, _ip, _dp]),
     "ampc_mppi_plan_set_geometry": (c_int, [c_void_p, c_int, c_int]),
+    "ampc_mppi_plan_set_step_offset": (c_int, [c_void_p, c_uint64]),
     "ampc_mppi_solve": (c_int, [c_void_p]),
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
@@ -96,6 +98,13 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def legacy_log_mode():
+    """ampc_legacy_log_mode(): 1 / 2 when the library reproduces the host C library's log() bit for
+    bit (glibc's FMA / non-FMA build) -- the device-generated numpy legacy stream is then numpy's
+    own, normals included -- 0 when it does not."""
+    return int(load().ampc_legacy_log_mode())
 
 
 def check(rc):
@@ -367,6 +376,11 @@ class MppiPlan:
         """Fix the rollout tile height (0 = automatic, 16/32/64) and the horizon the LDS layout is
         sized for, so results do not depend on what else shares the plan.  Call before upload()."""
         check(self.lib.ampc_mppi_plan_set_geometry(self._p, int(tile_rows), int(horizon_cap)))
+
+    def set_step_offset(self, first_step):
+        """Index of the first control step of the next closed loop (its Philox stream key), for
+        episodes run in segments."""
+        check(self.lib.ampc_mppi_plan_set_step_offset(self._p, int(first_step)))
 
     def set_noise_ids(self, ids):
         """ids [B]: the key of every problem's device noise stream (default: its index in the

@@ -16,6 +16,13 @@ Deviations, on purpose: ``mode='barrier'|'auglag'`` raise NotImplementedError at
 (the reference binds them to methods that do not exist, ilqr.py:71-74); ``state_dim`` returns
 ``model.state_dim + ctrl_dim`` (the reference's property references an undefined name,
 ilqr.py:84-87).
+
+Precision.  The solve is f64, like the reference.  A full iLQR solve is a chain of up to 50
+discrete line-search / acceptance / convergence decisions (``ratio > 0.3``, ``||du|| < 1e-3``,
+ilqr.py:207-263); in f32 one of them eventually falls the other way and the solve then stops at
+a different -- equally converged -- iterate: measured against the reference's golden solves the
+f32 states deviate by up to 4e-3 relative (tests/test_gpu_ilqr.py), outside north_star's 1e-4.
+``precision="f32"`` is therefore refused unless ``allow_inexact=True`` is passed as well.
 """
 import numpy as np
 
@@ -26,7 +33,7 @@ from .mppi import _quad_cost_blocks
 
 class IterativeLQR(Controller):
     def __init__(self, system, task, model, horizon, reuse_feedback=-1, ubounds=None, mode=None,
-                 verbose=False, precision=None, device=None):
+                 verbose=False, precision=None, device=None, allow_inexact=False):
         super().__init__(system, task, model)
         if not hasattr(model, "stage_into"):
             raise TypeError("IterativeLQR needs a device-stageable model (autompc_amd.sysid.MLP); "
@@ -49,6 +56,12 @@ class IterativeLQR(Controller):
         self.mode = mode
         self.verbose = verbose
         self.precision = precision or getattr(model, "precision", "f64")
+        if self.precision != "f64" and not allow_inexact:
+            raise ValueError("IterativeLQR solves in f64: an f32 solve takes different line-search / "
+                             "convergence decisions than the reference and ends up to 4e-3 away from "
+                             "its result (parity tolerance 1e-4).  Pass allow_inexact=True to run the "
+                             "f32 kernels anyway.")
+        self.allow_inexact = bool(allow_inexact)
         self.device = device if device is not None else getattr(model, "device", 0)
         self.compute_ilqr = self.compute_ilqr_default
         self._handle = self._plan = None

@@ -31,6 +31,29 @@ def _quad_cost_blocks(cost):
     return Q, R, F, np.asarray(cost.get_goal(), dtype=np.float64)
 
 
+class _ActSequence(np.ndarray):
+    """The host copy of a controller's warm-start sequence, handed out by ``MPPI.act_sequence``:
+    a plain writable array (the reference exposes a plain attribute that callers edit in place,
+    e.g. ``ctl.act_sequence[:] = 0``) that tells its controller when it was written to, so the
+    edit reaches the device copy before the next solve."""
+
+    def __new__(cls, array, owner):
+        obj = np.asarray(array).view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if self._owner is not None:
+            self._owner._act_dirty = True
+
+    def __reduce__(self):                      # pickles / deep-copies as a plain array
+        return np.asarray(self).copy().__reduce__()
+
+
 class MPPI(Controller):
     def __init__(self, system, task, model, **kwargs):
         super().__init__(system, task, model)
@@ -50,9 +73,11 @@ class MPPI(Controller):
         self.precision = kwargs.get("precision", getattr(model, "precision", "f64"))
         self.device = kwargs.get("device", getattr(model, "device", 0))
         self.per_particle_terminal = bool(kwargs.get("per_particle_terminal", False))
-        if self.noise not in ("numpy", "numpy_device", "device"):
-            raise ValueError("noise must be 'numpy' (parity, host draw), 'numpy_device' (numpy's "
-                             "legacy stream generated on the device) or 'device' (Philox, fast)")
+        if self.noise not in ("numpy", "numpy_host", "numpy_device", "device"):
+            raise ValueError("noise must be 'numpy' (the reference's draw from numpy's global legacy "
+                             "stream, bit for bit; generated on the device when that is provably exact, "
+                             "on the host otherwise), 'numpy_host' (always the host draw), "
+                             "'numpy_device' (always on the device) or 'device' (Philox, fast)")
         bounds = task.get_ctrl_bounds()
         self.umin = bounds[:, 0].copy()
         self.umax = bounds[:, 1].copy()
@@ -92,16 +117,17 @@ class MPPI(Controller):
 
     @property
     def act_sequence(self):
-        """The warm-start sequence (H, nu) in units of umax.  The array handed out is READ-ONLY:
-        after a solve the live copy is on the device, so an in-place edit of the host copy
-        (``ctl.act_sequence[0] += d`` works on the reference's plain attribute) would be silently
-        lost.  Assign through the setter instead: ``ctl.act_sequence = new_array``."""
+        """The warm-start sequence (H, nu) in units of umax -- after a solve the live copy is on the
+        device, so reading it downloads it.  The array handed out shares memory with the
+        controller's host copy and is writable like the reference's plain attribute
+        (mppi.py:97-99): item / slice assignment (``ctl.act_sequence[:] = 0``,
+        ``ctl.act_sequence[0] += d``) marks the host copy as newer and it is uploaded before the
+        next solve.  Writes that bypass ``__setitem__`` (``np.copyto``, ufunc ``out=``) are not
+        seen; assign through the setter for those."""
         if self._plan is not None and not self._act_dirty:
             a, _, _, _ = self._plan.download(act_seq=True, u=False)
             self._act_host = a.reshape(self.H, self.dim_ctrl)
-        view = self._act_host.view()
-        view.setflags(write=False)
-        return view
+        return _ActSequence(self._act_host, self)
 
     @act_sequence.setter
     def act_sequence(self, value):
@@ -117,10 +143,18 @@ class MPPI(Controller):
         x0 = self.model.update_state(constate[:-nu], constate[-nu:], new_obs)
         plan = self._device()
         act = self._act_host if self._act_dirty else None
-        if self.noise == "numpy":
+        mode = self.noise
+        if mode == "numpy":
+            # np.random.normal(scale, size=(N, H, nu)) from the global legacy generator
+            # (mppi.py:16-24, :126).  The device reproduces that draw bit for bit when the
+            # library has proven its restatement of the host C library's log() against log()
+            # itself (ampc_legacy_log_mode) and the global generator is the MT19937 it models.
+            exact = _lib.legacy_log_mode() != 0 and np.random.get_state(legacy=True)[0] == "MT19937"
+            mode = "numpy_device" if exact else "numpy_host"
+        if mode == "numpy_host":
             eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
             plan.upload(x0=x0, act_seq=act, eps=eps)
-        elif self.noise == "numpy_device":
+        elif mode == "numpy_device":
             # the same draw from the same global generator state, made on the device; the host
             # generator is then put into the state the draw would have left it in
             plan.upload(x0=x0, act_seq=act)

@@ -242,6 +242,7 @@ struct ampc_mppi_plan {
   ampc_handle* h = nullptr;
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
+  uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
   int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
   int static_lv = 0;      // which LDS map variant (StaticShape LV) the plan's tile uses
   int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
@@ -254,7 +255,7 @@ struct ampc_mppi_plan {
   // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
   // call is generated speculatively on a side stream (it only depends on the generator state this
   // call leaves behind) and used if the next call indeed starts from that state.
-  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly, lg_win;
+  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly, lg_win, lg_logtab;
   hipStream_t lg_side = nullptr;
   hipEvent_t lg_ev = nullptr;
   int lg_cur = 0;                 // buffer the speculation (if any) was written to

@@ -158,7 +158,10 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
       if (j < nu) {
         const T a = aseq[t * nu + j];
         T A = e_next[e] + a;
-        A = fmin(fmax(A, lo_r[e]), hi_r[e]);      // np.minimum(hi, np.maximum(lo, .)) (mppi.py:135)
+        // np.minimum(hi, np.maximum(lo, .)) (mppi.py:135) -- by comparison, so that a NaN warm
+        // start or noise value poisons the sample's cost as it does there (fmin/fmax drop NaNs)
+        A = A < lo_r[e] ? lo_r[e] : A;
+        A = A > hi_r[e] ? hi_r[e] : A;
         const T ec = A - a;
         if (valid && args.write_eps_out) epso[((size_t)t * N + n) * nu + j] = ec;
         if (args.lds_eps >= 0) lds[args.lds_eps + (t * M + m) * nu + j] = ec;

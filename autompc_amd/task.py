@@ -38,6 +38,12 @@ class Task:
     def set_term_cond(self, term_cond):
         self._term_cond = term_cond
 
+    def has_user_term_cond(self):
+        """True when set_term_cond installed a condition after the last set_num_steps (the
+        reference keeps both in one slot, tasks/task.py:52,101; the batched evaluator needs to know
+        whether the episode length is known up front)."""
+        return self._term_cond is not None
+
     def term_cond(self, traj):
         if self._term_cond is not None:
             return bool(self._term_cond(traj))

@@ -70,15 +70,61 @@ def _task_goal(cost, obs_dim):
     return np.zeros(obs_dim)
 
 
+def _num_steps_lambda(num_steps):
+    return lambda traj: len(traj) >= num_steps
+
+
+def episode_of(task):
+    """(max_steps, term_cond) of the episode ``PipelineTuner.eval_cfg`` simulates for `task`
+    (tuning/pipeline_tuner.py:222-231): ``simulate(controller, init_obs, task.term_cond,
+    max_steps=task.get_num_steps())`` when the task has a step count, simulate()'s own default
+    of 10000 steps otherwise (utils/simulation.py:11).  term_cond is None when the task's
+    termination condition is the one ``set_num_steps`` installs, ``len(traj) >= num_steps``
+    (tasks/task.py:41-53) -- the episode length is then known up front, see
+    ``default_episode_controls`` -- and the task's ``term_cond`` method otherwise (a user
+    condition set with ``set_term_cond``; it has to be asked on the host)."""
+    has_n = bool(task.has_num_steps())
+    max_steps = int(task.get_num_steps()) if has_n else 10000
+    probe = getattr(task, "has_user_term_cond", None)
+    if probe is not None:                       # autompc_amd.Task
+        user = bool(probe())
+    else:                                       # a reference-style task object: recognise the
+        fn = getattr(task, "_term_cond", None)  # closure set_num_steps installs by its code
+        if fn is None:
+            user = False
+        else:
+            ref = _num_steps_lambda(0)
+            cells = [c.cell_contents for c in (getattr(fn, "__closure__", None) or ())]
+            code = getattr(fn, "__code__", None)
+            user = not (has_n and code is not None and code.co_code == ref.__code__.co_code
+                        and code.co_consts == ref.__code__.co_consts and cells == [task.get_num_steps()])
+    return max_steps, (task.term_cond if user else None)
+
+
+def default_episode_controls(task):
+    """Control steps of an episode that ends on ``len(traj) >= num_steps``: simulate() asks the
+    condition after it has appended the new observation (utils/simulation.py:59-63), so the
+    episode has num_steps rows = num_steps - 1 controls (one control when num_steps <= 1 -- the
+    first question is asked about a two-row trajectory -- and none when max_steps = num_steps
+    is 0).  Without a step count: simulate()'s default max_steps."""
+    if not task.has_num_steps():
+        return 10000
+    n = int(task.get_num_steps())
+    return min(n, max(1, n - 1))
+
+
 class CandidateEvaluator:
     """Evaluates MPPI + QuadCost candidates for one (system, task, model, surrogate) on one GPU."""
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0,
-                 tile_rows=32, horizon_cap=30):
+                 tile_rows=32, horizon_cap=30, term_check_every=8):
         """tile_rows / horizon_cap fix the rollout geometry (MppiPlan.set_geometry) so that a
         candidate's score is bit-identical for any batch it is evaluated in; horizon_cap defaults
-        to the top of the reference's MPPI horizon range (mppi.py:52-55)."""
+        to the top of the reference's MPPI horizon range (mppi.py:52-55).  term_check_every: with
+        a user termination condition the episode runs on the device in segments of this many
+        control steps, the condition being asked on the host in between."""
         self.tile_rows, self.horizon_cap = int(tile_rows), int(horizon_cap)
+        self.term_check_every = max(1, int(term_check_every))
         if not hasattr(model, "stage_into"):
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         self.system, self.task, self.model = system, task, model
@@ -87,23 +133,46 @@ class CandidateEvaluator:
         b = task.get_ctrl_bounds()
         self.umin, self.umax = b[:, 0].copy(), b[:, 1].copy()
         self.goal = _task_goal(task.get_cost(), system.obs_dim)
+        self.last_lengths = None
 
     def evaluate(self, candidates, n_steps=None, seed=0, init_obs=None, eps_all=None,
                  act_init=None, return_trajectories=False, index_offset=0, timing=None):
         """Closed-loop score of every candidate (a list of dicts with keys horizon, sigma, lmda,
-        num_path, Q, R, F -- Q/R/F either diagonals or full matrices).
+        num_path, Q, R, F -- Q/R/F either diagonals or full matrices): the ``surr_cost`` of
+        pipeline_tuner.py:213-258.
+
+        Episode.  With ``n_steps=None`` (the tuner's call) the episode is the one eval_cfg
+        simulates: ``task.term_cond`` with ``max_steps = task.get_num_steps()``, i.e.
+        ``num_steps`` rows = ``num_steps - 1`` control steps for a task that only has a step
+        count (``default_episode_controls``); a user termination condition (``set_term_cond``) is
+        honoured exactly -- the device runs ``term_check_every`` steps at a time, the host asks the
+        condition about every new row in order, a finished candidate leaves the batch and is
+        scored on its own rows.  An explicit ``n_steps`` is ``simulate(..., max_steps=n_steps)``
+        with no termination condition: exactly that many control steps.
 
         All randomness of candidate i is keyed by (seed, index_offset + i): its warm start comes
         from ``default_rng([seed, index_offset + i])`` and its device noise from the Philox
         stream of that global index.  A rank that evaluates the shard ``all[lo:hi]`` with
         ``index_offset=lo`` therefore returns exactly the scores a single process returns for
-        those candidates (the per-candidate ``surr_cost`` of pipeline_tuner.py:213-258).
+        those candidates.
+
+        return_trajectories: also returns obs [B, rows, nx] and ctrls [B, rows, nu]; with a
+        termination condition, candidates that stopped early are NaN-padded to the longest one
+        and ``self.last_lengths`` holds every candidate's row count.
 
         timing: an optional dict; on return timing["timing"] holds the average HIP-event duration of
-        the rollout / update kernels over the closed loop's control steps (bench.py roofline leg)."""
+        the rollout / update kernels over the closed loop's control steps (bench.py roofline leg)
+        and timing["control_steps"] the number of control steps the episode ran."""
         B = len(candidates)
         if B == 0:
             return (np.zeros(0), None, None) if return_trajectories else np.zeros(0)
+        too_long = [int(c["horizon"]) for c in candidates if int(c["horizon"]) > self.horizon_cap]
+        if too_long:
+            # the LDS layout (and with it the summation order) would follow the batch's longest
+            # horizon: scores would silently depend on what else is in the batch
+            raise ValueError("candidate horizon %d exceeds the evaluator's horizon_cap %d; construct "
+                             "CandidateEvaluator(horizon_cap=...) for the range being searched"
+                             % (max(too_long), self.horizon_cap))
         opened = []                       # device objects, closed on every exit path
         try:
             return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
@@ -112,12 +181,10 @@ class CandidateEvaluator:
             for obj in reversed(opened):
                 obj.close()
 
-    def _evaluate(self, candidates, n_steps, seed, init_obs, eps_all, act_init, return_trajectories,
-                  index_offset, opened, timing=None):
-        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+    # -- pieces ---------------------------------------------------------------------------------
+    def _stage(self, candidates, opened):
+        nu, no = self.system.ctrl_dim, self.system.obs_dim
         B = len(candidates)
-        n_steps = int(n_steps if n_steps is not None else self.task.get_num_steps())
-        init_obs = self.task.get_init_obs() if init_obs is None else np.asarray(init_obs)
         h = _lib.Handle(self.device, self.precision)
         opened.append(h)
         self.model.stage_into(h)
@@ -131,13 +198,32 @@ class CandidateEvaluator:
             sur = _lib.Handle(self.device, self.precision)
             opened.append(sur)
             self.surrogate.stage_into(sur)
-        Hs = [int(c["horizon"]) for c in candidates]
-        plan = _lib.MppiPlan(h, [int(c["num_path"]) for c in candidates], Hs,
-                             [float(c["sigma"]) for c in candidates],
-                             [float(c["lmda"]) for c in candidates], cost_index=np.arange(B))
+        return h, sur
+
+    def _plan(self, h, candidates, which, noise_ids, act_seq, opened):
+        """MPPI plan over the candidates `which` (indices into the staged cost blocks)."""
+        plan = _lib.MppiPlan(h, [int(candidates[i]["num_path"]) for i in which],
+                             [int(candidates[i]["horizon"]) for i in which],
+                             [float(candidates[i]["sigma"]) for i in which],
+                             [float(candidates[i]["lmda"]) for i in which], cost_index=np.asarray(which))
         opened.append(plan)
         plan.set_geometry(self.tile_rows, self.horizon_cap)
-        plan.set_noise_ids(index_offset + np.arange(B))
+        plan.set_noise_ids(np.asarray(noise_ids)[which])
+        plan.upload(act_seq=act_seq)
+        return plan
+
+    def _evaluate(self, candidates, n_steps, seed, init_obs, eps_all, act_init, return_trajectories,
+                  index_offset, opened, timing=None):
+        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        B = len(candidates)
+        if n_steps is not None:
+            n_ctl, term_cond = int(n_steps), None
+        else:
+            max_steps, term_cond = episode_of(self.task)
+            n_ctl = default_episode_controls(self.task) if term_cond is None else max_steps
+        init_obs = self.task.get_init_obs() if init_obs is None else np.asarray(init_obs)
+        h, sur = self._stage(candidates, opened)
+        Hs = [int(c["horizon"]) for c in candidates]
         if act_init is None:
             # MPPI.__init__ / reset() draw the warm start ~ N(0, sigma) (mppi.py:97-99); here from
             # a stream seeded by (seed, global candidate index)
@@ -145,28 +231,139 @@ class CandidateEvaluator:
                 np.random.default_rng([int(seed), index_offset + i]).normal(
                     scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
                 for i, c in enumerate(candidates)])
-        plan.upload(act_seq=act_init)
-        if timing is not None:
-            plan.set_timing(True)
+        act_init = np.asarray(act_init, dtype=np.float64).ravel()
+        noise_ids = index_offset + np.arange(B)
         try:
             terms = cost_terms(self.task.get_cost(), no, nu)
         except TypeError:
             terms = None                  # a user-defined cost object: score it through its own
-        if terms is not None:             # Python interface from the downloaded trajectories
-            res = plan.closed_loop_scored(np.tile(init_obs, (B, 1)), n_steps, terms, seed=seed,
-                                          eps_all=eps_all, surrogate=sur,
+        if timing is not None:            # Python interface from the downloaded trajectories
+            timing["control_steps"] = n_ctl
+        x0 = np.tile(init_obs, (B, 1))
+        if term_cond is not None:
+            return self._evaluate_segmented(candidates, h, sur, x0, n_ctl, term_cond, seed, eps_all,
+                                            act_init, noise_ids, terms, return_trajectories, opened,
+                                            timing)
+        self.last_lengths = np.full(B, n_ctl + 1)
+        if n_ctl == 0:                    # max_steps = 0: the one-row trajectory is scored as is
+            obs, ctrls = x0[:, None, :].copy(), np.zeros((B, 1, nu))
+            scores = self._score(h, terms, obs, ctrls)
+            return (scores, obs, ctrls) if return_trajectories else scores
+        plan = self._plan(h, candidates, np.arange(B), noise_ids, act_init, opened)
+        if timing is not None:
+            plan.set_timing(True)
+        if terms is not None:
+            res = plan.closed_loop_scored(x0, n_ctl, terms, seed=seed, eps_all=eps_all, surrogate=sur,
                                           return_trajectories=return_trajectories)
             scores, obs, ctrls = res if return_trajectories else (res, None, None)
         else:
-            obs, ctrls = plan.closed_loop(np.tile(init_obs, (B, 1)), n_steps, seed=seed,
-                                          eps_all=eps_all, surrogate=sur)
-            scores = score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
+            obs, ctrls = plan.closed_loop(x0, n_ctl, seed=seed, eps_all=eps_all, surrogate=sur)
+            scores = self._score(h, None, obs, ctrls)
         if timing is not None:
             timing["timing"] = plan.timing()
         return (scores, obs, ctrls) if return_trajectories else scores
 
+    def _score(self, h, terms, obs, ctrls):
+        no = self.system.obs_dim
+        if terms is not None:
+            return h.score_trajectories(terms, obs, ctrls, obs_dim=no)
+        return score_trajectories(self.task.get_cost(), obs[:, :, :no], ctrls)
 
-def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None):
+    def _evaluate_segmented(self, candidates, h, sur, x0, max_steps, term_cond, seed, eps_all,
+                            act_init, noise_ids, terms, return_trajectories, opened, timing):
+        """An episode with a termination condition only the host can evaluate
+        (utils/simulation.py:62-63).  A candidate's closed loop does not depend on what else is in
+        the plan (fixed geometry, noise keyed by its global index and the step index), so running it
+        a few steps past its end and dropping it from the batch at the next segment boundary leaves
+        every row it keeps bit-identical to an unsegmented run."""
+        from ..trajectory import Trajectory
+        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        B = len(candidates)
+        Hs = np.array([int(c["horizon"]) for c in candidates])
+        a_off = np.concatenate([[0], np.cumsum(Hs * nu)])
+        e_sz = np.array([int(c["num_path"]) * int(c["horizon"]) * nu for c in candidates])
+        e_off = np.concatenate([[0], np.cumsum(e_sz)])
+        if eps_all is not None:
+            eps_all = np.asarray(eps_all, dtype=np.float64).reshape(-1, int(e_off[-1]))
+            if eps_all.shape[0] < max_steps:
+                raise ValueError("eps_all holds %d control steps, the episode may run %d"
+                                 % (eps_all.shape[0], max_steps))
+        obs = np.full((B, max_steps + 1, nx), np.nan)
+        ctl = np.full((B, max_steps + 1, nu), np.nan)
+        obs[:, 0] = x0
+        lengths = np.full(B, max_steps + 1)
+        alive = np.arange(B)
+        acts = [act_init[a_off[i]:a_off[i + 1]] for i in range(B)]
+        plan, plan_of, step0 = None, None, 0
+        t_sum, t_cnt = {"rollout_ms": 0.0, "update_ms": 0.0}, 0
+        while step0 < max_steps and alive.size:
+            k = min(self.term_check_every, max_steps - step0)
+            if plan is None:
+                plan = self._plan(h, candidates, alive, noise_ids, np.concatenate([acts[i] for i in alive]),
+                                  opened)
+                plan_of = alive.copy()
+                if timing is not None:
+                    plan.set_timing(True)
+            plan.set_step_offset(step0)
+            eps_seg = None
+            if eps_all is not None:
+                eps_seg = np.concatenate([np.concatenate([eps_all[s, e_off[i]:e_off[i + 1]] for i in plan_of])
+                                          for s in range(step0, step0 + k)])
+            o, c = plan.closed_loop(obs[plan_of, step0], k, seed=seed, eps_all=eps_seg, surrogate=sur)
+            obs[plan_of, step0 + 1:step0 + k + 1] = o[:, 1:]
+            ctl[plan_of, step0:step0 + k] = c[:, :k]
+            still = []
+            for i in plan_of:
+                done = False
+                for t in range(step0 + 1, step0 + k + 1):      # rows 0..t exist, control row t is zero
+                    rows_c = ctl[i, :t + 1].copy()
+                    rows_c[t] = 0.0
+                    if term_cond(Trajectory(self.system, t + 1, obs[i, :t + 1, :no].copy(), rows_c)):
+                        lengths[i], done = t + 1, True
+                        break
+                if not done:
+                    still.append(i)
+            step0 += k
+            if len(still) != len(plan_of):
+                # the survivors continue in a smaller plan, warm starts carried over
+                a, _, _, _ = plan.download(act_seq=True, u=False)
+                off = np.concatenate([[0], np.cumsum(Hs[plan_of] * nu)])
+                for j, i in enumerate(plan_of):
+                    acts[i] = a[off[j]:off[j + 1]]
+                if timing is not None:
+                    tm = plan.timing()
+                    for key in t_sum:
+                        t_sum[key] += tm[key] * tm["count"]
+                    t_cnt += tm["count"]
+                plan.close()
+                opened.remove(plan)
+                plan = None
+            alive = np.array(still, dtype=int)
+        if timing is not None:
+            if plan is not None:
+                tm = plan.timing()
+                for key in t_sum:
+                    t_sum[key] += tm[key] * tm["count"]
+                t_cnt += tm["count"]
+            timing["timing"] = {"rollout_ms": t_sum["rollout_ms"] / max(t_cnt, 1),
+                                "update_ms": t_sum["update_ms"] / max(t_cnt, 1), "count": t_cnt}
+            timing["control_steps"] = int(step0)
+        scores = np.empty(B)
+        for L in np.unique(lengths):
+            idx = np.nonzero(lengths == L)[0]
+            o, c = obs[idx, :L].copy(), ctl[idx, :L].copy()
+            c[:, L - 1] = 0.0                                  # simulate()'s trailing zero control row
+            scores[idx] = self._score(h, terms, o, c)
+            obs[idx, L:], ctl[idx, L - 1] = np.nan, 0.0
+            ctl[idx, L:] = np.nan
+        self.last_lengths = lengths
+        if return_trajectories:
+            Lmax = int(lengths.max())
+            return scores, obs[:, :Lmax], ctl[:, :Lmax]
+        return scores
+
+
+def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None, stats=None):
     """Score ``candidates`` with ``local_eval(sub_list, lo) -> scores`` on this rank's contiguous
     shard ``candidates[lo:hi]`` and all-gather the scores so every rank returns the full vector
     (candidate order).  ``lo`` is the global index of the shard's first candidate: an evaluator that
@@ -174,6 +371,9 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None)
     score for a candidate whatever the world size.
     Uses the default torch.distributed process group when one is initialised; with none (or world
     size 1) it is a plain local evaluation.
+
+    stats: an optional dict that receives what the exchange was -- "backend", "ranks_in_gather",
+    "gather_ms" (wall time of the all-gather on this rank, synchronised), "device".
 
     A rank whose local evaluation raises still takes part in the all-gather (its slot carries a
     failure marker), so the other ranks are not left waiting inside the collective; afterwards
@@ -187,6 +387,8 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None)
     n = len(candidates)
     lo, hi = shard_bounds(n, rank, world)
     if world == 1:
+        if stats is not None:
+            stats.update(backend=None, ranks_in_gather=1, gather_ms=0.0, device=None)
         return np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)
     error = None
     try:
@@ -203,8 +405,17 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None)
     slot[:hi - lo] = torch.from_numpy(local).to(dev)
     slot[per] = 0.0 if error is None else 1.0          # failure marker of this rank
     gathered = torch.empty(world * (per + 1), dtype=torch.float64, device=dev)
+    import time
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
     dist.all_gather_into_tensor(gathered, slot)
+    if dev.type == "cuda":
+        torch.cuda.synchronize(dev)
     g = gathered.cpu().numpy().reshape(world, per + 1)
+    if stats is not None:
+        stats.update(backend=dist.get_backend(), ranks_in_gather=int(g.shape[0]),
+                     gather_ms=1e3 * (time.perf_counter() - t0), device=str(dev))
     if error is not None:
         raise error
     failed = [r for r in range(world) if g[r, per] != 0.0]

@@ -9,6 +9,12 @@ batches (``ask``), a whole batch is evaluated at once -- sharded over the ranks 
 random search over the reference's configuration ranges (what SMAC's initial design is);
 any other proposer can drive ``ask``/``tell`` by passing ``sampler``.
 
+Both cost columns of the result are scores of the episode ``eval_cfg`` simulates --
+``simulate(controller, init_obs, task.term_cond, max_steps=task.get_num_steps())`` after a
+``controller.reset()`` (:222-231 surrogate, :244-251 true dynamics): ``num_steps`` rows =
+``num_steps - 1`` control steps unless the task carries a user termination condition, which is
+honoured on both paths (CandidateEvaluator.evaluate).
+
 Scores that are not finite (a diverged rollout) count as ``inf``, as ``eval_cfg`` does for a
 controller that raises ``LinAlgError`` (:236-239).
 """
@@ -28,8 +34,15 @@ class BatchPipelineTuner:
     """``evaluator.evaluate(candidates, seed=..., index_offset=...) -> scores`` is the only thing
     required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
 
-    def __init__(self, system, evaluator, batch_size=64, sampler=None):
+    def __init__(self, system, evaluator, batch_size=64, sampler=None, truedyn_noise="device",
+                 eval_kwargs=None):
+        """truedyn_noise: the noise mode of the controllers scored against the true dynamics
+        (MPPI(noise=...): "device" Philox, or "numpy" / "numpy_device" = the reference's global
+        legacy stream).  eval_kwargs: extra keyword arguments for every ``evaluator.evaluate`` call
+        (e.g. a recorded noise stream to replay)."""
         self.system, self.evaluator = system, evaluator
+        self.truedyn_noise = truedyn_noise
+        self.eval_kwargs = dict(eval_kwargs or {})
         self.batch_size = int(batch_size)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -101,7 +114,7 @@ class BatchPipelineTuner:
         task.set_ctrl_bounds(ev.umin, ev.umax)
         ctl = MPPI(self.system, task, ev.model, horizon=int(cand["horizon"]),
                    num_path=int(cand["num_path"]), sigma=float(cand["sigma"]),
-                   lmda=float(cand["lmda"]), noise="device", seed=seed,
+                   lmda=float(cand["lmda"]), noise=self.truedyn_noise, seed=seed,
                    precision=ev.precision, device=ev.device)
         ctl.reset()
         kw = {"max_steps": ev.task.get_num_steps()} if ev.task.has_num_steps() else {}
@@ -121,7 +134,8 @@ class BatchPipelineTuner:
             # randomness keyed by (seed, global evaluation index): scores do not depend on the
             # world size or on the batch size
             scores = evaluate_sharded(
-                lambda shard, lo, d=done: self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo),
+                lambda shard, lo, d=done: self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo,
+                                                                  **self.eval_kwargs),
                 batch)
             td = None
             if truedyn is not None:

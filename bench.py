@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
-PROFILE_TAG = "r02"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r03"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
 
 
 def parse():
@@ -173,9 +173,12 @@ def cpu_baseline_ilqr(system, spec, x0s, budget_s):
                             "HalfCheetah iLQR H=50 solves from the bench's initial states (oracle: numpy f64)")
 
 
-def cpu_baseline_c5(system, spec, cands, budget_s):
+def cpu_baseline_c5(system, spec, cands, budget_s, n_ctl=16):
     """One control step of one candidate's closed loop = one MPPI solve + one surrogate step: the
-    unit the c5 value counts.  The oracle takes one such step per call, candidate after candidate."""
+    unit the c5 value counts.  Same structure as the c3 baseline: the oracle in strict_reference
+    mode (per-step pred_batch + the reference's per-particle Python cost loop, mppi.py:73-78),
+    steady state -- the first `n_ctl` candidates' controllers are built and take one closed-loop
+    step before timing; every timed call advances the next controller's closed loop by one step."""
     from oracle.costs import QuadCostOracle
     from oracle.mlp import MLPOracle, make_params
     from oracle.mppi import MPPIOracle
@@ -184,20 +187,28 @@ def cpu_baseline_c5(system, spec, cands, budget_s):
     om = MLPOracle(system, make_params(p["weights"], p["biases"], "relu", p["xu_means"],
                                        p["xu_std"], p["dy_means"], p["dy_std"]))
     x0 = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
-    state = {"i": 0}
-
-    def run_once():
-        c = cands[state["i"] % len(cands)]
-        state["i"] += 1
-        np.random.seed(state["i"])
+    loops = []
+    np.random.seed(0)
+    for c in cands[:n_ctl]:
         ctl = MPPIOracle(om, QuadCostOracle(np.diag(c["Q"]), np.diag(c["R"]), np.diag(c["F"]), np.zeros(nx)),
                          np.tile([-1.0, 1.0], (nu, 1)), horizon=c["horizon"], num_path=c["num_path"],
-                         sigma=c["sigma"], lmda=c["lmda"])
-        u, _ = ctl.run(np.concatenate([x0, np.zeros(nu)]), x0)
-        om.pred(x0, u)
-    return _baseline_record(_timed_legs(run_once, budget_s, target=64),
-                            "closed-loop control steps (MPPI solve + surrogate step) of the bench's candidates, "
-                            "one candidate after another (oracle: numpy f64, vectorised cost)")
+                         sigma=c["sigma"], lmda=c["lmda"], strict_reference=True)
+        loops.append({"ctl": ctl, "x": x0.copy(), "cs": np.concatenate([x0, np.zeros(nu)])})
+    state = {"i": 0}
+
+    def advance(lp):
+        u, lp["cs"] = lp["ctl"].run(lp["cs"], lp["x"])
+        lp["x"] = om.pred(lp["x"], u)
+    for lp in loops:
+        advance(lp)
+
+    def run_once():
+        advance(loops[state["i"] % len(loops)])
+        state["i"] += 1
+    return _baseline_record(_timed_legs(run_once, budget_s, target=4 * len(loops)),
+                            "steady-state closed-loop control steps (MPPI solve + surrogate step) of the bench's "
+                            "first %d candidates in turn (oracle: numpy f64 pred_batch per step + the reference's "
+                            "per-particle Python cost loop)" % len(loops))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -387,6 +398,8 @@ def secondary_workload(args, R):
     else:
         from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
         task.set_num_steps(200)
+        from autompc_amd.tuning.batch_eval import default_episode_controls
+        n_ctl = default_episode_controls(task)     # eval_cfg's episode: 200 rows = 199 control steps
         # BASELINE config 5: one candidate list for the whole job, contiguous shards of B per GPU,
         # randomness keyed by the global candidate index (scores independent of the world size),
         # scores exchanged with one all-gather (RCCL over xGMI under the nccl backend)
@@ -396,13 +409,15 @@ def secondary_workload(args, R):
 
         def step(i):
             scores = evaluate_sharded(
-                lambda shard, lo: ev.evaluate(shard, n_steps=200, seed=max(i, 0), index_offset=lo,
-                                              timing=last), cands)
+                lambda shard, lo: ev.evaluate(shard, seed=max(i, 0), index_offset=lo, timing=last),
+                cands)
             if not np.all(np.isfinite(scores)) or scores.shape[0] != B * world:
                 raise RuntimeError("candidate scores incomplete")
         label = ("c5: %d tuning candidates (MPPI horizon/sigma/lmda/num_path + QuadCost weights from "
-                 "the reference's config ranges) x 200-step closed loop per step per GPU" % B)
-        unit_per_step = B * 200
+                 "the reference's config ranges) x one eval_cfg episode (task.set_num_steps(200): 200 rows = "
+                 "%d closed-loop control steps, pipeline_tuner.py:222-231) per step per GPU" % (B, n_ctl))
+        unit_per_step = B * n_ctl
+        extra["control_steps_per_episode"] = n_ctl
         metric, unit = "MPC solves/sec (MPPI inside the batched closed-loop candidate evaluator)", "solves/s"
         elapsed, n_pre = timed_loop(R, step, steps, warm, 0.0)
         kt = last.get("timing")
@@ -412,7 +427,7 @@ def secondary_workload(args, R):
             flops = per_ctrl_step * (2 * mlp_macs + 2 * (nx * nx + nx) + 2 * nu * nu + 2 * nu)
             all_steps = sum(c["num_path"] * c["horizon"] for c in cands) * \
                 (2 * mlp_macs + 2 * (nx * nx + nx) + 2 * nu * nu + 2 * nu)
-            extra["algorithmic_tflops"] = steps * 200 * all_steps / elapsed / 1e12
+            extra["algorithmic_tflops"] = steps * n_ctl * all_steps / elapsed / 1e12
             if kt and kt.get("count"):
                 ach = flops / (kt["rollout_ms"] * 1e-3) / 1e12
                 tr = measured_traffic(args, B, "mppi_rollout_kernel")
@@ -437,6 +452,52 @@ def secondary_workload(args, R):
                 out["cpu_baseline"] = cpu_baseline_c5(system, spec, cands, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+
+
+def c5_sharded_record(args, R, per_gpu=64, probes=4):
+    """north_star's multi-GPU path inside the default (c3) bench line of an N > 1 run: BASELINE
+    config 5's candidate sharding -- per_gpu * world candidates, contiguous shards, randomness keyed
+    by the global candidate index, ONE all_gather_into_tensor of the scores (RCCL over xGMI under
+    backend nccl) -- run once after an untimed pass.  Rank 0 then re-evaluates `probes` candidates
+    spread over all shards on its own GPU: the gathered scores must be what a single rank
+    computes.  Every rank takes part; rank 0 returns the record."""
+    from autompc_amd.synthetic import make_workload
+    from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
+    from autompc_amd.tuning.batch_eval import default_episode_controls, shard_bounds
+    system, task, model, spec = make_workload("c3", precision=args.precision, device=R.local_rank)
+    task.set_num_steps(200)
+    world = R.world
+    cands = random_candidates(system, per_gpu * world, seed=0)
+    ev = CandidateEvaluator(system, task, model, precision=args.precision, device=R.local_rank)
+
+    def local(shard, lo):
+        return ev.evaluate(shard, seed=0, index_offset=lo)
+    evaluate_sharded(local, cands)                       # untimed pass (plans, clocks)
+    stats = {}
+    R.sync_all()
+    t0 = time.perf_counter()
+    scores = evaluate_sharded(local, cands, stats=stats)
+    R.sync_all()
+    elapsed = R.max_over_ranks(time.perf_counter() - t0)
+    if R.rank != 0:
+        return None
+    n = len(cands)
+    idx = sorted({min(n - 1, (2 * k + 1) * n // (2 * probes)) for k in range(probes)})
+    dev = 0.0
+    for gi in idx:
+        alone = ev.evaluate([cands[gi]], seed=0, index_offset=gi)[0]
+        dev = max(dev, abs(alone - scores[gi]))
+    n_ctl = default_episode_controls(task)
+    return {"workload": "BASELINE config 5: %d candidates = %d per GPU, contiguous shards, one eval_cfg "
+                        "episode each (200 rows = %d control steps)" % (n, per_gpu, n_ctl),
+            "candidates": n, "candidates_per_gpu": per_gpu, "control_steps_per_episode": n_ctl,
+            "value": n * n_ctl / elapsed, "unit": "solves/s", "elapsed_s": elapsed,
+            "backend": stats.get("backend"), "ranks_in_gather": stats.get("ranks_in_gather"),
+            "gather_ms": stats.get("gather_ms"), "gather_device": stats.get("device"),
+            "probe_candidates": idx, "probe_shards": [next(r for r in range(world)
+                                                           if shard_bounds(n, r, world)[0] <= gi < shard_bounds(n, r, world)[1])
+                                                      for gi in idx],
+            "max_abs_score_deviation_vs_single_rank": dev, "scores_finite": bool(np.all(np.isfinite(scores)))}
 
 
 # ----------------------------------------------------------------------------------------------
@@ -522,6 +583,9 @@ def main():
 
     elapsed, kt, info, spec, n_pre = timed_run(args.precision, args.steps, args.warmup, args.preheat)
     nx, nu, N, H, B = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"], batch
+    sharded = None
+    if world > 1 and args.workload == "c3" and not args.no_extras:
+        sharded = c5_sharded_record(args, R)             # collective: every rank calls it
 
     if rank == 0:
         solves = world * args.steps * B
@@ -555,6 +619,8 @@ def main():
                          "algorithmic_bytes_per_launch": info["bytes"],
                          "workgroups": info["workgroups"], "samples_per_workgroup": info["samples_per_wg"]},
         }
+        if sharded is not None:
+            out["c5_sharded"] = sharded
         if world == 1 and args.precision == "f64" and not args.no_extras:
             # the exact-f32 MFMA mode of the same kernel (v_mfma_f32_16x16x4_f32): reported next to
             # the f64 headline, with its measured deviation from the f64 solve on identical inputs

@@ -118,7 +118,7 @@ int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path, const int*
 int ampc_mppi_plan_destroy(ampc_mppi_plan* p);
 /* Fix the launch geometry instead of letting the library derive it from the batch: tile_rows
  * (0 automatic, or 16 / 32 / 64 samples per rollout workgroup; a height that does not fit LDS
- * falls back to the largest that does) and horizon_cap (the LDS / partial-sum layout is sized
+ * for the staged model / horizon is an error) and horizon_cap (the LDS / partial-sum layout is sized
  * for max(horizon_cap, longest horizon in the plan)).  Summation orders inside a solve depend on
  * the geometry; with both fixed, a problem's results are bit-identical whatever else shares the
  * plan -- the candidate evaluator uses this so that a candidate's surrogate score
@@ -142,8 +142,17 @@ int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
  * with its cached second value) is in the state (key[624], pos, has_gauss, cached) -- the tuple
  * np.random.get_state() returns -- and hands back the state the generator is left in, to be
  * installed with np.random.set_state().  The raw MT19937 stream, the uniform doubles and every
- * accept / reject decision are bit-identical to numpy's; the normals are identical except where
- * the device's log() rounds differently from the host libm's (last bit).  Synchronises. */
+ * accept / reject decision are bit-identical to numpy's; so are the normals when
+ * ampc_legacy_log_mode() != 0 (see below).  Synchronises. */
+/* Whether ampc_mppi_legacy_normal's normals are numpy's bit for bit.  numpy's legacy_gauss calls
+ * the C library's log(); at first use the library locates glibc's log tables in the loaded libm
+ * and checks its operation-by-operation restatement of glibc's algorithm (glibc >= 2.28,
+ * sysdeps/ieee754/dbl-64/e_log.c) against log() itself:
+ *   1  log() is glibc's FMA build and is reproduced exactly      } normals bit-identical
+ *   2  log() is glibc's non-FMA build and is reproduced exactly  } to numpy's
+ *   0  another log(): the device uses its own (normals within 3 ulp of numpy's; generator state,
+ *      uniforms and accept / reject decisions still exact). */
+int ampc_legacy_log_mode(void);
 int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
                             double cached, uint32_t* key_out, int* pos_out, int* has_gauss_out,
                             double* cached_out);
@@ -198,6 +207,13 @@ int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_
 int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate, const double* init_obs,
                           int n_steps, uint64_t seed, const double* eps_all, double* traj_obs,
                           double* traj_ctrls);
+/* Index of the first control step of the plan's NEXT closed loop (default 0): step s of that loop
+ * draws its device noise from the Philox stream (seed, first_step + s, noise id).  An episode that
+ * is run in several segments -- simulate() with a user termination condition
+ * (utils/simulation.py:62-63, tasks/task.py:92-101) evaluated on the host between segments, each
+ * segment starting from the state the previous one ended in -- thereby consumes exactly the noise
+ * the unsegmented episode would. */
+int ampc_mppi_plan_set_step_offset(ampc_mppi_plan* p, uint64_t first_step);
 
 /* ---- trajectory scoring --------------------------------------------------------------------
  * Cost.__call__ (costs/cost.py:27-41) for n_traj finished trajectories of n_rows rows each:

@@ -166,5 +166,10 @@ class ILQROracle:
         u = ctrls[0] + Ks[0] @ (state - states[0])
         return u, np.concatenate([state, u])
 
+    def reset(self):
+        """IterativeLQR.reset (ilqr.py:78-82): nothing the default solve reads survives a reset
+        (every run() re-solves from the zero guess)."""
+        self.last = None
+
     def traj_to_state(self, traj):
         return self.model.traj_to_state(traj)

@@ -346,6 +346,87 @@ def gen_closed_loop():
     save("loop_ilqr", H=12, dt=0.05, obs=traj2.obs, ctrls=traj2.ctrls, score=cost(traj2), **common)
 
 
+# ------------------------------------------------- closed loop, eval_cfg's call shape
+def gen_evalcfg():
+    """The tuner's objective exactly as PipelineTuner.eval_cfg computes it
+    (tuning/pipeline_tuner.py:213-258): ``task.set_num_steps(T)``; controller built, then
+    ``controller.reset()``; ``simulate(controller, task.get_init_obs(), task.term_cond,
+    sim_model=surrogate, max_steps=task.get_num_steps())``; ``task.get_cost()(traj)``; then the
+    same again with a fresh controller against ``dynamics=truedyn``.  ``task.term_cond`` is
+    ``len(traj) >= num_steps`` (tasks/task.py:41-53) and simulate() breaks on it after extending
+    the trajectory (utils/simulation.py:52-64), so an episode has num_steps rows = num_steps - 1
+    controls.  A third case sets a user termination condition that fires before num_steps.
+    (The factories need ConfigSpace, which is absent: the controller is constructed directly with
+    the hyper-parameters ``pipeline(cfg, task, trajs)`` would pass.)"""
+    nx, hidden, act, mseed = 3, [48, 48], "tanh", 51
+    system = make_system(nx, 1, dt=0.05)
+    model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+    cost = make_cost(system, "dense", 600)
+    Q, R, F = cost.get_cost_matrices()
+    init = np.array([0.25, -0.15, 0.1])
+    common = dict(nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed,
+                  wsum=weight_checksum(p), Q=Q, R=R, F=F, goal=cost.get_goal(), init=init)
+
+    def truedyn(x, u):
+        return model.pred(x, u)
+
+    def eval_cfg(make_controller, task, with_truedyn=True):
+        out = {}
+        controller = make_controller()
+        controller.reset()
+        surr_traj = quiet(simulate, controller, task.get_init_obs(), task.term_cond, sim_model=model,
+                          max_steps=task.get_num_steps(), silent=True)
+        out["surr_obs"], out["surr_ctrls"] = surr_traj.obs, surr_traj.ctrls
+        out["surr_cost"] = task.get_cost()(surr_traj)
+        if with_truedyn:
+            controller = make_controller()
+            controller.reset()
+            td_traj = quiet(simulate, controller, task.get_init_obs(), task.term_cond,
+                            dynamics=truedyn, max_steps=task.get_num_steps(), silent=True)
+            out["truedyn_obs"], out["truedyn_ctrls"] = td_traj.obs, td_traj.ctrls
+            out["truedyn_cost"] = task.get_cost()(td_traj)
+        return out
+
+    def mppi_task(T):
+        task = Task(system)
+        task.set_cost(cost)
+        task.set_ctrl_bound("u0", -1.0, 1.0)
+        task.set_init_obs(init)
+        task.set_num_steps(T)
+        return task
+
+    hyper = dict(horizon=9, num_path=96, sigma=0.7, lmda=0.6)
+    meta = dict(N=hyper["num_path"], H=hyper["horizon"], sigma=hyper["sigma"], lmda=hyper["lmda"],
+                bounds=np.array([-1.0, 1.0]))
+    # -- MPPI, default termination ---------------------------------------------------------
+    T = 14
+    task = mppi_task(T)
+    np.random.seed(6)
+    out = eval_cfg(lambda: quiet(MPPI, system, task, model, **hyper), task)
+    assert len(out["surr_obs"]) == T and len(out["truedyn_obs"]) == T
+    save("loop_evalcfg_mppi", np_seed=6, num_steps=T, **meta, **out, **common)
+    # -- MPPI, user termination condition that fires early ------------------------------------
+    T, min_len, thresh = 40, 4, 0.12
+    task = mppi_task(T)
+    task.set_term_cond(lambda traj: len(traj) >= min_len and abs(traj[-1].obs[0]) < thresh)
+    assert task.has_num_steps() and task.get_num_steps() == T
+    np.random.seed(8)
+    out = eval_cfg(lambda: quiet(MPPI, system, task, model, **hyper), task)
+    n = len(out["surr_obs"])
+    assert min_len < n < T - 5, n
+    save("loop_evalcfg_term", np_seed=8, num_steps=T, term_min_len=min_len, term_thresh=thresh,
+         **meta, **out, **common)
+    # -- iLQR, default termination -----------------------------------------------------------
+    T = 11
+    task2 = Task(system)
+    task2.set_cost(cost)
+    task2.set_init_obs(init)
+    task2.set_num_steps(T)
+    out = eval_cfg(lambda: IterativeLQR(system, task2, model, 12), task2)
+    assert len(out["surr_obs"]) == T
+    save("loop_evalcfg_ilqr", num_steps=T, H=12, dt=0.05, **out, **common)
+
+
 # ------------------------------------------------------------------- score terms
 def gen_cost_terms():
     """Cost.__call__ of threshold / box / summed costs on a batch of trajectories."""
@@ -651,7 +732,7 @@ def gen_linear_wide():
 
 
 GENERATORS = {"linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
-              "closed_loop": gen_closed_loop, "cost_terms": gen_cost_terms}
+              "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):

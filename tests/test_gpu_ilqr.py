@@ -25,7 +25,7 @@ def _names():
     return out
 
 
-def _hip_ilqr(p, nx, nu, Q, R, F, goal, H, dt, bounds, precision="f64"):
+def _hip_ilqr(p, nx, nu, Q, R, F, goal, H, dt, bounds, precision="f64", **kw):
     from autompc_amd import MLP, IterativeLQR, QuadCost, Task
     system = make_system(nx, nu, dt=dt)
     m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
@@ -37,7 +37,7 @@ def _hip_ilqr(p, nx, nu, Q, R, F, goal, H, dt, bounds, precision="f64"):
     task.set_cost(QuadCost(system, Q, R, F, goal=goal))
     if bounds is not None:
         task.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
-    return IterativeLQR(system, task, m, H)
+    return IterativeLQR(system, task, m, H, **kw)
 
 
 @pytest.mark.parametrize("name", _names())
@@ -51,8 +51,9 @@ def test_ilqr_matches_reference_golden(name):
     conv, states, ctrls, Ks, ks = ctl.compute_ilqr_default(g["x0"], np.zeros((H, nu)))
     assert conv == bool(g["converged"])
     # iLQR amplifies rounding through up to 50 Riccati sweeps and 50 discrete line-search
-    # decisions; the non-converged tanh case is chaotic in its last digits.
-    tol = 1e-6 if conv else 1e-3
+    # decisions; measured agreement is 1e-15 (converged) ... 6e-14 (the 50-iteration tanh solve
+    # that does not converge), profiles/r02_dropin_ilqr.log.
+    tol = 1e-6
     assert rel_err(states, g["states"]) < tol
     assert rel_err(ctrls, g["ctrls"]) < tol
     assert rel_err(Ks, g["Ks"]) < tol * 10
@@ -289,3 +290,41 @@ def test_f32_ilqr_sweep_kernels_agree_and_track_f64(monkeypatch, nx, nu, hidden)
     orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q, R, F, np.zeros(nx)), dt, H, max_iter=1)
     conv, st, ct, Ks, ks = orc.solve(x0[0], np.zeros((H, nu)))
     assert rel_err(a["states"][0], st) < 2e-3 and rel_err(a["Ks"][0], Ks) < 5e-3
+
+
+def test_f32_ilqr_is_outside_the_parity_mode():
+    """north_star: results within 1e-4 relative of the reference on trajectory state and cost.
+    A FULL f32 solve (every iteration, every line-search / convergence decision in float) of the
+    reference's golden problems does not meet that in general -- a decision eventually falls the
+    other way and the solve stops at a different iterate (measured: up to 4e-3 on the states of the
+    bounded problems; the unbounded HalfCheetah solve stays within 1e-4) -- so the drop-in class
+    refuses f32 unless the caller opts in, and what f32 delivers is pinned here."""
+    g = golden("ilqr_hc6_relu_free")
+    nx, nu, H = int(g["nx"]), int(g["nu"]), int(g["H"])
+    p = golden_params(nx, nu, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    with pytest.raises(ValueError, match="allow_inexact"):
+        _hip_ilqr(p, nx, nu, g["Q"], g["R"], g["F"], g["goal"], H, float(g["dt"]), None, precision="f32")
+    worst = {}
+    for name in ["ilqr_hc6_relu_free", "ilqr_hc6_relu_bounded", "ilqr_p64_tanh_bounded",
+                 "ilqr_p64_tanh_clipped"]:
+        g = golden(name)
+        nx, nu, H = int(g["nx"]), int(g["nu"]), int(g["H"])
+        p = golden_params(nx, nu, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+        bounds = (g["bounds"][0], g["bounds"][1]) if bool(g["bounded"]) else None
+        ctl = _hip_ilqr(p, nx, nu, g["Q"], g["R"], g["F"], g["goal"], H, float(g["dt"]), bounds,
+                        precision="f32", allow_inexact=True)
+        conv, states, ctrls, Ks, ks = ctl.compute_ilqr_default(g["x0"], np.zeros((H, nu)))
+        assert conv == bool(g["converged"])
+        worst[name] = rel_err(states, g["states"])
+        cost = QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"])
+        dt = float(g["dt"])
+
+        def objective(xs, us):                      # eval_obj, ilqr.py:124-131
+            return sum(dt * (cost.eval_obs_cost(xs[t]) + cost.eval_ctrl_cost(us[t])) for t in range(H)) \
+                + cost.eval_term_obs_cost(xs[H])
+        ref = objective(g["states"], g["ctrls"])
+        # a different converged iterate of the same problem: the optimised cost agrees to ~1e-5
+        assert abs(objective(states, ctrls) - ref) < 1e-3 * abs(ref)
+        assert worst[name] < 2e-2
+    assert worst["ilqr_hc6_relu_free"] < 1e-4
+    print("f32 iLQR state deviation from the reference:", worst)

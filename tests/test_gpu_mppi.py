@@ -263,19 +263,38 @@ def test_fused_update_with_an_all_inf_tile_matches_the_plain_update(precision, m
     assert rel_err(out["1"][0], out["0"][0]) < tol and rel_err(out["1"][1], out["0"][1]) < tol
 
 
-def test_act_sequence_getter_is_read_only():
-    """in-place edits of the host copy would be lost after a solve -- they must fail."""
+def test_act_sequence_in_place_edits_reach_the_device():
+    """The reference's act_sequence is a plain attribute that callers edit in place
+    (mppi.py:97-99).  After a solve the live copy is on the device: an in-place edit of the array
+    the getter hands out must be uploaded before the next solve, exactly like an assignment."""
     from autompc_amd import MPPI
     nx = 2
     p = omlp.random_params(nx, 1, [64, 64], "relu", seed=2)
     system, model, task = _hip_stack(p, nx, 1, np.eye(nx), 0.01 * np.eye(1), np.eye(nx), np.zeros(nx), (-1, 1))
-    ctl = MPPI(system, task, model, horizon=5, num_path=64)
-    ctl.run(np.zeros(3), np.zeros(2))
-    with pytest.raises(ValueError):
-        ctl.act_sequence[0] = 0.0
-    new = np.zeros((5, 1))
-    ctl.act_sequence = new                      # the setter is the supported path
-    np.testing.assert_array_equal(ctl.act_sequence, new)
+    results = []
+    for mode in ("in_place", "slice", "setter"):
+        np.random.seed(5)
+        ctl = MPPI(system, task, model, horizon=5, num_path=64)
+        ctl.run(np.zeros(3), np.zeros(2))
+        if mode == "in_place":
+            seq = ctl.act_sequence
+            seq[:] = 0.0
+            seq[1] += 0.25
+        elif mode == "slice":
+            ctl.act_sequence[:] = 0.0
+            ctl.act_sequence[1, 0] = 0.25
+        else:
+            new = np.zeros((5, 1))
+            new[1] = 0.25
+            ctl.act_sequence = new
+        expect = np.zeros((5, 1))
+        expect[1] = 0.25
+        np.testing.assert_array_equal(np.asarray(ctl.act_sequence), expect)
+        u, _ = ctl.run(np.zeros(3), np.full(2, 0.1))
+        results.append((u, np.asarray(ctl.act_sequence).copy()))
+    for u, a in results[1:]:
+        np.testing.assert_array_equal(u, results[0][0])
+        np.testing.assert_array_equal(a, results[0][1])
 
 
 @pytest.mark.parametrize("shape", [(17, 6, [256, 256], "relu"), (17, 6, [256, 256], "tanh"),

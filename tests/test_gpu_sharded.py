@@ -50,16 +50,27 @@ def test_score_is_independent_of_batch_and_position():
     assert ev.evaluate([cands[3]], seed=5, index_offset=4)[0] != full[3]
 
 
-def _worker(rank, world, port, n, n_steps, q):
+def _worker(rank, world, port, n, n_steps, q, backend="gloo"):
+    import torch
     import torch.distributed as dist
-    from autompc_amd.tuning import evaluate_sharded, random_candidates
+    from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    system, ev = _evaluator(n_steps)                    # both ranks on device 0 (1-GPU box)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":                               # one process per GPU, RCCL over xGMI
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+        system, task, m = _setup(n_steps)
+        ev = CandidateEvaluator(system, task, m, device=rank)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        system, ev = _evaluator(n_steps)                # both ranks on device 0 (1-GPU box)
     cands = random_candidates(system, n, seed=1)
-    scores = evaluate_sharded(lambda shard, lo: ev.evaluate(shard, seed=5, index_offset=lo), cands)
-    q.put((rank, scores))
+    stats = {}
+    scores = evaluate_sharded(lambda shard, lo: ev.evaluate(shard, seed=5, index_offset=lo), cands,
+                              stats=stats)
+    q.put((rank, scores, stats))
     dist.destroy_process_group()
 
 
@@ -76,15 +87,44 @@ def test_two_ranks_reproduce_the_single_process_scores(n):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, n_steps, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=600) for _ in range(2))
+    got = {r: (sc, st) for r, sc, st in (q.get(timeout=600) for _ in range(2))}
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     system, ev = _evaluator(n_steps)
     ref = ev.evaluate(random_candidates(system, n, seed=1), seed=5)
     assert np.all(np.isfinite(ref))
-    np.testing.assert_allclose(got[0], ref, rtol=1e-12)
-    np.testing.assert_allclose(got[1], ref, rtol=1e-12)
+    for r in range(2):
+        np.testing.assert_allclose(got[r][0], ref, rtol=1e-12)
+        assert got[r][1]["backend"] == "gloo" and got[r][1]["ranks_in_gather"] == 2
+
+
+def test_nccl_all_gather_across_two_gpus():
+    """The RCCL leg of evaluate_sharded (backend "nccl", one process per GPU, scores all-gathered
+    over xGMI): needs two visible GPUs; on the 1-GPU box it is skipped (RCCL refuses two ranks on
+    one device) and the gloo test above covers the plumbing."""
+    import torch
+    import torch.multiprocessing as mp
+    from autompc_amd.tuning import random_candidates
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs for the nccl (RCCL) backend")
+    n, n_steps = 9, 10
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, n_steps, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (sc, st) for r, sc, st in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    system, ev = _evaluator(n_steps)
+    ref = ev.evaluate(random_candidates(system, n, seed=1), seed=5)
+    for r in range(2):
+        np.testing.assert_allclose(got[r][0], ref, rtol=1e-12)
+        assert got[r][1]["backend"] == "nccl" and got[r][1]["ranks_in_gather"] == 2
+        assert got[r][1]["device"].startswith("cuda")
 
 
 def test_full_size_c5_batch():

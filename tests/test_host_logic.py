@@ -7,6 +7,7 @@ import pickle
 import numpy as np
 import pytest
 
+from autompc_amd import System
 from helpers import make_system
 
 
@@ -182,3 +183,98 @@ def test_mlp_training_fits_a_linear_system_on_the_host():
     assert np.sqrt(np.mean((pred - truth) ** 2)) < 0.05
     keys = m.get_parameters()
     assert set(keys) == {"net_state", "xu_means", "xu_std", "dy_means", "dy_std"}
+
+
+# ---- episode semantics of the tuner's objective (pipeline_tuner.py:222-231) ---------------------
+class _ReferenceStyleTask:
+    """The termination-condition slot exactly as the reference's Task keeps it
+    (tasks/task.py:39-53, 73-101): set_num_steps installs a closure over num_steps."""
+
+    def __init__(self):
+        self._term_cond = None
+        self._num_steps = None
+
+    def set_num_steps(self, num_steps):
+        self._term_cond = lambda traj: len(traj) >= num_steps
+        self._num_steps = num_steps
+
+    def has_num_steps(self):
+        return self._num_steps is not None
+
+    def get_num_steps(self):
+        return self._num_steps
+
+    def term_cond(self, traj):
+        return self._term_cond(traj) if self._term_cond is not None else False
+
+    def set_term_cond(self, term_cond):
+        self._term_cond = term_cond
+
+
+def _host_simulate_rows(task):
+    """Rows simulate() returns for the task's own termination condition (utils/simulation.py:52-64)."""
+    rows = 1
+    for _ in range(task.get_num_steps() if task.has_num_steps() else 10000):
+        rows += 1
+        if task.term_cond([None] * rows):
+            break
+    return rows
+
+
+def test_default_episode_is_num_steps_rows():
+    from autompc_amd import Task
+    from autompc_amd.tuning.batch_eval import default_episode_controls, episode_of
+    system = System(["x"], ["u"])
+    for make in (lambda: Task(system), _ReferenceStyleTask):
+        for n in (0, 1, 2, 7, 200):
+            task = make()
+            task.set_num_steps(n)
+            max_steps, tc = episode_of(task)
+            assert max_steps == n and tc is None
+            assert default_episode_controls(task) + 1 == _host_simulate_rows(task)
+        assert default_episode_controls(make()) == 10000
+    task = Task(system)
+    task.set_num_steps(7)
+    assert default_episode_controls(task) == 6          # 7 rows, 6 controls
+
+
+def test_user_term_cond_is_recognised():
+    from autompc_amd import Task
+    from autompc_amd.tuning.batch_eval import episode_of
+    system = System(["x"], ["u"])
+    for make in (lambda: Task(system), _ReferenceStyleTask):
+        task = make()
+        task.set_num_steps(30)
+        task.set_term_cond(lambda traj: len(traj) >= 5)
+        max_steps, tc = episode_of(task)
+        assert max_steps == 30 and tc is not None and tc([0] * 5) and not tc([0] * 4)
+        task.set_num_steps(12)                          # a later set_num_steps replaces it again
+        assert episode_of(task) == (12, None)
+        other = make()
+        other.set_term_cond(lambda traj: len(traj) >= 3)
+        max_steps, tc = episode_of(other)
+        assert max_steps == 10000 and tc is not None
+    # a closure over a different count than the task's is not the default condition
+    odd = _ReferenceStyleTask()
+    odd.set_num_steps(9)
+    odd._num_steps = 20
+    assert episode_of(odd)[1] is not None
+
+
+def test_evaluator_rejects_horizon_above_cap():
+    from autompc_amd.tuning import CandidateEvaluator
+
+    class _Stub:
+        state_dim = 1
+
+        def stage_into(self, h):
+            raise AssertionError("must fail before touching the device")
+    from autompc_amd import QuadCost, Task
+    system = System(["x"], ["u"])
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(1), np.eye(1), np.eye(1)))
+    task.set_ctrl_bounds([-1.0], [1.0])
+    ev = CandidateEvaluator(system, task, _Stub(), horizon_cap=20)
+    cand = dict(horizon=21, sigma=1.0, lmda=1.0, num_path=16, Q=[1.0], R=[1.0], F=[1.0])
+    with pytest.raises(ValueError, match="horizon_cap"):
+        ev.evaluate([cand])

@@ -10,7 +10,7 @@ from conftest import GOLDEN, golden
 from helpers import (check_weights, cost_from_golden, golden_params, make_system, rel_err)
 from oracle import mlp as omlp
 from oracle.analytic import CubicIntegrator
-from oracle.closed_loop import simulate
+from oracle.closed_loop import eval_cfg_episode, simulate
 from oracle.costs import QuadCostOracle
 from oracle.ilqr import ILQROracle
 from oracle.mlp import MLPOracle
@@ -172,3 +172,53 @@ def test_closed_loop_ilqr_matches_reference():
     obs, ctrls = simulate(ctl, g["init"], model, 15)
     assert rel_err(obs, g["obs"]) < 1e-6 and rel_err(ctrls, g["ctrls"]) < 1e-6
     assert abs(cost.traj_cost(obs, ctrls) - g["score"]) < 1e-6 * abs(g["score"])
+
+
+def _evalcfg_setup(g):
+    nx = int(g["nx"])
+    system = make_system(nx, 1, dt=0.05)
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], True)
+    check_weights(p, g)
+    return system, MLPOracle(system, p), cost_from_golden(g)
+
+
+@pytest.mark.parametrize("name", ["loop_evalcfg_mppi", "loop_evalcfg_term"])
+def test_evalcfg_mppi_matches_reference(name):
+    """The tuner's objective through eval_cfg's call shape (pipeline_tuner.py:213-258): reset()
+    after construction, task.term_cond (num_steps rows = num_steps - 1 controls, or the user's
+    condition), max_steps = num_steps; surrogate branch, then the true-dynamics branch continuing
+    the same global noise stream."""
+    g = golden(name)
+    system, model, cost = _evalcfg_setup(g)
+    T = int(g["num_steps"])
+    tc = None
+    if "term_thresh" in g.files:
+        min_len, thresh = int(g["term_min_len"]), float(g["term_thresh"])
+        tc = lambda obs, ctrls: len(obs) >= min_len and abs(obs[-1][0]) < thresh   # noqa: E731
+    np.random.seed(int(g["np_seed"]))
+
+    def controller():
+        return MPPIOracle(model, cost, np.array([g["bounds"]]), horizon=int(g["H"]),
+                          num_path=int(g["N"]), sigma=float(g["sigma"]), lmda=float(g["lmda"]))
+    s, obs, ctrls = eval_cfg_episode(controller(), g["init"], model, T, cost.traj_cost, term_cond=tc)
+    assert obs.shape == g["surr_obs"].shape
+    if tc is None:
+        assert len(obs) == T                 # num_steps rows, num_steps - 1 controls
+    assert rel_err(obs, g["surr_obs"]) < 1e-8 and rel_err(ctrls, g["surr_ctrls"]) < 1e-8
+    assert abs(s - g["surr_cost"]) < 1e-8 * abs(g["surr_cost"])
+    s2, obs2, ctrls2 = eval_cfg_episode(controller(), g["init"], model, T, cost.traj_cost, term_cond=tc,
+                                        dynamics=lambda x, u: model.pred(x, u))
+    assert obs2.shape == g["truedyn_obs"].shape
+    assert rel_err(obs2, g["truedyn_obs"]) < 1e-8 and rel_err(ctrls2, g["truedyn_ctrls"]) < 1e-8
+    assert abs(s2 - g["truedyn_cost"]) < 1e-8 * abs(g["truedyn_cost"])
+
+
+def test_evalcfg_ilqr_matches_reference():
+    g = golden("loop_evalcfg_ilqr")
+    system, model, cost = _evalcfg_setup(g)
+    ctl = ILQROracle(model, cost, float(g["dt"]), int(g["H"]))
+    ctl.state_dim = int(g["nx"]) + 1
+    s, obs, ctrls = eval_cfg_episode(ctl, g["init"], model, int(g["num_steps"]), cost.traj_cost)
+    assert len(obs) == int(g["num_steps"])
+    assert rel_err(obs, g["surr_obs"]) < 1e-6 and rel_err(ctrls, g["surr_ctrls"]) < 1e-6
+    assert abs(s - g["surr_cost"]) < 1e-6 * abs(g["surr_cost"])
