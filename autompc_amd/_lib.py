@@ -42,7 +42,7 @@ SIGNATURES = {
     "ampc_mlp_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_mlp_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_sindy": (c_int, [c_void_p, c_int, c_int, c_int, _ip, _ip, _ip, _dp, _dp, c_int, c_double,
-                               c_int]),
+                               c_int, c_int, _ip, _ip]),
     "ampc_sindy_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_sindy_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]),
@@ -210,8 +210,15 @@ class Handle:
         self.nx, self.nu = nx, B.shape[1]
         self._sindy = False
 
-    def set_sindy(self, nx, nu, kind, arg0, arg1, param, xi, continuous, dt, strict_reference=True):
+    def set_sindy(self, nx, nu, kind, arg0, arg1, param, xi, continuous, dt, strict_reference=True,
+                  pair_var=None, pair_exp=None):
+        """pair_var / pair_exp: the (variable, exponent) pairs monomial features (kind 6) index
+        with arg0 (first pair) and arg1 (number of pairs)."""
         kind = np.ascontiguousarray(kind, dtype=np.int32)
+        pair_var = np.ascontiguousarray(pair_var if pair_var is not None else [], dtype=np.int32)
+        pair_exp = np.ascontiguousarray(pair_exp if pair_exp is not None else [], dtype=np.int32)
+        if pair_var.shape != pair_exp.shape or pair_var.ndim != 1:
+            raise ValueError("pair_var and pair_exp must be 1-d arrays of equal length")
         arg0 = np.ascontiguousarray(arg0, dtype=np.int32)
         arg1 = np.ascontiguousarray(arg1, dtype=np.int32)
         param, xi = as_f64(param), as_f64(xi)
@@ -220,7 +227,9 @@ class Handle:
             raise ValueError("SINDy descriptor shapes are inconsistent")
         check(self.lib.ampc_set_sindy(self._h, nx, nu, nf, iptr(kind), iptr(arg0), iptr(arg1),
                                       dptr(param), dptr(xi), int(bool(continuous)),
-                                      float(dt or 0.0), int(bool(strict_reference))))
+                                      float(dt or 0.0), int(bool(strict_reference)),
+                                      int(pair_var.shape[0]), iptr(pair_var) if pair_var.size else None,
+                                      iptr(pair_exp) if pair_exp.size else None))
         self.nx, self.nu = nx, nu
         self._sindy = True
 

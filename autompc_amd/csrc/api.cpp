@@ -1443,13 +1443,25 @@ static int sindy_pred_impl(ampc_handle* h, const double* states, const double* c
 
 extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind,
                               const int* arg0, const int* arg1, const double* param,
-                              const double* xi, int continuous, double dt, int strict_reference) {
+                              const double* xi, int continuous, double dt, int strict_reference,
+                              int n_pairs, const int* pair_var, const int* pair_exp) {
   REQUIRE(h && kind && arg0 && arg1 && param && xi, "ampc_set_sindy: NULL argument");
   REQUIRE(nx >= 1 && nx <= 64 && nu >= 1 && nu <= kMaxNu, "ampc_set_sindy: nx in 1..64, nu in 1..16");
   REQUIRE(n_feat >= 1 && n_feat <= 4096, "ampc_set_sindy: n_feat in 1..4096");
-  for (int k = 0; k < n_feat; ++k)
+  REQUIRE(n_pairs >= 0 && n_pairs <= 10 * 4096 && (n_pairs == 0 || (pair_var && pair_exp)),
+          "ampc_set_sindy: bad monomial pair list");
+  for (int j = 0; j < n_pairs; ++j)
+    REQUIRE(pair_var[j] >= 0 && pair_var[j] < nx + nu && pair_exp[j] >= 1 && pair_exp[j] <= 64,
+            "ampc_set_sindy: monomial pair needs a variable index and an exponent in 1..64");
+  for (int k = 0; k < n_feat; ++k) {
+    if (kind[k] == SF_MONO) {
+      REQUIRE(arg1[k] >= 1 && arg1[k] <= 10 && arg0[k] >= 0 && arg0[k] + arg1[k] <= n_pairs,
+              "ampc_set_sindy: monomial feature needs 1..10 pairs inside the pair list");
+      continue;
+    }
     REQUIRE(kind[k] >= 0 && kind[k] <= 5 && arg0[k] >= 0 && arg0[k] < nx + nu && arg1[k] >= 0 &&
                 arg1[k] < nx + nu, "ampc_set_sindy: bad feature descriptor");
+  }
   HIP_OK(hipSetDevice(h->device));
   // product form (SindyDev): distinct trig arguments and powers, two factor indices per feature
   std::vector<int> tvar, pvar, fx(n_feat, 0), fy(n_feat, 0), tslot(n_feat, -1);
@@ -1470,9 +1482,12 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
       tslot[k] = slot;
     }
   }
-  int n_trig = (int)tvar.size(), n_pow = (int)pvar.size();
-  int n_tab = 2 * n_trig + n_pow + 1;
-  if (n_tab > kSindyMaxTab) n_trig = n_pow = n_tab = 0;      // direct evaluation instead
+  std::vector<int> moff, mcnt;                                // one table entry per monomial feature
+  for (int k = 0; k < n_feat; ++k)
+    if (kind[k] == SF_MONO) { tslot[k] = (int)moff.size(); moff.push_back(arg0[k]); mcnt.push_back(arg1[k]); }
+  int n_trig = (int)tvar.size(), n_pow = (int)pvar.size(), n_mon = (int)moff.size();
+  int n_tab = 2 * n_trig + n_pow + n_mon + 1;
+  if (n_tab > kSindyMaxTab) n_trig = n_pow = n_mon = n_tab = 0;      // direct evaluation instead
   if (n_tab > 0) {
     const int one = n_tab - 1;
     for (int k = 0; k < n_feat; ++k) {
@@ -1482,11 +1497,12 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
         case 2: fx[k] = -(2 * tslot[k] + 1) - 1; fy[k] = one; break;
         case 3: fx[k] = arg0[k]; fy[k] = 2 * tslot[k]; break;
         case 4: fx[k] = arg0[k]; fy[k] = 2 * tslot[k] + 1; break;
+        case SF_MONO: fx[k] = -(2 * n_trig + n_pow + tslot[k]) - 1; fy[k] = one; break;
         default: fx[k] = -(2 * n_trig + tslot[k]) - 1; fy[k] = one; break;
       }
     }
   }
-  std::vector<int> ints(7 * (size_t)n_feat, 0);
+  std::vector<int> ints(9 * (size_t)n_feat + 2 * (size_t)n_pairs + 2, 0);
   std::memcpy(ints.data(), kind, n_feat * sizeof(int));
   std::memcpy(ints.data() + n_feat, arg0, n_feat * sizeof(int));
   std::memcpy(ints.data() + 2 * n_feat, arg1, n_feat * sizeof(int));
@@ -1494,6 +1510,14 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
   std::memcpy(ints.data() + 4 * n_feat, fy.data(), n_feat * sizeof(int));
   if (n_trig > 0) std::memcpy(ints.data() + 5 * n_feat, tvar.data(), n_trig * sizeof(int));
   if (n_pow > 0) std::memcpy(ints.data() + 6 * n_feat, pvar.data(), n_pow * sizeof(int));
+  if (n_mon > 0) {
+    std::memcpy(ints.data() + 7 * n_feat, moff.data(), n_mon * sizeof(int));
+    std::memcpy(ints.data() + 8 * n_feat, mcnt.data(), n_mon * sizeof(int));
+  }
+  for (int j = 0; j < n_pairs; ++j) {
+    ints[9 * (size_t)n_feat + 2 * j] = pair_var[j];
+    ints[9 * (size_t)n_feat + 2 * j + 1] = pair_exp[j];
+  }
   HIP_OK(h->sindy_int.reserve(ints.size() * sizeof(int)));
   HIP_OK(hipMemcpy(h->sindy_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
   std::vector<double> flt((size_t)n_feat * (nx + 3), 0.0);
@@ -1502,6 +1526,7 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
   if (n_trig > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 1), tpar.data(), n_trig * 8);
   if (n_pow > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 2), ppar.data(), n_pow * 8);
   h->s_ntrig = n_trig; h->s_npow = n_pow; h->s_ntab = n_tab;
+  h->s_nmon = n_mon; h->s_npool = n_pairs;
   HIP_OK(h->sindy_flt.reserve(flt.size() * h->esz()));
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
   else HIP_OK(upload_converted<float>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));

@@ -13,8 +13,12 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libautompc_hip.so")
 OBJ = os.path.join(HERE, "build")
-HEADERS = ["host_common.hpp", "shapes.hpp", "legacy_rng_kernels.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp", "ilqr_kernels.hpp", "ilqr_ls4.hpp",
-           "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp", os.path.join(ROOT, "include", "autompc_hip.h")]
+import glob                                                   # noqa: E402
+
+
+def _headers():
+    """Every header a translation unit may include: all of csrc/*.hpp and the public C header."""
+    return sorted(glob.glob(os.path.join(HERE, "*.hpp"))) + [os.path.join(ROOT, "include", "autompc_hip.h")]
 # (object name, source file, extra flags)
 UNITS = [("api", "api.cpp", [])] + [
     ("%s_%s" % (fam, t), "launch_%s.cpp" % fam, ["-DAMPC_T=%s" % t] + (["-DAMPC_T_IS_F64=1"] if t == "double" else []))
@@ -29,12 +33,27 @@ def _hipcc():
     return "hipcc"
 
 
-def _stale():
-    if not os.path.exists(OUT):
+def _obj_path(out, name):
+    return os.path.join(OBJ, "%s.%s.o" % (os.path.basename(out), name))
+
+
+def _unit_stale(out, unit):
+    """An object is stale when it is older than its source, any header or this script.  Judged per
+    OBJECT, not per library: a hand-made relink must never hide objects that were compiled against
+    older headers (struct layouts are shared between the translation units)."""
+    obj = _obj_path(out, unit[0])
+    if not os.path.exists(obj):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(HERE, f) for f in SOURCES] + [__file__] + [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(HERE, unit[1]), __file__] + _headers()
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _stale(out=OUT):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(_unit_stale(out, u) or os.path.getmtime(_obj_path(out, u[0])) > t for u in UNITS)
 
 
 def build(force=False, verbose=True, extra_flags=(), out=None):
@@ -42,13 +61,14 @@ def build(force=False, verbose=True, extra_flags=(), out=None):
     if not force and not extra_flags and out == OUT and not _stale():
         return out
     os.makedirs(OBJ, exist_ok=True)
+    todo = [u for u in UNITS if force or extra_flags or _unit_stale(out, u)]
     base = [_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
             "-Wno-pass-failed", "-I", os.path.join(ROOT, "include")] + list(extra_flags)
     tag = os.path.basename(out)
 
     def compile_unit(unit):
         name, source, flags = unit
-        obj = os.path.join(OBJ, "%s.%s.o" % (tag, name))
+        obj = _obj_path(out, name)
         cmd = base + flags + ["-c", os.path.join(HERE, source), "-o", obj]
         if verbose:
             print("[autompc_amd] hipcc %s %s -> %s" % (source, " ".join(flags), os.path.basename(obj)), flush=True)
@@ -57,7 +77,8 @@ def build(force=False, verbose=True, extra_flags=(), out=None):
 
     workers = min(len(UNITS), max(1, os.cpu_count() or 1))
     with concurrent.futures.ThreadPoolExecutor(workers) as pool:
-        objs = list(pool.map(compile_unit, UNITS))
+        list(pool.map(compile_unit, todo))
+    objs = [_obj_path(out, u[0]) for u in UNITS]
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
     subprocess.run(link, check=True)
     os.replace(out + ".tmp", out)

@@ -103,7 +103,7 @@ struct ampc_handle {
   bool has_mlp = false;
   bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
   bool has_model() const { return has_mlp || has_sindy; }
-  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0;
+  int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0, s_nmon = 0, s_npool = 0;
   double s_dt = 0.0;
   DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
   int nx = 0, nu = 0, n_hidden = 0, act = 0;
@@ -135,7 +135,7 @@ template <> inline MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf
 // LDS bytes the kernels need on top of their own regions for the staged feature program
 template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
   if (h->s_ntab == 0) return 0;
-  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, sizeof(T)) * sizeof(T);
+  const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, h->s_nmon, h->s_npool, sizeof(T)) * sizeof(T);
   return b <= (size_t)kSindyStageBytes ? b + 2 * sizeof(T) : 0;
 }
 
@@ -147,6 +147,8 @@ template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
   const int nf = h->s_nfeat;
   m.kind = ip; m.a0 = ip + nf; m.a1 = ip + 2 * nf;
   m.fx = ip + 3 * nf; m.fy = ip + 4 * nf; m.tvar = ip + 5 * nf; m.pvar = ip + 6 * nf;
+  m.moff = ip + 7 * nf; m.mcnt = ip + 8 * nf; m.mpool = ip + 9 * nf;
+  m.n_mon = h->s_nmon; m.n_pool = h->s_npool;
   const T* fp = (const T*)h->sindy_flt.p;
   m.par = fp; m.xi = fp + nf;
   m.tpar = fp + (size_t)nf * (h->nx + 1);

@@ -7,8 +7,11 @@
 // (sindy.py:134-152, basis_funcs.py:8-126).  The model is tiny (CartPole: 5 variables, 55
 // features, 4x55 coefficients): this is VALU / latency-bound plumbing for BASELINE config 1, not
 // an MFMA workload, so one thread owns one sample and keeps its state in LDS columns
-// ([i][lane]: conflict-free).  PARITY UNPINNED: pysindy is absent from the image and the
-// reference tree (see oracle/sindy.py); checked against the oracle's restatement only.
+// ([i][lane]: conflict-free).  Pinned by tests/golden/sindy_*.npz: outputs of the reference's own
+// pred_batch / pred_diff_batch over a stand-in for the absent pysindy package that restates only
+// CustomLibrary's feature enumeration (tests/golden/gen_golden.py, oracle/sindy.py).
+// Polynomial cross terms (basis_funcs.py:27-93, sindy.py:143-145) are monomial features: a product
+// of up to 10 integer powers of distinct variables, described by (variable, exponent) pairs.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -17,7 +20,7 @@
 
 namespace ampc {
 
-enum { SF_ID = 0, SF_SIN = 1, SF_COS = 2, SF_XSIN = 3, SF_XCOS = 4, SF_POW = 5 };
+enum { SF_ID = 0, SF_SIN = 1, SF_COS = 2, SF_XSIN = 3, SF_XCOS = 4, SF_POW = 5, SF_MONO = 6 };
 
 template <typename T> struct SindyDev {
   int nx, nu, n_feat, continuous, strict;   // strict: reproduce the reference's Jacobian quirks
@@ -34,7 +37,13 @@ template <typename T> struct SindyDev {
   // table entry (the constant for single-factor features).  No data-dependent branches, so the
   // feature loop unrolls and its loads overlap.  n_tab == 0: features are evaluated directly from
   // (kind, a0, a1, par) -- libraries whose table would not fit.
-  int n_trig, n_pow, n_tab;   // n_tab = 2 n_trig + n_pow + 1
+  int n_trig, n_pow, n_tab;   // n_tab = 2 n_trig + n_pow + n_mon + 1
+  // Monomial features (kind SF_MONO: a0 = first (variable, exponent) pair in mpool, a1 = number of
+  // pairs).  In product form every monomial is a table entry behind the powers.
+  int n_mon, n_pool;
+  const int* moff;      // [n_mon] first pair of table monomial j
+  const int* mcnt;      // [n_mon] its number of pairs
+  const int* mpool;     // [n_pool][2] (variable, exponent >= 1)
   const int* fx;        // [n_feat]
   const int* fy;        // [n_feat]
   const int* tvar;      // [n_trig] variable index of a trig argument
@@ -47,9 +56,10 @@ constexpr int kSindyMaxTab = 160;   // table entries kept per thread (in LDS col
 constexpr int kSindyStageBytes = 48 * 1024;   // programs up to this size are copied to LDS
 
 // Elements of T the staged program occupies (floats first, then the int arrays, 8-byte aligned).
-__host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_trig, int n_pow, size_t tsize) {
+__host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_trig, int n_pow, int n_mon,
+                                                   int n_pool, size_t tsize) {
   const size_t flt = (size_t)n_feat * nx + n_trig + n_pow;
-  const size_t ints = (size_t)2 * n_feat + n_trig + n_pow;
+  const size_t ints = (size_t)2 * n_feat + n_trig + n_pow + 2 * (size_t)n_mon + 2 * (size_t)n_pool;
   return flt + (ints * sizeof(int) + tsize - 1) / tsize + 2;
 }
 
@@ -70,6 +80,9 @@ __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area
   T* ppar = tpar + nt;
   int* fx = reinterpret_cast<int*>(ppar + np + 1);
   int* fy = fx + nf; int* tvar = fy + nf; int* pvar = tvar + nt;
+  int* moff = pvar + np; int* mcnt = moff + g.n_mon; int* mpool = mcnt + g.n_mon;
+  for (int j = tid; j < g.n_mon; j += nthr) { moff[j] = g.moff[j]; mcnt[j] = g.mcnt[j]; }
+  for (int j = tid; j < 2 * g.n_pool; j += nthr) mpool[j] = g.mpool[j];
   for (int k = tid; k < nf; k += nthr) { fx[k] = g.fx[k]; fy[k] = g.fy[k]; }
   for (int e = tid; e < nx * nf; e += nthr) xi[e] = g.xi[e];
   for (int j = tid; j < nt; j += nthr) { tpar[j] = g.tpar[j]; tvar[j] = g.tvar[j]; }
@@ -77,7 +90,30 @@ __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area
   __syncthreads();
   SindyDev<T> s = g;
   s.xi = xi; s.tpar = tpar; s.ppar = ppar; s.fx = fx; s.fy = fy; s.tvar = tvar; s.pvar = pvar;
+  s.moff = moff; s.mcnt = mcnt; s.mpool = mpool;
   return s;
+}
+
+// x ** e for a small integer e >= 0 by repeated multiplication (the reference multiplies
+// arg ** exp factors into a running product, basis_funcs.py:40-44; <= 1 ulp per factor either way)
+template <typename T> __device__ __forceinline__ T sindy_ipow(T x, int e) {
+  T r = T(1);
+  for (int i = 0; i < e; ++i) r *= x;
+  return r;
+}
+
+// prod_j v[var_j] ** exp_j over `cnt` pairs starting at pair `off`; skip >= 0: pair `skip`
+// contributes exp * v ** (exp - 1) instead (the partial derivative, basis_funcs.py:74-84)
+template <typename T>
+__device__ __forceinline__ T sindy_monomial(const int* __restrict__ pool, int off, int cnt, const T* v,
+                                            int vs, int skip = -1) {
+  T val = T(1);
+  for (int j = 0; j < cnt; ++j) {
+    const int var = pool[2 * (off + j)], e = pool[2 * (off + j) + 1];
+    const T x = v[var * vs];
+    val *= (j == skip) ? T(e) * sindy_ipow<T>(x, e - 1) : sindy_ipow<T>(x, e);
+  }
+  return val;
 }
 
 template <typename T>
@@ -106,6 +142,8 @@ __device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int
       tr[(2 * j + 1) * ts] = cos(arg);
     }
     for (int j = 0; j < m.n_pow; ++j) tr[(2 * m.n_trig + j) * ts] = pow(v[m.pvar[j] * vs], m.ppar[j]);
+    for (int j = 0; j < m.n_mon; ++j)
+      tr[(2 * m.n_trig + m.n_pow + j) * ts] = sindy_monomial<T>(m.mpool, m.moff[j], m.mcnt[j], v, vs);
     tr[(m.n_tab - 1) * ts] = T(1);
     // pass 2: features as products of two entries
     auto feature = [&](int k) -> T {
@@ -144,7 +182,9 @@ __device__ __forceinline__ void sindy_step(const SindyDev<T>& m, const T* v, int
   } else {
     for (int i = 0; i < m.nx; ++i) out[i * os] = T(0);
     for (int k = 0; k < m.n_feat; ++k) {
-      const T f = sindy_feature<T>(m.kind[k], v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
+      const T f = m.kind[k] == SF_MONO
+                      ? sindy_monomial<T>(m.mpool, m.a0[k], m.a1[k], v, vs)
+                      : sindy_feature<T>(m.kind[k], v[m.a0[k] * vs], v[m.a1[k] * vs], m.par[k]);
       for (int i = 0; i < m.nx; ++i) out[i * os] += m.xi[i * m.n_feat + k] * f;
     }
   }
@@ -196,6 +236,20 @@ __global__ void sindy_jacobian_kernel(const SindyDev<T> m, const T* __restrict__
   const T twice = m.strict ? T(2) : T(1);
   for (int k = 0; k < m.n_feat; ++k) {
     const int kind = m.kind[k], c0 = m.a0[k], c1 = m.a1[k];
+    if (kind == SF_MONO) {
+      // d/dv_i of prod_j v_j ** e_j (basis_funcs.py:74-84).  The reference's name lookup finds a
+      // cross-term feature through exactly one argument order, so nothing is counted twice here.
+      for (int f = 0; f < c1; ++f) {
+        T g = T(1);
+        for (int j = 0; j < c1; ++j) {
+          const int vj = m.mpool[2 * (c0 + j)], e = m.mpool[2 * (c0 + j) + 1];
+          g *= (j == f) ? T(e) * sindy_ipow<T>(var(vj), e - 1) : sindy_ipow<T>(var(vj), e);
+        }
+        const int vf = m.mpool[2 * (c0 + f)];
+        for (int i = 0; i < nx; ++i) add(i, vf, m.xi[i * m.n_feat + k] * g);
+      }
+      continue;
+    }
     const T va = var(c0), vb = var(c1), par = m.par[k];
     T g0 = T(0), g1 = T(0);
     switch (kind) {

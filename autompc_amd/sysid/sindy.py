@@ -3,7 +3,8 @@
 Mirrors the reference's ``autompc.sysid.SINDy`` / ``SINDyFactory`` (reference:
 autompc/sysid/sindy.py:24-253; basis functions autompc/sysid/basis_funcs.py:8-126): same
 constructor hyper-parameters, same library (identity; sin / cos up to ``trig_freq``; the four trig
-interaction terms; powers up to ``poly_degree``), same ``time_mode`` semantics
+interaction terms; powers up to ``poly_degree``; the polynomial cross terms of
+basis_funcs.py:27-93), same ``time_mode`` semantics
 
     discrete:    x' = Theta([x,u]) Xi'          continuous:    x' = x + dt Theta([x,u]) Xi'
 
@@ -12,7 +13,6 @@ is pinned by tests/golden/sindy_*.npz, generated from the reference's own code (
 oracle/sindy.py); only the feature ORDER rests on the documented enumeration of the absent
 ``pysindy~=1.0`` package.  ``train`` (out of the hot path) is a numpy sequentially-thresholded
 least squares (what ``ps.STLSQ`` does: ridge alpha 0.05, 20 iterations) and is not pinned.
-Polynomial cross terms (``poly_cross_terms``) are not implemented.
 """
 import itertools
 
@@ -21,13 +21,33 @@ import numpy as np
 from .. import _lib
 from .model import Model, ModelFactory
 
-K_ID, K_SIN, K_COS, K_XSIN, K_XCOS, K_POW = range(6)
+K_ID, K_SIN, K_COS, K_XSIN, K_XCOS, K_POW, K_MONO = range(7)
 
 
-def build_library(n_vars, trig_freq=0, trig_interaction=False, poly_degree=1):
-    """Feature descriptors (kind, a, b, param) in the order pysindy's CustomLibrary enumerates them:
-    library functions in list order, each over itertools.combinations of the variables."""
+def cross_term_exponents(degree):
+    """The exponent tuples get_cross_term_basis_funcs(degree) turns into basis functions, in its
+    order (basis_funcs.py:27-40): all exponent vectors in {0..degree-1}^degree (last axis fastest)
+    that sum to `degree`, zeros dropped, first occurrence of every trimmed tuple kept.  Each
+    tuple (e_0, .., e_{n-1}) is the n-argument function prod_j x_j ** e_j."""
+    out, seen = [], set()
+    for exp in itertools.product(range(degree), repeat=degree):
+        if sum(exp) != degree:
+            continue
+        tr = tuple(e for e in exp if e > 0)
+        if tr not in seen:
+            seen.add(tr)
+            out.append(tr)
+    return out
+
+
+def build_library(n_vars, trig_freq=0, trig_interaction=False, poly_degree=1, poly_cross_terms=False):
+    """Feature descriptors (kind, a, b, param, pair_var, pair_exp) in the order pysindy's
+    CustomLibrary enumerates them: library functions in list order, each over
+    itertools.combinations of the variables.  A monomial feature (kind K_MONO, the polynomial cross
+    terms) has a = index of its first (variable, exponent) pair in pair_var / pair_exp and b = its
+    number of pairs."""
     kind, a0, a1, par = [], [], [], []
+    pair_var, pair_exp = [], []
 
     def add(k, a, b, p):
         kind.append(k); a0.append(a); a1.append(b); par.append(float(p))
@@ -51,14 +71,31 @@ def build_library(n_vars, trig_freq=0, trig_interaction=False, poly_degree=1):
     for d in range(2, poly_degree + 1):
         for i in range(n_vars):
             add(K_POW, i, i, d)
+    if poly_cross_terms:                     # sindy.py:143-145: after ALL the pure powers
+        for d in range(2, poly_degree + 1):
+            for tr in cross_term_exponents(d):
+                if len(tr) > 10:
+                    raise ValueError("n_args > 10")          # as basis_funcs.py:71-72
+                for combo in itertools.combinations(range(n_vars), len(tr)):
+                    add(K_MONO, len(pair_var), len(tr), 0.0)
+                    pair_var.extend(combo)
+                    pair_exp.extend(tr)
     return (np.array(kind, dtype=np.int32), np.array(a0, dtype=np.int32),
-            np.array(a1, dtype=np.int32), np.array(par, dtype=np.float64))
+            np.array(a1, dtype=np.int32), np.array(par, dtype=np.float64),
+            np.array(pair_var, dtype=np.int32), np.array(pair_exp, dtype=np.int32))
 
 
 def _features(lib, V):
-    kind, a0, a1, par = lib
-    A, B = V[:, a0], V[:, a1]
+    kind, a0, a1, par, pair_var, pair_exp = lib
+    mono = kind == K_MONO
+    A = V[:, np.where(mono, 0, a0)]
+    B = V[:, np.where(mono, 0, a1)]
     out = np.empty_like(A)
+    for k in np.nonzero(mono)[0]:
+        val = np.ones(V.shape[0])
+        for j in range(a0[k], a0[k] + a1[k]):
+            val = val * V[:, pair_var[j]] ** int(pair_exp[j])
+        out[:, k] = val
     for k, fn in ((K_ID, lambda a, b, p: a), (K_SIN, lambda a, b, p: np.sin(p * a)),
                   (K_COS, lambda a, b, p: np.cos(p * a)), (K_XSIN, lambda a, b, p: a * np.sin(p * b)),
                   (K_XCOS, lambda a, b, p: a * np.cos(p * b)), (K_POW, lambda a, b, p: a ** p)):
@@ -78,12 +115,11 @@ class SINDy(Model):
                  trig_interaction=False, time_mode="discrete", precision="f64", device=0,
                  strict_reference=True):
         super().__init__(system)
-        if _as_bool(poly_cross_terms):
-            raise NotImplementedError("polynomial cross terms are not implemented")
         if time_mode not in ("discrete", "continuous"):
             raise ValueError("time_mode must be 'discrete' or 'continuous'")
         self.method, self.lasso_alpha, self.threshold = method, lasso_alpha, threshold
         self.poly_basis, self.poly_degree = _as_bool(poly_basis), int(poly_degree)
+        self.poly_cross_terms = _as_bool(poly_cross_terms)
         self.trig_basis, self.trig_freq = _as_bool(trig_basis), int(trig_freq)
         self.trig_interaction = _as_bool(trig_interaction)
         self.time_mode = time_mode
@@ -91,7 +127,8 @@ class SINDy(Model):
         n = system.obs_dim + system.ctrl_dim
         self.library = build_library(n, self.trig_freq if self.trig_basis else 0,
                                      self.trig_basis and self.trig_interaction,
-                                     self.poly_degree if self.poly_basis else 1)
+                                     self.poly_degree if self.poly_basis else 1,
+                                     self.poly_basis and self.poly_cross_terms)
         self.coefficients = np.zeros((system.obs_dim, self.library[0].shape[0]))
         self._handle = None
 
@@ -152,10 +189,10 @@ class SINDy(Model):
 
     # -- device staging / inference (HIP) --------------------------------------------------
     def stage_into(self, handle):
-        kind, a0, a1, par = self.library
+        kind, a0, a1, par, pair_var, pair_exp = self.library
         handle.set_sindy(self.system.obs_dim, self.system.ctrl_dim, kind, a0, a1, par,
                          self.coefficients, self.time_mode == "continuous", self.system.dt,
-                         self.strict_reference)
+                         self.strict_reference, pair_var=pair_var, pair_exp=pair_exp)
 
     def _dev(self):
         if self._handle is None:

@@ -85,6 +85,9 @@ int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double*
  * host).  Feature k is kind[k] applied to variables v = [x, u]:
  *   0 v_a   1 sin(p v_a)   2 cos(p v_a)   3 v_a sin(p v_b)   4 v_a cos(p v_b)   5 v_a ** p
  * with a = arg0[k], b = arg1[k], p = param[k]; xi [nx][n_feat] are the coefficients.
+ *   6 monomial  prod_j v_{pair_var[j]} ** pair_exp[j]  over the arg1[k] (1..10) pairs starting at
+ *     pair arg0[k] of the pair list (n_pairs, pair_var, pair_exp; NULL / 0 without monomials):
+ *     the polynomial cross terms of basis_funcs.py:27-93 (sindy.py:143-145), gradient :74-84.
  *   discrete:   x' = Theta(v) xi'        continuous:  x' = x + dt Theta(v) xi'        (nx <= 64)
  * strict_reference != 0 reproduces the reference Jacobian's quirks (interaction terms counted
  * twice, polynomial gradient without the exponent factor; basis_funcs.py:24-25), as pinned by
@@ -92,7 +95,8 @@ int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double*
  * plans and the closed loop all work on a handle holding a SINDy model. */
 int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind, const int* arg0,
                    const int* arg1, const double* param, const double* xi, int continuous,
-                   double dt, int strict_reference);
+                   double dt, int strict_reference, int n_pairs, const int* pair_var,
+                   const int* pair_exp);
 int ampc_sindy_pred_batch(ampc_handle* h, const double* states, const double* ctrls, double* out,
                           int n);
 int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,

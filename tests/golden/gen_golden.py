@@ -635,6 +635,11 @@ SINDY_CASES = [
                                     trig_interaction=True, time_mode="continuous"), False, 62),
     ("poly4_disc", 2, 1, dict(poly_basis=True, poly_degree=4, time_mode="discrete"), True, 63),
     ("identity_cont", 5, 2, dict(time_mode="continuous"), False, 64),
+    # polynomial cross terms (basis_funcs.py:27-93): degree 2 (x y) and degree 3 (x y^2, x^2 y, x y z)
+    ("cross3", 3, 2, dict(poly_basis="true", poly_degree=3, poly_cross_terms="true",
+                          time_mode="discrete"), True, 65),
+    ("cross4_trig_cont", 2, 1, dict(poly_basis=True, poly_degree=4, poly_cross_terms=True, trig_basis=True,
+                                    trig_freq=1, trig_interaction=True, time_mode="continuous"), False, 66),
 ]
 
 
@@ -654,6 +659,7 @@ def gen_sindy():
                    trig_freq=int(hyper.get("trig_freq", 0)) if hyper.get("trig_basis") else 0,
                    trig_interaction=bool(hyper.get("trig_interaction")) and bool(hyper.get("trig_basis")),
                    poly_degree=int(hyper.get("poly_degree", 1)) if hyper.get("poly_basis") else 1,
+                   poly_cross_terms=bool(hyper.get("poly_cross_terms")) and bool(hyper.get("poly_basis")),
                    Xi=model.model.coefficients(), feature_names=np.array(model.model.get_feature_names()),
                    states=states, ctrls=ctrls, pred_batch=pb, diff_pred=db, diff_jx=jx, diff_ju=ju,
                    pred0=model.pred(states[0], ctrls[0]), diff0_pred=d0[0], diff0_jx=d0[1], diff0_ju=d0[2])

@@ -150,9 +150,10 @@ def test_c5_scale_batch_matches_oracle_per_candidate():
                     abs(scores[b] - ref) / abs(ref))
         # north_star: 1e-4 relative on trajectory state and cost; sharp softmin weights (costs up
         # to 1e4 x state^2 against lmda ~ 1) amplify last-bit differences over 50 closed-loop steps
-        assert rel_err(obs[b], np.array(o_obs)) < 1e-6, (b, c)
-        assert rel_err(ctrls[b], np.array(o_ctl)) < 1e-6, (b, c)
-        assert abs(scores[b] - ref) < 1e-6 * abs(ref), (b, c)
+        # (measured worst case over the batch: 6e-7, profiles/r03_*; asserted with margin)
+        assert rel_err(obs[b], np.array(o_obs)) < 1e-5, (b, c)
+        assert rel_err(ctrls[b], np.array(o_ctl)) < 1e-5, (b, c)
+        assert abs(scores[b] - ref) < 1e-5 * abs(ref), (b, c)
     print("c5-scale batch: worst relative deviation from the oracle %.2e" % worst)
 
 
@@ -303,27 +304,38 @@ def test_candidate_evaluator_scores_what_eval_cfg_scores(name, check_every):
 
 
 def test_term_cond_batch_is_per_candidate_and_batch_invariant():
-    """Candidates that stop at different rows inside one batch: each is scored on its own rows, and
-    its score is bit-identical to evaluating it alone or with another segment length."""
+    """Candidates that stop at different rows inside one batch (here: when the control energy spent
+    so far exceeds a budget; one candidate never does and runs to max_steps): each is scored on its
+    own rows, and its score is bit-identical to evaluating it alone with another segment length."""
     from autompc_amd.tuning import CandidateEvaluator
     g = golden("loop_evalcfg_term")
     system, p, task = _evalcfg_stack(g)
+    budget, T = 0.6, int(g["num_steps"])
+    task.set_term_cond(lambda traj: float(np.sum(traj.ctrls ** 2)) > budget)
     cands = [dict(horizon=6 + 2 * i, sigma=0.3 + 0.2 * i, lmda=0.5, num_path=64 + 32 * i,
-                  Q=g["Q"] * (1.0 + i), R=g["R"], F=g["F"]) for i in range(4)]
+                  Q=g["Q"] * (1.0 + i), R=g["R"] * rm, F=g["F"]) for i, rm in enumerate([1.0, 30.0, 1e3, 1e5])]
     ev = CandidateEvaluator(system, task, _hip_model(system, p), term_check_every=5)
     s, obs, ctrls = ev.evaluate(cands, seed=3, return_trajectories=True)
     lengths = ev.last_lengths.copy()
-    min_len, thresh = int(g["term_min_len"]), float(g["term_thresh"])
-    assert len(set(lengths.tolist())) > 1 and lengths.max() <= int(g["num_steps"]) + 1
+    print("rows per candidate:", lengths.tolist())
+    assert len(set(lengths.tolist())) > 1 and lengths.max() <= T + 1
     for b, L in enumerate(lengths):
-        # the condition first holds exactly at the candidate's last row (or the cap was hit)
-        hits = [t + 1 for t in range(1, L) if t + 1 >= min_len and abs(obs[b, t, 0]) < thresh]
-        assert (hits and hits[0] == L) or (not hits and L == int(g["num_steps"]) + 1)
+        # the condition first holds exactly at the candidate's last row (or max_steps was reached)
+        energy = np.cumsum(np.sum(ctrls[b, :L] ** 2, axis=1))
+        hits = [t + 1 for t in range(1, L) if energy[t - 1] > budget]      # asked with row t's control still zero
+        assert (hits and hits[0] == L) or (not hits and L == T + 1)
         assert np.all(np.isnan(obs[b, L:])) and np.all(ctrls[b, L - 1] == 0.0)
+        assert np.all(np.isfinite(obs[b, :L]))
     ev1 = CandidateEvaluator(system, task, _hip_model(system, p), term_check_every=1)
     for b in range(len(cands)):
         alone = ev1.evaluate([cands[b]], seed=3, index_offset=b)
-        assert alone[0] == s[b]
+        assert alone[0] == s[b] and ev1.last_lengths.tolist() == [lengths[b]]
+    # a score is the task cost of exactly the rows kept
+    cost = task.get_cost()
+    from autompc_amd.trajectory import Trajectory
+    for b, L in enumerate(lengths):
+        ref = cost(Trajectory(system, int(L), obs[b, :L].copy(), ctrls[b, :L].copy()))
+        assert abs(s[b] - ref) < 1e-10 * abs(ref)
 
 
 def test_batch_tuner_columns_are_the_reference_eval_cfg_costs():

@@ -89,7 +89,8 @@ def test_ilqr_on_sindy_model_reduces_cost():
     assert ctl.final_obj < zero._objective(xs, np.zeros((15, 1)))
 
 
-SINDY_GOLDENS = ["sindy_c1_trig", "sindy_poly3_trig2_cont", "sindy_poly4_disc", "sindy_identity_cont"]
+SINDY_GOLDENS = ["sindy_c1_trig", "sindy_poly3_trig2_cont", "sindy_poly4_disc", "sindy_identity_cont",
+                 "sindy_cross3", "sindy_cross4_trig_cont"]
 
 
 def oracle_from_golden(g, strict=True):
@@ -97,7 +98,8 @@ def oracle_from_golden(g, strict=True):
     return system, SINDyOracle(system, g["Xi"], trig_freq=int(g["trig_freq"]),
                                trig_interaction=bool(g["trig_interaction"]),
                                poly_degree=int(g["poly_degree"]), time_mode=str(g["time_mode"]),
-                               strict_reference=strict)
+                               strict_reference=strict,
+                               poly_cross_terms=bool(g["poly_cross_terms"]) if "poly_cross_terms" in g.files else False)
 
 
 @pytest.mark.parametrize("name", SINDY_GOLDENS)
@@ -107,11 +109,11 @@ def test_sindy_oracle_matches_reference(name):
     g = golden(name)
     _, m = oracle_from_golden(g)
     assert m.Xi.shape[1] == len(g["feature_names"])
-    assert rel_err(m.pred_batch(g["states"], g["ctrls"]), g["pred_batch"]) < 1e-14
+    assert rel_err(m.pred_batch(g["states"], g["ctrls"]), g["pred_batch"]) < 1e-13
     o, jx, ju = m.pred_diff_batch(g["states"], g["ctrls"])
-    assert rel_err(o, g["diff_pred"]) < 1e-14
+    assert rel_err(o, g["diff_pred"]) < 1e-13
     assert rel_err(jx, g["diff_jx"]) < 1e-13 and rel_err(ju, g["diff_ju"]) < 1e-13
-    assert rel_err(m.pred(g["states"][0], g["ctrls"][0]), g["pred0"]) < 1e-14
+    assert rel_err(m.pred(g["states"][0], g["ctrls"][0]), g["pred0"]) < 1e-13
     o0, jx0, ju0 = m.pred_diff(g["states"][0], g["ctrls"][0])
     assert rel_err(jx0, g["diff0_jx"]) < 1e-13 and rel_err(ju0, g["diff0_ju"]) < 1e-13
     if int(g["poly_degree"]) > 1 or bool(g["trig_interaction"]):
@@ -163,3 +165,32 @@ def test_ilqr_on_sindy_matches_reference():
     assert conv == bool(g["ilqr_converged"])
     assert rel_err(st, g["ilqr_states"]) < 1e-7 and rel_err(ct, g["ilqr_ctrls"]) < 1e-7
     assert rel_err(Ks, g["ilqr_Ks"]) < 1e-6
+
+
+def test_cross_term_library_matches_reference_names():
+    """Polynomial cross terms (basis_funcs.py:27-93): exponent tuples in the reference's order and
+    the features pysindy's enumeration makes of them, against the reference's own feature names."""
+    from oracle.sindy import cross_term_exponents
+    assert cross_term_exponents(2) == [(1, 1)]
+    assert cross_term_exponents(3) == [(1, 2), (2, 1), (1, 1, 1)]
+    assert cross_term_exponents(4) == [(1, 3), (2, 2), (3, 1), (1, 1, 2), (1, 2, 1), (2, 1, 1), (1, 1, 1, 1)]
+    g = golden("sindy_cross3")
+    feats = build_library(5, poly_degree=3, poly_cross_terms=True)
+    var = ["x0", "x1", "x2", "u0", "u1"]
+    names = []
+    for kind, c, p in feats:
+        if kind == "id":
+            names.append(var[c[0]])
+        elif kind == "pow":
+            names.append("%s**%d" % (var[c[0]], p))
+        else:
+            names.append("".join("%s^%d " % (var[j], e) for j, e in zip(c, p)))
+    assert names == [str(n) for n in g["feature_names"]]
+    # the product library (what the device is handed) enumerates the same features
+    from autompc_amd.sysid.sindy import K_MONO, build_library as product_library
+    kind, a0, a1, par, pv, pe = product_library(5, poly_degree=3, poly_cross_terms=True)
+    assert len(kind) == len(feats)
+    for k, (okind, c, p) in enumerate(feats):
+        if okind == "mono":
+            assert kind[k] == K_MONO
+            assert tuple(pv[a0[k]:a0[k] + a1[k]]) == c and tuple(pe[a0[k]:a0[k] + a1[k]]) == p
