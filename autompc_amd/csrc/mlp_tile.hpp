@@ -99,6 +99,20 @@ __device__ __forceinline__ int tail_col(int lane) { return lane & 3; }
 
 // Row of accumulator register r held by lane-quad q (= lane >> 4); column is lane & 15.
 //   f64 16x16x4: row = q + 4 r      f32 16x16x4: row = 4 q + r
+// Physical LDS row of logical tile row `row` in the ACTIVATION buffers.  f32: bits 2 and 3 of the
+// row index are swapped.  An f32 accumulator lane (i, q) holds rows 4q .. 4q+3 of column i, so one
+// ds_write_b32 of a wave stores rows {r, 4+r} (lanes 0-31) and {8+r, 12+r} (lanes 32-63) x 16
+// columns; with the row stride = 2 (mod 32) dwords that the A-fragment reads need (16 rows x 2
+// consecutive k per 32-lane group -> banks 2i + q), rows r and 4+r start 8 banks apart and half of
+// every store group lands on a busy bank (SQ_LDS_BANK_CONFLICT 17.5 % of LDS cycles in round 2).
+// No plain stride serves both patterns (reads need stride = 2 mod 4, stores 4 * stride = 16 mod 32);
+// with the swap the store rows are 16 banks apart (physical r and 8+r) and the 16 rows of a read
+// still cover the 16 even banks.  f64 (ds_write_b64 serves one accumulator row per 16-lane group)
+// has no such conflict and keeps the identity.
+template <typename T> __device__ __forceinline__ constexpr int act_row(int row) {
+  return sizeof(T) == 4 ? ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1)) : row;
+}
+
 template <typename T> __device__ __forceinline__ int acc_row(int q, int r);
 template <> __device__ __forceinline__ int acc_row<double>(int q, int r) { return q + 4 * r; }
 template <> __device__ __forceinline__ int acc_row<float>(int q, int r) { return 4 * q + r; }
@@ -422,8 +436,9 @@ struct NoSide { __device__ __forceinline__ void operator()() const {} };
 // `mid` is invoked once, right after the barrier an OWN layer takes behind its first group (never
 // for !OWN): caller work placed there issues between this layer's MFMAs instead of on the serial
 // chain at the end of a step.
+// APERM: A is an activation buffer (rows stored at act_row<T>()); false for the [x | u] operand.
 template <typename T, int NT, int MT, int KS, int G, bool PIPE = false, bool OWN = false, int SG = G,
-          typename Mid = NoSide>
+          bool APERM = false, typename Mid = NoSide>
 __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_stride,
                                                  rsrc_t wr, unsigned wl, int lane,
                                                  const T (&first)[G][NT],
@@ -435,7 +450,7 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
   constexpr int FS = G / SG;       // sub-groups that arrive pre-loaded in `first`
   static_assert(!OWN || (NG & (NG - 1)) == 0, "rotated k order needs a power-of-two group count");
   const int i = lane & 15, q = lane >> 4;
-  const T* arow = A + i * a_stride + q;
+  const T* arow = A + (APERM ? act_row<T>(i) : i) * a_stride + q;
   T b[2][SG][NT];
   if constexpr (FS == 1) {       // whole-group streaming: the pre-loaded group IS buffer 0
 #pragma unroll
@@ -793,7 +808,7 @@ struct TileNet {
       constexpr int KIND = decltype(kind_tag)::value;
       constexpr int RS = sizeof(T) == 8 ? 4 : 1;                    // acc_row(q, r) = acc_row(q, 0) + RS*r
       const T* bias = lds + L.bias + l * m.hpad + 16 * NT * w + i;
-      T* d0 = dst + acc_row<T>(q, 0) * as + 16 * NT * w + i;
+      T* d0 = dst + act_row<T>(acc_row<T>(q, 0)) * as + 16 * NT * w + i;   // (+ ro: bits 0-1 and >= 4 only)
       T* z0 = DERIV ? dz + (size_t)l * dz_layer_stride + (size_t)acc_row<T>(q, 0) * m.hpad + 16 * NT * w + i : nullptr;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -901,10 +916,10 @@ struct TileNet {
       constexpr int SGH = sizeof(T) == 8 ? GH / 2 : GH;
 #endif
 #ifdef AMPC_X_SIDELATE
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH>(
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH, true>(
           act, as, wr, slice_h(m, l, w), lane, pfn, acc, w);
 #else
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH>(
+      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH, true>(
           act, as, wr, slice_h(m, l, w), lane, pfn, acc, w, [&] {
             if (l == 1) { side(); side_done = true; }
           });
@@ -931,7 +946,7 @@ struct TileNet {
       for (int n = 0; n < NOMAX; ++n) oacc[mt][n] = acc_t{0, 0, 0, 0};
     }
     {
-      const T* arow = act + i * as + q + 4 * w * KSW;
+      const T* arow = act + act_row<T>(i) * as + q + 4 * w * KSW;
       if constexpr (WIDE) {
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks)
