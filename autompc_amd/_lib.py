@@ -38,6 +38,9 @@ SIGNATURES = {
     "ampc_precision": (c_int, [c_void_p]),
     "ampc_set_mlp": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(_dp),
                              POINTER(_dp), _dp, _dp, _dp, _dp]),
+    "ampc_jit_status": (c_int, [c_void_p, c_char_p, c_int]),
+    "ampc_jit_wait": (c_int, [c_void_p]),
+    "ampc_plan_kernel_kind": (c_int, [c_void_p, c_void_p]),
     "ampc_set_linear": (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
     "ampc_mlp_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_mlp_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
@@ -199,6 +202,18 @@ class Handle:
                                     dptr(norm[3])))
         self.nx, self.nu = nx, nu
         self._sindy = False
+
+    def jit_status(self):
+        """(state, message): 0 no run-time compiled kernels involved, 1 the shape plugin of the staged
+        model is being compiled, 2 ready, -1 failed."""
+        buf = ctypes.create_string_buffer(512)
+        st = self.lib.ampc_jit_status(self._h, buf, 512)
+        return st, buf.value.decode()
+
+    def jit_wait(self):
+        """Block until the kernels specialised for the staged model's shape are compiled; plans
+        created afterwards use them."""
+        check(self.lib.ampc_jit_wait(self._h))
 
     def set_linear(self, A, B):
         """x' = A x + B u (ARX / Koopman prediction, arx.py:151-154, koopman.py:170-173)."""
@@ -445,6 +460,10 @@ class MppiPlan:
             dptr(scores), dptr(obs), dptr(ctl)))
         return (scores, obs, ctl) if return_trajectories else scores
 
+    def kernel_kind(self):
+        """0 run-time-shape kernels, 1 a shape registered at build time, 2 a run-time compiled plugin."""
+        return int(self.lib.ampc_plan_kernel_kind(self._p, None))
+
     def set_outputs(self, keep_eps_out=True):
         check(self.lib.ampc_mppi_plan_set_outputs(self._p, int(bool(keep_eps_out))))
 
@@ -504,6 +523,9 @@ class IlqrPlan:
         check(self.lib.ampc_ilqr_plan_timing(self._p, dptr(ms), ctypes.byref(n)))
         return {"riccati_ms": ms[0], "iter_ms": ms[1], "forward_ms": ms[2], "jacobian_ms": ms[3],
                 "launches": n.value}
+
+    def kernel_kind(self):
+        return int(self.lib.ampc_plan_kernel_kind(None, self._p))
 
     def stats(self):
         """Work of the last solve: iterations launched and line-search candidate rows rolled out

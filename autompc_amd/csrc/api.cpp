@@ -6,6 +6,7 @@
 #include "legacy_rng_kernels.hpp"      // (non-template kernels: this translation unit only)
 #include <link.h>                      // dl_iterate_phdr: the C library's log() tables (host_log_mode)
 #include <mutex>
+#include "jit_host.hpp"                // shape plugins compiled at run time
 
 thread_local std::string g_err;
 
@@ -26,6 +27,45 @@ extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// Start (or find) the shape plugin of the staged model as soon as model and observation dimension
+// are both known; never blocks.
+static void jit_kick(ampc_handle* h) {
+  if (!h->has_mlp || h->obs_dim < 1) return;
+  if (h->precision == AMPC_F64) {
+    if (static_shape_of<double>(h, h->md) < 0) (void)jit::get<double>(h);
+  } else {
+    if (static_shape_of<float>(h, h->mf) < 0) (void)jit::get<float>(h);
+  }
+}
+
+extern "C" int ampc_jit_status(ampc_handle* h, char* msg, int msg_len) {
+  if (!h) return 0;
+  std::string m;
+  const int st = h->precision == AMPC_F64 ? jit::status<double>(h, &m) : jit::status<float>(h, &m);
+  if (msg && msg_len > 0) { std::strncpy(msg, m.c_str(), (size_t)msg_len - 1); msg[msg_len - 1] = 0; }
+  return st;
+}
+
+extern "C" int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr_plan* ilqr) {
+  const int sid = mppi ? mppi->static_shape : (ilqr ? ilqr->static_shape : -1);
+  const JitPlugin* j = mppi ? mppi->jit : (ilqr ? ilqr->jit : nullptr);
+  return sid < 0 ? 0 : (j ? 2 : 1);
+}
+
+extern "C" int ampc_jit_wait(ampc_handle* h) {
+  REQUIRE(h, "ampc_jit_wait: NULL handle");
+  jit_kick(h);
+  if (!jit::eligible(h)) return 0;
+  const bool reg = h->precision == AMPC_F64 ? static_shape_of<double>(h, h->md) >= 0
+                                            : static_shape_of<float>(h, h->mf) >= 0;
+  if (reg) return 0;
+  const JitPlugin* j = h->precision == AMPC_F64 ? jit::get<double>(h, true) : jit::get<float>(h, true);
+  if (j) return 0;
+  std::string m;
+  (void)(h->precision == AMPC_F64 ? jit::status<double>(h, &m) : jit::status<float>(h, &m));
+  return fail("ampc_jit_wait: " + m);
 }
 
 extern "C" int ampc_create(int device, int precision, void* stream, ampc_handle** out) {
@@ -317,6 +357,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   if (rc) return rc;
   h->has_mlp = true;
   h->has_sindy = false;
+  jit_kick(h);            // (needs obs_dim: if the cost is set later, ampc_set_quad_costs starts it)
   return 0;
 }
 
@@ -377,6 +418,7 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
         if (i != j && R[((size_t)c * nu + i) * nu + j] != 0.0) diag = false;
   }
   h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
+  jit_kick(h);
   return 0;
 }
 
@@ -476,11 +518,14 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   // shape-specialised kernel: registered shape, 16- or 32-row tile, and the LDS map the shape
   // implies (ping-pong activations + separate partials -- tile_lds_for picked it iff it fits)
   p->static_shape = -1;
+  p->jit = nullptr;
   if (!h->has_sindy && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
-    const int sid = static_shape_of<T>(h, m);
+    int sid = static_shape_of<T>(h, m);
+    if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;      // run-time compiled shape
     const int lv = sid >= 0 ? lds_variant_of<T>(m, p->L, M, h->nw) : -1;
     // instantiated: 16-row tiles with the richest map, 32-row tiles with any of the three
     if (lv == 0 || (lv > 0 && p->mt == 2)) { p->static_shape = sid; p->static_lv = lv; }
+    else p->jit = nullptr;
   }
   std::vector<MppiProblem<T>> pr(p->B);
   std::vector<int> tile_prob;
@@ -1037,12 +1082,15 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   p->use_mfma_sweep = env_int("AMPC_RICCATI", 1) != 0;
   p->par_passes = env_int("AMPC_LS4_PAR", 1) != 0;
   p->static_shape = -1;
+  p->jit = nullptr;
   if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
-    const int sid = static_shape_of<T>(h, m);
+    int sid = static_shape_of<T>(h, m);
+    if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;      // run-time compiled shape
     if (sid >= 0) {
       const TileLds S = tile_lds_dims((int)sizeof(T), m.hpad, m.k1p, m.nxp, m.n_hidden, 16, h->nw, true, true);
       if (std::memcmp(&S, &p->L, sizeof(TileLds)) == 0) p->static_shape = sid;
     }
+    if (p->static_shape < 0) p->jit = nullptr;
   }
   REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
   REQUIRE((size_t)wk.total * sizeof(T) <= kLdsLimit,

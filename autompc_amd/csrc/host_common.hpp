@@ -33,7 +33,7 @@ using namespace ampc;
 // ---------------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------------
-extern thread_local std::string g_err;     // defined in api.cpp
+extern thread_local std::string g_err;     // defined in api.cpp (in jit_plugin.cpp for a shape plugin)
 inline int fail(const std::string& msg) {
   g_err = msg;
   return -1;
@@ -81,6 +81,24 @@ static constexpr size_t kLdsLimit = 160 * 1024;
 inline int env_int(const char* name, int dflt) {
   const char* v = std::getenv(name);
   return v ? std::atoi(v) : dflt;
+}
+
+// ---------------------------------------------------------------------------------------------
+// shape plugin: the launchers of ONE model shape, compiled at run time (shapes.hpp, jit_host.hpp)
+// ---------------------------------------------------------------------------------------------
+struct ampc_mppi_plan;
+struct ampc_ilqr_plan;
+struct JitPlugin {
+  void* dl = nullptr;
+  int (*mppi_solve)(ampc_mppi_plan*) = nullptr;          // mppi_solve_impl<T>
+  int (*ilqr_iter)(ampc_ilqr_plan*, int) = nullptr;      // ilqr_launch_iter<T>
+  int (*ilqr_refresh)(ampc_ilqr_plan*) = nullptr;        // ilqr_refresh_jacobians<T>
+  const char* (*last_error)() = nullptr;
+};
+// result of a plugin call -> this library's error slot
+inline int jit_result(const JitPlugin* j, int rc) {
+  if (rc != 0) g_err = std::string("shape plugin: ") + (j->last_error ? j->last_error() : "error");
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -246,6 +264,7 @@ struct ampc_mppi_plan {
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
   int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
+  const JitPlugin* jit = nullptr;   // the shape's kernels live in a run-time compiled plugin (id 0 there)
   int static_lv = 0;      // which LDS map variant (StaticShape LV) the plan's tile uses
   int tile_m = 16;      // samples per rollout workgroup (16*mt for the MLP tile, 64 for SINDy)
   std::vector<int> N, H, cost_idx, a_off;
@@ -319,6 +338,7 @@ struct ampc_ilqr_plan {
   ampc_handle* h = nullptr;
   int B = 0, H = 0, ls_n = 10, bounded = 0, term_goal = 0;
   int static_shape = -1;     // >= 0: registered shape whose specialised kernels run (shapes.hpp)
+  const JitPlugin* jit = nullptr;   // ... in a run-time compiled plugin (shape id 0 there)
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;

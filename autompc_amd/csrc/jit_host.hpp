@@ -1,0 +1,201 @@
+// jit_host.hpp -- run-time specialisation of the kernels for the staged model's shape (api.cpp only).
+//
+// The reference's MLP configuration space is 1-4 hidden layers of 16-256 units (mlp.py:113-122); the
+// library pads every hidden layer of a model to one width hpad in {64, 128, 192, 256}, so for a
+// given system there are 16 kernel shapes (n_hidden x hpad).  shapes.hpp registers the benchmark
+// systems' default networks; every other shape a tuner produces is compiled here on first use:
+//
+//   ampc_set_mlp      shape not registered -> look for  <cache>/shape_<key>_<srchash>.so ; if it is
+//                     absent, start  /bin/sh -c "hipcc ... (4 units in parallel) && link && mv"
+//                     in the background (posix_spawn) and return at once
+//   plan creation     plugin present (or just finished) -> dlopen, check ampc_jit_info against the
+//                     model, plan->jit = plugin, plan->static_shape = 0;  otherwise the DynShape
+//                     kernels run (1.1-1.9x slower) and the next plan looks again
+//   ampc_jit_wait     block until the build of the handle's shape has finished (tools / tests)
+//
+// <cache> = $AMPC_JIT_CACHE or <package>/jit_cache (in-tree: it travels with the package).  The key
+// holds precision + shape, the file name also a hash of every source the plugin is compiled from,
+// so a plugin is never used with other headers than the ones this library was built from.
+// AMPC_JIT=0 disables all of it.  Same arithmetic in the same order as DynShape: results are
+// bit-identical (tests/test_gpu_jit.py).
+#pragma once
+#include <dlfcn.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+
+#include "host_common.hpp"
+
+extern char** environ;
+
+namespace jit {
+
+struct Entry {
+  int state = 0;            // 0 unknown, 1 building, 2 ready, -1 failed
+  pid_t pid = -1;
+  std::string so, log;
+  JitPlugin plug;
+  int info[8] = {0};
+};
+
+inline std::mutex& mu() { static std::mutex m; return m; }
+inline std::map<std::string, Entry>& table() { static std::map<std::string, Entry> t; return t; }
+
+inline std::string package_dir() {          // directory of libautompc_hip.so
+  Dl_info di;
+  if (dladdr((const void*)&package_dir, &di) == 0 || !di.dli_fname) return ".";
+  std::string p = di.dli_fname;
+  const size_t k = p.rfind('/');
+  return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+inline const std::vector<std::string>& source_files() {
+  static const std::vector<std::string> f = {
+      "host_common.hpp", "shapes.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "mppi_kernels.hpp",
+      "ilqr_kernels.hpp", "ilqr_ls4.hpp", "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp",
+      "launch_mppi.cpp", "launch_mlp.cpp", "launch_ilqr.cpp", "jit_plugin.cpp", "../../include/autompc_hip.h"};
+  return f;
+}
+
+// FNV-1a over the plugin's sources: "" if one of them is missing (a package shipped without csrc/)
+inline const std::string& source_hash() {
+  static const std::string h = [] {
+    uint64_t x = 1469598103934665603ull;
+    const std::string dir = package_dir() + "/csrc/";
+    for (const std::string& f : source_files()) {
+      std::ifstream in(dir + f, std::ios::binary);
+      if (!in) return std::string();
+      char buf[1 << 14];
+      while (in.read(buf, sizeof(buf)) || in.gcount() > 0) {
+        for (std::streamsize i = 0; i < in.gcount(); ++i) { x ^= (unsigned char)buf[i]; x *= 1099511628211ull; }
+      }
+    }
+    char out[24];
+    std::snprintf(out, sizeof(out), "%016llx", (unsigned long long)x);
+    return std::string(out);
+  }();
+  return h;
+}
+
+inline std::string cache_dir() {
+  const char* e = std::getenv("AMPC_JIT_CACHE");
+  return e && *e ? std::string(e) : package_dir() + "/jit_cache";
+}
+
+inline bool exists(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }
+
+inline std::string hipcc_path() {
+  const char* e = std::getenv("HIPCC");
+  if (e && *e && exists(e)) return e;
+  return exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc";
+}
+
+template <typename T> inline std::string key_of(const ampc_handle* h) {
+  char k[96];
+  std::snprintf(k, sizeof(k), "%s_x%d_u%d_o%d_h%d_w%d", sizeof(T) == 8 ? "f64" : "f32", h->nx, h->nu,
+                h->obs_dim, h->n_hidden, h->hpad);
+  return k;
+}
+
+// shapes the StaticShape kernels exist for (what the registered ones are used with)
+inline bool eligible(const ampc_handle* h) {
+  return env_int("AMPC_JIT", 1) != 0 && h->has_mlp && !h->has_sindy && h->act != 4 /* linear staging */ &&
+         h->nx >= 1 && h->nx <= 32 && h->obs_dim >= 1 && h->n_hidden >= 1 && h->n_hidden <= kMaxHidden &&
+         (h->hpad == 64 || h->hpad == 128 || h->hpad == 192 || h->hpad == 256) && !source_hash().empty();
+}
+
+inline bool load(Entry& e, const ampc_handle* h, size_t tsize) {
+  void* dl = dlopen(e.so.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!dl) { e.state = -1; e.log = std::string("dlopen: ") + dlerror(); return false; }
+  e.plug.dl = dl;
+  e.plug.mppi_solve = (int (*)(ampc_mppi_plan*))dlsym(dl, "ampc_jit_mppi_solve");
+  e.plug.ilqr_iter = (int (*)(ampc_ilqr_plan*, int))dlsym(dl, "ampc_jit_ilqr_iter");
+  e.plug.ilqr_refresh = (int (*)(ampc_ilqr_plan*))dlsym(dl, "ampc_jit_ilqr_refresh");
+  e.plug.last_error = (const char* (*)())dlsym(dl, "ampc_jit_last_error");
+  auto info = (void (*)(int*))dlsym(dl, "ampc_jit_info");
+  if (!e.plug.mppi_solve || !e.plug.ilqr_iter || !e.plug.ilqr_refresh || !e.plug.last_error || !info) {
+    e.state = -1; e.log = "plugin lacks an entry point"; return false;
+  }
+  info(e.info);
+  const int want[6] = {h->nx, h->nu, h->obs_dim, h->n_hidden, h->hpad, (int)tsize};
+  for (int i = 0; i < 6; ++i)
+    if (e.info[i] != want[i]) { e.state = -1; e.log = "plugin was compiled for another shape"; return false; }
+  if (e.info[7] != (int)(sizeof(ampc_mppi_plan) + sizeof(ampc_ilqr_plan) + sizeof(ampc_handle))) {
+    e.state = -1; e.log = "plugin was compiled against other plan structs"; return false;
+  }
+  e.state = 2;
+  return true;
+}
+
+template <typename T> inline void start_build(Entry& e, const ampc_handle* h, const std::string& key) {
+  const std::string dir = cache_dir(), src = package_dir() + "/csrc", inc = package_dir() + "/../include";
+  ::mkdir(dir.c_str(), 0755);
+  const std::string tmp = dir + "/build_" + key + "_" + std::to_string((long)getpid());
+  std::ostringstream sh;
+  const std::string cc = hipcc_path();
+  sh << "mkdir -p '" << tmp << "' && cd '" << tmp << "' || exit 1\n";
+  std::ostringstream fl;
+  fl << "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-pass-failed -I '" << inc
+     << "' -DAMPC_JIT_PLUGIN -DAMPC_T=" << (sizeof(T) == 8 ? "double -DAMPC_T_IS_F64=1" : "float")
+     << " -DAMPC_JIT_NX=" << h->nx << " -DAMPC_JIT_NU=" << h->nu << " -DAMPC_JIT_NO=" << h->obs_dim
+     << " -DAMPC_JIT_NH=" << h->n_hidden << " -DAMPC_JIT_HPAD=" << h->hpad;
+  for (const char* u : {"launch_mppi", "launch_mlp", "launch_ilqr", "jit_plugin"})
+    sh << "'" << cc << "' " << fl.str() << " -c '" << src << "/" << u << ".cpp' -o " << u << ".o &\n";
+  sh << "wait\n"
+     << "test -f launch_mppi.o -a -f launch_mlp.o -a -f launch_ilqr.o -a -f jit_plugin.o || exit 2\n"
+     << "'" << cc << "' --offload-arch=gfx950 -shared -fPIC launch_mppi.o launch_mlp.o launch_ilqr.o jit_plugin.o"
+     << " -o plugin.so || exit 3\n"
+     << "mv plugin.so '" << e.so << "' && cd / && rm -rf '" << tmp << "'\n";
+  e.log = dir + "/shape_" + key + ".log";
+  const std::string script = "exec > '" + e.log + "' 2>&1\n" + sh.str();
+  const char* argv[] = {"/bin/sh", "-c", script.c_str(), nullptr};
+  pid_t pid = -1;
+  if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, environ) != 0) {
+    e.state = -1; e.log = "posix_spawn(/bin/sh) failed"; return;
+  }
+  e.pid = pid;
+  e.state = 1;
+}
+
+// reap a finished build; `block`: wait for it
+inline void poll(Entry& e, const ampc_handle* h, size_t tsize, bool block) {
+  if (e.state != 1) return;
+  int st = 0;
+  const pid_t r = waitpid(e.pid, &st, block ? 0 : WNOHANG);
+  if (r == 0) return;                                   // still running
+  if (exists(e.so)) { load(e, h, tsize); return; }
+  e.state = -1;
+  e.log = "build failed, see " + e.log;
+}
+
+// plugin for the handle's staged shape, or nullptr (not eligible / still building / failed)
+template <typename T> inline const JitPlugin* get(const ampc_handle* h, bool block = false) {
+  if (!eligible(h)) return nullptr;
+  std::lock_guard<std::mutex> g(mu());
+  const std::string key = key_of<T>(h);
+  Entry& e = table()[key];
+  if (e.state == 0) {
+    e.so = cache_dir() + "/shape_" + key + "_" + source_hash() + ".so";
+    if (exists(e.so)) load(e, h, sizeof(T));
+    else start_build<T>(e, h, key);
+  }
+  poll(e, h, sizeof(T), block);
+  return e.state == 2 ? &e.plug : nullptr;
+}
+
+template <typename T> inline int status(const ampc_handle* h, std::string* msg) {
+  if (!eligible(h)) return 0;
+  std::lock_guard<std::mutex> g(mu());
+  auto it = table().find(key_of<T>(h));
+  if (it == table().end()) return 0;
+  if (msg) *msg = it->second.state == 2 ? it->second.so : it->second.log;
+  return it->second.state;
+}
+
+}  // namespace jit

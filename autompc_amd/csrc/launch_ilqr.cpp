@@ -8,6 +8,9 @@
 #endif
 
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
+#ifndef AMPC_JIT_PLUGIN
+  if (p->jit) return jit_result(p->jit, p->jit->ilqr_iter(p, mode));
+#endif
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
   hipEvent_t* e = mode == 1 ? p->ev_cur : nullptr;
@@ -23,18 +26,23 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     case NUV: { auto rk = ilqr_riccati_mfma_kernel<T, NUV, SHT>; HIP_OK(allow_lds(rk, mb));          \
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; break; }
     bool done = false;
-    if (mfma_sweep && h->nx <= 32) {
+    // (the control dimensions the latency-optimised sweep is validated for; a shape-specialised
+    //  build takes the same decision as the run-time-shape one, so both give identical results)
+    const bool nu_ok = h->nu == 1 || h->nu == 2 || h->nu == 3 || h->nu == 4 || h->nu == 6 || h->nu == 8;
+    if (mfma_sweep && h->nx <= 32 && nu_ok) {
       if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto rk = ilqr_riccati_mfma_kernel<T, SH::nu, SH>; HIP_OK(allow_lds(rk, mb));   \
         hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; }
         AMPC_STATIC_DISPATCH(p->static_shape, 0);    // (the sweep never evaluates the activation)
 #undef AMPC_SD_BODY
       } else {
+#ifndef AMPC_JIT_PLUGIN
         switch (h->nu) {
           AMPC_RIC_NU(1, DynShape) AMPC_RIC_NU(2, DynShape) AMPC_RIC_NU(3, DynShape)
           AMPC_RIC_NU(4, DynShape) AMPC_RIC_NU(6, DynShape) AMPC_RIC_NU(8, DynShape)
           default: break;
         }
+#endif
       }
     }
 #undef AMPC_RIC_NU
@@ -44,7 +52,11 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a); }
       AMPC_STATIC_DISPATCH(p->static_shape, 0);
 #undef AMPC_SD_BODY
-    } else if (h->nx > 32) {
+    }
+#ifdef AMPC_JIT_PLUGIN
+    else return fail("shape plugin entered without its static shape");
+#else
+    else if (h->nx > 32) {
       auto rk = ilqr_riccati_kernel<T, true>;
       HIP_OK(allow_lds(rk, rb));
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
@@ -53,9 +65,11 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       HIP_OK(allow_lds(rk, rb));
       hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
     }
+#endif
     HIP_OK(hipGetLastError());
   }
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
+#ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     auto k = ilqr_iter_kernel<T, 1, 4, 1>;
     HIP_OK(allow_lds(k, p->lds_bytes));
@@ -64,6 +78,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
   }
+#endif
   // f64 MLP models with <= 32 states: candidates four at a time on 4x4x4 MFMA tiles (ilqr_ls4.hpp)
   if constexpr (sizeof(T) == 8) {
     // one hidden -> hidden layer: that layer partly resident on chip (registers + LDS)
@@ -97,6 +112,9 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
 #undef AMPC_LS4_ONE
 #undef AMPC_LS4_SHAPE
       } else {
+#ifdef AMPC_JIT_PLUGIN
+        return fail("shape plugin entered without its static shape");
+#else
 #define AMPC_LS4_CASE(NTV, RESV)                                                               \
         case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
           HIP_OK(allow_lds(k, lb));                                                            \
@@ -107,6 +125,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
           default: return fail("internal: unsupported hidden width for the four-row line search");
         }
 #undef AMPC_LS4_CASE
+#endif
       }
       HIP_OK(hipGetLastError());
       if (e) HIP_OK(hipEventRecord(e[2], h->stream));
@@ -119,11 +138,15 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
   } else {
+#ifdef AMPC_JIT_PLUGIN
+    return fail("shape plugin entered without its static shape");
+#else
     AMPC_DISPATCH(h, 1, {
       auto k = ilqr_iter_kernel<T, NT, W, 0, DynShape, WD>;
       HIP_OK(allow_lds(k, p->lds_bytes));
       hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
     });
+#endif
   }
   HIP_OK(hipGetLastError());
   if (e) HIP_OK(hipEventRecord(e[2], h->stream));

@@ -7,6 +7,7 @@
 #error "compile with -DAMPC_T=double or -DAMPC_T=float"
 #endif
 
+#ifndef AMPC_JIT_PLUGIN       // (a shape plugin only carries the launchers that have static variants)
 // ---------------------------------------------------------------------------------------------
 // Model.pred_batch / pred_diff_batch
 // ---------------------------------------------------------------------------------------------
@@ -69,13 +70,19 @@ int pred_impl(ampc_handle* h, const double* states, const double* ctrls, double*
   return 0;
 }
 
+#endif  // AMPC_JIT_PLUGIN
+
 // Jacobians of every (problem, t) row of the nominal trajectories whose problem asked for it.
 template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
+#ifndef AMPC_JIT_PLUGIN
+  if (p->jit) return jit_result(p->jit, p->jit->ilqr_refresh(p));
+#endif
   ampc_handle* h = p->h;
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
   const int n_pad = round_up(rows, 64);
   const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
+#ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
                        sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,
@@ -84,6 +91,7 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     if (p->ev_cur) { HIP_OK(hipEventRecord(p->ev_cur[3], h->stream)); HIP_OK(hipEventRecord(p->ev_cur[4], h->stream)); }
     return 0;
   }
+#endif
   {
     const int mt = 1, M = 16, tiles = (rows + M - 1) / M;
     TileLds L = tile_lds_for<T>(h, m, M, 0);
@@ -96,12 +104,17 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
       AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
     } else {
+#ifdef AMPC_JIT_PLUGIN
+      (void)mt;
+      return fail("shape plugin entered without its static shape");
+#else
       AMPC_DISPATCH(h, mt, {
         auto k = mlp_forward_kernel<T, NT, MT, W, true, DynShape, WD>;
         HIP_OK(allow_lds(k, lb));
         hipLaunchKernelGGL(k, dim3(tiles), dim3(64 * W), lb, h->stream, m, L, (const T*)p->states.p,
                            (const T*)p->ctrls.p, (T*)nullptr, (T*)p->dz.p, rows, n_pad, rm);
       });
+#endif
     }
   }
   if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[3], h->stream));
@@ -122,18 +135,24 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
       AMPC_STATIC_DISPATCH(p->static_shape, 0);       // (the chain multiplies stored derivatives)
 #undef AMPC_SD_BODY
     } else {
+#ifdef AMPC_JIT_PLUGIN
+      return fail("shape plugin: Jacobian tile height other than 16 (AMPC_JMT) needs the library's kernels");
+#else
       AMPC_DISPATCH(h, jmt, {
         auto k = mlp_jacobian_kernel<T, NT, MT, W, DynShape, WD>;
         HIP_OK(allow_lds(k, jl));
         hipLaunchKernelGGL(k, dim3(jtiles), dim3(64 * W), jl, h->stream, m, (const T*)h->wout_plain,
                            (const T*)p->dz.p, rows, n_pad, (T*)p->jx.p, (T*)p->ju.p, rm);
       });
+#endif
     }
   }
   HIP_OK(hipGetLastError());
   if (p->ev_cur) HIP_OK(hipEventRecord(p->ev_cur[4], h->stream));
   return 0;
 }
+
+#ifndef AMPC_JIT_PLUGIN
 
 // x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
 template <typename T>
@@ -164,4 +183,5 @@ int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* 
 
 template int pred_impl<AMPC_T>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
 template int surrogate_step<AMPC_T>(ampc_handle*, ampc_handle*, const void*, const void*, void*, int);
+#endif  // AMPC_JIT_PLUGIN
 template int ilqr_refresh_jacobians<AMPC_T>(ampc_ilqr_plan*);

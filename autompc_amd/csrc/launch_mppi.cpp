@@ -8,6 +8,9 @@
 #endif
 
 template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
+#ifndef AMPC_JIT_PLUGIN
+  if (p->jit) return jit_result(p->jit, p->jit->mppi_solve(p));     // same function, compiled for the shape
+#endif
   ampc_handle* h = p->h;
   MppiArgs<T> a = make_args<T>(p);
   hipEvent_t* e = nullptr;
@@ -23,13 +26,16 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
     p->ev_used += 3;
     HIP_OK(hipEventRecord(e[0], h->stream));
   }
+#ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);
     const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
                       sindy_stage_bytes<T>(h);
     HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
     hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
-  } else if (p->static_shape >= 0) {
+  } else
+#endif
+  if (p->static_shape >= 0) {
     // shape-specialised instantiation (dimensions, strides and LDS offsets are immediates)
     // (relu -- the reference's default, mlp.py:126-128 -- gets its own instantiation; the other
     // activations share one with a run-time switch.  (tile rows, LDS map): (16, 0) (32, 0) (32, 1) (32, 2))
@@ -57,11 +63,15 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
       default: return fail("internal: unknown static shape");
     }
   } else {
+#ifdef AMPC_JIT_PLUGIN
+    return fail("shape plugin entered without its static shape");
+#else
     AMPC_DISPATCH(h, p->mt, {
       auto k = mppi_rollout_kernel<T, NT, MT, W, DynShape, WD>;
       HIP_OK(allow_lds(k, p->lds_bytes));
       hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(64 * W), p->lds_bytes, h->stream, a);
     });
+#endif
   }
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
   if (p->lds_eps >= 0) {

@@ -11,9 +11,19 @@
 //   2  CartPole      4 states, 1 control,  2 x 64     (benchmarks/cartpole.py)
 //   3  HalfCheetah with a 2 x 128 network (the config-space default hidden size, mlp.py:120-124)
 // Adding a shape = adding a line (costs ~1 minute of build time per precision).
+//
+// A shape that is NOT listed gets the same kernels at run time: ampc_set_mlp starts an
+// out-of-process hipcc build of a "shape plugin" -- launch_{mppi,mlp,ilqr}.cpp + jit_plugin.cpp
+// compiled with -DAMPC_JIT_PLUGIN and the registry below replaced by the one staged shape
+// (-DAMPC_JIT_NX=.. etc.) -- cached on disk by shape + source hash, dlopen'ed by the next plan built
+// on that model (jit_host.hpp); until it is ready the DynShape kernels run.
 #pragma once
+#ifdef AMPC_JIT_PLUGIN
+#define AMPC_STATIC_SHAPES(X) X(0, AMPC_JIT_NX, AMPC_JIT_NU, AMPC_JIT_NO, AMPC_JIT_NH, AMPC_JIT_HPAD)
+#else
 #define AMPC_STATIC_SHAPES(X) \
   X(0, 17, 6, 17, 2, 256)     \
   X(1, 2, 1, 2, 2, 64)        \
   X(2, 4, 1, 4, 2, 64)        \
   X(3, 17, 6, 17, 2, 128)
+#endif

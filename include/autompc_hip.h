@@ -59,6 +59,25 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
                  const double* xu_mean, const double* xu_std, const double* dy_mean,
                  const double* dy_std);
 
+/* ---- kernels specialised for the staged model's shape -------------------------------------------
+ * The reference's MLP configuration space is 1-4 hidden layers of 16-256 units (mlp.py:113-122).
+ * Kernels specialised for a model shape (all dimensions, strides and LDS offsets immediates; 1.1-1.9x
+ * faster than the run-time-shape kernels) are built in for the benchmark systems' default networks
+ * (csrc/shapes.hpp).  For any other MLP shape the library compiles them itself: once a handle has
+ * both a model and a cost (the observation dimension is part of the shape), an out-of-process hipcc
+ * build of a "shape plugin" starts in the background -- cached on disk in $AMPC_JIT_CACHE (default
+ * <package>/jit_cache), keyed by precision, shape and a hash of the kernel sources -- and plans
+ * created after it has finished use it; until then the run-time-shape kernels run.  Results are
+ * bit-identical either way.  AMPC_JIT=0 in the environment disables it.
+ *   ampc_jit_status  0 nothing to do (registered shape, SINDy / linear model, JIT disabled), 1 building,
+ *                    2 ready, -1 failed; msg (optional) receives the plugin path or the build log's path
+ *   ampc_jit_wait    block until the handle's shape is ready (returns 0) or failed (< 0)            */
+int ampc_jit_status(ampc_handle* h, char* msg, int msg_len);
+int ampc_jit_wait(ampc_handle* h);
+/* Which kernels a plan launches (pass one plan, NULL for the other): 0 run-time-shape, 1 a shape
+ * registered at build time, 2 a shape plugin compiled at run time. */
+int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr_plan* ilqr);
+
 /* ---- model: linear dynamics (alternative to ampc_set_mlp) ----------------------------------
  * x' = A x + B u with A [nx][nx], B [nx][nu] row-major: the prediction of autompc.sysid.ARX
  * (arx.py:151-164, state = stacked observation/control history + constant 1) and

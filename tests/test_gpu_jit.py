@@ -1,0 +1,120 @@
+"""Kernels specialised at run time for the staged model's shape (csrc/jit_host.hpp, shapes.hpp): the
+reference's MLP configuration space is 1-4 hidden layers of 16-256 units (mlp.py:113-122); shapes
+outside the build-time registry get their StaticShape kernels from a plugin compiled by hipcc on
+first use.  Same arithmetic in the same order: every result must be bit-identical to the
+run-time-shape kernels.  Needs MI355X (and hipcc, which the image has)."""
+import numpy as np
+import pytest
+
+from helpers import rel_err
+from oracle import mlp as omlp
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [
+    # nx, nu, hidden, activation  (none of these is in csrc/shapes.hpp)
+    (11, 5, [256, 256], "relu"),
+    (12, 3, [192, 160, 192], "tanh"),
+    (5, 2, [40], "relu"),
+]
+
+
+def _handle(nx, nu, hidden, act, precision, seed=3):
+    from autompc_amd import _lib
+    p = omlp.random_params(nx, nu, hidden, act, seed=seed)
+    h = _lib.Handle(0, precision)
+    h.set_mlp(nx, nu, p["weights"], p["biases"], act, p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+    h.set_quad_costs(np.eye(nx), 0.05 * np.eye(nu), 2 * np.eye(nx), np.zeros(nx))
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    return h
+
+
+def _mppi(h, nx, nu, tile_rows):
+    from autompc_amd import _lib
+    N, H = 512, 12
+    plan = _lib.MppiPlan(h, [N], [H], [0.5], [0.7])
+    if tile_rows:
+        plan.set_geometry(tile_rows, 0)
+    rng = np.random.default_rng(5)
+    plan.upload(rng.uniform(-0.2, 0.2, size=(1, nx)), rng.normal(scale=0.3, size=H * nu),
+                rng.normal(scale=0.7, size=N * H * nu))
+    plan.solve()
+    out = plan.download(costs=True, eps_out=True)
+    kind = plan.kernel_kind()
+    plan.close()
+    return kind, out
+
+
+def _ilqr(h, nx, nu):
+    from autompc_amd import _lib
+    B, H = 3, 20
+    plan = _lib.IlqrPlan(h, B, H, 0.05)
+    x0 = np.random.default_rng(2).uniform(-0.3, 0.3, size=(B, nx))
+    out = plan.solve(x0, np.zeros((B, H, nu)), max_iter=15)
+    kind = plan.kernel_kind()
+    plan.close()
+    return kind, out
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_jit_kernels_equal_the_runtime_shape_kernels(shape, precision, monkeypatch, tmp_path):
+    nx, nu, hidden, act = shape
+    if shape == SHAPES[2] and precision == "f64":
+        # one case goes through a fresh cache directory: the build itself is exercised, not a cached
+        # plugin of an earlier run
+        monkeypatch.setenv("AMPC_JIT_CACHE", str(tmp_path))
+    monkeypatch.setenv("AMPC_JIT", "0")
+    h = _handle(nx, nu, hidden, act, precision)
+    assert h.jit_status()[0] == 0
+    ref_m = {tr: _mppi(h, nx, nu, tr) for tr in (16, 32)}
+    ref_i = _ilqr(h, nx, nu)
+    assert all(k == 0 for k, _ in ref_m.values()) and ref_i[0] == 0
+    h.close()
+
+    monkeypatch.setenv("AMPC_JIT", "1")
+    h = _handle(nx, nu, hidden, act, precision)
+    st, msg = h.jit_status()
+    assert st in (1, 2), msg
+    # a plan created while the plugin is still compiling runs the run-time-shape kernels
+    early_kind, early = _mppi(h, nx, nu, 16)
+    assert early_kind in (0, 2)
+    h.jit_wait()
+    st, msg = h.jit_status()
+    assert st == 2 and msg.endswith(".so"), msg
+    for tr in (16, 32):
+        kind, got = _mppi(h, nx, nu, tr)
+        assert kind == 2, "plan did not pick the run-time compiled kernels"
+        for a, b in zip(got, ref_m[tr][1]):
+            np.testing.assert_array_equal(a, b)
+    for a, b in zip(early, ref_m[16][1]):
+        np.testing.assert_array_equal(a, b)
+    kind, got = _ilqr(h, nx, nu)
+    assert kind == 2
+    ref = ref_i[1]
+    if precision == "f64":
+        assert np.array_equal(got["iters"], ref["iters"]) and np.array_equal(got["converged"], ref["converged"])
+        for key in ("states", "ctrls", "Ks", "ks", "objective"):
+            np.testing.assert_array_equal(got[key], ref[key])
+    else:
+        # f32 iLQR (outside the parity mode, control/ilqr.py): with compile-time extents hipcc forms
+        # packed f32 multiplies / adds in the sweep's scalar loops where the run-time-shape build
+        # emits fused multiply-adds -- rounding-level differences (measured 5e-6 relative)
+        assert rel_err(got["states"], ref["states"]) < 1e-4 and rel_err(got["ctrls"], ref["ctrls"]) < 1e-3
+    h.close()
+
+
+def test_registered_shape_and_other_models_need_no_plugin():
+    from autompc_amd import _lib
+    h = _handle(17, 6, [256, 256], "relu", "f64")        # shapes.hpp entry 0
+    assert h.jit_status()[0] == 0
+    h.jit_wait()
+    plan = _lib.MppiPlan(h, [256], [10], [1.0], [1.0])
+    assert plan.kernel_kind() == 1
+    plan.close()
+    h.close()
+    h = _lib.Handle(0, "f64")                           # a linear model is staged through the MLP tile
+    h.set_linear(0.9 * np.eye(3), 0.1 * np.ones((3, 1)))
+    h.set_quad_costs(np.eye(3), np.eye(1), np.eye(3), np.zeros(3))
+    assert h.jit_status()[0] == 0
+    h.close()
