@@ -327,9 +327,7 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
     REQUIRE(hidden_sizes[l] >= 1 && hidden_sizes[l] <= 256, "ampc_set_mlp: hidden size 1..256");
     hmax = hidden_sizes[l] > hmax ? hidden_sizes[l] : hmax;
   }
-  // more than 32 states: four output column tiles, built for the 64-wide tile only (the linear models
-  // that need it are staged with a hidden width equal to their state dimension)
-  REQUIRE(nx <= 32 || hmax <= 64, "ampc_set_mlp: state dims 33..64 need hidden layers of at most 64 units");
+  (void)hmax;   // (more than 32 states: the WIDE tile, three or four output column tiles, any hidden width)
   h->nx = nx; h->nu = nu; h->n_hidden = n_hidden; h->act = activation;
   for (int l = 0; l < kMaxHidden; ++l) h->hidden[l] = l < n_hidden ? hidden_sizes[l] : 0;
   // Workgroup shape: 8 waves (two per SIMD) whenever the padded width allows whole 16-column
@@ -1155,21 +1153,26 @@ extern "C" int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* 
   HIP_OK(hipStreamSynchronize(p->h->stream));
   double acc[4] = {0, 0, 0, 0};
   const size_t n = p->ev_used / 5;
-  for (size_t i = 0; i < n; ++i)
+  size_t live = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (i < p->ev_live.size() && !p->ev_live[i]) continue;     // queued past convergence: a no-op
+    ++live;
     for (int k = 0; k < 4; ++k) {
       float ms = 0;
       HIP_OK(hipEventElapsedTime(&ms, p->ev[5 * i + k], p->ev[5 * i + k + 1]));
       acc[k] += ms;
     }
-  for (int k = 0; k < 4; ++k) kernel_ms[k] = n ? acc[k] / n : 0.0;
-  if (iterations) *iterations = (int)n;
+  }
+  for (int k = 0; k < 4; ++k) kernel_ms[k] = live ? acc[k] / live : 0.0;
+  if (iterations) *iterations = (int)live;
   p->ev_used = 0;
+  p->ev_live.clear();
   return 0;
 }
 
 extern "C" int ampc_ilqr_plan_stats(ampc_ilqr_plan* p, long long* iterations, long long* candidate_rows) {
   REQUIRE(p, "ampc_ilqr_plan_stats: NULL plan");
-  if (iterations) *iterations = p->last_iterations;
+  if (iterations) *iterations = p->last_effective;     // performed (launched: last_iterations)
   if (candidate_rows) *candidate_rows = p->last_ls_rows;
   return 0;
 }
@@ -1222,6 +1225,9 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   constexpr int kPoll = 4;
   int it = 0, batch = 0, pending = -1;     // pending: batch whose flags are in flight
   bool done = false;
+  // (ev_cur points into p->ev: never leave it set behind an early return)
+  struct EvGuard { ampc_ilqr_plan* p; ~EvGuard() { p->ev_cur = nullptr; } } ev_guard{p};
+  const size_t ev_first = p->ev_used / 5;  // this solve's first timed iteration
   while (it < max_iter && !done) {
     const int n = std::min(kPoll, max_iter - it);
     for (int k = 0; k < n; ++k) {
@@ -1235,9 +1241,10 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
         p->ev_cur = &p->ev[p->ev_used];
         p->ev_used += 5;
       }
-      if (int rc = ilqr_launch_iter<T>(p, 1)) return rc;      // backward sweep + line search + accept
-      if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
+      int rc = ilqr_launch_iter<T>(p, 1);                     // backward sweep + line search + accept
+      if (rc == 0) rc = ilqr_refresh_jacobians<T>(p);
       p->ev_cur = nullptr;
+      if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
     }
     it += n;
     const int slot = batch & 1;
@@ -1261,6 +1268,12 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   if (status) std::memcpy(status, flags.data() + 3 * B, B * sizeof(int));
   p->last_ls_rows = 0;
   for (int b = 0; b < B; ++b) p->last_ls_rows += flags[5 * B + b];
+  p->last_effective = 0;
+  for (int b = 0; b < B; ++b) p->last_effective = std::max(p->last_effective, flags[2 * B + b]);
+  if (p->timing) {           // iterations past the last one any problem performed were no-ops
+    p->ev_live.resize(p->ev_used / 5, 1);
+    for (size_t i = ev_first + (size_t)p->last_effective; i < p->ev_live.size(); ++i) p->ev_live[i] = 0;
+  }
   if (states) HIP_OK(download_converted<T>(states, p->states.p, (size_t)B * (H + 1) * nx, h->stream));
   if (ctrls) HIP_OK(download_converted<T>(ctrls, p->ctrls.p, (size_t)B * H * nu, h->stream));
   if (Ks) HIP_OK(download_converted<T>(Ks, p->Ks.p, (size_t)B * H * nu * nx, h->stream));

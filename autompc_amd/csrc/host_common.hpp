@@ -211,7 +211,7 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
 }
 
 // (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.  The body sees W, NT, MT and WD
-// (wide outputs: model states 33..64, the 64-wide tile only).
+// (wide outputs: model states 33..64).
 #define AMPC_CASE(WV, NTV, MTV, WDV, ...) \
   case ((WV) * 100 + (NTV) * 10 + (MTV)) * 2 + (WDV): { constexpr int W = WV, NT = NTV, MT = MTV; constexpr bool WD = WDV != 0; (void)WD; __VA_ARGS__; } break;
 #define AMPC_DISPATCH_W(WIDEV, WV, NTV, MTV, ...)                            \
@@ -222,6 +222,9 @@ template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
       AMPC_CASE(4, 3, 1, 0, __VA_ARGS__) AMPC_CASE(4, 3, 2, 0, __VA_ARGS__) AMPC_CASE(4, 3, 4, 0, __VA_ARGS__) \
       AMPC_CASE(8, 2, 1, 0, __VA_ARGS__) AMPC_CASE(8, 2, 2, 0, __VA_ARGS__) AMPC_CASE(8, 2, 4, 0, __VA_ARGS__) \
       AMPC_CASE(4, 1, 1, 1, __VA_ARGS__) AMPC_CASE(4, 1, 2, 1, __VA_ARGS__) AMPC_CASE(4, 1, 4, 1, __VA_ARGS__) \
+      AMPC_CASE(8, 1, 1, 1, __VA_ARGS__) AMPC_CASE(8, 1, 2, 1, __VA_ARGS__) AMPC_CASE(8, 1, 4, 1, __VA_ARGS__) \
+      AMPC_CASE(4, 3, 1, 1, __VA_ARGS__) AMPC_CASE(4, 3, 2, 1, __VA_ARGS__) AMPC_CASE(4, 3, 4, 1, __VA_ARGS__) \
+      AMPC_CASE(8, 2, 1, 1, __VA_ARGS__) AMPC_CASE(8, 2, 2, 1, __VA_ARGS__) AMPC_CASE(8, 2, 4, 1, __VA_ARGS__) \
       default: return fail("internal: unsupported (W, NT, MT, wide) combination");  \
     }                                                                        \
   } while (0)
@@ -356,6 +359,10 @@ struct ampc_ilqr_plan {
   std::vector<hipEvent_t> ev;   // 5 per timed iteration
   size_t ev_used = 0;
   hipEvent_t* ev_cur = nullptr; // the running iteration's five events (null: not timed)
+  // timed iterations that did real work: the polled loop queues up to 2 * kPoll iterations past
+  // convergence (no-ops); only the first max_b iters[b] iterations of a solve count in the averages
+  std::vector<unsigned char> ev_live;   // one flag per timed iteration (ev_used / 5 of them)
+  int last_effective = 0;               // iterations of the last solve in which a problem was active
   // convergence polling: the `active` flags of one batch of iterations are copied to pinned host
   // memory behind that batch and read while the NEXT batch is already queued
   int* poll_host = nullptr;     // [2][B] pinned

@@ -30,14 +30,7 @@
 
 namespace ampc {
 
-// phase marks of the iLQR kernels (tools/phasetime_ilqr.py): only in the AMPC_X_PHASETIME build
-#if defined(AMPC_X_PHASETIME) && !defined(AMPC_X_WAVETIME)
-#define AMPC_IMARK(idx) AMPC_MARK(idx)
-#define AMPC_IMARK_ALWAYS(idx) AMPC_MARK_ALWAYS(idx)
-#else
-#define AMPC_IMARK(idx) do { } while (0)
-#define AMPC_IMARK_ALWAYS(idx) do { } while (0)
-#endif
+// (AMPC_IMARK / AMPC_IPROBE_STEP: phase marks of the timing experiments, nothing in the product -- probe.hpp)
 
 constexpr int kRicThreads = 512;  // workgroup of the backward-sweep kernel
 constexpr int kIlqrMaxLs = 16;   // line-search candidates live in the 16 rows of one MFMA tile
@@ -272,9 +265,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   commit_step();
   __syncthreads();
   for (int t = H - 1; t >= 0; --t) {
-#ifdef AMPC_X_PHASETIME
-    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
-#endif
+    AMPC_IPROBE_STEP(t == H / 2);
     AMPC_IMARK(20);
     if (t > 0) fetch_step(t - 1);
     for (int idx = tid; idx < nx * n; idx += NTHR) {       // VJ = V J
@@ -661,9 +652,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   int sing_any = 0;
   AMPC_IMARK_ALWAYS(30);
   for (int t = H - 1; t >= 0; --t) {
-#ifdef AMPC_X_PHASETIME
-    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == H / 2) ? 1 : 0;
-#endif
+    AMPC_IPROBE_STEP(t == H / 2);
     AMPC_IMARK(20);
     // ---- A: VJ = V J on the tile waves; side threads issue the next step's loads
     if (sid >= 0 && t > 0) fetch_step(t - 1);
@@ -935,9 +924,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
   const bool cdiag = args.cost_diag != 0;
   for (int t = 0; t < H; ++t) {
-#ifdef AMPC_X_PHASETIME
-    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (args.mode == 1 && t == H / 2) ? 1 : 0;
-#endif
+    AMPC_IPROBE_STEP(args.mode == 1 && t == H / 2);
     AMPC_IMARK(40);
     if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
     // controls for this step

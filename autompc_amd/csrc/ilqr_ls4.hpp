@@ -277,9 +277,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     if (lane < nx) xu[w * xs + lane] = st[lane];
     fetch_law(0);
     for (int t = 0; t <= H; ++t) {
-#ifdef AMPC_X_PHASETIME
-      if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (args.mode == 1 && pass == 0 && t == H / 2) ? 1 : 0;
-#endif
+      AMPC_IPROBE_STEP(args.mode == 1 && pass == 0 && t == H / 2);
       AMPC_IMARK(40);
       // ---- between steps, on row w: x_t = x_{t-1} + net output, then u_t
       if (t > 0 && lane < nx) {

@@ -153,13 +153,6 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   return 0;
 }
 
-#if defined(AMPC_X_PHASETIME) && defined(AMPC_T_IS_F64)
-// experiment only (tools/phasetime_ilqr.py): the f64 iLQR kernel's copy of the marks
-extern "C" int ampc_x_phase_marks_ilqr(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
-  return 0;
-}
-#endif
+AMPC_PROBE_HOST_ILQR      // (timing-experiment builds only: read-back of the marks, probe.hpp)
 
 template int ilqr_launch_iter<AMPC_T>(ampc_ilqr_plan*, int);

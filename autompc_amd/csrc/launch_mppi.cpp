@@ -93,23 +93,6 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   return 0;
 }
 
-#if defined(AMPC_X_WAVETIME) && defined(AMPC_T_IS_F64)
-// experiment only (tools/wavetime.py): per-wave marks of one time step of the f64 rollout kernel
-extern "C" int ampc_x_wave_marks(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_wave_marks), 8 * 16 * sizeof(long long)));
-  return 0;
-}
-#endif
-
-#if defined(AMPC_X_PHASETIME) && defined(AMPC_T_IS_F64)
-// experiment only (tools/phasetime.py): read back the phase marks of the f64 rollout kernel; lives
-// in the unit that owns that kernel because __device__ variables are per code object.
-extern "C" int ampc_x_phase_marks(long long* out) {
-  HIP_OK(hipDeviceSynchronize());
-  HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));
-  return 0;
-}
-#endif
+AMPC_PROBE_HOST_MPPI      // (timing-experiment builds only: read-back of the marks, probe.hpp)
 
 template int mppi_solve_impl<AMPC_T>(ampc_mppi_plan*);

@@ -27,6 +27,8 @@
 
 #include <type_traits>
 
+#include "probe.hpp"
+
 namespace ampc {
 
 constexpr int kMaxHidden = 4;  // hidden layers supported (reference config space: 1..4)
@@ -39,22 +41,14 @@ template <typename T> struct Acc;
 template <> struct Acc<double> { using type = d4; };
 template <> struct Acc<float> { using type = f4; };
 
-// AMPC_X_* macros are timing experiments only (tools/variants.sh); never defined in the product.
+// (Probe::* are timing-experiment switches, all false in the product build: probe.hpp)
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
-#ifdef AMPC_X_NOMFMA
-  c[0] += a * b;
-  return c;
-#else
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-#endif
+  if constexpr (Probe::no_mfma) { c[0] += a * b; return c; }
+  else return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) {
-#ifdef AMPC_X_NOMFMA
-  c[0] += a * b;
-  return c;
-#else
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
+  if constexpr (Probe::no_mfma) { c[0] += a * b; return c; }
+  else return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 // timing experiments: the MFMAs of one layer class replaced by a single FMA (dependencies kept)
 template <bool REAL, typename T, typename A>
@@ -62,21 +56,7 @@ __device__ __forceinline__ A mfma16_x(T a, T b, A c) {
   if constexpr (REAL) return mfma16(a, b, c);
   else { c[0] += a * b; return c; }
 }
-#ifdef AMPC_X_NOHID
-constexpr bool kRealHid = false;
-#else
-constexpr bool kRealHid = true;
-#endif
-#ifdef AMPC_X_NOL0
-constexpr bool kRealL0 = false;
-#else
-constexpr bool kRealL0 = true;
-#endif
-#ifdef AMPC_X_NOOUT
-constexpr bool kRealOut = false;
-#else
-constexpr bool kRealOut = true;
-#endif
+constexpr bool kRealHid = !Probe::no_hid, kRealL0 = !Probe::no_l0, kRealOut = !Probe::no_out;
 
 // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products (blocks); 16 cycles against the 64 of
 // the 16x16x4.  Lane layout (probed on gfx950, tools/mfma44_probe.cpp), block = (lane/4)%4:
@@ -86,11 +66,8 @@ constexpr bool kRealOut = true;
 // the 16x16x4 MFMA takes -- so the same register feeds both; B is shared by the four blocks and
 // D gives 16 rows x 4 columns, one value per lane.
 __device__ __forceinline__ double mfma4(double a, double b, double c) {
-#ifdef AMPC_X_NOMFMA
-  return c + a * b;
-#else
-  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
-#endif
+  if constexpr (Probe::no_mfma) return c + a * b;
+  else return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float mfma4(float, float, float c) { return c; }   // f64 only (tail4 is never set for f32)
 // row / column (relative to 16) of the value mfma4 leaves in this lane
@@ -378,11 +355,11 @@ template <typename T> __device__ __forceinline__ rsrc_t weight_rsrc(const T* bas
 
 template <typename T, int NT>
 __device__ __forceinline__ void load_frag(rsrc_t r, unsigned so, unsigned lo, T (&b)[NT]) {
-#ifdef AMPC_X_NOLOAD
+  if constexpr (Probe::no_load) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) b[nt] = T((threadIdx.x + nt) & 7) * T(1e-3);
-  return;
-#endif
+    for (int nt = 0; nt < NT; ++nt) b[nt] = T((threadIdx.x + nt) & 7) * T(1e-3);
+    return;
+  }
   const unsigned vo = lo * (unsigned)sizeof(T), sb = so * (unsigned)sizeof(T);
   constexpr int BYTES = NT * (int)sizeof(T);
   if constexpr (BYTES == 16) {
@@ -476,78 +453,53 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
           acc[mt][nt] = mfma16_x<(KS < 16 ? kRealL0 : kRealHid)>(a[mt], bv, acc[mt][nt]);
         }
     }
-#ifndef AMPC_X_NOSCHED
     // (8-wave tiles only; measured neutral-to-negative with one wave per SIMD)
     // Issue order for this sub-group: LDS fragment reads run one k-step pair AHEAD of the MFMAs
     // that consume them, weight loads for the next sub-group are spread between MFMA clusters.
     //   masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read
-    if (PIPE && KS >= 8) {
-#ifdef AMPC_X_VMEMFIRST
-      // all of the next sub-group's weight loads up front: the full sub-group of MFMAs covers them
-      __builtin_amdgcn_sched_group_barrier(0x020, SG, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+    if constexpr (PIPE && KS >= 8 && !Probe::no_sched) {
+      if constexpr (Probe::vmem_first) {
+        // all of the next sub-group's weight loads up front: the full sub-group of MFMAs covers them
+        __builtin_amdgcn_sched_group_barrier(0x020, SG, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll
-      for (int i = 0; i < SG / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
-      }
-#else
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
+        for (int i = 0; i < SG / 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+        }
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll
-      for (int i = 0; i < SG / 2; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        for (int i = 0; i < SG / 2; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
       }
-#endif
     }
-#endif
     if (OWN && sgi == FS - 1) {
       lds_barrier();
       mid();
     }
-#ifdef AMPC_X_VALUPAD      // calibration: 64 extra int32 VALU instructions per layer call, spread over 8 sub-groups
-    if (KS >= 16 && sgi >= 2 && sgi < 10) {
-      int padv = lane;
+    if constexpr (Probe::valu_pad) {      // calibration: 64 extra int32 VALU instructions per layer call
+      if (KS >= 16 && sgi >= 2 && sgi < 10) {
+        int padv = lane;
 #pragma unroll
-      for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
-      asm volatile("" :: "v"(padv));
+        for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_u32 %0, %0, 1" : "+v"(padv));
+        asm volatile("" :: "v"(padv));
+      }
     }
-#endif
-#ifdef AMPC_X_VALUPAD64    // calibration: 64 extra f64 VALU instructions per layer call
-    if (KS >= 16 && sgi >= 2 && sgi < 10) {
-      double padd = (double)lane;
+    if constexpr (Probe::valu_pad64) {    // calibration: 64 extra f64 VALU instructions per layer call
+      if (KS >= 16 && sgi >= 2 && sgi < 10) {
+        double padd = (double)lane;
 #pragma unroll
-      for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_f64 %0, %0, 1.0" : "+v"(padd));
-      asm volatile("" :: "v"(padd));
+        for (int pi = 0; pi < 8; ++pi) asm volatile("v_add_f64 %0, %0, 1.0" : "+v"(padd));
+        asm volatile("" :: "v"(padd));
+      }
     }
-#endif
   }
 }
 
-#ifdef AMPC_X_WAVETIME
-// Low-perturbation timeline (tools/wavetime.py): every wave of workgroup 7 keeps its own
-// s_memtime marks of ONE time step in registers (TileNet::xm) and dumps them at kernel end.
-__device__ long long g_wave_marks[8 * 16];
-#define AMPC_MARK(idx) do { if (_xon) _xm[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-#define AMPC_MARK_ALWAYS(idx) do { } while (0)
-#elif defined(AMPC_X_PHASETIME)
-__device__ long long g_phase_marks[64];
-#define AMPC_MARK(idx)                                                              \
-  do {                                                                              \
-    if (blockIdx.x == 7 && threadIdx.x == 0 && g_phase_marks[63] == 1)              \
-      g_phase_marks[idx] = (long long)__builtin_amdgcn_s_memtime();                 \
-  } while (0)
-// unconditional variant for coarse, once-per-kernel marks
-#define AMPC_MARK_ALWAYS(idx)                                                       \
-  do {                                                                              \
-    if (blockIdx.x == 7 && threadIdx.x == 0)                                        \
-      g_phase_marks[idx] = (long long)__builtin_amdgcn_s_memtime();                 \
-  } while (0)
-#else
-#define AMPC_MARK(idx) do { } while (0)
-#define AMPC_MARK_ALWAYS(idx) do { } while (0)
-#endif
 
 // ---- the fused network on one tile -------------------------------------------------------------
 // LEAN: what stays resident in registers between calls, for callers that need registers
@@ -582,12 +534,8 @@ struct TileNet {
   T pf0[KS0RES][NT];
   // layer 0 resident?  (wave-uniform; a function of the model only)
   __device__ __forceinline__ static bool resident0(const MlpDev<T>& m) {
-#ifdef AMPC_X_NORES0
-    return false;
-#else
     // (f64 tiles of 32 / 64 rows have no registers to spare: they keep the streamed scheme)
-    return LEAN < 2 && (sizeof(T) == 4 || MT == 1) && m.k1p <= 4 * KS0RES;
-#endif
+    return !Probe::no_res0 && LEAN < 2 && (sizeof(T) == 4 || MT == 1) && m.k1p <= 4 * KS0RES;
   }
 
   // wave-uniform element offsets (from MlpDev::wbase) of this wave's fragment streams; the lane's
@@ -651,10 +599,7 @@ struct TileNet {
   // for the NEXT call is requested at the end of a call, together with layer 0's fragments, so it
   // has the caller's whole inter-call phase to arrive (measured +1 % f64, +3 % f32 on c3).
   T pfn[GH][NT];
-#ifdef AMPC_X_WAVETIME
-  long long xm[16];
-  bool xon = false;
-#endif
+  ProbeWave<Probe::wave_time> probe;    // (empty in the product build)
 
   // Once per kernel, before the first run(): resident biases / output weights + the first prefetch.
   __device__ __forceinline__ void init(const MlpDev<T>& m_in) {
@@ -753,10 +698,7 @@ struct TileNet {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, q = lane >> 4;
-#ifdef AMPC_X_WAVETIME
-    auto& _xm = xm;
-    const bool _xon = xon;
-#endif
+    AMPC_PROBE_LOCALS(probe);
     T* act = lds + L.act;            // buffer the next layer reads
     T* act_other = lds + L.act2;     // buffer the next epilogue may write (== act if single-buffered)
     const bool pingpong = L.act2 != L.act;
@@ -910,20 +852,11 @@ struct TileNet {
       // f64 streams the weights in half-groups (32-64 VGPRs less: the 64-row tile stops spilling,
       // +2 %, and the 16-row tile has room for the early prefetch); f32 keeps whole groups
       // (half-groups measured -4 % there)
-#ifdef AMPC_X_SG8
-      constexpr int SGH = GH;
-#else
-      constexpr int SGH = sizeof(T) == 8 ? GH / 2 : GH;
-#endif
-#ifdef AMPC_X_SIDELATE
-      layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH, true>(
-          act, as, wr, slice_h(m, l, w), lane, pfn, acc, w);
-#else
+      constexpr int SGH = (sizeof(T) == 8 && !Probe::sg8) ? GH / 2 : GH;
       layer_mma_static<T, NT, MT, KSH, GH, (W == 8), OWN, SGH, true>(
           act, as, wr, slice_h(m, l, w), lane, pfn, acc, w, [&] {
-            if (l == 1) { side(); side_done = true; }
+            if (!Probe::side_late && l == 1) { side(); side_done = true; }
           });
-#endif
       AMPC_MARK(4);
       prefetch_next(l + 1);
       // single buffer: every wave must finish reading act before it is overwritten;

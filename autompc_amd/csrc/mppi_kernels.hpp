@@ -187,11 +187,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   // the time loop has no separate cost phase; the stage cost of x_0 is added here.
   if (diag) c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, true);
 
-#ifdef AMPC_X_WAVETIME
-  auto& _xm = net.xm;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) _xm[i] = 0;
-#endif
+  AMPC_PROBE_KERNEL_BEGIN(net.probe);
   // the (at most ceil(nx / TPS)) state columns this thread updates: goal and diagonal Q weight
   constexpr int XPT = ((WIDE ? 64 : 32) + TPS - 1) / TPS;
   T qd_r[XPT], gl_r[XPT];
@@ -202,20 +198,13 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     gl_r[e] = i < no ? goal[i] : T(0);
   }
   for (int t = 0; t < H; ++t) {
-#ifdef AMPC_X_WAVETIME
-    net.xon = (blockIdx.x == 7 && t == 5);
-    const bool _xon = net.xon;
-#elif defined(AMPC_X_PHASETIME)
-    if (blockIdx.x == 7 && threadIdx.x == 0) g_phase_marks[63] = (t == 5) ? 1 : 0;
-#endif
+    AMPC_PROBE_STEP(net.probe, t == 5);
     AMPC_MARK(0);
     // ---- stage cost of (x_t, u_t): partial per thread, reduced once after the loop ------------
-#ifndef AMPC_X_NOCOST
-    if (!diag) {
+    if (!diag && !Probe::no_cost) {
       c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false);
       c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false);
     }
-#endif
     AMPC_MARK(1);
     // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
     // The next step's actions do not depend on this step's output: they are formed while the
@@ -240,12 +229,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     AMPC_MARK(11);
   }
 
-#ifdef AMPC_X_WAVETIME
-  if (blockIdx.x == 7 && (threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) g_wave_marks[(threadIdx.x >> 6) * 16 + i] = _xm[i];
-  }
-#endif
+  AMPC_PROBE_KERNEL_END();
   // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------
   T term = quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, diag);
   T c = c_part + pr.lam_over_sigma * ca_part;

@@ -52,6 +52,10 @@ def parse():
                          "resident: one numpy-drawn noise set uploaded before timing and reused")
     ap.add_argument("--batch", type=int, default=0,
                     help="independent problems per step per GPU (default: 1 solve; c4 256; c5 64)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="c4: split the batch over this many handles / streams driven by as many host "
+                         "threads (the latency-bound sweep and line search of one group overlap the "
+                         "Jacobian chain of another)")
     ap.add_argument("--preheat", type=float, default=0.6,
                     help="seconds of untimed solves before the warm-up steps, so that short runs "
                          "(--steps 20) are timed at the settled clock like long ones")
@@ -339,25 +343,47 @@ def secondary_workload(args, R):
     roof = None
 
     if args.workload == "c4":
-        stream = R.torch.cuda.current_stream().cuda_stream
-        h = _lib.Handle(R.local_rank, args.precision, stream=stream)
-        model.stage_into(h)
+        import threading
+        G = max(1, min(args.groups, B))
         Q, Rm, F = task.get_cost().get_cost_matrices()
-        h.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
-        plan = _lib.IlqrPlan(h, B, 50, system.dt)
         rng = np.random.default_rng(rank)
         x0 = rng.uniform(-0.1, 0.1, size=(B, nx))
         ug = np.zeros((B, 50, nu))
+        bounds_g = [(g * B // G, (g + 1) * B // G) for g in range(G)]
+        handles, plans = [], []
+        for g, (lo, hi) in enumerate(bounds_g):
+            # group 0 on torch's current stream (the one the bench synchronises), the others on
+            # streams of their own
+            hg = _lib.Handle(R.local_rank, args.precision,
+                             stream=R.torch.cuda.current_stream().cuda_stream if g == 0 else None)
+            model.stage_into(hg)
+            hg.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
+            handles.append(hg)
+            plans.append(_lib.IlqrPlan(hg, hi - lo, 50, system.dt))
+        h, plan = handles[0], plans[0]
         iters = []
 
         rows = []
 
+        def solve_group(g, res):
+            lo, hi = bounds_g[g]
+            res[g] = plans[g].solve(x0[lo:hi], ug[lo:hi], max_iter=50)   # (ctypes releases the GIL)
+
         def step(i):
-            out = plan.solve(x0, ug, max_iter=50)
+            res = [None] * G
+            if G == 1:
+                solve_group(0, res)
+            else:
+                th = [threading.Thread(target=solve_group, args=(g, res)) for g in range(G)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
             if i >= warm:
-                iters.append(float(out["iters"].mean()))
-                rows.append(plan.stats()["candidate_rows"] / float(B))
-        label = "c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU" % B
+                iters.append(float(np.mean(np.concatenate([r["iters"] for r in res]))))
+                rows.append(sum(pl.stats()["candidate_rows"] for pl in plans) / float(B))
+        label = ("c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU"
+                 "%s" % (B, "" if G == 1 else " in %d groups on %d streams" % (G, G)))
         unit_per_step = B
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
         elapsed, n_pre = timed_loop(R, step, steps, warm, min(args.preheat, 0.3),

@@ -284,8 +284,9 @@ int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
  * over the iterations since the last call, and their number; then resets the counters. */
 int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable);
 int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations);
-/* Work of the last ampc_ilqr_solve: iterations launched, and candidate rows the line searches
- * rolled out, summed over the plan's problems.  The reference rolls out all ls_max_iter = 10 step
+/* Work of the last ampc_ilqr_solve: iterations performed (the largest per-problem count; the
+ * polled loop may have queued a few no-op launches beyond it, which the timing averages skip), and
+ * candidate rows the line searches rolled out, summed over the plan's problems.  The reference rolls out all ls_max_iter = 10 step
  * sizes in every iteration (ilqr.py:196-205) and then accepts the first that passes its test; the
  * f64 MLP path rolls them out four at a time and stops at the first accepted one (same decisions,
  * same results), so its row count is a multiple of 4 per iteration.  Either pointer may be NULL. */

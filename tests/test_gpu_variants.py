@@ -104,7 +104,7 @@ def test_mppi_dimension_extremes(nx, nu, H):
 def test_unsupported_shapes_fail_loudly():
     from autompc_amd import _lib
     h = _lib.Handle(0, "f64")
-    for nx, hidden in ((33, [128]), (65, [64]), (4, [300])):   # wide states need hidden <= 64
+    for nx, hidden in ((65, [64]), (4, [300]), (70, [256, 256])):   # more than 64 states / 256 units
         p = omlp.random_params(nx, 1, hidden, "relu", seed=0)
         with pytest.raises(_lib.AmpcError):
             h.set_mlp(nx, 1, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"],
@@ -114,9 +114,14 @@ def test_unsupported_shapes_fail_loudly():
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
 @pytest.mark.parametrize("nx,nu,hidden,act", [(33, 1, [64], "relu"), (40, 3, [64, 64], "tanh"),
-                                              (64, 2, [48, 64], "relu"), (50, 6, [32], "selu")])
+                                              (64, 2, [48, 64], "relu"), (50, 6, [32], "selu"),
+                                              # hidden layers wider than 64 (every (waves, column-tile) shape)
+                                              (33, 2, [128], "relu"), (41, 6, [256, 256], "relu"),
+                                              (48, 4, [192, 160], "tanh"), (64, 8, [100, 128, 90], "sigmoid"),
+                                              (37, 3, [256, 200, 256, 130], "selu")])
 def test_wide_state_networks_match_the_oracle(nx, nu, hidden, act, precision):
-    """33..64 model states (four output tiles): prediction, Jacobians and an MPPI solve."""
+    """33..64 model states (three or four output tiles), hidden layers of any width the reference's
+    configuration space allows (mlp.py:113-122): prediction, Jacobians and an MPPI solve."""
     from autompc_amd import _lib
     p = omlp.random_params(nx, nu, hidden, act, seed=nx)
     h = _handle(p, nx, nu, act, precision)
@@ -148,4 +153,30 @@ def test_wide_state_networks_match_the_oracle(nx, nu, hidden, act, precision):
     orc.act_sequence = act0.copy()
     uo, _ = orc.run(np.concatenate([x0, np.zeros(nu)]), x0, eps_nhu=eps)
     assert rel_err(c, orc.last_costs) < 1e-9 and rel_err(u[0], uo) < 1e-8
-    plan.close(); h.close()
+    plan.close()
+    for tile_rows in (32, 64):                         # taller tiles of the same solve
+        plan = _lib.MppiPlan(h, [N], [H], [1.0], [1.0])
+        try:
+            plan.set_geometry(tile_rows, 0)
+        except _lib.AmpcError:                          # (that height does not fit LDS for this model)
+            plan.close()
+            continue
+        plan.upload(x0, act0, eps)
+        plan.solve()
+        _, u2, c2, _ = plan.download(costs=True)
+        assert rel_err(c2, orc.last_costs) < 1e-9 and rel_err(u2[0], uo) < 1e-8
+        plan.close()
+    if nx + nu <= 63:                                  # (the Riccati workspace of a wide model lives in one wave)
+        from oracle.ilqr import ILQROracle
+        Hh, dt = 8, 0.05
+        iplan = _lib.IlqrPlan(h, 2, Hh, dt)
+        xs = rng.uniform(-0.2, 0.2, size=(2, nx))
+        out = iplan.solve(xs, np.zeros((2, Hh, nu)), max_iter=6)
+        for b in range(2):
+            io = ILQROracle(MLPOracle(make_system(nx, nu, dt=dt), p), QuadCostOracle(Q, R, F, np.zeros(nx)), dt, Hh,
+                            max_iter=6)
+            conv, st, ct, _, _ = io.solve(xs[b], np.zeros((Hh, nu)))
+            assert int(out["iters"][b]) == io.n_iter and out["status"][b] == 0
+            assert rel_err(out["states"][b], st) < 1e-7 and rel_err(out["ctrls"][b], ct) < 1e-6
+        iplan.close()
+    h.close()
