@@ -169,7 +169,12 @@ def test_wide_state_networks_match_the_oracle(nx, nu, hidden, act, precision):
     if nx + nu <= 63:                                  # (the Riccati workspace of a wide model lives in one wave)
         from oracle.ilqr import ILQROracle
         Hh, dt = 8, 0.05
-        iplan = _lib.IlqrPlan(h, 2, Hh, dt)
+        try:
+            iplan = _lib.IlqrPlan(h, 2, Hh, dt)
+        except _lib.AmpcError as e:                    # (f64 Riccati workspace of ~50 states: > 160 KB LDS)
+            assert "LDS" in str(e)
+            h.close()
+            return
         xs = rng.uniform(-0.2, 0.2, size=(2, nx))
         out = iplan.solve(xs, np.zeros((2, Hh, nu)), max_iter=6)
         for b in range(2):
