@@ -65,6 +65,7 @@ class IterativeLQR(Controller):
         self.device = device if device is not None else getattr(model, "device", 0)
         self.compute_ilqr = self.compute_ilqr_default
         self._handle = self._plan = None
+        self._jit_pending = False
         self.reset()
 
     def reset(self):
@@ -74,21 +75,31 @@ class IterativeLQR(Controller):
         self._guess = None
 
     def _device(self):
-        if self._plan is None:
+        if self._plan is not None and self._jit_pending:
+            # the kernels specialised for this model's shape were still compiling when the plan
+            # was made (csrc/jit_host.hpp): switch over once they are ready (same results)
+            st = self._handle.jit_status()[0]
+            if st == 2:
+                self._plan.close()
+                self._plan = None
+            self._jit_pending = st == 1
+        bounded = self.ubounds is not None
+        if self._handle is None:
             h = _lib.Handle(self.device, self.precision)
             self.model.stage_into(h)
             Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
             h.set_quad_costs(Q, R, F, goal)
-            bounded = self.ubounds is not None
             if bounded:
                 h.set_ctrl_bounds(np.asarray(self.ubounds[0], dtype=float),
                                   np.asarray(self.ubounds[1], dtype=float))
             self._handle = h
+        if self._plan is None:
             # QuadCost(strict_reference=False) opts out of the reference's goal-less terminal
             # gradient (cost.py:195): the device sweep then seeds v_N = (F+F')(x_N - goal) too
             tg = not getattr(self.task.get_cost(), "strict_reference", True)
-            self._plan = _lib.IlqrPlan(h, 1, self.horizon, self.dt, clip_to_bounds=bounded,
+            self._plan = _lib.IlqrPlan(self._handle, 1, self.horizon, self.dt, clip_to_bounds=bounded,
                                        terminal_goal=tg)
+            self._jit_pending = self._plan.kernel_kind() == 0 and self._handle.jit_status()[0] == 1
         return self._plan
 
     def __getstate__(self):

@@ -85,6 +85,7 @@ class MPPI(Controller):
         self._scale = np.sqrt(self.sigma)
         self._handle = None
         self._plan = None
+        self._jit_pending = False
         self._init_sequence()
 
     # -- construction-time state (mppi.py:96-105) ------------------------------------
@@ -94,17 +95,31 @@ class MPPI(Controller):
         self.cur_step = 0
 
     def _device(self):
-        if self._plan is None:
+        if self._plan is not None and self._jit_pending:
+            # the kernels specialised for this model's shape were still compiling when the plan
+            # was made (csrc/jit_host.hpp): switch over once they are ready -- same results, the
+            # warm start moves with it
+            st = self._handle.jit_status()[0]
+            if st == 2:
+                if not self._act_dirty:
+                    a, _, _, _ = self._plan.download(act_seq=True, u=False)
+                    self._act_host = a.reshape(self.H, self.dim_ctrl)
+                self._plan.close()
+                self._plan = None
+            self._jit_pending = st == 1
+        if self._handle is None:
             h = _lib.Handle(self.device, self.precision)
             self.model.stage_into(h)
             Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
             h.set_quad_costs(Q, R, F, goal)
             h.set_ctrl_bounds(self.umin, self.umax)
-            term = _lib.TERM_PER_PARTICLE if self.per_particle_terminal else _lib.TERM_REFERENCE
             self._handle = h
-            self._plan = _lib.MppiPlan(h, [self.num_path], [self.H], [self.sigma], [self.lmda],
+        if self._plan is None:
+            term = _lib.TERM_PER_PARTICLE if self.per_particle_terminal else _lib.TERM_REFERENCE
+            self._plan = _lib.MppiPlan(self._handle, [self.num_path], [self.H], [self.sigma], [self.lmda],
                                        term_mode=term)
             self._act_dirty = True
+            self._jit_pending = self._plan.kernel_kind() == 0 and self._handle.jit_status()[0] == 1
         return self._plan
 
     def __getstate__(self):

@@ -118,3 +118,48 @@ def test_registered_shape_and_other_models_need_no_plugin():
     h.set_quad_costs(np.eye(3), np.eye(1), np.eye(3), np.zeros(3))
     assert h.jit_status()[0] == 0
     h.close()
+
+
+def test_controllers_switch_to_the_compiled_kernels_mid_run(monkeypatch, tmp_path):
+    """A drop-in controller keeps its plan for its lifetime; when the shape plugin finishes
+    compiling after the first run() the controller moves its warm start into a new plan on the
+    specialised kernels.  The sequence of controls is the one the run-time-shape kernels give."""
+    from autompc_amd import MLP, MPPI, IterativeLQR, QuadCost, Task
+    from helpers import make_system
+    nx, nu, hidden = 7, 2, [96, 80]
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, hidden, "tanh", seed=12)
+
+    def model():
+        m = MLP(system, n_hidden_layers=2, hidden_size_1=96, hidden_size_2=80, nonlintype="tanh")
+        m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+        return m
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx)))
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    obs0 = np.random.default_rng(0).uniform(-0.2, 0.2, size=nx)
+
+    def drive(wait_after_first):
+        np.random.seed(3)
+        ctl = MPPI(system, task, model(), horizon=8, num_path=128, sigma=0.5, lmda=0.8)
+        ilq = IterativeLQR(system, task, model(), 10)
+        cs, obs, us, kinds = np.concatenate([obs0, np.zeros(nu)]), obs0.copy(), [], []
+        for k in range(4):
+            u, cs = ctl.run(cs, obs)
+            ui, _ = ilq.run(np.concatenate([obs, np.zeros(nu)]), obs)
+            us.append(np.concatenate([u, ui]))
+            kinds.append((ctl._plan.kernel_kind(), ilq._plan.kernel_kind()))
+            obs = obs + 0.05 * np.tanh(u).sum() * np.ones(nx)
+            if k == 0 and wait_after_first:
+                ctl._handle.jit_wait()
+                ilq._handle.jit_wait()
+        return np.array(us), kinds
+    monkeypatch.setenv("AMPC_JIT", "0")
+    ref, kinds0 = drive(False)
+    assert all(k == (0, 0) for k in kinds0)
+    monkeypatch.setenv("AMPC_JIT", "1")
+    monkeypatch.setenv("AMPC_JIT_CACHE", str(tmp_path))       # nothing cached: the build runs now
+    got, kinds1 = drive(True)
+    assert kinds1[-1] == (2, 2), kinds1
+    np.testing.assert_array_equal(got, ref)
