@@ -758,11 +758,16 @@ static int host_log_mode() {
   static std::once_flag once;
   static int mode = 0;
   std::call_once(once, [] {
-    if (env_int("AMPC_LEGACY_LOG", 1) == 0) return;       // test hook: force the device's own log()
+    // test hook: 0 forces the device's own log(); 1 / 2 force that build's restatement onto the
+    // device whatever the host's log() is (the device code of the build this host does not run
+    // is checked against the CPU restatement of the same build, tests/test_gpu_legacy_noise.py)
+    const int forced = env_int("AMPC_LEGACY_LOG", -1);
+    if (forced == 0) return;
     LogLocate ctx;
     dl_iterate_phdr(log_locate_cb, &ctx);
     if (!ctx.found) return;
     std::memcpy(g_log_table, ctx.found, sizeof(g_log_table));
+    if (forced == 1 || forced == 2) { mode = forced; return; }
     bool ok1 = true, ok2 = true;
     uint64_t s = 0x9e3779b97f4a7c15ull;
     for (int j = 0; j < 200000 && (ok1 || ok2); ++j) {

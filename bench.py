@@ -56,6 +56,8 @@ def parse():
                     help="c4: split the batch over this many handles / streams driven by as many host "
                          "threads (the latency-bound sweep and line search of one group overlap the "
                          "Jacobian chain of another)")
+    ap.add_argument("--tile-rows", type=int, default=32, choices=[16, 32, 64],
+                    help="c5: samples per rollout workgroup of the candidate evaluator")
     ap.add_argument("--preheat", type=float, default=0.6,
                     help="seconds of untimed solves before the warm-up steps, so that short runs "
                          "(--steps 20) are timed at the settled clock like long ones")
@@ -430,7 +432,8 @@ def secondary_workload(args, R):
         # randomness keyed by the global candidate index (scores independent of the world size),
         # scores exchanged with one all-gather (RCCL over xGMI under the nccl backend)
         cands = random_candidates(system, B * world, seed=0)
-        ev = CandidateEvaluator(system, task, model, precision=args.precision, device=R.local_rank)
+        ev = CandidateEvaluator(system, task, model, precision=args.precision, device=R.local_rank,
+                                tile_rows=args.tile_rows)
         last = {}
 
         def step(i):

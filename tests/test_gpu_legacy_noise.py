@@ -199,3 +199,55 @@ def test_consecutive_calls_and_interleaved_host_draws():
         np.random.set_state(st_dev)
     plan.close()
     h.close()
+
+
+_FORCED_BUILD_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
+from oracle import glibc_log
+from autompc_amd import _lib
+import test_gpu_legacy_noise as T
+build = {build}
+assert _lib.legacy_log_mode() == build
+table = glibc_log.locate()
+N, H, nu, sigma = 2048, 20, 3, 0.0049
+h, plan = T._plan(N, H, sigma, nx=2, nu=nu)
+np.random.seed(77)
+st0 = np.random.get_state()
+rs = np.random.RandomState()
+rs.set_state(st0)
+# numpy's legacy_gauss, with log() replaced by the restated build: pairs of uniforms -> polar
+# method, accepted pairs in order; value 2k is f * x2, value 2k + 1 is f * x1
+need = N * H * nu
+u = rs.random_sample(4 * need)
+x1, x2 = 2.0 * u[0::2] - 1.0, 2.0 * u[1::2] - 1.0
+r2 = x1 * x1 + x2 * x2
+ok = (r2 < 1.0) & (r2 != 0.0)
+lg, _ = glibc_log.restated_log(r2[ok], table, build)
+f = np.sqrt(-2.0 * lg / r2[ok])
+g = np.empty(2 * ok.sum())
+g[0::2], g[1::2] = f * x2[ok], f * x1[ok]
+ref = (np.sqrt(sigma) * g[:need]).reshape(N, H, nu)
+_, e = T._device_draw(plan)
+got = e.reshape(H, N, nu).transpose(1, 0, 2)
+assert np.array_equal(got, ref), float(np.max(np.abs(got - ref)))
+print("BUILD_OK", build, int(np.sum(got != np.random.normal(scale=np.sqrt(sigma), size=(N, H, nu)))))
+"""
+
+
+@pytest.mark.parametrize("build", [1, 2])
+def test_each_restated_build_of_log_on_the_device(build):
+    """The host of a GPU box runs ONE of glibc's two builds of log(); the device carries both
+    restatements (csrc/glibc_log.hpp).  Each is forced onto the device in a fresh process
+    (AMPC_LEGACY_LOG) and compared bit for bit with numpy's polar method evaluated on the host with
+    the CPU restatement of the same build (oracle/glibc_log.c, itself checked against the library's
+    machine code for both builds: profiles/r03_glibc_log_validation.log)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMPC_LEGACY_LOG=str(build))
+    out = subprocess.run([sys.executable, "-c", _FORCED_BUILD_SCRIPT.format(root=root, build=build)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "BUILD_OK %d" % build in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

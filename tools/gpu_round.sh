@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session for the record: parity tests, smoke, every bench line, rocprofv3 summaries.
-# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r02
+# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r03
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -17,6 +17,8 @@ b c3_f64_batch8 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline
 b arx_f64 --workload arx --cpu-seconds 10
 b c1_sindy_f64 --workload c1 --cpu-seconds 10
 b c4_ilqr_f64 --workload c4 --steps 3 --warmup 1
+b c4_ilqr_f64_b1024 --workload c4 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline
+b c4_ilqr_f64_b1024_groups4 --workload c4 --batch 1024 --groups 4 --steps 2 --warmup 1 --no-cpu-baseline
 b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 # launcher plumbing: `bench.py --gpus 2` starts its own two ranks; both mapped onto this box's one
 # GPU (gloo for the barriers / all-gather; RCCL refuses two ranks on one device).  Not a performance number.
@@ -24,6 +26,10 @@ AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
+timeout 600 python tools/jit_rate.py > $OUT/jit_rate.log 2>&1
+timeout 900 python tools/fuzz_gpu.py 400 31 > $OUT/fuzz_gpu.log 2>&1
+timeout 900 python tools/fuzz_gpu.py 400 32 >> $OUT/fuzz_gpu.log 2>&1
+timeout 120 python tools/validate_glibc_log.py > $OUT/glibc_log.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f64_b1 --steps 100 --warmup 10 > $OUT/profile_c3.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f32_b1 --precision f32 --steps 100 --warmup 10 > $OUT/profile_c3f32.log 2>&1
 bash tools/gpu_profile.sh $TAG c4_f64_b256 --workload c4 --steps 2 --warmup 1 > $OUT/profile_c4.log 2>&1
