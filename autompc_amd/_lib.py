@@ -65,6 +65,7 @@ SIGNATURES = {
     "ampc_mppi_solve": (c_int, [c_void_p]),
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
+    "ampc_mppi_run": (c_int, [c_void_p, _dp, _dp, c_int, c_uint64, c_uint64, _dp]),
     "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
     "ampc_mppi_plan_set_outputs": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
@@ -425,6 +426,19 @@ class MppiPlan:
         e = np.empty(self.sum_nhnu) if eps_out else None
         check(self.lib.ampc_mppi_download(self._p, dptr(a), dptr(uu), dptr(c), dptr(e)))
         return a, uu, c, e
+
+    def run(self, x0, act_seq=None, philox=None):
+        """One control step in a single call: x0 (and optionally a new warm start) in, noise (the
+        buffer as it is, or fresh Philox noise when philox=(seed, stream)), solve, controls
+        [B, nu] out."""
+        nx, nu = self.handle.nx, self.handle.nu
+        x0 = self._flat(x0, self.B * nx, "x0")
+        act_seq = self._flat(act_seq, self.sum_hnu, "act_seq")
+        u = np.empty((self.B, nu))
+        seed, stream = philox if philox is not None else (0, 0)
+        check(self.lib.ampc_mppi_run(self._p, dptr(x0), dptr(act_seq), 0 if philox is None else 1,
+                                     int(seed), int(stream), dptr(u)))
+        return u
 
     def set_x0_dev(self, ptr):
         check(self.lib.ampc_mppi_set_x0_dev(self._p, c_void_p(ptr)))

@@ -164,29 +164,40 @@ class MPPI(Controller):
             # (mppi.py:16-24, :126).  The device reproduces that draw bit for bit when the
             # library has proven its restatement of the host C library's log() against log()
             # itself (ampc_legacy_log_mode) and the global generator is the MT19937 it models.
-            exact = _lib.legacy_log_mode() != 0 and np.random.get_state(legacy=True)[0] == "MT19937"
-            mode = "numpy_device" if exact else "numpy_host"
-        if mode == "numpy_host":
-            eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
-            plan.upload(x0=x0, act_seq=act, eps=eps)
-        elif mode == "numpy_device":
-            # the same draw from the same global generator state, made on the device; the host
-            # generator is then put into the state the draw would have left it in
-            plan.upload(x0=x0, act_seq=act)
-            np.random.set_state(plan.legacy_normal(np.random.get_state()))
+            state = np.random.get_state() if _lib.legacy_log_mode() != 0 else None
+            mode = "numpy_device" if state is not None and state[0] == "MT19937" else "numpy_host"
         else:
-            plan.upload(x0=x0, act_seq=act)
-            plan.generate_eps(self.seed, self.cur_step)
-        self._act_dirty = False
-        plan.solve()
-        self.cur_step += 1
+            state = None
         if return_details:
+            if mode == "numpy_host":
+                eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
+                plan.upload(x0=x0, act_seq=act, eps=eps)
+            elif mode == "numpy_device":
+                plan.upload(x0=x0, act_seq=act)
+                np.random.set_state(plan.legacy_normal(state if state is not None else np.random.get_state()))
+            else:
+                plan.upload(x0=x0, act_seq=act)
+                plan.generate_eps(self.seed, self.cur_step)
+            self._act_dirty = False
+            plan.solve()
             a, u, costs, eps_out = plan.download(costs=True, eps_out=True)
             self.last_costs = costs
             self.last_eps = eps_out.reshape(self.H, self.num_path, nu)
             self._act_host = a.reshape(self.H, nu)
         else:
-            _, u, _, _ = plan.download(act_seq=False, u=True)
+            # the hot call: everything of this control step in one library call (ampc_mppi_run)
+            if mode == "numpy_host":
+                plan.upload(eps=np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu)))
+                u = plan.run(x0, act)
+            elif mode == "numpy_device":
+                # the same draw from the same global generator state, made on the device; the host
+                # generator is then put into the state the draw would have left it in
+                np.random.set_state(plan.legacy_normal(state if state is not None else np.random.get_state()))
+                u = plan.run(x0, act)
+            else:
+                u = plan.run(x0, act, philox=(self.seed, self.cur_step))
+            self._act_dirty = False
+        self.cur_step += 1
         ret_action = u[0].copy()
         return ret_action, np.concatenate([x0, ret_action])
 

@@ -623,6 +623,8 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly, &p->lg_win, &p->lg_logtab};
+  if (p->pin_x0) (void)hipHostFree(p->pin_x0);
+  if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   if (p->lg_ev) (void)hipEventDestroy(p->lg_ev);
   for (DevBuf* b : bufs) b->release();
@@ -996,6 +998,40 @@ extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u,
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64 ? mppi_download_impl<double>(p, act_seq, u, costs, eps_out)
                                      : mppi_download_impl<float>(p, act_seq, u, costs, eps_out);
+}
+
+// MPPI.run() in one call: x0 (and optionally a new warm start) in, noise, solve, controls out, ONE
+// host synchronisation; x0 and the controls travel through pinned staging buffers.
+template <typename T>
+static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
+                         uint64_t seed, uint64_t stream, double* u) {
+  ampc_handle* h = p->h;
+  const size_t nx0 = (size_t)p->B * h->nx, nuo = (size_t)p->B * h->nu;
+  if (!p->pin_x0) {
+    HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocDefault));
+  }
+  T* px = (T*)p->pin_x0;
+  for (size_t i = 0; i < nx0; ++i) px[i] = (T)x0[i];
+  HIP_OK(hipMemcpyAsync(p->x0.p, px, nx0 * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  if (act_seq) HIP_OK(upload_converted<T>(p->act[p->cur].p, act_seq, (size_t)p->sum_hnu, h->stream));
+  if (noise == 1)
+    if (int rc = mppi_generate_impl<T>(p, seed, stream)) return rc;
+  if (int rc = mppi_solve_impl<T>(p)) return rc;
+  HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const T* pu = (const T*)p->pin_u;
+  for (size_t i = 0; i < nuo; ++i) u[i] = (double)pu[i];
+  return 0;
+}
+
+extern "C" int ampc_mppi_run(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
+                             uint64_t seed, uint64_t stream, double* u) {
+  REQUIRE(p && x0 && u, "ampc_mppi_run: NULL argument");
+  REQUIRE(noise == 0 || noise == 1, "ampc_mppi_run: noise must be 0 (resident) or 1 (Philox)");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64 ? mppi_run_impl<double>(p, x0, act_seq, noise, seed, stream, u)
+                                     : mppi_run_impl<float>(p, x0, act_seq, noise, seed, stream, u);
 }
 
 extern "C" int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev) {

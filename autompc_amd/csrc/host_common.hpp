@@ -266,6 +266,8 @@ struct ampc_mppi_plan {
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
+  void* pin_x0 = nullptr;     // ampc_mppi_run: pinned staging of x0 in / controls out (compute precision)
+  void* pin_u = nullptr;
   int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
   const JitPlugin* jit = nullptr;   // the shape's kernels live in a run-time compiled plugin (id 0 there)
   int static_lv = 0;      // which LDS map variant (StaticShape LV) the plan's tile uses

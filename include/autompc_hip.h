@@ -198,6 +198,15 @@ int ampc_mppi_solve(ampc_mppi_plan* p);
  *   eps_out [sum_p H_p*N_p*nu] post-clip noise, per problem [H][N][nu] (as do_rollouts returns) */
 int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* costs,
                        double* eps_out);
+/* MPPI.run (mppi.py:154-168) for the plan's B controllers in ONE call with one host synchronisation:
+ *   x0 [B][nx] in;  act_seq (optional, NULL = keep the device's warm start) in;
+ *   noise: 0 = the plan's noise buffer as it is (ampc_mppi_upload / ampc_mppi_legacy_normal),
+ *          1 = fresh Philox noise keyed by (seed, stream), as ampc_mppi_generate_eps;
+ *   solve;  u [B][nu] = act_seq[p][0] * umax out.
+ * Equivalent to ampc_mppi_upload + ampc_mppi_generate_eps + ampc_mppi_solve + ampc_mppi_download(u),
+ * without their intermediate synchronisations (the drop-in classes' hot call). */
+int ampc_mppi_run(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise, uint64_t seed,
+                  uint64_t stream, double* u);
 /* Overwrite x0 of every problem from a device buffer [B][nx] in compute precision (closed-loop
  * evaluator: no host round trip). */
 int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev);

@@ -24,17 +24,24 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = {"pred": 0.0, "jac": 0.0, "mppi_cost": 0.0, "mppi_act": 0.0, "ilqr": 0.0}
     bad = []
+    n_jit = [0]
     for case in range(n_cases):
-        nx = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 18, 19, 20, 21, 25, 32]))
+        nx = int(rng.choice([1, 2, 3, 5, 8, 12, 16, 17, 18, 19, 20, 21, 25, 32, 33, 40, 50, 64]))
         nu = int(rng.choice([1, 2, 3, 6, 9, 16]))
-        if nx + nu > 48:
+        if nx <= 32 and nx + nu > 48:
             nu = 48 - nx
+        if nx > 32 and nx + nu > 80:          # (the WIDE tile: first-layer K up to 80)
+            nu = 80 - nx
         nl = int(rng.integers(1, 5))
         hidden = [int(rng.choice([16, 33, 64, 100, 128, 150, 192, 256])) for _ in range(nl)]
         act = str(rng.choice(["relu", "tanh", "sigmoid", "selu"]))
         prec = "f64" if rng.random() < 0.7 else "f32"
         tol = 1e-9 if prec == "f64" else 2e-4
         os.environ["AMPC_MT"] = str(rng.choice([0, 1, 2, 4]))
+        # a quarter of the cases wait for the kernels compiled at run time for the case's shape
+        # (csrc/jit_host.hpp) and run on those; the rest stay on the run-time-shape kernels
+        use_jit = rng.random() < 0.25
+        os.environ["AMPC_JIT"] = "1" if use_jit else "0"
         system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
         p = omlp.random_params(nx, nu, hidden, act, seed=int(rng.integers(1 << 30)))
         p["xu_means"] = rng.normal(scale=0.2, size=nx + nu)
@@ -45,7 +52,7 @@ def main():
                 **{"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)})
         m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
         m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
-        tag = "case %d nx=%d nu=%d hidden=%s %s %s MT=%s" % (case, nx, nu, hidden, act, prec, os.environ["AMPC_MT"])
+        tag = "case %d nx=%d nu=%d hidden=%s %s %s MT=%s jit=%d" % (case, nx, nu, hidden, act, prec, os.environ["AMPC_MT"], use_jit)
         try:
             n = int(rng.choice([1, 7, 16, 33, 200]))
             s, c = rng.normal(size=(n, nx)), rng.normal(size=(n, nu))
@@ -76,6 +83,10 @@ def main():
                              horizon=H, num_path=N, sigma=sigma, lmda=lmda)
             np.random.seed(seed)
             ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+            if use_jit:
+                ctl._device()
+                ctl._handle.jit_wait()
+                n_jit[0] += ctl._device().kernel_kind() == 2
             obs = rng.uniform(-0.1, 0.1, size=nx)
             cs = np.concatenate([obs, np.zeros(nu)])
             st = np.random.get_state()
@@ -88,11 +99,14 @@ def main():
             if ec > tol or ea > 100 * tol:
                 bad.append((tag + " N=%d H=%d" % (N, H), "mppi", ec, ea))
             # iLQR (f64 only; a few iterations, compare the first accepted trajectory loosely)
-            if prec == "f64" and case % 3 == 0:
+            if prec == "f64" and case % 3 == 0 and nx + nu <= 45:
                 Hh = int(rng.integers(3, 15))
                 t2 = Task(system)
                 t2.set_cost(QuadCost(system, Q, R, F, goal=goal))
                 il = IterativeLQR(system, t2, m, Hh)
+                if use_jit:
+                    il._device()
+                    il._handle.jit_wait()
                 n_it = int(rng.integers(1, 7))
                 oil = ILQROracle(omodel, QuadCostOracle(Q, R, F, goal), system.dt, Hh, max_iter=n_it)
                 r1 = il._device().solve(obs[None, :], np.zeros((1, Hh, nu)), n_it)
@@ -194,7 +208,7 @@ def main():
     print("worst error / tolerance:", {k: float("%.3g" % v) for k, v in worst.items()})
     for b in bad:
         print("VIOLATION", b)
-    print("%d cases, %d violations" % (n_cases, len(bad)))
+    print("%d cases (%d of them on run-time compiled kernels), %d violations" % (n_cases, n_jit[0], len(bad)))
     return 1 if bad else 0
 
 
