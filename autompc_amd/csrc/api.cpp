@@ -622,7 +622,8 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
-                    &p->lg_scale, &p->lg_xraw, &p->lg_poly, &p->lg_win, &p->lg_logtab};
+                    &p->lg_scale, &p->lg_xraw, &p->lg_poly, &p->lg_win, &p->lg_logtab, &p->lg_gather};
+  if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
@@ -830,12 +831,16 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
   }
   HIP_OK(p->lg_cnt.reserve(((size_t)n_wg + 1) * sizeof(int)));
   HIP_OK(p->lg_fin.reserve(2 * sizeof(long long)));
-  HIP_OK(p->lg_scale.reserve((size_t)p->B * sizeof(double)));
-  std::vector<double> sc(p->B);
-  for (int b = 0; b < p->B; ++b) sc[b] = std::sqrt(p->sigma[b]);
-  const long long fin0[2] = {-1, 0};
-  HIP_OK(hipMemcpyAsync(p->lg_scale.p, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIP_OK(hipMemcpyAsync(p->lg_fin.p, fin0, sizeof(fin0), hipMemcpyHostToDevice, h->stream));
+  constexpr size_t kGather = 3 * sizeof(long long) + kMtN * sizeof(uint32_t);
+  HIP_OK(p->lg_gather.reserve(kGather));
+  if (!p->lg_pin) HIP_OK(hipHostMalloc(&p->lg_pin, kGather, hipHostMallocDefault));
+  if (!p->lg_scale_set) {            // sqrt(sigma_b): once per plan
+    HIP_OK(p->lg_scale.reserve((size_t)p->B * sizeof(double)));
+    std::vector<double> sc(p->B);
+    for (int b = 0; b < p->B; ++b) sc[b] = std::sqrt(p->sigma[b]);
+    HIP_OK(hipMemcpy(p->lg_scale.p, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice));
+    p->lg_scale_set = true;
+  }
   // the raw stream: the speculation of the previous call if this call starts where that one ended
   const bool hit = p->lg_spec && p->lg_spec_pos == pos && p->lg_spec_blocks >= nblocks &&
                    std::memcmp(p->lg_spec_key.data(), key, kMtN * sizeof(uint32_t)) == 0;
@@ -857,7 +862,8 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
   const uint32_t* u = stream + pos;                 // the generator's next output
   int* cnt = (int*)p->lg_cnt.p;
   hipLaunchKernelGGL(polar_count_kernel, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, cnt);
-  hipLaunchKernelGGL(polar_scan_kernel, dim3(1), dim3(256), 0, h->stream, cnt, n_wg, cnt + n_wg);
+  hipLaunchKernelGGL(polar_scan_kernel, dim3(1), dim3(256), 0, h->stream, cnt, n_wg, cnt + n_wg,
+                     (long long*)p->lg_fin.p);
   if (shift)
     hipLaunchKernelGGL(legacy_first_value_kernel<T>, dim3(1), dim3(64), 0, h->stream, cached,
                        (const double*)p->lg_scale.p, (T*)p->eps.p);
@@ -873,19 +879,20 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
                      (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, (long long*)p->lg_fin.p,
                      (const double*)p->lg_logtab.p);
   HIP_OK(hipGetLastError());
-  long long fin[2];
-  int total = 0;
-  HIP_OK(hipMemcpyAsync(fin, p->lg_fin.p, sizeof(fin), hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipMemcpyAsync(&total, cnt + n_wg, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  // fin, the pair count and the stream block the generator ends in: one copy, one synchronisation
+  hipLaunchKernelGGL(legacy_gather_kernel, dim3(1), dim3(256), 0, h->stream, (const long long*)p->lg_fin.p,
+                     (const int*)(cnt + n_wg), (const uint32_t*)stream, pos, (long long*)p->lg_gather.p);
+  HIP_OK(hipMemcpyAsync(p->lg_pin, p->lg_gather.p, kGather, hipMemcpyDeviceToHost, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
+  const long long* gl = (const long long*)p->lg_pin;
+  const long long fin[2] = {gl[0], gl[1]};
+  const int total = (int)gl[2];
   REQUIRE(total >= n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
   // generator state after the last consumed word
   long long idx = (long long)pos + 4 * (fin[0] + 1);
-  long long blk = idx / kMtN;
   int po = (int)(idx % kMtN);
-  if (po == 0 && idx > 0) { blk -= 1; po = kMtN; }  // randomkit regenerates lazily: pos == 624
-  std::vector<uint32_t> last(kMtN);
-  HIP_OK(hipMemcpy(last.data(), stream + (size_t)blk * kMtN, kMtN * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (po == 0 && idx > 0) po = kMtN;               // randomkit regenerates lazily: pos == 624
+  const uint32_t* last = (const uint32_t*)(gl + 3);
   for (int i = 0; i < kMtN; ++i) key_out[i] = mt_untemper(last[i]);
   *pos_out = po;
   const bool odd = ((n - shift) & 1) != 0;

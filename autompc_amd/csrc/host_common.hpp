@@ -281,7 +281,9 @@ struct ampc_mppi_plan {
   // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
   // call is generated speculatively on a side stream (it only depends on the generator state this
   // call leaves behind) and used if the next call indeed starts from that state.
-  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly, lg_win, lg_logtab;
+  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly, lg_win, lg_logtab, lg_gather;
+  void* lg_pin = nullptr;         // pinned landing buffer of lg_gather (fin, total, the final stream block)
+  bool lg_scale_set = false;      // sqrt(sigma_b) uploaded (the sigmas of a plan never change)
   hipStream_t lg_side = nullptr;
   hipEvent_t lg_ev = nullptr;
   int lg_cur = 0;                 // buffer the speculation (if any) was written to

@@ -9,7 +9,10 @@ from autompc_amd.synthetic import make_workload
 
 for name in ("c3", "c2", "arx"):
     system, task, model, spec = make_workload(name)
-    for noise in ("device", "numpy_device", "numpy"):
+    only = os.environ.get("DROPIN_ONLY")
+    for noise in ("device", "numpy", "numpy_host"):        # "numpy" is the default mode of MPPI()
+        if only and (name, noise) != tuple(only.split(":")):
+            continue
         np.random.seed(0)
         ctl = MPPI(system, task, model, horizon=spec["horizon"], num_path=spec["num_path"], sigma=1.0,
                    lmda=1.0, noise=noise)
@@ -18,7 +21,7 @@ for name in ("c3", "c2", "arx"):
         one = zeros(system, 1)
         one.obs[0, :] = obs
         cs = ctl.traj_to_state(one)
-        n = 20 if noise == "numpy" else 200
+        n = 20 if noise == "numpy_host" else 300
         for _ in range(5):
             u, cs = ctl.run(cs, obs)
         t0 = time.perf_counter()
@@ -26,6 +29,8 @@ for name in ("c3", "c2", "arx"):
             u, cs = ctl.run(cs, obs)
         dt = time.perf_counter() - t0
         print("%-4s MPPI.run noise=%-12s %8.1f calls/s  (%.3f ms per call)" % (name, noise, n / dt, 1e3 * dt / n))
+if os.environ.get("DROPIN_ONLY"):
+    sys.exit(0)
 system, task, model, spec = make_workload("c3")
 from autompc_amd import QuadCost, Task
 t2 = Task(system)

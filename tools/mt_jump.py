@@ -8,8 +8,8 @@ g = t^J mod phi, and because A^i s is just the window of the stream i words furt
     x[J + p] = XOR over { i : g_i = 1 } of x[i + p]           (p = 0 .. 623)
 -- a correlation of the bit vector g with the first 19937 + 624 words of the stream, which every
 segment of the stream can evaluate independently.  This script computes phi with Berlekamp-Massey
-from a generated bit sequence and then g_s = t^(s*J) mod phi for s = 1 .. S (J = 200 blocks of 624
-words), and stores them as uint32 words in autompc_amd/data/mt19937_jump.npz.  Pure integer
+from a generated bit sequence and then g_s = t^(s*J) mod phi for s = 1 .. S (J = 64 blocks of 624
+words: a segment is what one workgroup regenerates sequentially, ~35 us), and stores them as uint32 words in autompc_amd/data/mt19937_jump.npz.  Pure integer
 arithmetic (polynomials are Python ints, bit j = coefficient of t^j); takes a few seconds.
 The result is checked against numpy's own generator before it is written.
 """
@@ -19,9 +19,9 @@ import sys
 import numpy as np
 
 N, M, DEG = 624, 397, 19937
-JUMP_BLOCKS = 200
+JUMP_BLOCKS = 64
 J = JUMP_BLOCKS * N
-S_MAX = 48
+S_MAX = 150
 
 
 def raw_stream(key, nwords):
