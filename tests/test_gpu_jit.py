@@ -163,3 +163,20 @@ def test_controllers_switch_to_the_compiled_kernels_mid_run(monkeypatch, tmp_pat
     got, kinds1 = drive(True)
     assert kinds1[-1] == (2, 2), kinds1
     np.testing.assert_array_equal(got, ref)
+
+
+def test_failed_build_falls_back_to_the_runtime_shape_kernels(monkeypatch):
+    """A plugin that cannot be built (here: a cache directory that cannot be created) must never
+    break a solve: the run-time-shape kernels keep serving, the status says what happened."""
+    from autompc_amd import _lib
+    monkeypatch.setenv("AMPC_JIT", "1")
+    monkeypatch.setenv("AMPC_JIT_CACHE", "/proc/no_such_dir/ampc")
+    nx, nu = 6, 2
+    h = _handle(nx, nu, [72, 72], "relu", "f64", seed=4)
+    with pytest.raises(_lib.AmpcError):
+        h.jit_wait()
+    st, msg = h.jit_status()
+    assert st == -1 and msg
+    kind, out = _mppi(h, nx, nu, 16)
+    assert kind == 0 and np.all(np.isfinite(out[1]))
+    h.close()
