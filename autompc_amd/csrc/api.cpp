@@ -1273,6 +1273,7 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   constexpr int kPoll = 4;
   int it = 0, batch = 0, pending = -1;     // pending: batch whose flags are in flight
   bool done = false;
+  p->active_hint = B;
   // (ev_cur points into p->ev: never leave it set behind an early return)
   struct EvGuard { ampc_ilqr_plan* p; ~EvGuard() { p->ev_cur = nullptr; } } ev_guard{p};
   const size_t ev_first = p->ev_used / 5;  // this solve's first timed iteration
@@ -1302,9 +1303,10 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
     if (pending >= 0) {
       const int ps = pending & 1;
       HIP_OK(hipEventSynchronize(p->poll_ev[ps]));
-      bool any = false;
-      for (int b = 0; b < B; ++b) any |= p->poll_host[(size_t)ps * B + b] != 0;
-      if (!any) done = true;
+      int live = 0;
+      for (int b = 0; b < B; ++b) live += p->poll_host[(size_t)ps * B + b] != 0;
+      p->active_hint = live;          // (as of two batches ago: an upper bound of the current count)
+      if (live == 0) done = true;
     }
     pending = batch++;
   }

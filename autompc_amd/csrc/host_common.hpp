@@ -367,6 +367,9 @@ struct ampc_ilqr_plan {
   // convergence (no-ops); only the first max_b iters[b] iterations of a solve count in the averages
   std::vector<unsigned char> ev_live;   // one flag per timed iteration (ev_used / 5 of them)
   int last_effective = 0;               // iterations of the last solve in which a problem was active
+  int active_hint = 0;                  // problems known to be still active (from the last poll; never
+                                        // below the true count): few enough and the passes of a line
+                                        // search run side by side on the idle CUs
   // convergence polling: the `active` flags of one batch of iterations are copied to pinned host
   // memory behind that batch and read while the NEXT batch is already queued
   int* poll_host = nullptr;     // [2][B] pinned

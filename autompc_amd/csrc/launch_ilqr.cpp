@@ -91,7 +91,9 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (lb > 0 && lb <= kLdsLimit) {
       // few problems: the passes of a line search side by side on otherwise idle CUs
       const int npass = (p->ls_n + 3) / 4;
-      a.par_passes = (mode == 1 && p->par_passes && p->B * npass <= h->n_cus) ? 1 : 0;
+      // (retired problems' workgroups exit at once, so what has to fit is the ACTIVE problems' passes)
+      const int live = (p->active_hint > 0 && p->active_hint < p->B) ? p->active_hint : p->B;
+      a.par_passes = (mode == 1 && p->par_passes && live * npass <= h->n_cus) ? 1 : 0;
       const dim3 grid(p->B, a.par_passes ? npass : 1);
       if (p->static_shape >= 0) {
         // (the activation is a compile-time constant for relu AND tanh here: with the run-time

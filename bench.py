@@ -363,7 +363,7 @@ def secondary_workload(args, R):
             handles.append(hg)
             plans.append(_lib.IlqrPlan(hg, hi - lo, 50, system.dt))
         h, plan = handles[0], plans[0]
-        iters = []
+        iters, conv = [], []
 
         rows = []
 
@@ -383,6 +383,7 @@ def secondary_workload(args, R):
                     t.join()
             if i >= warm:
                 iters.append(float(np.mean(np.concatenate([r["iters"] for r in res]))))
+                conv.append(float(np.mean(np.concatenate([r["converged"] for r in res]))))
                 rows.append(sum(pl.stats()["candidate_rows"] for pl in plans) / float(B))
         label = ("c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU"
                  "%s" % (B, "" if G == 1 else " in %d groups on %d streams" % (G, G)))
@@ -391,6 +392,29 @@ def secondary_workload(args, R):
         elapsed, n_pre = timed_loop(R, step, steps, warm, min(args.preheat, 0.3),
                                     before_timed=lambda: plan.set_timing(True))
         kt = plan.timing()
+        # the same problems with the controls bounded to +-0.25 (the reference's bounded golden problem,
+        # tests/golden/ilqr_hc6_relu_bounded.npz: clipping in the forward pass, ilqr.py:62-64, 203-204):
+        # these solves CONVERGE well inside the 50-iteration cap, the unbounded ones above never do
+        variant = None
+        if not args.no_extras:
+            hb = _lib.Handle(R.local_rank, args.precision, stream=R.torch.cuda.current_stream().cuda_stream)
+            model.stage_into(hb)
+            hb.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
+            hb.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
+            pb = _lib.IlqrPlan(hb, B, 50, system.dt, clip_to_bounds=True)
+            pb.solve(x0, ug, max_iter=50)
+            R.sync_all()
+            tb = time.perf_counter()
+            ob = pb.solve(x0, ug, max_iter=50)
+            R.sync_all()
+            eb = R.max_over_ranks(time.perf_counter() - tb)
+            variant = {"workload": "the same %d problems with controls clipped to +-0.25 (bounded golden problem)" % B,
+                       "value": world * B / eb, "unit": "solves/s", "ms_per_step": 1e3 * eb,
+                       "mean_iterations_per_solve": float(ob["iters"].mean()),
+                       "converged_fraction": float(ob["converged"].mean()),
+                       "max_iterations": int(ob["iters"].max())}
+            pb.close()
+            hb.close()
         if rank == 0:
             # work of one solve of one problem: per iteration the Jacobian chain over H rows
             # and the forward pass of the accepted trajectory; the line search as EXECUTED -- candidate
@@ -404,6 +428,10 @@ def secondary_workload(args, R):
             per_solve = it * (jac + row) + ls_rows * row
             ls = ls_rows / it * row                      # line-search flops of one problem-iteration
             extra["mean_iterations_per_solve"] = it
+            extra["converged_fraction"] = float(np.mean(conv))
+            extra["iteration_cap"] = 50
+            if variant is not None:
+                extra["converging_variant"] = variant
             extra["mean_line_search_rows_per_iteration"] = ls_rows / it
             extra["algorithmic_tflops"] = world * steps * B * per_solve / elapsed / 1e12
             extra["reference_work_tflops"] = world * steps * B * it * (jac + 11 * row) / elapsed / 1e12
