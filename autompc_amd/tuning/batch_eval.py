@@ -363,6 +363,146 @@ class CandidateEvaluator:
         return scores
 
 
+class IlqrCandidateEvaluator:
+    """Closed-loop surrogate scores of iLQR + QuadCost candidates -- the other controller the
+    reference's tuner searches over (IterativeLQRFactory: horizon 5-25, control/ilqr.py:31-41;
+    QuadCostFactory gains, quad_cost_factory.py:46-58) -- as ``PipelineTuner.eval_cfg`` computes
+    them (tuning/pipeline_tuner.py:213-258): ``controller.reset()``, ``simulate(controller,
+    init_obs, task.term_cond, sim_model=surrogate, max_steps=num_steps)``, ``cost(traj)``; a
+    singular ``Quu`` (the reference's ``LinAlgError``, ilqr.py:179) scores ``inf`` (:236-239).
+
+    ``IterativeLQR.run`` re-solves from a zero guess at every control step (ilqr.py:267-295 with the
+    default ``reuse_feedback``), so a control step of the batch is ONE batched device solve
+    (``ampc_ilqr_solve``: every candidate of a horizon group is a problem of the plan, each with its
+    own cost block) followed by one batched surrogate step.  Everything is deterministic: a
+    candidate's score does not depend on the batch it is in or on the rank that evaluates it."""
+
+    def __init__(self, system, task, model, surrogate=None, precision="f64", device=0):
+        if not hasattr(model, "stage_into"):
+            raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
+        if precision != "f64":
+            raise ValueError("iLQR solves in f64 (control/ilqr.py: f32 is outside the parity mode)")
+        self.system, self.task, self.model = system, task, model
+        self.surrogate = surrogate if surrogate is not None else model
+        self.precision, self.device = precision, device
+        self.bounded = bool(task.are_ctrl_bounded())
+        b = task.get_ctrl_bounds()
+        self.umin, self.umax = b[:, 0].copy(), b[:, 1].copy()
+        self.goal = _task_goal(task.get_cost(), system.obs_dim)
+        self.last_lengths = None
+
+    def evaluate(self, candidates, n_steps=None, seed=0, init_obs=None, return_trajectories=False,
+                 index_offset=0, max_iter=50):
+        """candidates: dicts with keys horizon, Q, R, F (diagonals or full matrices).  Episode as in
+        CandidateEvaluator.evaluate (eval_cfg's, or exactly n_steps control steps).  seed and
+        index_offset are accepted for interface compatibility (nothing here is random)."""
+        B = len(candidates)
+        if B == 0:
+            return (np.zeros(0), None, None) if return_trajectories else np.zeros(0)
+        opened = []
+        try:
+            return self._evaluate(candidates, n_steps, init_obs, return_trajectories, int(max_iter), opened)
+        finally:
+            for obj in reversed(opened):
+                obj.close()
+
+    def _evaluate(self, candidates, n_steps, init_obs, return_trajectories, max_iter, opened):
+        from ..trajectory import Trajectory
+        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        B = len(candidates)
+        if n_steps is not None:
+            n_ctl, term_cond = int(n_steps), None
+        else:
+            max_steps, term_cond = episode_of(self.task)
+            n_ctl = default_episode_controls(self.task) if term_cond is None else max_steps
+        init_obs = self.task.get_init_obs() if init_obs is None else np.asarray(init_obs)
+        # one plan per horizon: the problems of a plan share the horizon, not the cost
+        groups = {}
+        for i, c in enumerate(candidates):
+            groups.setdefault(int(c["horizon"]), []).append(i)
+        sur = _lib.Handle(self.device, self.precision)
+        opened.append(sur)
+        self.surrogate.stage_into(sur)
+        plans = {}
+        for H, idx in groups.items():
+            h = _lib.Handle(self.device, self.precision)
+            opened.append(h)
+            self.model.stage_into(h)
+            h.set_quad_costs(np.stack([_as_matrix(candidates[i]["Q"], no) for i in idx]),
+                             np.stack([_as_matrix(candidates[i]["R"], nu) for i in idx]),
+                             np.stack([_as_matrix(candidates[i]["F"], no) for i in idx]),
+                             np.tile(self.goal, (len(idx), 1)))
+            if self.bounded:
+                h.set_ctrl_bounds(self.umin, self.umax)
+            plan = _lib.IlqrPlan(h, len(idx), H, self.system.dt, cost_index=np.arange(len(idx)),
+                                 clip_to_bounds=self.bounded)
+            opened.append(plan)
+            plans[H] = (plan, np.array(idx))
+        obs = np.full((B, n_ctl + 1, nx), np.nan)
+        ctl = np.full((B, n_ctl + 1, nu), np.nan)
+        obs[:, 0] = init_obs
+        lengths = np.full(B, n_ctl + 1)
+        failed = np.zeros(B, dtype=bool)          # singular Quu: the reference's LinAlgError -> inf
+        alive = np.ones(B, dtype=bool)
+        for t in range(n_ctl):
+            if not alive.any():
+                break
+            for H, (plan, idx) in plans.items():
+                live = alive[idx]
+                if not live.any():
+                    continue
+                # (finished candidates keep their slot: the solve is per problem, their result is unused)
+                x = np.where(live[:, None], obs[idx, t], obs[idx, 0])
+                out = plan.solve(x, np.zeros((len(idx), H, nu)), max_iter=max_iter)
+                u = out["ctrls"][:, 0]              # u = ubar_0 + K_0 (x - xbar_0) with x = xbar_0
+                bad = live & (out["status"] == 1)
+                failed[idx[bad]] = True
+                alive[idx[bad]] = False
+                go = live & ~bad
+                if go.any():
+                    nxt = sur.pred_batch(x[go], u[go])
+                    sel = idx[go]
+                    ctl[sel, t] = u[go]
+                    obs[sel, t + 1] = nxt
+            if term_cond is not None:
+                for i in np.nonzero(alive)[0]:
+                    rows_c = ctl[i, :t + 2].copy()
+                    rows_c[t + 1] = 0.0
+                    if term_cond(Trajectory(self.system, t + 2, obs[i, :t + 2, :no].copy(), rows_c)):
+                        lengths[i] = t + 2
+                        alive[i] = False
+        try:
+            terms = cost_terms(self.task.get_cost(), no, nu)
+        except TypeError:
+            terms = None
+        scores = np.full(B, np.inf)
+        ok = ~failed
+        for L in np.unique(lengths[ok]):
+            idx = np.nonzero(ok & (lengths == L))[0]
+            o, c = obs[idx, :L].copy(), ctl[idx, :L].copy()
+            c[:, L - 1] = 0.0                       # simulate()'s trailing zero control row
+            if terms is not None:
+                scores[idx] = sur.score_trajectories(terms, o, c, obs_dim=no)
+            else:
+                scores[idx] = score_trajectories(self.task.get_cost(), o[:, :, :no], c)
+            obs[idx, L:], ctl[idx, L - 1] = np.nan, 0.0
+            ctl[idx, L:] = np.nan
+        self.last_lengths = lengths
+        if return_trajectories:
+            Lmax = int(lengths.max())
+            return scores, obs[:, :Lmax], ctl[:, :Lmax]
+        return scores
+
+
+def random_ilqr_candidates(system, n, seed=0):
+    """Candidates drawn from the reference's ranges: iLQR horizon 5-25 (control/ilqr.py:36-38),
+    QuadCost diagonal gains log-uniform in [1e-3, 1e4] (quad_cost_factory.py:46-58)."""
+    rng = np.random.default_rng(seed)
+    no, nu = system.obs_dim, system.ctrl_dim
+    return [dict(horizon=int(rng.integers(5, 26)), Q=10 ** rng.uniform(-3, 4, size=no),
+                 R=10 ** rng.uniform(-3, 4, size=nu), F=10 ** rng.uniform(-3, 4, size=no)) for _ in range(n)]
+
+
 def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None, stats=None):
     """Score ``candidates`` with ``local_eval(sub_list, lo) -> scores`` on this rank's contiguous
     shard ``candidates[lo:hi]`` and all-gather the scores so every rank returns the full vector

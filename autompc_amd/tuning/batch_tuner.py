@@ -22,7 +22,7 @@ from collections import namedtuple
 
 import numpy as np
 
-from .batch_eval import evaluate_sharded, random_candidates
+from .batch_eval import IlqrCandidateEvaluator, evaluate_sharded, random_candidates, random_ilqr_candidates
 
 # same fields, same order as the reference's namedtuple (pipeline_tuner.py:19-21)
 PipelineTuneResult = namedtuple("PipelineTuneResult", [
@@ -55,7 +55,8 @@ class BatchPipelineTuner:
         self._inc_cfg, self._inc_cost, self._inc_truedyn = None, float("inf"), None
 
     def _random_search(self, n, rng):
-        return random_candidates(self.system, n, seed=int(rng.integers(1 << 31)))
+        draw = random_ilqr_candidates if isinstance(self.evaluator, IlqrCandidateEvaluator) else random_candidates
+        return draw(self.system, n, seed=int(rng.integers(1 << 31)))
 
     # -- ask / tell ---------------------------------------------------------------------------
     def ask(self, n, rng):
@@ -101,7 +102,7 @@ class BatchPipelineTuner:
         """Score of one candidate's controller against the true dynamics ``truedyn(obs, ctrl) ->
         obs`` (eval_cfg's second branch, pipeline_tuner.py:241-256): the MPPI solves run on the
         device, the dynamics callback runs on the host between them."""
-        from .. import MPPI, QuadCost, Task, simulate
+        from .. import MPPI, IterativeLQR, QuadCost, Task, simulate
         ev = self.evaluator
         no, nu = self.system.obs_dim, self.system.ctrl_dim
 
@@ -112,10 +113,14 @@ class BatchPipelineTuner:
         task.set_cost(QuadCost(self.system, mat(cand["Q"], no), mat(cand["R"], nu), mat(cand["F"], no),
                                goal=ev.goal))
         task.set_ctrl_bounds(ev.umin, ev.umax)
-        ctl = MPPI(self.system, task, ev.model, horizon=int(cand["horizon"]),
-                   num_path=int(cand["num_path"]), sigma=float(cand["sigma"]),
-                   lmda=float(cand["lmda"]), noise=self.truedyn_noise, seed=seed,
-                   precision=ev.precision, device=ev.device)
+        if "num_path" not in cand:            # an iLQR candidate (horizon + cost weights)
+            ctl = IterativeLQR(self.system, task, ev.model, int(cand["horizon"]), precision=ev.precision,
+                               device=ev.device)
+        else:
+            ctl = MPPI(self.system, task, ev.model, horizon=int(cand["horizon"]),
+                       num_path=int(cand["num_path"]), sigma=float(cand["sigma"]),
+                       lmda=float(cand["lmda"]), noise=self.truedyn_noise, seed=seed,
+                       precision=ev.precision, device=ev.device)
         ctl.reset()
         kw = {"max_steps": ev.task.get_num_steps()} if ev.task.has_num_steps() else {}
         traj = simulate(ctl, ev.task.get_init_obs(), ev.task.term_cond, dynamics=truedyn, **kw)

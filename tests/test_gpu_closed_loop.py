@@ -373,3 +373,67 @@ def test_host_simulate_with_task_term_cond_matches_eval_cfg_ilqr():
     assert len(traj) == int(g["num_steps"])
     assert rel_err(traj.obs, g["surr_obs"]) < 1e-7 and rel_err(traj.ctrls, g["surr_ctrls"]) < 1e-7
     assert abs(task.get_cost()(traj) - g["surr_cost"]) < 1e-7 * abs(g["surr_cost"])
+
+
+# ---- iLQR candidates: the tuner's other controller (IterativeLQRFactory, control/ilqr.py:31-41) --
+def test_ilqr_candidate_evaluator_matches_eval_cfg_golden():
+    """The reference's eval_cfg episode with an iLQR controller (loop_evalcfg_ilqr.npz) through the
+    batched evaluator, and the tuner's two cost columns on top of it."""
+    from autompc_amd.tuning import BatchPipelineTuner, IlqrCandidateEvaluator
+    g = golden("loop_evalcfg_ilqr")
+    system, p, task = _evalcfg_stack(g)
+    ev = IlqrCandidateEvaluator(system, task, _hip_model(system, p))
+    cand = dict(horizon=int(g["H"]), Q=g["Q"], R=g["R"], F=g["F"])
+    scores, obs, ctrls = ev.evaluate([cand], return_trajectories=True)
+    assert ev.last_lengths.tolist() == [int(g["num_steps"])]
+    assert rel_err(obs[0], g["surr_obs"]) < 1e-7 and rel_err(ctrls[0], g["surr_ctrls"]) < 1e-7
+    assert abs(scores[0] - g["surr_cost"]) < 1e-7 * abs(g["surr_cost"])
+    truth = MLPOracle(system, p)
+    tuner = BatchPipelineTuner(system, ev, batch_size=1, sampler=lambda n, rng: [cand] * n)
+    best, res = tuner.run(1, np.random.default_rng(0), truedyn=lambda o, u: truth.pred(o, u))
+    assert abs(res.costs[0] - g["surr_cost"]) < 1e-7 * abs(g["surr_cost"])
+    assert abs(res.truedyn_costs[0] - g["truedyn_cost"]) < 1e-7 * abs(g["truedyn_cost"])
+
+
+def test_ilqr_candidate_batch_equals_the_drop_in_controller_per_candidate():
+    """Heterogeneous iLQR candidates (horizons 5-25, gains over several decades, bounded controls) in
+    one batch: every candidate's closed loop is the one host simulate() + the drop-in IterativeLQR
+    produce for it alone; a candidate whose Quu is singular scores inf like eval_cfg's LinAlgError
+    branch (pipeline_tuner.py:236-239) without disturbing the others."""
+    from autompc_amd import IterativeLQR, QuadCost, Task, simulate
+    from autompc_amd.tuning import IlqrCandidateEvaluator, random_ilqr_candidates
+    nx, nu, T = 4, 2, 9
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [64, 48], "tanh", seed=21)
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), 2.0 * np.eye(nx)))
+    task.set_ctrl_bounds(-0.6 * np.ones(nu), 0.6 * np.ones(nu))
+    task.set_init_obs(np.array([0.3, -0.2, 0.25, 0.1]))
+    task.set_num_steps(T)
+    model = _hip_model(system, p)
+    cands = random_ilqr_candidates(system, 6, seed=4)
+    for c in cands:
+        c["Q"], c["R"], c["F"] = c["Q"] ** 0.3, c["R"] ** 0.3, c["F"] ** 0.3
+    cands[1]["horizon"] = cands[0]["horizon"]                   # two candidates share a plan
+    ev = IlqrCandidateEvaluator(system, task, model)
+    scores, obs, ctrls = ev.evaluate(cands, return_trajectories=True)
+    assert np.all(np.isfinite(scores))
+    for b, c in enumerate(cands):
+        t1 = Task(system)
+        t1.set_cost(QuadCost(system, np.diag(c["Q"]), np.diag(c["R"]), np.diag(c["F"])))
+        t1.set_ctrl_bounds(-0.6 * np.ones(nu), 0.6 * np.ones(nu))
+        ctl = IterativeLQR(system, t1, model, c["horizon"])
+        ctl.reset()
+        traj = simulate(ctl, task.get_init_obs(), task.term_cond, sim_model=model, max_steps=T)
+        assert len(traj) == T
+        assert rel_err(obs[b], traj.obs) < 1e-9 and rel_err(ctrls[b], traj.ctrls) < 1e-9
+        assert abs(scores[b] - task.get_cost()(traj)) < 1e-9 * abs(scores[b])
+    np.testing.assert_array_equal(ev.evaluate(cands[2:4]), scores[2:4])      # batch-invariant
+    # singular Quu: the control has no effect on the model and R = 0
+    p2 = {k: ([w.copy() for w in v] if isinstance(v, list) else v) for k, v in p.items()}
+    p2["weights"][0][:, nx:] = 0.0
+    ev2 = IlqrCandidateEvaluator(system, task, _hip_model(system, p2))
+    good = dict(horizon=8, Q=np.ones(nx), R=0.1 * np.ones(nu), F=np.ones(nx))
+    sing = dict(horizon=8, Q=np.ones(nx), R=np.zeros(nu), F=np.ones(nx))
+    s2 = ev2.evaluate([good, sing, good])
+    assert np.isinf(s2[1]) and np.isfinite(s2[0]) and s2[0] == s2[2]
