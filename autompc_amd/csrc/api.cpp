@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 100; }
+extern "C" int ampc_version(void) { return 103; }   // 1.03: round 3 (ampc_set_sindy gained the monomial pair list)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

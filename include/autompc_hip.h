@@ -37,7 +37,7 @@ enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU
 enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 
 const char* ampc_last_error(void);
-int ampc_version(void);
+int ampc_version(void);   /* 100 * major + minor; 103: ampc_set_sindy takes the monomial pair list */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */

@@ -205,6 +205,44 @@ def main():
                     bad.append(("closed loop case %d cand %d" % (case, b), "score", e, 0.0))
         except Exception as ex:      # noqa: BLE001
             bad.append(("closed loop case %d" % case, "exception", repr(ex)[:200], 0.0))
+    # ---- SINDy libraries (incl. polynomial cross terms), both time modes, strict and true Jacobians ----
+    from autompc_amd import SINDy
+    from oracle.sindy import SINDyOracle
+    worst.update({"sindy_pred": 0.0, "sindy_jac": 0.0})
+    for case in range(max(6, n_cases // 10)):
+        nx, nu = int(rng.integers(1, 6)), int(rng.integers(1, 3))
+        tf = int(rng.integers(0, 4))
+        inter = bool(tf > 0 and rng.random() < 0.5)
+        pd = int(rng.integers(1, 5))
+        cross = bool(pd > 1 and rng.random() < 0.6)
+        if cross and nx + nu > 5 and pd > 3:
+            pd = 3                                   # (keeps the library below the 4096-feature limit)
+        mode = str(rng.choice(["discrete", "continuous"]))
+        strict = bool(rng.random() < 0.5)
+        prec = "f64" if rng.random() < 0.7 else "f32"
+        tol = 1e-11 if prec == "f64" else 2e-4
+        system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+        tag = "sindy case %d nx=%d nu=%d trig=%d inter=%d poly=%d cross=%d %s strict=%d %s" % (
+            case, nx, nu, tf, inter, pd, cross, mode, strict, prec)
+        try:
+            m = SINDy(system, trig_basis=tf > 0, trig_freq=max(tf, 1), trig_interaction=inter, poly_basis=pd > 1,
+                      poly_degree=pd, poly_cross_terms=cross, time_mode=mode, precision=prec, strict_reference=strict)
+            nf = m.coefficients.shape[1]
+            Xi = (rng.random((nx, nf)) < 0.3) * rng.normal(scale=0.2, size=(nx, nf))
+            m.set_coefficients(Xi)
+            orc = SINDyOracle(system, Xi, trig_freq=tf, trig_interaction=inter, poly_degree=pd, time_mode=mode,
+                              strict_reference=strict, poly_cross_terms=cross)
+            s_, c_ = rng.normal(scale=0.8, size=(37, nx)), rng.normal(scale=0.8, size=(37, nu))
+            e = rel(m.pred_batch(s_, c_), orc.pred_batch(s_, c_))
+            o_, jx, ju = m.pred_diff_batch(s_, c_)
+            _, ojx, oju = orc.pred_diff_batch(s_, c_)
+            ej = max(rel(jx, ojx), rel(ju, oju) if np.max(np.abs(oju)) > 0 else 0.0)
+            worst["sindy_pred"] = max(worst["sindy_pred"], e / tol)
+            worst["sindy_jac"] = max(worst["sindy_jac"], ej / (10 * tol))
+            if e > tol or ej > 10 * tol:
+                bad.append((tag, "sindy pred/jac", e, ej))
+        except Exception as ex:      # noqa: BLE001
+            bad.append((tag, "exception", repr(ex)[:200], 0.0))
     print("worst error / tolerance:", {k: float("%.3g" % v) for k, v in worst.items()})
     for b in bad:
         print("VIOLATION", b)
