@@ -127,3 +127,25 @@ def test_truedyn_scores_are_recorded_but_do_not_steer(monkeypatch):
         assert res.inc_truedyn_costs[i] == res.truedyn_costs[j]
     with pytest.raises(ValueError):
         tuner.tell(res.cfgs[:2], [1.0, 2.0], truedyn_scores=[1.0])
+
+
+def test_default_sampler_follows_the_evaluator_kind():
+    """BatchPipelineTuner's random search draws MPPI candidates for the MPPI evaluator and iLQR
+    candidates (horizon 5-25 + cost weights, control/ilqr.py:36-38) for the iLQR evaluator."""
+    from autompc_amd import System
+    from autompc_amd.tuning import BatchPipelineTuner, IlqrCandidateEvaluator, random_ilqr_candidates
+    system = System(["x0", "x1"], ["u0"])
+    cands = random_ilqr_candidates(system, 50, seed=1)
+    assert all(5 <= c["horizon"] <= 25 and "num_path" not in c for c in cands)
+    assert all(c["Q"].shape == (2,) and c["R"].shape == (1,) and np.all(c["Q"] >= 1e-3) and np.all(c["Q"] <= 1e4)
+               for c in cands)
+
+    class _Ilqr(IlqrCandidateEvaluator):
+        def __init__(self):                 # (no device: only the type matters to the sampler)
+            pass
+
+        def evaluate(self, candidates, seed=0, index_offset=0):
+            return np.array([float(c["horizon"]) for c in candidates])
+    tuner = BatchPipelineTuner(system, _Ilqr(), batch_size=4)
+    best, res = tuner.run(8, np.random.default_rng(0))
+    assert all("num_path" not in c for c in res.cfgs) and best["horizon"] == min(c["horizon"] for c in res.cfgs)
