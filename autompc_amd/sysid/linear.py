@@ -83,6 +83,11 @@ class ARX(_LinearModel):
     """state = [obs_t, (obs_{t-1}, ctrl_{t-1}), .., (obs_{t-k+1}, ctrl_{t-k+1}), 1]
     (arx.py:47-60, 104-105); the control of the current step is the model input."""
 
+    # update_state(state, u, pred(state, u)[:obs_dim]) == pred(state, u): a closed loop on this model
+    # may carry the predicted state forward (the device-resident evaluator does); Koopman re-lifts
+    # the observation every step (koopman.py:160-168) and may not
+    device_closed_loop = True
+
     def __init__(self, system, history=4, precision="f64", device=0):
         super().__init__(system, precision, device)
         self.k = int(history)

@@ -129,6 +129,17 @@ class CandidateEvaluator:
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         self.system, self.task, self.model = system, task, model
         self.surrogate = surrogate if surrogate is not None else model
+        # The device loop hands the surrogate's predicted STATE to the next solve.  That is
+        # simulate()'s loop (controller.run -> model.update_state(state, u, obs), simulation.py:52-58)
+        # exactly when the model state is the observation (MLP, SINDy), or when controller and
+        # surrogate are one model whose update_state reproduces its own prediction (ARX).
+        if model.state_dim != system.obs_dim:
+            if not (getattr(model, "device_closed_loop", False) and self.surrogate is model):
+                raise TypeError(
+                    "%s keeps a model state that is not the observation and rebuilds it from every new "
+                    "observation (update_state): the device-resident closed loop cannot represent that; "
+                    "score such candidates with simulate() and the drop-in controller"
+                    % type(model).__name__)
         self.precision, self.device = precision, device
         b = task.get_ctrl_bounds()
         self.umin, self.umax = b[:, 0].copy(), b[:, 1].copy()
@@ -239,7 +250,14 @@ class CandidateEvaluator:
             terms = None                  # a user-defined cost object: score it through its own
         if timing is not None:            # Python interface from the downloaded trajectories
             timing["control_steps"] = n_ctl
-        x0 = np.tile(init_obs, (B, 1))
+        init_obs = np.asarray(init_obs, dtype=np.float64)
+        if init_obs.shape == (nx,):
+            state0 = init_obs
+        else:                            # the model state of the one-row trajectory simulate() starts from
+            from ..trajectory import Trajectory
+            state0 = self.model.traj_to_state(Trajectory(self.system, 1, init_obs[None, :no].copy(),
+                                                         np.zeros((1, nu))))
+        x0 = np.tile(state0, (B, 1))
         if term_cond is not None:
             return self._evaluate_segmented(candidates, h, sur, x0, n_ctl, term_cond, seed, eps_all,
                                             act_init, noise_ids, terms, return_trajectories, opened,

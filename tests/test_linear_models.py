@@ -203,6 +203,34 @@ def test_device_mppi_closed_loop_matches_reference(tag):
 
 
 @pytest.mark.gpu
+def test_candidate_evaluator_on_arx_matches_reference_simulate():
+    """The reference's simulate() with MPPI on its fitted ARX model (history 3: the model state is
+    the stacked history, not the observation) replayed through the device-resident evaluator;
+    Koopman, whose controller state is re-lifted from every observation, is refused."""
+    from autompc_amd.tuning import CandidateEvaluator
+    g = golden("linear_arx3")
+    system, m = _host_model("arx3", g)
+    m.set_parameters({"coeffs": np.concatenate([g["A"][:3], g["B"][:3]], axis=1)})
+    task = _task(system, g, True)
+    N, H, T, scale = int(g["N"]), int(g["H"]), 6, np.sqrt(float(g["sigma"]))
+    np.random.seed(int(g["np_seed"]))
+    act0 = np.random.normal(scale=scale, size=(H, 1))
+    eps = np.stack([np.random.normal(scale=scale, size=(N, H, 1)) for _ in range(T)])
+    ev = CandidateEvaluator(system, task, m)
+    cand = dict(horizon=H, sigma=float(g["sigma"]), lmda=float(g["lmda"]), num_path=N, Q=g["Q"], R=g["R"], F=g["F"])
+    scores, obs, ctrls = ev.evaluate([cand], n_steps=T, init_obs=g["init"], eps_all=eps, act_init=act0,
+                                     return_trajectories=True)
+    assert obs.shape[2] == m.state_dim
+    assert rel_err(obs[0][:, :3], g["mppi_obs"]) < 1e-8 and rel_err(ctrls[0], g["mppi_ctrls"]) < 1e-8
+    assert abs(scores[0] - g["mppi_score"]) < 1e-7 * abs(g["mppi_score"])
+    gk = golden("linear_koop_full")
+    systemk, mk = _host_model("koop_full", gk)
+    mk.set_parameters({"A": gk["A"], "B": gk["B"]})
+    with pytest.raises(TypeError, match="update_state"):
+        CandidateEvaluator(systemk, _task(systemk, gk, True), mk)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("tag", CASES)
 def test_device_ilqr_matches_reference(tag):
     from autompc_amd import IterativeLQR, simulate
