@@ -400,6 +400,9 @@ class IlqrCandidateEvaluator:
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         if precision != "f64":
             raise ValueError("iLQR solves in f64 (control/ilqr.py: f32 is outside the parity mode)")
+        if model.state_dim != system.obs_dim:
+            raise TypeError("IlqrCandidateEvaluator carries the observation as the model state (MLP, SINDy); "
+                            "score %s candidates with simulate() and the drop-in controller" % type(model).__name__)
         self.system, self.task, self.model = system, task, model
         self.surrogate = surrogate if surrogate is not None else model
         self.precision, self.device = precision, device

@@ -35,7 +35,7 @@ class BatchPipelineTuner:
     required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
 
     def __init__(self, system, evaluator, batch_size=64, sampler=None, truedyn_noise="device",
-                 eval_kwargs=None):
+                 eval_kwargs=None, keep_trajs=False):
         """truedyn_noise: the noise mode of the controllers scored against the true dynamics
         (MPPI(noise=...): "device" Philox, or "numpy" / "numpy_device" = the reference's global
         legacy stream).  eval_kwargs: extra keyword arguments for every ``evaluator.evaluate`` call
@@ -43,6 +43,10 @@ class BatchPipelineTuner:
         self.system, self.evaluator = system, evaluator
         self.truedyn_noise = truedyn_noise
         self.eval_kwargs = dict(eval_kwargs or {})
+        # keep_trajs: also record every candidate's surrogate trajectory as (obs rows, control rows)
+        # lists, what the reference keeps in info["surr_traj"] (pipeline_tuner.py:234) and returns
+        # as PipelineTuneResult.surr_trajs; they travel between ranks with all_gather_object
+        self.keep_trajs = bool(keep_trajs)
         self.batch_size = int(batch_size)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -52,6 +56,7 @@ class BatchPipelineTuner:
     def reset(self):
         self.cfgs, self.costs, self.inc_cfgs, self.inc_costs = [], [], [], []
         self.truedyn_costs, self.inc_truedyn_costs = [], []
+        self.surr_trajs = []
         self._inc_cfg, self._inc_cost, self._inc_truedyn = None, float("inf"), None
 
     def _random_search(self, n, rng):
@@ -94,7 +99,8 @@ class BatchPipelineTuner:
                                   inc_cfgs=list(self.inc_cfgs), costs=list(self.costs),
                                   inc_costs=list(self.inc_costs),
                                   truedyn_costs=list(self.truedyn_costs),
-                                  inc_truedyn_costs=list(self.inc_truedyn_costs), surr_trajs=[],
+                                  inc_truedyn_costs=list(self.inc_truedyn_costs),
+                                  surr_trajs=list(self.surr_trajs),
                                   truedyn_trajs=[], surr_tune_result=None)
 
     # -- the loop -----------------------------------------------------------------------------
@@ -126,6 +132,16 @@ class BatchPipelineTuner:
         traj = simulate(ctl, ev.task.get_init_obs(), ev.task.term_cond, dynamics=truedyn, **kw)
         return float(ev.task.get_cost()(traj))
 
+    @staticmethod
+    def _gather_trajs(kept, n):
+        """Every rank's {batch index: trajectory} -> the batch's trajectories in candidate order."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            parts = [None] * dist.get_world_size()
+            dist.all_gather_object(parts, kept)
+            kept = {k: v for part in parts for k, v in part.items()}
+        return [kept[i] for i in range(n)]
+
     def run(self, n_iters, rng, seed=0, truedyn=None):
         """Evaluate `n_iters` candidates in batches of `batch_size`.  Every rank must call this
         with an identically seeded `rng` (proposals are drawn redundantly on every rank so that
@@ -138,10 +154,22 @@ class BatchPipelineTuner:
             batch = self.ask(n, rng)
             # randomness keyed by (seed, global evaluation index): scores do not depend on the
             # world size or on the batch size
-            scores = evaluate_sharded(
-                lambda shard, lo, d=done: self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo,
-                                                                  **self.eval_kwargs),
-                batch)
+            kept = {}
+
+            def local(shard, lo, d=done):
+                if not self.keep_trajs:
+                    return self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo, **self.eval_kwargs)
+                sc, obs, ctl = self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo,
+                                                       return_trajectories=True, **self.eval_kwargs)
+                lens = getattr(self.evaluator, "last_lengths", None)
+                no = self.system.obs_dim
+                for i in range(len(shard)):
+                    L = int(lens[i]) if lens is not None else obs.shape[1]
+                    kept[lo + i] = (obs[i, :L, :no].tolist(), ctl[i, :L].tolist())
+                return sc
+            scores = evaluate_sharded(local, batch)
+            if self.keep_trajs:
+                self.surr_trajs.extend(self._gather_trajs(kept, n))
             td = None
             if truedyn is not None:
                 td = evaluate_sharded(

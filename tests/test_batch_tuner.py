@@ -16,20 +16,31 @@ class _FormulaEvaluator:
     def __init__(self):
         self.calls = []
 
-    def evaluate(self, candidates, seed=0, index_offset=0):
+    def evaluate(self, candidates, seed=0, index_offset=0, return_trajectories=False):
         self.calls.append((len(candidates), seed, index_offset))
         out = []
         for c in candidates:
             s = abs(c["sigma"] - 0.7) + 0.01 * c["horizon"] + float(np.sum(np.log10(c["Q"])) ** 2) * 1e-3
             out.append(np.nan if c["horizon"] == 13 else s)      # one "diverged" family
-        return np.array(out)
+        if not return_trajectories:
+            return np.array(out)
+        # ragged "trajectories": candidate i keeps horizon % 4 + 2 rows of a 6-row, NaN-padded array
+        B = len(candidates)
+        self.last_lengths = np.array([c["horizon"] % 4 + 2 for c in candidates])
+        obs = np.full((B, 6, 3), np.nan)
+        ctl = np.full((B, 6, 2), np.nan)
+        for i, c in enumerate(candidates):
+            L = self.last_lengths[i]
+            obs[i, :L] = c["sigma"] + np.arange(L)[:, None]
+            ctl[i, :L] = c["lmda"]
+        return np.array(out), obs, ctl
 
 
-def _run(n_iters, batch):
+def _run(n_iters, batch, keep_trajs=False):
     from autompc_amd.tuning import BatchPipelineTuner
     system = make_system(3, 2)
     ev = _FormulaEvaluator()
-    tuner = BatchPipelineTuner(system, ev, batch_size=batch)
+    tuner = BatchPipelineTuner(system, ev, batch_size=batch, keep_trajs=keep_trajs)
     best, res = tuner.run(n_iters, np.random.default_rng(4), seed=10)
     return ev, best, res
 
@@ -84,8 +95,8 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ev, best, res = _run(21, 8)
-    q.put((rank, res.costs, [c[0] for c in ev.calls], [c[2] for c in ev.calls]))
+    ev, best, res = _run(21, 8, keep_trajs=True)
+    q.put((rank, res.costs, [c[0] for c in ev.calls], [c[2] for c in ev.calls], res.surr_trajs))
     dist.destroy_process_group()
 
 
@@ -99,12 +110,18 @@ def test_two_ranks_agree_and_split_the_work():
         p.start()
     got = {}
     for _ in range(2):
-        rank, costs, sizes, offsets = q.get(timeout=120)
-        got[rank] = (costs, sizes, offsets)
+        rank, costs, sizes, offsets, trajs = q.get(timeout=120)
+        got[rank] = (costs, sizes, offsets, trajs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    _, _, single = _run(21, 8)
+    _, _, single = _run(21, 8, keep_trajs=True)
+    # surr_trajs (pipeline_tuner.py:234, PipelineTuneResult): every rank ends up with every
+    # candidate's (obs rows, control rows), in evaluation order, cut to the candidate's own length
+    assert len(single.surr_trajs) == 21
+    for cfg, (o, c) in zip(single.cfgs, single.surr_trajs):
+        assert len(o) == len(c) == cfg["horizon"] % 4 + 2 and o[0][0] == cfg["sigma"] and c[-1][1] == cfg["lmda"]
+    assert got[0][3] == single.surr_trajs and got[1][3] == single.surr_trajs
     np.testing.assert_array_equal(got[0][0], single.costs)
     np.testing.assert_array_equal(got[1][0], single.costs)
     assert got[0][1] == [4, 4, 3] and got[1][1] == [4, 4, 2]    # shards of batches 8, 8, 5
