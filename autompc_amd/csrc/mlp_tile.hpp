@@ -244,6 +244,12 @@ __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m *
 
 // (constexpr on plain integers: the shape-specialised kernels evaluate it at compile time, the host
 // at plan build -- both must agree, see StaticShape below)
+// Row stride of the output-layer partials [W][M][.]: nxp in f64; nxp + 4 in f32, where a wave's
+// ds_write_b32 stores accumulator rows r and 4 + r of 16 columns per 32-lane group -- with a stride
+// of 32 dwords both rows hit the same 16 banks (the last third of round 2's f32 store conflicts),
+// with 36 they are 16 banks apart.
+__host__ __device__ constexpr int part_stride(int esz, int nxp) { return esz == 4 ? nxp + 4 : nxp; }
+
 __host__ __device__ constexpr TileLds tile_lds_dims(int esz, int hpad, int k1p, int nxp, int n_hidden,
                                                     int M, int W, bool separate_partials,
                                                     bool double_act) {
@@ -261,9 +267,9 @@ __host__ __device__ constexpr TileLds tile_lds_dims(int esz, int hpad, int k1p, 
     L.act = o; o += M * L.act_stride;
     L.act2 = L.act;
     if (double_act && n_hidden > 1) { L.act2 = o; o += M * L.act_stride; }
-    L.part = o; o += W * M * nxp;
+    L.part = o; o += W * M * part_stride(esz, nxp);
   } else {
-    const int a = L.act_stride, b = W * nxp;
+    const int a = L.act_stride, b = W * part_stride(esz, nxp);
     L.act = o; L.act2 = o; L.part = o; o += M * (a > b ? a : b);
   }
   L.xu = o; o += M * L.xu_stride;
@@ -922,7 +928,8 @@ struct TileNet {
     if (!side_done) side();
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
-    T* part = lds + L.part + w * M * m.nxp;
+    const int ps = part_stride((int)sizeof(T), m.nxp);
+    T* part = lds + L.part + w * M * ps;
     const int nfull = m.tail4 ? 1 : no;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -932,10 +939,10 @@ struct TileNet {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * mt + acc_row<T>(q, r);
-            part[row * m.nxp + 16 * n + i] = oacc[mt][n][r];
+            part[row * ps + 16 * n + i] = oacc[mt][n][r];
           }
         }
-      if (m.tail4) part[(16 * mt + tail_row(lane)) * m.nxp + 16 + tail_col(lane)] = tacc[mt];
+      if (m.tail4) part[(16 * mt + tail_row(lane)) * ps + 16 + tail_col(lane)] = tacc[mt];
     }
     AMPC_MARK(13);
     lds_barrier();
@@ -947,10 +954,11 @@ struct TileNet {
                                              int row, int col) {
     const MlpDev<T> m = SH::template fold<T>(m_in);
     const TileLds L = SH::template fold_lds<T, M, W>(L_in);
-    const T* p = lds + L.part + row * m.nxp + col;
+    const int ps = part_stride((int)sizeof(T), m.nxp);
+    const T* p = lds + L.part + row * ps + col;
     T y = lds[L.bias + m.n_hidden * m.hpad + col];
 #pragma unroll
-    for (int w = 0; w < W; ++w) y += p[w * M * m.nxp];
+    for (int w = 0; w < W; ++w) y += p[w * M * ps];
     return y;
   }
 };
