@@ -66,6 +66,8 @@ SIGNATURES = {
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
     "ampc_mppi_run": (c_int, [c_void_p, _dp, _dp, c_int, c_uint64, c_uint64, _dp]),
+    "ampc_mppi_run_legacy": (c_int, [c_void_p, _dp, _dp, POINTER(c_uint32), c_int, c_int, c_double,
+                                     POINTER(c_uint32), _ip, _ip, _dp, _dp]),
     "ampc_mppi_plan_info": (c_int, [c_void_p, _ip, _ip, _dp, _dp]),
     "ampc_mppi_plan_set_outputs": (c_int, [c_void_p, c_int]),
     "ampc_mppi_plan_set_timing": (c_int, [c_void_p, c_int]),
@@ -376,9 +378,9 @@ class MppiPlan:
         path = os.path.join(_HERE, "data", "mt19937_jump.npz")
         if os.path.exists(path):
             d = np.load(path)
-            polys = np.ascontiguousarray(d["polys"], dtype=np.uint32)
-            check(lib.ampc_set_mt_jump_table(polys.ctypes.data_as(POINTER(c_uint32)), polys.shape[0],
-                                             int(d["jump_blocks"])))
+            for j in d["jumps"]:           # one table per segment length
+                polys = np.ascontiguousarray(d["polys_%d" % int(j)], dtype=np.uint32)
+                check(lib.ampc_set_mt_jump_table(polys.ctypes.data_as(POINTER(c_uint32)), polys.shape[0], int(j)))
 
     def legacy_normal(self, state):
         """Fill the noise buffer with numpy's legacy normal draw for the generator state `state`
@@ -396,6 +398,19 @@ class MppiPlan:
                                                ctypes.byref(pos_out), ctypes.byref(hg_out),
                                                ctypes.byref(cached_out)))
         return ("MT19937", key_out, pos_out.value, hg_out.value, cached_out.value)
+
+    def legacy_normal_inplace(self, ls):
+        """legacy_normal() on numpy's global generator where it lives (ls: _npstate.LegacyState):
+        the library reads the MT19937 key from numpy's memory and writes the state after the draw
+        back into it -- no get_state() / set_state() conversions (~100 us of a 450 us call)."""
+        self._install_jump_table(self.lib)
+        pos_out, hg_out, cached_out = c_int(), c_int(), c_double()
+        with ls.lock:
+            check(self.lib.ampc_mppi_legacy_normal(self._p, ls.key_ptr, int(ls.key[624]), ls.has_gauss.value,
+                                                   ls.gauss.value, ls.key_ptr, ctypes.byref(pos_out),
+                                                   ctypes.byref(hg_out), ctypes.byref(cached_out)))
+            ls.key[624] = pos_out.value
+            ls.has_gauss.value, ls.gauss.value = hg_out.value, cached_out.value
 
     def set_geometry(self, tile_rows=0, horizon_cap=0):
         """Fix the rollout tile height (0 = automatic, 16/32/64) and the horizon the LDS layout is
@@ -438,6 +453,25 @@ class MppiPlan:
         seed, stream = philox if philox is not None else (0, 0)
         check(self.lib.ampc_mppi_run(self._p, dptr(x0), dptr(act_seq), 0 if philox is None else 1,
                                      int(seed), int(stream), dptr(u)))
+        return u
+
+    def run_legacy_inplace(self, x0, act_seq, ls):
+        """run() with the reference's own noise: numpy's legacy draw from the global generator
+        where it lives (ls: _npstate.LegacyState; see legacy_normal_inplace) and the solve, in one
+        library call with one synchronisation (ampc_mppi_run_legacy)."""
+        self._install_jump_table(self.lib)
+        nx, nu = self.handle.nx, self.handle.nu
+        x0 = self._flat(x0, self.B * nx, "x0")
+        act_seq = self._flat(act_seq, self.sum_hnu, "act_seq")
+        u = np.empty((self.B, nu))
+        pos_out, hg_out, cached_out = c_int(), c_int(), c_double()
+        with ls.lock:
+            check(self.lib.ampc_mppi_run_legacy(self._p, dptr(x0), dptr(act_seq), ls.key_ptr, int(ls.key[624]),
+                                                ls.has_gauss.value, ls.gauss.value, ls.key_ptr,
+                                                ctypes.byref(pos_out), ctypes.byref(hg_out),
+                                                ctypes.byref(cached_out), dptr(u)))
+            ls.key[624] = pos_out.value
+            ls.has_gauss.value, ls.gauss.value = hg_out.value, cached_out.value
         return u
 
     def set_x0_dev(self, ptr):

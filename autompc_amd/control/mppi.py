@@ -19,7 +19,7 @@ What runs where
 """
 import numpy as np
 
-from .. import _lib
+from .. import _lib, _npstate
 from .controller import Controller, ControllerFactory
 
 
@@ -164,17 +164,24 @@ class MPPI(Controller):
             # (mppi.py:16-24, :126).  The device reproduces that draw bit for bit when the
             # library has proven its restatement of the host C library's log() against log()
             # itself (ampc_legacy_log_mode) and the global generator is the MT19937 it models.
-            state = np.random.get_state() if _lib.legacy_log_mode() != 0 else None
-            mode = "numpy_device" if state is not None and state[0] == "MT19937" else "numpy_host"
+            # The generator's state is read and updated where numpy keeps it (_npstate) when that
+            # layout is recognised, through get_state() / set_state() otherwise.
+            ls = state = None
+            if _lib.legacy_log_mode() != 0:
+                ls = _npstate.get()
+                if ls is None:
+                    state = np.random.get_state()
+            mode = "numpy_device" if ls is not None or (state is not None and state[0] == "MT19937") else "numpy_host"
         else:
             state = None
+            ls = _npstate.get() if mode == "numpy_device" else None
         if return_details:
             if mode == "numpy_host":
                 eps = np.random.normal(scale=self._scale, size=(self.num_path, self.H, nu))
                 plan.upload(x0=x0, act_seq=act, eps=eps)
             elif mode == "numpy_device":
                 plan.upload(x0=x0, act_seq=act)
-                np.random.set_state(plan.legacy_normal(state if state is not None else np.random.get_state()))
+                self._legacy_draw(plan, ls, state)
             else:
                 plan.upload(x0=x0, act_seq=act)
                 plan.generate_eps(self.seed, self.cur_step)
@@ -192,14 +199,24 @@ class MPPI(Controller):
             elif mode == "numpy_device":
                 # the same draw from the same global generator state, made on the device; the host
                 # generator is then put into the state the draw would have left it in
-                np.random.set_state(plan.legacy_normal(state if state is not None else np.random.get_state()))
-                u = plan.run(x0, act)
+                if ls is not None:
+                    u = plan.run_legacy_inplace(x0, act, ls)
+                else:
+                    self._legacy_draw(plan, ls, state)
+                    u = plan.run(x0, act)
             else:
                 u = plan.run(x0, act, philox=(self.seed, self.cur_step))
             self._act_dirty = False
         self.cur_step += 1
         ret_action = u[0].copy()
         return ret_action, np.concatenate([x0, ret_action])
+
+    @staticmethod
+    def _legacy_draw(plan, ls, state):
+        if ls is not None:
+            plan.legacy_normal_inplace(ls)
+        else:
+            np.random.set_state(plan.legacy_normal(state if state is not None else np.random.get_state()))
 
     def traj_to_state(self, traj):
         return np.concatenate([self.model.traj_to_state(traj), traj[-1].ctrl])

@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 103; }   // 1.03: round 3 (ampc_set_sindy gained the monomial pair list)
+extern "C" int ampc_version(void) { return 104; }   // 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -622,12 +622,14 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
-                    &p->lg_scale, &p->lg_xraw, &p->lg_poly, &p->lg_win, &p->lg_logtab, &p->lg_gather};
+                    &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
+                    &p->lg_win, &p->lg_logtab, &p->lg_gather};
   if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
-  if (p->lg_ev) (void)hipEventDestroy(p->lg_ev);
+  for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
+  if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
@@ -679,41 +681,71 @@ extern "C" int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t
                                      : mppi_generate_impl<float>(p, seed, stream);
 }
 // numpy's legacy normal stream generated on the device (legacy_rng_kernels.hpp)
-static std::vector<uint32_t> g_mt_polys;      // [n][624] jump polynomials (tools/mt_jump.py), host copy
-static int g_mt_jump_blocks = 0;
+// Jump polynomial tables (tools/mt_jump.py), host copies, ascending in segment length.  Short
+// segments make a short chain (a short-horizon plan's run-ahead is ready within a control step or
+// two), long segments need fewer jump evaluations per block (config 3's run-ahead: 24 k blocks).
+struct MtJumpTable {
+  int jump_blocks = 0;
+  std::vector<uint32_t> polys;                  // [n][624]
+  long long cap() const { return (long long)(polys.size() / kMtN) * jump_blocks; }   // blocks it covers
+};
+constexpr int kMtMaxTables = 4;
+static std::vector<MtJumpTable> g_mt_tables;
 static constexpr int kMtHead = 34;            // blocks 0..33 come from the sequential head kernel
 
 extern "C" int ampc_set_mt_jump_table(const uint32_t* polys, int n_polys, int jump_blocks) {
   REQUIRE(polys && n_polys >= 1 && jump_blocks >= kMtHead, "ampc_set_mt_jump_table: bad table");
-  g_mt_polys.assign(polys, polys + (size_t)n_polys * kMtN);
-  g_mt_jump_blocks = jump_blocks;
+  MtJumpTable t;
+  t.jump_blocks = jump_blocks;
+  t.polys.assign(polys, polys + (size_t)n_polys * kMtN);
+  for (auto& old : g_mt_tables)
+    if (old.jump_blocks == jump_blocks) { old = std::move(t); return 0; }
+  REQUIRE((int)g_mt_tables.size() < kMtMaxTables, "ampc_set_mt_jump_table: too many tables");
+  g_mt_tables.push_back(std::move(t));
+  std::sort(g_mt_tables.begin(), g_mt_tables.end(),
+            [](const MtJumpTable& x, const MtJumpTable& y) { return x.jump_blocks < y.jump_blocks; });
   return 0;
 }
 
+// most blocks any installed table covers (0: none installed)
+static long long mt_jump_cap() {
+  long long c = 0;
+  for (const auto& t : g_mt_tables) c = std::max(c, t.cap());
+  return c;
+}
+
 // raw MT19937 stream of `nblocks` blocks from `key` into `stream` (enqueued on `st`): the head
-// sequentially, the rest block-parallel when the jump table covers it
+// sequentially, the rest block-parallel with the shortest segments whose table covers it
 static int launch_mt_stream(ampc_mppi_plan* p, hipStream_t st, const uint32_t* d_key, int nblocks,
                             uint32_t* stream) {
-  const int nseg = g_mt_jump_blocks > 0 ? (nblocks - 1 + g_mt_jump_blocks - 1) / g_mt_jump_blocks : 0;
-  const bool par = nseg >= 1 && nblocks > kMtHead && (size_t)(nseg - 1) * kMtN <= g_mt_polys.size();
+  int ti = -1;
+  for (int i = 0; i < (int)g_mt_tables.size() && ti < 0; ++i)
+    if (g_mt_tables[i].cap() >= nblocks) ti = i;
+  // block-parallel only where it pays: the head kernel (34 blocks, 22 us), the jump kernel (>= 23 us)
+  // and a segment cost more than generating up to ~128 blocks in one sequential kernel (0.66 us each)
+  const bool par = ti >= 0 && nblocks > std::max(kMtHead, env_int("AMPC_MT_PAR_MIN", 128));
   if (!par) {
     hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, st, d_key, nblocks, stream, (uint32_t*)nullptr);
     return 0;
   }
+  const MtJumpTable& t = g_mt_tables[ti];
+  const int nseg = (nblocks - 1 + t.jump_blocks - 1) / t.jump_blocks;
   HIP_OK(p->lg_xraw.reserve((size_t)(kMtHead - 1) * kMtN * sizeof(uint32_t)));
-  if (p->lg_poly.bytes == 0) {
-    HIP_OK(p->lg_poly.reserve(g_mt_polys.size() * sizeof(uint32_t)));
-    HIP_OK(hipMemcpy(p->lg_poly.p, g_mt_polys.data(), g_mt_polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  DevBuf& dpoly = p->lg_poly[ti];
+  if (dpoly.bytes != t.polys.size() * sizeof(uint32_t)) {
+    HIP_OK(dpoly.reserve(t.polys.size() * sizeof(uint32_t)));
+    HIP_OK(hipMemcpy(dpoly.p, t.polys.data(), t.polys.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    dpoly.bytes = t.polys.size() * sizeof(uint32_t);
   }
   hipLaunchKernelGGL(mt19937_stream_kernel, dim3(1), dim3(256), 0, st, d_key, kMtHead, stream, (uint32_t*)p->lg_xraw.p);
   if (nseg > 1) {
     HIP_OK(p->lg_win.reserve((size_t)(nseg - 1) * kMtN * sizeof(uint32_t)));
     HIP_OK(hipMemsetAsync(p->lg_win.p, 0, (size_t)(nseg - 1) * kMtN * sizeof(uint32_t), st));
     hipLaunchKernelGGL(mt19937_jump_kernel, dim3(nseg - 1, kMtSlices), dim3(256), 0, st,
-                       (const uint32_t*)p->lg_xraw.p, (const uint32_t*)p->lg_poly.p, (uint32_t*)p->lg_win.p);
+                       (const uint32_t*)p->lg_xraw.p, (const uint32_t*)dpoly.p, (uint32_t*)p->lg_win.p);
   }
   hipLaunchKernelGGL(mt19937_segment_kernel, dim3(nseg), dim3(256), 0, st, (const uint32_t*)p->lg_xraw.p,
-                     (const uint32_t*)p->lg_win.p, kMtHead, g_mt_jump_blocks, nblocks, stream);
+                     (const uint32_t*)p->lg_win.p, kMtHead, t.jump_blocks, nblocks, stream);
   return 0;
 }
 
@@ -790,50 +822,76 @@ static int host_log_mode() {
 
 extern "C" int ampc_legacy_log_mode(void) { return host_log_mode(); }
 
-static uint32_t mt_untemper(uint32_t y) {
-  y ^= y >> 18;
-  y ^= (y << 15) & 0xefc60000u;
-  uint32_t t = y;                                   // invert y ^= (y << 7) & 0x9d2c5680
-  for (int i = 0; i < 4; ++i) t = y ^ ((t << 7) & 0x9d2c5680u);
-  y = t;
-  t = y;                                            // invert y ^= y >> 11
-  for (int i = 0; i < 2; ++i) t = y ^ (t >> 11);
-  return t;
+// What the enqueue phase of a legacy draw leaves for the phases after it.
+struct LegacyDraw {
+  bool trivial = false;      // the single value asked for was the cached one: nothing was drawn
+  int pos = 0, shift = 0;
+  long long n = 0, n_pairs = 0, n_att = 0;
+};
+
+constexpr size_t kLegacyGather = 3 * sizeof(long long) + kMtN * sizeof(uint32_t);
+
+// blocks a draw of n_att attempts can touch, counted from the block holding the generator's key
+static int legacy_blocks_for(int start_pos, long long n_att) {
+  return (int)(((long long)start_pos + 4 * n_att) / kMtN) + 2;
 }
 
+// A legacy draw runs in three phases so that a caller can put a whole control step between them
+// (ampc_mppi_run_legacy) and synchronise ONCE:
+//   legacy_enqueue    main stream: the normals into the plan's noise buffer; what the host needs
+//                     afterwards (last attempt, cached value, the stream block the generator ends
+//                     in) gathered and copied to pinned memory
+//   legacy_speculate  side stream: keeps the raw MT19937 stream generated AHEAD of the draws
+//   legacy_finish     after the main stream has been synchronised: the generator state to hand back.
+//
+// Run-ahead.  Generating the raw stream is a latency-bound chain (sequential head, jump
+// polynomials, segments; ~125 us for one config-3 draw) and, run next to a rollout, it and the
+// rollout slow each other down (they share the CUs' LDS pipelines: measured 5x on the chain, +40 us
+// on the rollout).  So it is not done per call: a buffer holds the stream of SEVERAL calls
+// (AMPC_LEGACY_AHEAD, 8), and while the calls consume buffer c the side stream fills buffer 1 - c
+// with the continuation from block lg_next_from of c -- placed one call's worth before the end of c,
+// so that a call starting before that block still fits into c and a call starting at or after it
+// switches buffers.  The chain then has several control steps of time to finish and its cost is
+// paid once per several calls.  A call whose generator state is not the one the previous call left
+// (someone else drew from numpy's generator in between) generates its own words on the main
+// stream and the run-ahead starts again from there.
 template <typename T>
-static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
-                              uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out) {
+static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
+                          LegacyDraw* d) {
   ampc_handle* h = p->h;
   const long long n = p->sum_nhnu;
   const int shift = has_gauss ? 1 : 0;
   const long long n_pairs = (n - shift + 1) / 2;
+  d->pos = pos; d->shift = shift; d->n = n; d->n_pairs = n_pairs;
   if (n_pairs == 0) {          // the single value asked for is the cached one
     HIP_OK(p->lg_scale.reserve(sizeof(double)));
     const double sc = std::sqrt(p->sigma[0]);
     HIP_OK(hipMemcpyAsync(p->lg_scale.p, &sc, sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(legacy_first_value_kernel<T>, dim3(1), dim3(64), 0, h->stream, cached,
                        (const double*)p->lg_scale.p, (T*)p->eps.p);
-    HIP_OK(hipStreamSynchronize(h->stream));
-    std::memcpy(key_out, key, kMtN * sizeof(uint32_t));
-    *pos_out = pos; *has_gauss_out = 0; *cached_out = 0.0;
+    HIP_OK(hipStreamSynchronize(h->stream));          // (sc is on the stack)
+    d->trivial = true;
     return 0;
   }
-  // attempts to evaluate: acceptance probability pi/4, 2 % + 4096 slack (the count is checked)
-  const long long n_att = (long long)((double)n_pairs / 0.7853981633974483 * 1.02) + 4096;
-  auto blocks_for = [&](int start_pos) { return (int)(((long long)start_pos + 4 * n_att) / kMtN) + 2; };
-  const int nblocks = blocks_for(pos);
+  // attempts to evaluate: acceptance probability pi/4; the number needed for n_pairs acceptances
+  // has mean n_pairs / p and standard deviation sqrt(n_pairs (1 - p)) / p.  16 standard deviations
+  // + 64 of slack (the count is checked afterwards); words past the last consumed one cost
+  // generation time only, so the slack is kept small: a short horizon's draw then fits a few blocks.
+  const double kAcc = 0.7853981633974483;
+  const long long n_att = (long long)(((double)n_pairs + 16.0 * std::sqrt((double)n_pairs * (1.0 - kAcc))) / kAcc) + 64;
+  d->n_att = n_att;
+  const int nblocks = legacy_blocks_for(pos, n_att);
   const int n_wg = (int)((n_att + kPolarPerWg - 1) / kPolarPerWg);
   REQUIRE(n_wg <= 65536 * 16, "legacy normal: too many values for one call");
   if (!p->lg_side) {
     HIP_OK(hipStreamCreateWithFlags(&p->lg_side, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&p->lg_ev, hipEventDisableTiming));
+    for (hipEvent_t& e : p->lg_evs) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&p->lg_drawn, hipEventDisableTiming));
   }
   HIP_OK(p->lg_cnt.reserve(((size_t)n_wg + 1) * sizeof(int)));
   HIP_OK(p->lg_fin.reserve(2 * sizeof(long long)));
-  constexpr size_t kGather = 3 * sizeof(long long) + kMtN * sizeof(uint32_t);
-  HIP_OK(p->lg_gather.reserve(kGather));
-  if (!p->lg_pin) HIP_OK(hipHostMalloc(&p->lg_pin, kGather, hipHostMallocDefault));
+  HIP_OK(p->lg_gather.reserve(kLegacyGather));
+  if (!p->lg_pin) HIP_OK(hipHostMalloc(&p->lg_pin, kLegacyGather, hipHostMallocDefault));
   if (!p->lg_scale_set) {            // sqrt(sigma_b): once per plan
     HIP_OK(p->lg_scale.reserve((size_t)p->B * sizeof(double)));
     std::vector<double> sc(p->B);
@@ -841,24 +899,33 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
     HIP_OK(hipMemcpy(p->lg_scale.p, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice));
     p->lg_scale_set = true;
   }
-  // the raw stream: the speculation of the previous call if this call starts where that one ended
-  const bool hit = p->lg_spec && p->lg_spec_pos == pos && p->lg_spec_blocks >= nblocks &&
-                   std::memcmp(p->lg_spec_key.data(), key, kMtN * sizeof(uint32_t)) == 0;
-  int buf = p->lg_cur;
+  // where the words come from: the run-ahead if this call starts where the previous one ended
+  bool hit = p->lg_spec && p->lg_spec_pos == pos &&
+             std::memcmp(p->lg_spec_key.data(), key, kMtN * sizeof(uint32_t)) == 0;
+  if (hit && p->lg_next && p->lg_blk0 >= p->lg_next_from) {     // past the continuation's start: switch
+    p->lg_blk0 -= p->lg_next_from;
+    p->lg_cur = 1 - p->lg_cur;
+    p->lg_next = false;
+  }
+  if (hit && p->lg_blocks[p->lg_cur] - p->lg_blk0 < nblocks) hit = false;    // (buffer too short)
   if (hit) {
-    HIP_OK(hipStreamWaitEvent(h->stream, p->lg_ev, 0));
+    HIP_OK(hipStreamWaitEvent(h->stream, p->lg_evs[p->lg_cur], 0));
+    ++p->lg_hits;
   } else {
-    if (p->lg_spec) HIP_OK(hipStreamSynchronize(p->lg_side));       // (a stale speculation still running)
-    buf = p->lg_cur = 0;
+    HIP_OK(hipStreamSynchronize(p->lg_side));         // (a stale run-ahead may still be running)
+    p->lg_cur = 0; p->lg_blk0 = 0; p->lg_next = false; p->lg_hits = 0;
     HIP_OK(p->lg_key[0].reserve(kMtN * sizeof(uint32_t)));
     HIP_OK(p->lg_stream[0].reserve((size_t)nblocks * kMtN * sizeof(uint32_t)));
     HIP_OK(hipMemcpyAsync(p->lg_key[0].p, key, kMtN * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));          // (sources are stack / caller memory)
+    HIP_OK(hipStreamSynchronize(h->stream));          // (the source is caller memory)
     if (int rc = launch_mt_stream(p, h->stream, (const uint32_t*)p->lg_key[0].p, nblocks,
                                   (uint32_t*)p->lg_stream[0].p)) return rc;
+    HIP_OK(hipEventRecord(p->lg_drawn, h->stream));
+    HIP_OK(hipStreamWaitEvent(p->lg_side, p->lg_drawn, 0));      // (the side stream reads this buffer)
+    p->lg_blocks[0] = nblocks;
   }
   p->lg_spec = false;
-  uint32_t* stream = (uint32_t*)p->lg_stream[buf].p;
+  const uint32_t* stream = (const uint32_t*)p->lg_stream[p->lg_cur].p + (size_t)p->lg_blk0 * kMtN;
   const uint32_t* u = stream + pos;                 // the generator's next output
   int* cnt = (int*)p->lg_cnt.p;
   hipLaunchKernelGGL(polar_count_kernel, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, cnt);
@@ -879,44 +946,80 @@ static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, i
                      (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, (long long*)p->lg_fin.p,
                      (const double*)p->lg_logtab.p);
   HIP_OK(hipGetLastError());
-  // fin, the pair count and the stream block the generator ends in: one copy, one synchronisation
+  // fin, the pair count and the stream block the generator ends in: one copy back
   hipLaunchKernelGGL(legacy_gather_kernel, dim3(1), dim3(256), 0, h->stream, (const long long*)p->lg_fin.p,
-                     (const int*)(cnt + n_wg), (const uint32_t*)stream, pos, (long long*)p->lg_gather.p);
-  HIP_OK(hipMemcpyAsync(p->lg_pin, p->lg_gather.p, kGather, hipMemcpyDeviceToHost, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
+                     (const int*)(cnt + n_wg), stream, pos, (long long*)p->lg_gather.p);
+  HIP_OK(hipMemcpyAsync(p->lg_pin, p->lg_gather.p, kLegacyGather, hipMemcpyDeviceToHost, h->stream));
+  return 0;
+}
+
+static int legacy_speculate(ampc_mppi_plan* p, const LegacyDraw& d) {
+  if (d.trivial || p->lg_next || env_int("AMPC_LEGACY_SPECULATE", 1) == 0) return 0;
+  // the most blocks one call can touch (a position of 624 at entry)
+  const int per_call = legacy_blocks_for(kMtN, d.n_att);
+  // Continuation of the current buffer from one call's worth before its end.  Its length: `ahead`
+  // calls (2 right after a miss -- the very next call waits for it), at least two calls' worth so
+  // that every buffer serves at least one call, at most what the jump table covers.
+  const int c = p->lg_cur, nb = 1 - c;
+  const int from = std::max(0, p->lg_blocks[c] - per_call);
+  const int ahead = p->lg_hits == 0 ? 2 : std::max(2, env_int("AMPC_LEGACY_AHEAD", 8));
+  long long sb = (long long)ahead * per_call;
+  const long long cap = mt_jump_cap();
+  if (sb > cap) sb = std::max<long long>(cap, 2LL * per_call);
+  HIP_OK(p->lg_key[nb].reserve(kMtN * sizeof(uint32_t)));
+  HIP_OK(p->lg_stream[nb].reserve((size_t)sb * kMtN * sizeof(uint32_t)));
+  hipLaunchKernelGGL(mt19937_key_of_block_kernel, dim3(1), dim3(256), 0, p->lg_side,
+                     (const uint32_t*)p->lg_stream[c].p + (size_t)from * kMtN, (uint32_t*)p->lg_key[nb].p);
+  if (int rc = launch_mt_stream(p, p->lg_side, (const uint32_t*)p->lg_key[nb].p, (int)sb,
+                                (uint32_t*)p->lg_stream[nb].p)) return rc;
+  HIP_OK(hipEventRecord(p->lg_evs[nb], p->lg_side));
+  p->lg_blocks[nb] = (int)sb;
+  p->lg_next = true;
+  p->lg_next_from = from;
+  return 0;
+}
+
+// The main stream has been synchronised: p->lg_pin holds the gathered results.
+static int legacy_finish(ampc_mppi_plan* p, const LegacyDraw& d, const uint32_t* key, uint32_t* key_out,
+                         int* pos_out, int* has_gauss_out, double* cached_out) {
+  if (d.trivial) {
+    if (key_out != key) std::memcpy(key_out, key, kMtN * sizeof(uint32_t));
+    *pos_out = d.pos; *has_gauss_out = 0; *cached_out = 0.0;
+    return 0;
+  }
   const long long* gl = (const long long*)p->lg_pin;
   const long long fin[2] = {gl[0], gl[1]};
   const int total = (int)gl[2];
-  REQUIRE(total >= n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
+  REQUIRE(total >= d.n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
   // generator state after the last consumed word
-  long long idx = (long long)pos + 4 * (fin[0] + 1);
+  const long long idx = (long long)d.pos + 4 * (fin[0] + 1);
   int po = (int)(idx % kMtN);
-  if (po == 0 && idx > 0) po = kMtN;               // randomkit regenerates lazily: pos == 624
+  long long blk = idx / kMtN;
+  if (po == 0 && idx > 0) { po = kMtN; blk -= 1; }  // randomkit regenerates lazily: pos == 624
   const uint32_t* last = (const uint32_t*)(gl + 3);
   for (int i = 0; i < kMtN; ++i) key_out[i] = mt_untemper(last[i]);
   *pos_out = po;
-  const bool odd = ((n - shift) & 1) != 0;
+  const bool odd = ((d.n - d.shift) & 1) != 0;
   *has_gauss_out = odd ? 1 : 0;
   double cg = 0.0;
   if (odd) std::memcpy(&cg, &fin[1], sizeof(double));
   *cached_out = cg;
-  // speculate: the next call most likely starts from the state this one leaves behind (nothing else
-  // drew from the generator in between) and consumes about as many words.  Its stream is generated
-  // on the side stream into the other buffer while the caller's solve runs on the main stream.
-  if (env_int("AMPC_LEGACY_SPECULATE", 1) != 0) {
-    const int nb = 1 - buf;
-    const int sb = blocks_for(po);
-    HIP_OK(p->lg_key[nb].reserve(kMtN * sizeof(uint32_t)));
-    HIP_OK(p->lg_stream[nb].reserve((size_t)sb * kMtN * sizeof(uint32_t)));
-    p->lg_spec_key.assign(key_out, key_out + kMtN);
-    HIP_OK(hipMemcpyAsync(p->lg_key[nb].p, p->lg_spec_key.data(), kMtN * sizeof(uint32_t),
-                          hipMemcpyHostToDevice, p->lg_side));
-    if (int rc = launch_mt_stream(p, p->lg_side, (const uint32_t*)p->lg_key[nb].p, sb,
-                                  (uint32_t*)p->lg_stream[nb].p)) return rc;
-    HIP_OK(hipEventRecord(p->lg_ev, p->lg_side));
-    p->lg_spec = true; p->lg_spec_pos = po; p->lg_spec_blocks = sb; p->lg_cur = nb;
-  }
+  // what the next call has to present to take its words from the run-ahead
+  p->lg_spec_key.assign(key_out, key_out + kMtN);
+  p->lg_spec_pos = po;
+  p->lg_blk0 += (int)blk;
+  p->lg_spec = true;
   return 0;
+}
+
+template <typename T>
+static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
+                              uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out) {
+  LegacyDraw d;
+  if (int rc = legacy_enqueue<T>(p, key, pos, has_gauss, cached, &d)) return rc;
+  if (int rc = legacy_speculate(p, d)) return rc;
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  return legacy_finish(p, d, key, key_out, pos_out, has_gauss_out, cached_out);
 }
 
 extern "C" int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
@@ -1009,15 +1112,23 @@ extern "C" int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u,
 
 // MPPI.run() in one call: x0 (and optionally a new warm start) in, noise, solve, controls out, ONE
 // host synchronisation; x0 and the controls travel through pinned staging buffers.
+struct LegacyState {          // numpy's legacy generator state, in and out (ampc_mppi_run_legacy)
+  const uint32_t* key; int pos, has_gauss; double cached;
+  uint32_t* key_out; int* pos_out; int* has_gauss_out; double* cached_out;
+};
+
 template <typename T>
 static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
-                         uint64_t seed, uint64_t stream, double* u) {
+                         uint64_t seed, uint64_t stream, double* u, const LegacyState* lg = nullptr) {
   ampc_handle* h = p->h;
   const size_t nx0 = (size_t)p->B * h->nx, nuo = (size_t)p->B * h->nu;
   if (!p->pin_x0) {
     HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocDefault));
     HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocDefault));
   }
+  LegacyDraw draw;
+  if (lg)
+    if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw)) return rc;
   T* px = (T*)p->pin_x0;
   for (size_t i = 0; i < nx0; ++i) px[i] = (T)x0[i];
   HIP_OK(hipMemcpyAsync(p->x0.p, px, nx0 * sizeof(T), hipMemcpyHostToDevice, h->stream));
@@ -1026,10 +1137,30 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
     if (int rc = mppi_generate_impl<T>(p, seed, stream)) return rc;
   if (int rc = mppi_solve_impl<T>(p)) return rc;
   HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  // (the solve is on its way: the next call's raw stream goes to the side stream behind it)
+  if (lg)
+    if (int rc = legacy_speculate(p, draw)) return rc;
   HIP_OK(hipStreamSynchronize(h->stream));
+  if (lg)
+    if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
+      return rc;
   const T* pu = (const T*)p->pin_u;
   for (size_t i = 0; i < nuo; ++i) u[i] = (double)pu[i];
   return 0;
+}
+
+extern "C" int ampc_mppi_run_legacy(ampc_mppi_plan* p, const double* x0, const double* act_seq,
+                                    const uint32_t* key, int pos, int has_gauss, double cached,
+                                    uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out,
+                                    double* u) {
+  REQUIRE(p && x0 && u && key && key_out && pos_out && has_gauss_out && cached_out,
+          "ampc_mppi_run_legacy: NULL argument");
+  REQUIRE(pos >= 0 && pos <= kMtN, "ampc_mppi_run_legacy: pos must be in [0, 624]");
+  REQUIRE(p->sum_nhnu > 0, "ampc_mppi_run_legacy: empty plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  const LegacyState lg{key, pos, has_gauss, cached, key_out, pos_out, has_gauss_out, cached_out};
+  return p->h->precision == AMPC_F64 ? mppi_run_impl<double>(p, x0, act_seq, 0, 0, 0, u, &lg)
+                                     : mppi_run_impl<float>(p, x0, act_seq, 0, 0, 0, u, &lg);
 }
 
 extern "C" int ampc_mppi_run(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,

@@ -281,15 +281,23 @@ struct ampc_mppi_plan {
   // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
   // call is generated speculatively on a side stream (it only depends on the generator state this
   // call leaves behind) and used if the next call indeed starts from that state.
-  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly, lg_win, lg_logtab, lg_gather;
+  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly[4], lg_win, lg_logtab, lg_gather;
   void* lg_pin = nullptr;         // pinned landing buffer of lg_gather (fin, total, the final stream block)
   bool lg_scale_set = false;      // sqrt(sigma_b) uploaded (the sigmas of a plan never change)
+  // The raw MT19937 stream is generated AHEAD of the draws, several calls' worth per buffer, on a
+  // side stream (api.cpp: legacy_enqueue / legacy_speculate / legacy_finish):
   hipStream_t lg_side = nullptr;
-  hipEvent_t lg_ev = nullptr;
-  int lg_cur = 0;                 // buffer the speculation (if any) was written to
-  bool lg_spec = false;
-  int lg_spec_pos = 0, lg_spec_blocks = 0;
-  std::vector<uint32_t> lg_spec_key;
+  hipEvent_t lg_evs[2] = {nullptr, nullptr};   // buffer b completely generated
+  hipEvent_t lg_drawn = nullptr;   // main-stream generation finished (a call the run-ahead missed)
+  int lg_blocks[2] = {0, 0};      // blocks of 624 words held by lg_stream[b]
+  int lg_cur = 0;                 // buffer the generator's state currently lies in
+  int lg_blk0 = 0;                // ... and the block of it that is the generator's key
+  bool lg_spec = false;           // lg_cur / lg_blk0 / lg_spec_key / lg_spec_pos describe the state the
+  int lg_spec_pos = 0;            //   previous call left: a call presenting exactly it takes its words
+  std::vector<uint32_t> lg_spec_key;   // from the buffer
+  bool lg_next = false;           // lg_stream[1 - lg_cur] holds (or is receiving) the continuation
+  int lg_next_from = 0;           //   of lg_stream[lg_cur] from this block on
+  int lg_hits = 0;                // consecutive calls served from the run-ahead
   int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
   bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
   int cur = 0;          // act[cur] is the input of the next solve

@@ -37,7 +37,7 @@ enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU
 enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 
 const char* ampc_last_error(void);
-int ampc_version(void);   /* 100 * major + minor; 103: ampc_set_sindy takes the monomial pair list */
+int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -176,13 +176,16 @@ int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
  *   0  another log(): the device uses its own (normals within 3 ulp of numpy's; generator state,
  *      uniforms and accept / reject decisions still exact). */
 int ampc_legacy_log_mode(void);
+/* key_out may be key itself (the generator's own memory: the state is updated in place). */
 int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
                             double cached, uint32_t* key_out, int* pos_out, int* has_gauss_out,
                             double* cached_out);
 /* Jump polynomials of MT19937 (autompc_amd/data/mt19937_jump.npz, computed by tools/mt_jump.py):
- * polys[n_polys][624] = bits of t^(s * jump_blocks * 624) mod phi for s = 1 .. n_polys.  With the
+ * polys[n_polys][624] = bits of t^(s * jump_blocks * 624) mod phi for s = 1 .. n_polys.  With a
  * table installed (process-wide) ampc_mppi_legacy_normal generates the raw stream block-parallel
- * (one workgroup per jump_blocks blocks) instead of sequentially; results are identical. */
+ * (one workgroup per jump_blocks blocks) instead of sequentially; results are identical.  Up to 4
+ * tables with different jump_blocks may be installed side by side: a stream is generated with the
+ * shortest segments whose table covers it. */
 int ampc_set_mt_jump_table(const uint32_t* polys, int n_polys, int jump_blocks);
 /* ids[B]: the noise id of every problem (default: its index in the plan).  The candidate
  * evaluator passes each candidate's GLOBAL index, so that the noise -- and therefore the
@@ -207,6 +210,13 @@ int ampc_mppi_download(ampc_mppi_plan* p, double* act_seq, double* u, double* co
  * without their intermediate synchronisations (the drop-in classes' hot call). */
 int ampc_mppi_run(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise, uint64_t seed,
                   uint64_t stream, double* u);
+/* ampc_mppi_run with the reference's own noise: ampc_mppi_legacy_normal (numpy's legacy draw from
+ * the generator state key / pos / has_gauss / cached, mppi.py:16-24, :126) + ampc_mppi_run(noise 0) in
+ * one call with ONE synchronisation; the state after the draw comes back as from
+ * ampc_mppi_legacy_normal (key_out may be key).  The default mode of the drop-in MPPI.run(). */
+int ampc_mppi_run_legacy(ampc_mppi_plan* p, const double* x0, const double* act_seq, const uint32_t* key,
+                         int pos, int has_gauss, double cached, uint32_t* key_out, int* pos_out,
+                         int* has_gauss_out, double* cached_out, double* u);
 /* Overwrite x0 of every problem from a device buffer [B][nx] in compute precision (closed-loop
  * evaluator: no host round trip). */
 int ampc_mppi_set_x0_dev(ampc_mppi_plan* p, const void* x0_dev);

@@ -251,3 +251,47 @@ def test_each_restated_build_of_log_on_the_device(build):
     out = subprocess.run([sys.executable, "-c", _FORCED_BUILD_SCRIPT.format(root=root, build=build)],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "BUILD_OK %d" % build in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_inplace_generator_state_equals_the_get_set_state_path(monkeypatch):
+    """The default mode reads and updates numpy's global generator where numpy keeps it
+    (autompc_amd._npstate) instead of through get_state() / set_state().  Both routes must give the
+    same controls and leave the same generator state, with host draws in between, and numpy's own
+    stream must continue from it."""
+    from autompc_amd import MLP, MPPI, QuadCost, Task, _npstate
+    if _npstate.get() is None:
+        pytest.skip("numpy's RandomState layout not recognised on this box")
+    g = golden("mppi_c2_pendulum")
+    nx = int(g["nx"])
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
+    system = make_system(nx, 1)
+    m = MLP(system, n_hidden_layers=len(p["weights"]) - 1, nonlintype=p["activation"],
+            **{"hidden_size_%d" % (i + 1): w.shape[0] for i, w in enumerate(p["weights"][:-1])})
+    m.weights, m.biases = p["weights"], p["biases"]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    task.set_ctrl_bounds([g["bounds"][0]], [g["bounds"][1]])
+
+    def episode(inplace):
+        if not inplace:
+            monkeypatch.setattr(_npstate, "get", lambda: None)
+        np.random.seed(5)
+        ctl = MPPI(system, task, m, horizon=int(g["H"]), num_path=int(g["N"]) + 1, sigma=float(g["sigma"]),
+                   lmda=float(g["lmda"]))            # odd sample count: a cached Gaussian is carried
+        obs = np.array([0.05, -0.02])[:nx] if nx <= 2 else np.full(nx, 0.03)
+        constate = np.concatenate([obs, np.zeros(1)])
+        us = []
+        for k in range(7):
+            if k in (2, 5):
+                np.random.normal(size=k)             # someone else draws in between
+            u, constate = ctl.run(constate, obs)
+            us.append(u)
+        monkeypatch.undo()
+        return np.array(us), np.random.get_state(), np.random.normal(size=5)
+    ua, sa, ta = episode(True)
+    ub, sb, tb = episode(False)
+    np.testing.assert_array_equal(ua, ub)
+    np.testing.assert_array_equal(sa[1], sb[1])
+    assert sa[2:] == sb[2:]
+    np.testing.assert_array_equal(ta, tb)

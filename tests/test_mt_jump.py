@@ -4,6 +4,7 @@ s * J words further on must equal the correlation of g_s with the stream (CPU, n
 import os
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,9 +24,12 @@ def _temper(v):
     return (v ^ (v >> 18)) & 0xffffffff
 
 
-def test_jump_polynomials_reproduce_numpys_stream():
-    d = np.load(os.path.join(ROOT, "autompc_amd", "data", "mt19937_jump.npz"))
-    polys, jb = d["polys"], int(d["jump_blocks"])
+_TABLES = np.load(os.path.join(ROOT, "autompc_amd", "data", "mt19937_jump.npz"))
+
+
+@pytest.mark.parametrize("jb", [int(j) for j in _TABLES["jumps"]])      # one table per segment length
+def test_jump_polynomials_reproduce_numpys_stream(jb):
+    polys = _TABLES["polys_%d" % jb]
     assert polys.shape[1] == 624 and jb >= 34
     J = jb * 624
     rs = np.random.RandomState(2024)

@@ -8,8 +8,8 @@ g = t^J mod phi, and because A^i s is just the window of the stream i words furt
     x[J + p] = XOR over { i : g_i = 1 } of x[i + p]           (p = 0 .. 623)
 -- a correlation of the bit vector g with the first 19937 + 624 words of the stream, which every
 segment of the stream can evaluate independently.  This script computes phi with Berlekamp-Massey
-from a generated bit sequence and then g_s = t^(s*J) mod phi for s = 1 .. S (J = 64 blocks of 624
-words: a segment is what one workgroup regenerates sequentially, ~35 us), and stores them as uint32 words in autompc_amd/data/mt19937_jump.npz.  Pure integer
+from a generated bit sequence and then g_s = t^(s*J) mod phi for s = 1 .. S (J = 64 and 256 blocks of 624
+words: a segment is what one workgroup regenerates sequentially, ~150 us; the chain runs several control steps ahead of the draws), and stores them as uint32 words in autompc_amd/data/mt19937_jump.npz.  Pure integer
 arithmetic (polynomials are Python ints, bit j = coefficient of t^j); takes a few seconds.
 The result is checked against numpy's own generator before it is written.
 """
@@ -19,8 +19,7 @@ import sys
 import numpy as np
 
 N, M, DEG = 624, 397, 19937
-JUMP_BLOCKS = 64
-J = JUMP_BLOCKS * N
+JUMPS = (64, 256)     # segment lengths in blocks: one table each (short chains / few jump evaluations)
 S_MAX = 150
 
 
@@ -102,41 +101,47 @@ def main():
             base = mulmod(base, base)
             e >>= 1
         return result
-    g1 = powmod_t(J)
-    polys, g = [], 1
-    for s in range(1, S_MAX + 1):
-        g = mulmod(g, g1)
-        polys.append(g)
-    # check against numpy's generator: window at word offset 624 + s*J from the correlation
-    rs = np.random.RandomState(777)
-    key = rs.get_state()[1]
-    need = N + DEG + N
-    x = raw_stream(key, need)               # x[0] = stream word 624 relative to `key`
-    for s in (1, 3):
-        gs = polys[s - 1]
-        win = [0] * 4
-        for i in range(DEG):
-            if (gs >> i) & 1:
-                for p in range(4):
-                    win[p] ^= x[i + p]
-        chk = np.random.RandomState(777)
-        chk.set_state(("MT19937", key, N))
-        raw = chk.randint(0, 2 ** 32, size=s * J + 8, dtype=np.uint64)   # tempered outputs
-        y = win[:4]
-        t = []
-        for v in y:
-            v ^= v >> 11; v ^= (v << 7) & 0x9d2c5680; v ^= (v << 15) & 0xefc60000; v ^= v >> 18
-            t.append(v & 0xffffffff)
-        assert t == [int(a) for a in raw[s * J:s * J + 4]], "jump polynomial %d does not reproduce numpy's stream" % s
-    arr = np.zeros((S_MAX, N), dtype=np.uint32)
-    for s, gs in enumerate(polys):
-        for w in range(N):
-            arr[s, w] = (gs >> (32 * w)) & 0xffffffff
+
+    def table(jump_blocks):
+        """[S_MAX, 624] words of g_s = t^(s * jump_blocks * 624) mod phi, s = 1 .. S_MAX."""
+        J = jump_blocks * N
+        g1 = powmod_t(J)
+        polys, g = [], 1
+        for s in range(1, S_MAX + 1):
+            g = mulmod(g, g1)
+            polys.append(g)
+        # check against numpy's generator: window at word offset 624 + s*J from the correlation
+        rs = np.random.RandomState(777)
+        key = rs.get_state()[1]
+        need = N + DEG + N
+        x = raw_stream(key, need)               # x[0] = stream word 624 relative to `key`
+        for s in (1, 3):
+            gs = polys[s - 1]
+            win = [0] * 4
+            for i in range(DEG):
+                if (gs >> i) & 1:
+                    for p in range(4):
+                        win[p] ^= x[i + p]
+            chk = np.random.RandomState(777)
+            chk.set_state(("MT19937", key, N))
+            raw = chk.randint(0, 2 ** 32, size=s * J + 8, dtype=np.uint64)   # tempered outputs
+            y = win[:4]
+            t = []
+            for v in y:
+                v ^= v >> 11; v ^= (v << 7) & 0x9d2c5680; v ^= (v << 15) & 0xefc60000; v ^= v >> 18
+                t.append(v & 0xffffffff)
+            assert t == [int(a) for a in raw[s * J:s * J + 4]], "jump polynomial %d does not reproduce numpy's stream" % s
+        arr = np.zeros((S_MAX, N), dtype=np.uint32)
+        for s, gs in enumerate(polys):
+            for w in range(N):
+                arr[s, w] = (gs >> (32 * w)) & 0xffffffff
+        return arr
+    tables = {j: table(j) for j in JUMPS}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "autompc_amd", "data",
                        "mt19937_jump.npz")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    np.savez_compressed(out, polys=arr, jump_blocks=JUMP_BLOCKS)
-    print("wrote %s  (%d polynomials, jump = %d blocks)" % (out, S_MAX, JUMP_BLOCKS))
+    np.savez_compressed(out, jumps=np.array(sorted(tables)), **{"polys_%d" % j: a for j, a in tables.items()})
+    print("wrote %s  (%d polynomials each for jumps of %s blocks)" % (out, S_MAX, sorted(tables)))
 
 
 if __name__ == "__main__":
