@@ -547,7 +547,8 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None,
         rank = dist.get_rank() if world > 1 else 0
     n = len(candidates)
     lo, hi = shard_bounds(n, rank, world)
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        # (a one-rank process group still takes the collective below: the same code runs at any N)
         if stats is not None:
             stats.update(backend=None, ranks_in_gather=1, gather_ms=0.0, device=None)
         return np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)

@@ -295,3 +295,36 @@ def test_inplace_generator_state_equals_the_get_set_state_path(monkeypatch):
     np.testing.assert_array_equal(sa[1], sb[1])
     assert sa[2:] == sb[2:]
     np.testing.assert_array_equal(ta, tb)
+
+
+@pytest.mark.parametrize("N,H,nu,ahead", [(500, 10, 2, None), (37, 3, 1, "2"), (2048, 30, 3, "3"), (300, 12, 1, "5")])
+def test_run_ahead_over_many_calls_with_random_interruptions(N, H, nu, ahead, monkeypatch):
+    """The raw stream is generated several calls ahead into two alternating buffers (api.cpp:
+    legacy_enqueue / legacy_speculate).  60 calls -- through many buffer switches, with host draws
+    of random length at random calls (each invalidates the run-ahead), odd counts (cached Gaussian
+    carried over) and positions at block boundaries as they come -- must continue numpy's stream
+    exactly: normals, key, position, cache after every call."""
+    if ahead is not None:
+        monkeypatch.setenv("AMPC_LEGACY_AHEAD", ahead)
+    sigma = 0.0049
+    h, plan = _plan(N, H, sigma, nx=2, nu=nu)
+    rng = np.random.default_rng(N + H)
+    np.random.seed(99 + N)
+    for call in range(60):
+        if rng.random() < 0.15:
+            np.random.normal(size=int(rng.integers(1, 2000)))        # someone else draws
+        st0 = np.random.get_state()
+        ref = np.random.normal(scale=np.sqrt(sigma), size=(N, H, nu))
+        st_ref = np.random.get_state()
+        np.random.set_state(st0)
+        st_dev, e = _device_draw(plan)
+        got = e.reshape(H, N, nu).transpose(1, 0, 2)
+        np.testing.assert_array_equal(st_dev[1], st_ref[1], err_msg="key after call %d" % call)
+        assert st_dev[2:] == st_ref[2:], call
+        if _exact():
+            np.testing.assert_array_equal(got, ref, err_msg="normals of call %d" % call)
+        else:
+            assert np.max(np.abs(got - ref) / np.spacing(np.abs(ref))) <= 4.0
+        np.random.set_state(st_dev)
+    plan.close()
+    h.close()

@@ -127,6 +127,27 @@ def test_nccl_all_gather_across_two_gpus():
         assert got[r][1]["device"].startswith("cuda")
 
 
+def test_nccl_backend_single_rank_on_this_gpu():
+    """What a 1-GPU box can run of the RCCL leg: a one-rank "nccl" process group -- the RCCL
+    communicator is created on the device, the scores travel as a device tensor through
+    all_gather_into_tensor (evaluate_sharded's nccl branch), and come back equal to a plain
+    evaluation.  The cross-GPU exchange itself needs the test above."""
+    import torch.multiprocessing as mp
+    from autompc_amd.tuning import random_candidates
+    n, n_steps = 5, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_worker, args=(0, 1, _free_port(), n, n_steps, q, "nccl"))
+    proc.start()
+    _, scores, stats = q.get(timeout=600)
+    proc.join(timeout=120)
+    assert proc.exitcode == 0
+    system, ev = _evaluator(n_steps)
+    ref = ev.evaluate(random_candidates(system, n, seed=1), seed=5)
+    np.testing.assert_array_equal(scores, ref)
+    assert stats["backend"] == "nccl" and stats["ranks_in_gather"] == 1 and stats["device"].startswith("cuda")
+
+
 def test_full_size_c5_batch():
     """BASELINE config 5 at its per-GPU size: 64 candidates from the reference's full ranges (gains
     1e-3 .. 1e4) x 200 control steps.  Finite, reproducible, and every probed candidate scores
