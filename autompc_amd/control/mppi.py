@@ -119,7 +119,7 @@ class MPPI(Controller):
             self._plan = _lib.MppiPlan(self._handle, [self.num_path], [self.H], [self.sigma], [self.lmda],
                                        term_mode=term)
             self._act_dirty = True
-            self._jit_pending = self._plan.kernel_kind() == 0 and self._handle.jit_status()[0] == 1
+            self._jit_pending = self._plan.kernel_kind() in (0, 3) and self._handle.jit_status()[0] == 1
         return self._plan
 
     def __getstate__(self):

@@ -49,6 +49,7 @@ extern "C" int ampc_jit_status(ampc_handle* h, char* msg, int msg_len) {
 }
 
 extern "C" int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr_plan* ilqr) {
+  if (mppi && mppi->quad && mppi->static_shape < 0) return 3;     // (specialised four-row kernels report 1 / 2)
   const int sid = mppi ? mppi->static_shape : (ilqr ? ilqr->static_shape : -1);
   const JitPlugin* j = mppi ? mppi->jit : (ilqr ? ilqr->jit : nullptr);
   return sid < 0 ? 0 : (j ? 2 : 1);
@@ -474,7 +475,25 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   const MlpDev<T>& m = model_of<T>(h);
   const int nu = h->nu, nx = h->nx;
   const size_t extra = (size_t)p->max_h * nu + h->cost_stride + 3 * nu + 8;
-  if (h->has_sindy) {
+  // Four-row tiles (mppi_rollout4.hpp) when sixteen-row tiles would leave most of the chip idle:
+  // a rollout's time is its per-step latency, and a four-row step costs a quarter of the matrix
+  // pipe.  AMPC_QUAD: -1 automatic, 0 never, 1 whenever the shape is supported.
+  p->quad = false;
+  if (sizeof(T) == 8 && h->has_mlp && q4_supported(m.hpad, m.n_hidden, m.nxp, m.k1p)) {
+    long long tiles16 = 0;
+    for (int b = 0; b < p->B; ++b) tiles16 += (p->N[b] + 15) / 16;
+    const int mode = env_int("AMPC_QUAD", -1);
+    const bool fits = make_q4_lds(nu, m.k1p, m.nxp, m.hpad, m.n_hidden, h->cost_stride, p->max_h).total *
+                          sizeof(T) <= kLdsLimit;
+    p->quad = fits && (p->forced_quad || (p->forced_mt == 0 && env_int("AMPC_MT", 0) == 0 &&
+                                           (mode == 1 || (mode < 0 && tiles16 * 2 <= h->n_cus))));
+  }
+  REQUIRE(!p->forced_quad || p->quad,
+          "ampc_mppi_plan_set_geometry: four-row tiles need an f64 MLP of hidden width <= 64 (<= 128 with at "
+          "most two hidden layers) and at most 32 states");
+  if (p->quad) {
+    p->mt = 0;
+  } else if (h->has_sindy) {
     p->mt = 4;
   } else {
     p->mt = choose_mt<T>(h, m, p->sum_n, extra, p->forced_mt);
@@ -490,9 +509,11 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     for (int b = 1; b < p->B; ++b) mixed = mixed || p->H[b] != p->H[0];
     if (mixed && p->mt > 2 && env_int("AMPC_MT", 0) == 0 && p->forced_mt == 0) p->mt = 2;
   }
-  const int M = 16 * p->mt;
+  const int M = p->quad ? 4 : 16 * p->mt;
   p->tile_m = M;
-  if (h->has_sindy) {
+  if (p->quad) {
+    std::memset(&p->L, 0, sizeof(p->L));          // (the kernel derives its own map: make_q4_lds)
+  } else if (h->has_sindy) {
     std::memset(&p->L, 0, sizeof(p->L));
     p->L.extra = (2 * nx + nu + h->s_ntab) * 64;   // per-thread columns: [x|u], next x, value table
   } else {
@@ -504,6 +525,11 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   p->lds_aseq = round_up(p->lds_cost + h->cost_stride + 3 * nu, 4);
   p->lds_bytes = ((size_t)p->lds_aseq + (size_t)p->max_h * nu) * sizeof(T);
   REQUIRE(p->lds_bytes <= kLdsLimit, "mppi plan: model + horizon do not fit the 160 KB LDS");
+  if (p->quad) {
+    p->lds_bytes = (size_t)make_q4_lds(nu, m.k1p, m.nxp, m.hpad, m.n_hidden, h->cost_stride, p->max_h).total * sizeof(T);
+    p->lds_eps = env_int("AMPC_FUSED_UPDATE", 1) != 0 ? 0 : -1;       // (a flag here: the map has the region)
+    p->lds_red = 0;
+  } else
   {  // fused update: keep the tile's clipped noise [max_h][M][nu] (+ 2M reduction slots) in LDS
     const int e0 = round_up(p->lds_aseq + p->max_h * nu, 4);
     const size_t bytes = ((size_t)e0 + (size_t)p->max_h * M * nu + 2 * M) * sizeof(T);
@@ -517,7 +543,11 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   // implies (ping-pong activations + separate partials -- tile_lds_for picked it iff it fits)
   p->static_shape = -1;
   p->jit = nullptr;
-  if (!h->has_sindy && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
+  if (p->quad && env_int("AMPC_STATIC", 1) != 0) {          // (the four-row kernel has one LDS map)
+    int sid = static_shape_of<T>(h, m);
+    if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;
+    p->static_shape = sid;
+  } else if (!h->has_sindy && !p->quad && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
     int sid = static_shape_of<T>(h, m);
     if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;      // run-time compiled shape
     const int lv = sid >= 0 ? lds_variant_of<T>(m, p->L, M, h->nw) : -1;
@@ -1035,12 +1065,13 @@ extern "C" int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, i
 
 extern "C" int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int horizon_cap) {
   REQUIRE(p, "ampc_mppi_plan_set_geometry: NULL plan");
-  REQUIRE(tile_rows == 0 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64,
-          "ampc_mppi_plan_set_geometry: tile_rows must be 0 (automatic), 16, 32 or 64");
+  REQUIRE(tile_rows == 0 || tile_rows == 4 || tile_rows == 16 || tile_rows == 32 || tile_rows == 64,
+          "ampc_mppi_plan_set_geometry: tile_rows must be 0 (automatic), 4, 16, 32 or 64");
   REQUIRE(horizon_cap >= 0, "ampc_mppi_plan_set_geometry: horizon_cap < 0");
   HIP_OK(hipSetDevice(p->h->device));
   HIP_OK(hipStreamSynchronize(p->h->stream));
   p->forced_mt = tile_rows / 16;
+  p->forced_quad = tile_rows == 4;
   for (int hb : p->H) p->max_h = hb > p->max_h ? hb : p->max_h;
   if (horizon_cap > p->max_h) p->max_h = horizon_cap;
   p->lds_eps = -1;

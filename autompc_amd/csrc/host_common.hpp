@@ -23,6 +23,7 @@
 #include "ilqr_kernels.hpp"
 #include "ilqr_ls4.hpp"
 #include "mppi_kernels.hpp"
+#include "mppi_rollout4.hpp"
 #include "rng_kernels.hpp"
 #include "sindy_kernels.hpp"
 #include "score_kernels.hpp"
@@ -265,6 +266,8 @@ struct ampc_mppi_plan {
   ampc_handle* h = nullptr;
   int B = 0, term_mode = 0, mt = 1, n_tiles = 0, max_h = 0;
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
+  bool forced_quad = false;   // ... to the four-row kernel (tile_rows = 4)
+  bool quad = false;    // the four-row rollout kernel runs (mppi_rollout4.hpp); mt is 0 then
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
   void* pin_x0 = nullptr;     // ampc_mppi_run: pinned staging of x0 in / controls out (compute precision)
   void* pin_u = nullptr;

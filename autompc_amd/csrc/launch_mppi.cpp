@@ -26,6 +26,47 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
     p->ev_used += 3;
     HIP_OK(hipEventRecord(e[0], h->stream));
   }
+  if constexpr (sizeof(T) == 8) {
+    if (p->quad) {              // four-row tiles (mppi_rollout4.hpp): small problems, f64
+      void (*k)(MppiArgs<double>) = nullptr;
+      if (p->static_shape >= 0) {
+        switch (p->static_shape * 2 + (h->act == 0 ? 1 : 0)) {
+#define AMPC_SHAPE_QUAD_ONE(ID, NX, NU, NO, NH, HPAD, RELU)                                              \
+          case ID * 2 + RELU:                                                                            \
+            if constexpr (q4_supported(HPAD, NH, (NX + 15) / 16 * 16, (NX + NU + 7) / 8 * 8))            \
+              k = mppi_rollout4_kernel<HPAD / 64, NH, StaticShape<NX, NU, NO, NH, HPAD, RELU ? 0 : -1, 0>>; \
+            break;
+#define AMPC_SHAPE_QUAD(ID, NX, NU, NO, NH, HPAD)     \
+          AMPC_SHAPE_QUAD_ONE(ID, NX, NU, NO, NH, HPAD, 0) \
+          AMPC_SHAPE_QUAD_ONE(ID, NX, NU, NO, NH, HPAD, 1)
+          AMPC_STATIC_SHAPES(AMPC_SHAPE_QUAD)
+#undef AMPC_SHAPE_QUAD
+#undef AMPC_SHAPE_QUAD_ONE
+          default: break;
+        }
+        if (!k) return fail("internal: four-row rollout for an unsupported static shape");
+      } else {
+#ifdef AMPC_JIT_PLUGIN
+        return fail("shape plugin entered without its static shape");
+#else
+        switch (h->hpad / 64 * 10 + h->n_hidden) {
+          case 11: k = mppi_rollout4_kernel<1, 1>; break;
+          case 12: k = mppi_rollout4_kernel<1, 2>; break;
+          case 13: k = mppi_rollout4_kernel<1, 3>; break;
+          case 14: k = mppi_rollout4_kernel<1, 4>; break;
+          case 21: k = h->nxp <= 16 ? mppi_rollout4_kernel<2, 1, DynShape, true> : mppi_rollout4_kernel<2, 1>; break;
+          case 22: k = h->nxp <= 16 ? mppi_rollout4_kernel<2, 2, DynShape, true> : mppi_rollout4_kernel<2, 2>; break;
+          default: return fail("internal: four-row rollout for an unsupported shape");
+        }
+#endif
+      }
+      HIP_OK(allow_lds(k, p->lds_bytes));
+      hipLaunchKernelGGL(k, dim3(p->n_tiles), dim3(256), p->lds_bytes, h->stream, a);
+    }
+  }
+  if (p->quad) {
+    if (sizeof(T) != 8) return fail("internal: four-row rollout in f32");      // (launched above)
+  } else
 #ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);

@@ -75,7 +75,9 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
 int ampc_jit_status(ampc_handle* h, char* msg, int msg_len);
 int ampc_jit_wait(ampc_handle* h);
 /* Which kernels a plan launches (pass one plan, NULL for the other): 0 run-time-shape, 1 a shape
- * registered at build time, 2 a shape plugin compiled at run time. */
+ * registered at build time, 2 a shape plugin compiled at run time, 3 the run-time-shape four-row rollout kernel
+ * (small MPPI problems: f64, hidden width <= 64 -- <= 128 with at most two hidden layers --, at most
+ * 32 states, and so few samples that sixteen-row tiles would leave most compute units idle). */
 int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr_plan* ilqr);
 
 /* ---- model: linear dynamics (alternative to ampc_set_mlp) ----------------------------------
@@ -140,8 +142,8 @@ int ampc_mppi_plan_create(ampc_handle* h, int B, const int* num_path, const int*
                           int term_mode, ampc_mppi_plan** out);
 int ampc_mppi_plan_destroy(ampc_mppi_plan* p);
 /* Fix the launch geometry instead of letting the library derive it from the batch: tile_rows
- * (0 automatic, or 16 / 32 / 64 samples per rollout workgroup; a height that does not fit LDS
- * for the staged model / horizon is an error) and horizon_cap (the LDS / partial-sum layout is sized
+ * (0 automatic, or 4 / 16 / 32 / 64 samples per rollout workgroup; a height that does not fit LDS
+ * for the staged model / horizon, or 4 for a model the four-row kernel does not cover, is an error) and horizon_cap (the LDS / partial-sum layout is sized
  * for max(horizon_cap, longest horizon in the plan)).  Summation orders inside a solve depend on
  * the geometry; with both fixed, a problem's results are bit-identical whatever else shares the
  * plan -- the candidate evaluator uses this so that a candidate's surrogate score
