@@ -30,7 +30,7 @@ __host__ __device__ constexpr Q4Lds make_q4_lds(int nu, int k1p, int nxp, int hp
   Q4Lds L{};
   int o = 0;
   L.xs = k1p + 1; L.as = hpad + 1;
-  L.xu = o; o += 4 * L.xs;
+  L.xu = o; o += 4 * 4 * L.xs;                   // (one [4][xs] copy per wave when FULL, see the kernel)
   L.act0 = o; o += 4 * L.as;
   L.act1 = o; o += 4 * L.as;
   L.part = o; o += 4 * 4 * nxp;
@@ -62,6 +62,12 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   constexpr int W = 4, ROWS = 4, NTHR = 256, HP = 64 * NT, KSH = HP / 4, KSW = KSH / W, KS0MAX = 12;
+  constexpr bool FULL = KSH <= 16 || (ONE && KSH <= 32);     // output-layer scheme, see below
+  // FULL: every wave ends a step with the new state of all four rows in registers and keeps its OWN
+  // copy of the first layer's operand [x | u] in LDS -- nothing crosses waves between the output
+  // layer and the next first layer, so the barrier there goes (it stays for an odd number of hidden
+  // layers, where the first layer would overwrite the activations a slower wave is still reading).
+  constexpr bool BAR_A = !FULL || (NH & 1);
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   const bool diag = args.cost_diag != 0;
   const Q4Lds L = make_q4_lds(nu, mlp.k1p, nxp, HP, NH, cost_stride, args.max_h);
   const int xs = L.xs, as = L.as;
-  T* xu = lds + L.xu; T* part = lds + L.part; T* bias = lds + L.bias; T* cpar = lds + L.cpar;
+  T* xu = lds + L.xu + (FULL ? w * 4 * xs : 0); T* part = lds + L.part; T* bias = lds + L.bias; T* cpar = lds + L.cpar;
   T* aseq = lds + L.aseq; T* el = lds + L.eps;
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu; const T* goal = Fm + no * no;
   const T* blo = cpar + cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
@@ -112,7 +118,6 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   // redundant matrix-pipe work, but the wave that owns a row then holds its outputs in registers and
   // updates the state directly: no partial sums through LDS, one barrier less per step.  Otherwise
   // (long K and two output tiles) the k-steps are split over the waves as in ilqr_ls4_kernel.
-  constexpr bool FULL = KSH <= 16 || (ONE && KSH <= 32);
   constexpr int KSO = FULL ? KSH : KSW;
   T wout[KSO][2];
   {
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
     const int ts = (t + 1 < H) ? t + 1 : H - 1;  // a[:-1] = a[1:]; a[-1] = a[-2]
     aseq[i] = args.act_in[pr.a_off + ts * nu + j];
   }
-  for (int i = tid; i < ROWS * xs; i += NTHR) {
+  for (int i = FULL ? lane : tid; i < ROWS * xs; i += FULL ? 64 : NTHR) {
     const int row = i / xs, col = i - row * xs;
     xu[i] = col < nx ? args.x0[p * nx + col] : T(0);
   }
@@ -175,7 +180,14 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this wave's own LDS writes, read below)
   if (!diag)
     for (int t = lane; t < H; t += 64) c_part += quad_rows<T>(Rm, ul + (t * ROWS + m) * nu, nullptr, nu, 0, 1, false);
-  if (r < nu) xu[m * xs + nx + r] = ul[m * nu + r];
+  // where lane r's element of a step's controls [4][nu] goes in [x | u] (FULL: all four rows per wave)
+  const int cdst = (r / nu) * xs + nx + (r - (r / nu) * nu);
+  if (FULL) {
+    __syncthreads();                             // (the other rows' controls come from their waves)
+    if (r < ROWS * nu) xu[cdst] = ul[r];
+  } else if (r < nu) {
+    xu[m * xs + nx + r] = ul[m * nu + r];
+  }
   if (diag) c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, true);     // stage cost of x_0
 
   const int arow = lane & 3, ak = lane >> 4, drow = lane >> 4, dcol = lane & 15;
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   const T qd1 = (diag && 16 + dcol < no) ? Qm[(16 + dcol) * no + 16 + dcol] : T(0);
   const T gl1 = 16 + dcol < no ? goal[16 + dcol] : T(0);
   const T ob0 = bias[NH * HP + dcol], ob1 = tiles > 1 ? bias[NH * HP + 16 + dcol] : T(0);
-  T xr0 = dcol < nx ? xu[w * xs + dcol] : T(0), xr1 = 16 + dcol < nx ? xu[w * xs + 16 + dcol] : T(0);
+  T xr0 = dcol < nx ? xu[drow * xs + dcol] : T(0), xr1 = 16 + dcol < nx ? xu[drow * xs + 16 + dcol] : T(0);
   ProbeWave<Probe::wave_time> probe;             // (timing-experiment builds only, tools/wavetime4.py)
   AMPC_PROBE_KERNEL_BEGIN(probe);
   // A layer's k-steps go round NA independent accumulators: a v_mfma_f64_4x4x4 occupies the pipe
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   for (int t = 0; t < H; ++t) {
     AMPC_PROBE_STEP(probe, t == 5);
     AMPC_MARK(0);
-    lds_barrier();                               // state and controls of step t are in xu
+    if (BAR_A) lds_barrier();                    // state and controls of step t are in xu
     AMPC_MARK(1);
     if (!diag) c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, false);
     // ---- layer 0
@@ -260,7 +272,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
       T o0[NA], o1[NA];
 #pragma unroll
       for (int a = 0; a < NA; ++a) o0[a] = o1[a] = T(0);
-      const T un = (t + 1 < H && r < nu) ? ul[((t + 1) * ROWS + m) * nu + r] : T(0);   // (in flight under the MFMAs)
+      const T un = (t + 1 < H && r < ROWS * nu) ? ul[(t + 1) * ROWS * nu + r] : T(0);   // (in flight under the MFMAs)
       const T* ap = ain + arow * as + ak;
       T avo[KSO];
 #pragma unroll
@@ -271,20 +283,20 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
         if (tiles > 1) o1[ks % NA] = mfma4(avo[ks], wout[ks][1], o1[ks % NA]);
       }
       AMPC_MARK(6);
-      if (t + 1 < H && r < nu) xu[m * xs + nx + r] = un;
+      if (t + 1 < H && r < ROWS * nu) xu[cdst] = un;
       AMPC_MARK(7);
       AMPC_MARK(8);
-      if (drow == w) {                           // the lanes holding row w: columns dcol, 16 + dcol
-        if (dcol < nx) {                         // (they keep the row's state in registers: xr0, xr1)
-          xr0 += fold(o0) + ob0;
-          xu[w * xs + dcol] = xr0;
-          if (diag && dcol < no && t + 1 < H) { const T d = xr0 - gl0; c_part += qd0 * d * d; }
-        }
-        if (tiles > 1 && 16 + dcol < nx) {
-          xr1 += fold(o1) + ob1;
-          xu[w * xs + 16 + dcol] = xr1;
-          if (diag && 16 + dcol < no && t + 1 < H) { const T d = xr1 - gl1; c_part += qd1 * d * d; }
-        }
+      // every lane keeps its (row drow, columns dcol / 16 + dcol) of the state in registers; the
+      // costs of row w are accumulated by the lanes holding row w
+      if (dcol < nx) {
+        xr0 += fold(o0) + ob0;
+        xu[drow * xs + dcol] = xr0;
+        if (diag && drow == w && dcol < no && t + 1 < H) { const T d = xr0 - gl0; c_part += qd0 * d * d; }
+      }
+      if (tiles > 1 && 16 + dcol < nx) {
+        xr1 += fold(o1) + ob1;
+        xu[drow * xs + 16 + dcol] = xr1;
+        if (diag && drow == w && 16 + dcol < no && t + 1 < H) { const T d = xr1 - gl1; c_part += qd1 * d * d; }
       }
     } else {
       T o0[NA], o1[NA];

@@ -670,7 +670,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic["bytes"] if traffic else None,
                          "traffic_source": traffic["source"] if traffic else None,
-                         "kernel": "mppi_rollout_kernel", "kernel_ms": kt["rollout_ms"],
+                         "kernel": "mppi_rollout4_kernel" if info["samples_per_wg"] == 4 else "mppi_rollout_kernel",
+                         "kernel_ms": kt["rollout_ms"],
                          "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"],
                          "algorithmic_flops_per_launch": info["flops"],
                          "algorithmic_bytes_per_launch": info["bytes"],

@@ -32,6 +32,7 @@ timeout 900 python tools/fuzz_gpu.py 400 32 >> $OUT/fuzz_gpu.log 2>&1
 timeout 120 python tools/validate_glibc_log.py > $OUT/glibc_log.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f64_b1 --steps 600 --warmup 20 > $OUT/profile_c3.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f32_b1 --precision f32 --steps 600 --warmup 20 > $OUT/profile_c3f32.log 2>&1
+bash tools/gpu_profile.sh $TAG c2_f64_b1 --workload c2 --steps 2000 --warmup 50 > $OUT/profile_c2.log 2>&1
 bash tools/gpu_profile.sh $TAG c4_f64_b256 --workload c4 --steps 2 --warmup 1 > $OUT/profile_c4.log 2>&1
 bash tools/gpu_profile.sh $TAG c5_f64_b64 --workload c5 --steps 1 --warmup 1 > $OUT/profile_c5.log 2>&1
 cat $OUT/pytest_gpu.log | tail -3; cat $OUT/smoke.log | tail -1
