@@ -925,7 +925,14 @@ struct TileNet {
     AMPC_MARK(7);
     prefetch0(m);     // next call's first group: overlaps the reduction and the caller's work
     if (m.n_hidden > 1) prefetch_next(1);
-    if (!side_done) side();
+    // With ONE hidden layer no barrier has been passed since layer 0 read [x | u], and the side work
+    // (the rollout's next actions) writes the control columns of that operand: every wave must be
+    // past its layer-0 reads first.  (Deeper networks call side() inside hidden layer 1, behind the
+    // barrier that follows layer 0.)
+    if (!side_done) {
+      if (m.n_hidden == 1) lds_barrier();
+      side();
+    }
     if (L.part_alias) lds_barrier();  // partials reuse `act`: every wave must be done reading it
     AMPC_MARK(8);
     const int ps = part_stride((int)sizeof(T), m.nxp);

@@ -180,3 +180,48 @@ def test_failed_build_falls_back_to_the_runtime_shape_kernels(monkeypatch):
     kind, out = _mppi(h, nx, nu, 16)
     assert kind == 0 and np.all(np.isfinite(out[1]))
     h.close()
+
+
+def test_single_hidden_layer_specialised_rollout_next_to_other_kernels(monkeypatch, tmp_path):
+    """Regression (tools/fuzz_gpu.py seed 31 case 155): with ONE hidden layer nothing separated the
+    first layer's reads of [x | u] from the next step's controls being written into it; the
+    specialised eight-wave kernel, running next to the noise generator's side stream, then rolled
+    out the samples of its faster waves with the wrong controls (cost errors of 1e-2, different
+    from run to run).  The drop-in controller in its default noise mode against the oracle."""
+    from autompc_amd import MLP, MPPI, QuadCost, Task
+    from helpers import make_system
+    from oracle.costs import QuadCostOracle
+    from oracle.mlp import MLPOracle
+    from oracle.mppi import MPPIOracle
+    monkeypatch.setenv("AMPC_JIT", "1")
+    monkeypatch.setenv("AMPC_JIT_CACHE", str(tmp_path))
+    nx, nu, N, H = 16, 2, 64, 15
+    system = make_system(nx, nu)
+    rng = np.random.default_rng(155)
+    p = omlp.random_params(nx, nu, [100], "relu", seed=31)
+    A = rng.normal(size=(nx, nx))
+    Q, R, F, goal = A @ A.T / nx + 0.1 * np.eye(nx), np.diag(rng.uniform(0.01, 0.1, nu)), np.eye(nx), rng.normal(size=nx) * 0.1
+    task = Task(system)
+    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    task.set_ctrl_bounds(np.full(nu, -0.8), np.full(nu, 1.1))
+    obs = rng.uniform(-0.1, 0.1, size=nx)
+    for mt in ("1", "2"):
+        monkeypatch.setenv("AMPC_MT", mt)
+        for rep in range(4):
+            m = MLP(system, n_hidden_layers=1, hidden_size_1=100, nonlintype="relu")
+            m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+            m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+            np.random.seed(7)
+            orc = MPPIOracle(MLPOracle(system, p), QuadCostOracle(Q, R, F, goal), np.tile([-0.8, 1.1], (nu, 1)),
+                             horizon=H, num_path=N, sigma=0.6, lmda=0.9)
+            np.random.seed(7)
+            ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=0.6, lmda=0.9)
+            ctl._device()
+            ctl._handle.jit_wait()
+            assert ctl._device().kernel_kind() == 2 and ctl._device().info()["samples_per_wg"] == 16 * int(mt)
+            cs = np.concatenate([obs, np.zeros(nu)])
+            st = np.random.get_state()
+            orc.run(cs, obs)
+            np.random.set_state(st)
+            ctl.run(cs, obs, return_details=True)
+            assert rel_err(ctl.last_costs, orc.last_costs) < 1e-9, (mt, rep)

@@ -98,6 +98,20 @@ def main():
             worst["mppi_act"] = max(worst["mppi_act"], ea / (100 * tol))
             if ec > tol or ea > 100 * tol:
                 bad.append((tag + " N=%d H=%d" % (N, H), "mppi", ec, ea))
+                # keep the case (tools/fuzz_replay.py) and say what differs: the noise, or single samples' costs
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez("gpurun_out/fuzz_case_%d.npz" % case, nx=nx, nu=nu, hidden=hidden, act=act, prec=prec,
+                         mt=os.environ["AMPC_MT"], jit=int(use_jit), Q=Q, R=R, F=F, goal=goal, lo=lo, hi=hi, N=N, H=H,
+                         sigma=sigma, lmda=lmda, seed=seed, obs=obs, n_layers=nl,
+                         **{"W%d" % i: w for i, w in enumerate(p["weights"])},
+                         **{"b%d" % i: b for i, b in enumerate(p["biases"])},
+                         xu_means=p["xu_means"], xu_std=p["xu_std"], dy_means=p["dy_means"], dy_std=p["dy_std"],
+                         costs_ref=orc.last_costs, eps_ref=orc.last_eps)
+                de = np.abs(ctl.last_eps - orc.last_eps)
+                dc = np.abs(ctl.last_costs - orc.last_costs) / np.abs(orc.last_costs)
+                print("  mppi detail: kernel kind %d, rows/wg %d, max |d eps| %.3e at %s, samples with cost error > tol: %s"
+                      % (ctl._device().kernel_kind(), ctl._device().info()["samples_per_wg"], de.max(),
+                         np.unravel_index(np.argmax(de), de.shape), np.nonzero(dc > tol)[0][:20].tolist()), flush=True)
             # iLQR (f64 only; a few iterations, compare the first accepted trajectory loosely)
             if prec == "f64" and case % 3 == 0 and nx + nu <= 45:
                 Hh = int(rng.integers(3, 15))
