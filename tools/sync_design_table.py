@@ -32,7 +32,7 @@ rows = {
                            % (th(b["value"]), rb["kernel_ms"], rb["achieved"], 100 * rb["frac"]),
     "| c3, 8 per launch": "| c3, 8 per launch (64-row tiles) | f32 | %s | %.2f ms | %.1f | %.1f %% |"
                           % (th(fb["value"]), fb["kernel_ms"], fb["achieved_tflops"], 100 * fb["frac_of_f32_mfma_peak"]),
-    "| c2 Pendulum": "| c2 Pendulum MPPI 1024×30 (latency-bound, 64 WGs) | f64 | %s | %.3f ms | %.1f | %.1f %% |"
+    "| c2 Pendulum": "| c2 Pendulum MPPI 1024×30 (four-row kernel §4.1b, 256 WGs; latency-bound) | f64 | %s | %.3f ms | %.1f | %.1f %% |"
                      % (th(c2["value"]), c2["roofline"]["kernel_ms"], c2["roofline"]["achieved"], 100 * c2["roofline"]["frac"]),
     "| arx: MPPI": "| arx: MPPI 1024×30 on a 20-state ARX model (§8 f3; latency-bound) | f64 | %s | %.3f ms | %.1f | — |"
                    % (th(ax["value"]), ax["roofline"]["kernel_ms"], ax["roofline"]["achieved"]),
