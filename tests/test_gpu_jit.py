@@ -155,6 +155,7 @@ def test_controllers_switch_to_the_compiled_kernels_mid_run(monkeypatch, tmp_pat
                 ctl._handle.jit_wait()
                 ilq._handle.jit_wait()
         return np.array(us), kinds
+    monkeypatch.delenv("AMPC_QUAD", raising=False)
     monkeypatch.setenv("AMPC_JIT", "0")
     ref, kinds0 = drive(False)
     assert all(k == (3, 0) for k in kinds0)       # (128 samples: the four-row rollout kernel, run-time shape)

@@ -109,8 +109,9 @@ def test_specialised_and_runtime_shape_versions_give_the_same_bits(nx, nu, hidde
     h.close()
 
 
-def test_automatic_choice_and_refusals():
+def test_automatic_choice_and_refusals(monkeypatch):
     from autompc_amd import _lib
+    monkeypatch.delenv("AMPC_QUAD", raising=False)        # (the automatic rule is what is under test)
     from autompc_amd._lib import AmpcError
     system, p, h, _ = _handle(2, 1, [64, 64], "relu", False)
     small = _lib.MppiPlan(h, [1024], [30], [1.0], [1.0])          # 64 sixteen-row tiles on 256 CUs
