@@ -49,6 +49,7 @@ SIGNATURES = {
     "ampc_sindy_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_sindy_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]),
+    "ampc_set_affine_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "ampc_set_ctrl_bounds": (c_int, [c_void_p, _dp, _dp]),
     "ampc_mppi_plan_create": (c_int, [c_void_p, c_int, _ip, _ip, _dp, _dp, _ip, c_int,
                                       POINTER(c_void_p)]),
@@ -287,6 +288,29 @@ class Handle:
                 or goal.shape != (C, no):
             raise ValueError("cost block shapes are inconsistent")
         check(self.lib.ampc_set_quad_costs(self._h, C, no, dptr(Q), dptr(R), dptr(F), dptr(goal)))
+        self.obs_dim = no
+        self.n_costs = C
+
+    def set_cost_blocks(self, Q, R, F, goal, lin=None, lin_term=None, consts=None):
+        """Affine-quadratic cost blocks (ampc_set_affine_quad_costs; autompc_amd.costs.blocks): the
+        arrays of set_quad_costs plus lin [C,no], lin_term [C,no], consts [C,2] (None = zeros)."""
+        Q, R, F, goal = as_f64(Q), as_f64(R), as_f64(F), as_f64(goal)
+        if Q.ndim == 2:
+            Q, R, F, goal = Q[None], R[None], F[None], goal[None]
+            lin, lin_term, consts = (None if a is None else as_f64(a)[None] for a in (lin, lin_term, consts))
+        C, no = Q.shape[0], Q.shape[1]
+        if Q.shape != (C, no, no) or F.shape != (C, no, no) or R.shape != (C, self.nu, self.nu) \
+                or goal.shape != (C, no):
+            raise ValueError("cost block shapes are inconsistent")
+        extra = []
+        for a, shape in ((lin, (C, no)), (lin_term, (C, no)), (consts, (C, 2))):
+            if a is not None:
+                a = as_f64(a)
+                if a.shape != shape:
+                    raise ValueError("cost block shapes are inconsistent")
+            extra.append(a)
+        check(self.lib.ampc_set_affine_quad_costs(self._h, C, no, dptr(Q), dptr(R), dptr(F), dptr(goal),
+                                                  *(dptr(a) if a is not None else None for a in extra)))
         self.obs_dim = no
         self.n_costs = C
 

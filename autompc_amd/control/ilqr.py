@@ -28,7 +28,8 @@ import numpy as np
 
 from .. import _lib
 from .controller import Controller, ControllerFactory
-from .mppi import _quad_cost_blocks
+from .mppi import _stage_cost
+from ..costs.blocks import is_quad_sum
 
 
 class IterativeLQR(Controller):
@@ -65,6 +66,7 @@ class IterativeLQR(Controller):
         self.device = device if device is not None else getattr(model, "device", 0)
         self.compute_ilqr = self.compute_ilqr_default
         self._handle = self._plan = None
+        self._terminal_goal = False
         self._jit_pending = False
         self.reset()
 
@@ -87,18 +89,17 @@ class IterativeLQR(Controller):
         if self._handle is None:
             h = _lib.Handle(self.device, self.precision)
             self.model.stage_into(h)
-            Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
-            h.set_quad_costs(Q, R, F, goal)
+            blk = _stage_cost(h, self.task.get_cost(), self.system.obs_dim, self.system.ctrl_dim)
+            # QuadCost(strict_reference=False) opts out of the reference's goal-less terminal
+            # gradient (cost.py:195): the device sweep then seeds v_N = (F+F')(x_N - goal) + lin_term
+            self._terminal_goal = blk["terminal_goal"]
             if bounded:
                 h.set_ctrl_bounds(np.asarray(self.ubounds[0], dtype=float),
                                   np.asarray(self.ubounds[1], dtype=float))
             self._handle = h
         if self._plan is None:
-            # QuadCost(strict_reference=False) opts out of the reference's goal-less terminal
-            # gradient (cost.py:195): the device sweep then seeds v_N = (F+F')(x_N - goal) too
-            tg = not getattr(self.task.get_cost(), "strict_reference", True)
             self._plan = _lib.IlqrPlan(self._handle, 1, self.horizon, self.dt, clip_to_bounds=bounded,
-                                       terminal_goal=tg)
+                                       terminal_goal=self._terminal_goal)
             self._jit_pending = self._plan.kernel_kind() == 0 and self._handle.jit_status()[0] == 1
         return self._plan
 
@@ -148,7 +149,7 @@ class IterativeLQR(Controller):
 
     @staticmethod
     def is_compatible(system, task, model):
-        return bool(getattr(task.get_cost(), "is_quad", False)) and hasattr(model, "stage_into")
+        return is_quad_sum(task.get_cost()) and hasattr(model, "stage_into")
 
 
 class IterativeLQRFactory(ControllerFactory):

@@ -20,15 +20,19 @@ What runs where
 import numpy as np
 
 from .. import _lib, _npstate
+from ..costs.blocks import quad_sum_block, is_quad_sum
 from .controller import Controller, ControllerFactory
 
 
-def _quad_cost_blocks(cost):
-    if not getattr(cost, "is_quad", False):
-        raise TypeError("the HIP MPPI path evaluates quadratic costs in-kernel; got %r"
-                        % type(cost).__name__)
-    Q, R, F = cost.get_cost_matrices()
-    return Q, R, F, np.asarray(cost.get_goal(), dtype=np.float64)
+def _stage_cost(handle, cost, obs_dim, ctrl_dim):
+    """Hand `cost` -- a QuadCost or any (nested) sum of QuadCosts, this package's or the
+    reference's own objects, shared goal or not -- to the device as one affine-quadratic block
+    (costs/blocks.py; mppi.py:73-82 and ilqr.py:124-129 evaluate it term by term).  Returns the
+    block (its ``terminal_goal`` flag matters to iLQR only)."""
+    blk = quad_sum_block(cost, obs_dim, ctrl_dim)
+    handle.set_cost_blocks(blk["Q"], blk["R"], blk["F"], blk["goal"], blk["lin"], blk["lin_term"],
+                           blk["consts"])
+    return blk
 
 
 class _ActSequence(np.ndarray):
@@ -110,8 +114,7 @@ class MPPI(Controller):
         if self._handle is None:
             h = _lib.Handle(self.device, self.precision)
             self.model.stage_into(h)
-            Q, R, F, goal = _quad_cost_blocks(self.task.get_cost())
-            h.set_quad_costs(Q, R, F, goal)
+            _stage_cost(h, self.task.get_cost(), self.system.obs_dim, self.dim_ctrl)
             h.set_ctrl_bounds(self.umin, self.umax)
             self._handle = h
         if self._plan is None:
@@ -227,7 +230,7 @@ class MPPI(Controller):
 
     @staticmethod
     def is_compatible(system, task, model):
-        return bool(getattr(task.get_cost(), "is_quad", False)) and hasattr(model, "stage_into")
+        return is_quad_sum(task.get_cost()) and hasattr(model, "stage_into")
 
 
 class MPPIFactory(ControllerFactory):

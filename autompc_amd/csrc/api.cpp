@@ -383,22 +383,28 @@ extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, 
                       ones.data());
 }
 
-extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
-                                   const double* R, const double* F, const double* goal) {
-  REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
-  REQUIRE(h->has_model(), "ampc_set_quad_costs: set the model first");
-  REQUIRE(n_costs >= 1, "ampc_set_quad_costs: n_costs < 1");
-  REQUIRE(obs_dim >= 1 && obs_dim <= h->nx, "ampc_set_quad_costs: obs_dim must be <= state dim");
+extern "C" int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                                          const double* R, const double* F, const double* goal,
+                                          const double* lin, const double* lin_term, const double* consts) {
+  REQUIRE(h && Q && R && F && goal, "ampc_set_affine_quad_costs: NULL argument");
+  REQUIRE(h->has_model(), "ampc_set_affine_quad_costs: set the model first");
+  REQUIRE(n_costs >= 1, "ampc_set_affine_quad_costs: n_costs < 1");
+  REQUIRE(obs_dim >= 1 && obs_dim <= h->nx, "ampc_set_affine_quad_costs: obs_dim must be <= state dim");
   HIP_OK(hipSetDevice(h->device));
   const int no = obs_dim, nu = h->nu;
-  const int stride = round_up(2 * no * no + nu * nu + no, 4);
+  const int stride = cost_block_stride(no, nu);
   std::vector<double> flat((size_t)n_costs * stride, 0.0);
+  bool affine = false;
   for (int c = 0; c < n_costs; ++c) {
     double* d = flat.data() + (size_t)c * stride;
     std::memcpy(d, Q + (size_t)c * no * no, no * no * 8);
     std::memcpy(d + no * no, R + (size_t)c * nu * nu, nu * nu * 8);
     std::memcpy(d + no * no + nu * nu, F + (size_t)c * no * no, no * no * 8);
-    std::memcpy(d + 2 * no * no + nu * nu, goal + (size_t)c * no, no * 8);
+    std::memcpy(d + cost_off_goal(no, nu), goal + (size_t)c * no, no * 8);
+    if (lin) std::memcpy(d + cost_off_lin(no, nu), lin + (size_t)c * no, no * 8);
+    if (lin_term) std::memcpy(d + cost_off_lint(no, nu), lin_term + (size_t)c * no, no * 8);
+    if (consts) std::memcpy(d + cost_off_c(no, nu), consts + (size_t)c * 2, 2 * 8);
+    for (int i = cost_off_lin(no, nu); i < cost_off_c(no, nu) + 2; ++i) affine = affine || d[i] != 0.0;
   }
   HIP_OK(h->cost_buf.reserve(flat.size() * h->esz()));
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
@@ -407,6 +413,7 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
   h->n_costs = n_costs;
   h->obs_dim = obs_dim;
   h->cost_stride = stride;
+  h->cost_affine = affine ? 1 : 0;
   bool diag = true;
   for (int c = 0; c < n_costs && diag; ++c) {
     for (int i = 0; i < no && diag; ++i)
@@ -419,6 +426,12 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
   h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
   jit_kick(h);
   return 0;
+}
+
+extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                                   const double* R, const double* F, const double* goal) {
+  REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
+  return ampc_set_affine_quad_costs(h, n_costs, obs_dim, Q, R, F, goal, nullptr, nullptr, nullptr);
 }
 
 extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {

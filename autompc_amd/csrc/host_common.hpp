@@ -136,7 +136,7 @@ struct ampc_handle {
   MlpDev<float> mf{};
 
   // cost blocks / bounds ----------------------------------------------------------------------
-  int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0;
+  int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0, cost_affine = 0;
   DevBuf cost_buf;
   bool has_bounds = false;
   std::vector<double> lo, hi;
@@ -328,6 +328,7 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.term_mode = p->term_mode;
   a.max_h = p->max_h;
   a.cost_diag = h->cost_diag;
+  a.cost_affine = h->cost_affine;
   a.lds_eps = p->lds_eps;
   a.lds_red = p->lds_red;
   a.write_eps_out = (p->keep_eps_out || p->lds_eps < 0) ? 1 : 0;
@@ -397,7 +398,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.lds = p->L;
   a.lds_work = p->lds_work;
   a.H = p->H; a.obs_dim = h->obs_dim; a.cost_stride = h->cost_stride; a.bounded = p->bounded;
-  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag; a.term_goal = p->term_goal;
+  a.ls_n = p->ls_n; a.mode = mode; a.cost_diag = h->cost_diag; a.cost_affine = h->cost_affine; a.term_goal = p->term_goal;
   a.dt = (T)p->dt; a.u_threshold = (T)p->u_threshold; a.ls_cost_threshold = (T)p->ls_cost_threshold;
   for (int j = 0; j < kIlqrMaxLs; ++j) a.alphas[j] = (T)std::pow(p->ls_discount, (double)j);
   a.costs_par = (const T*)h->cost_buf.p;

@@ -44,11 +44,12 @@ template <typename T> struct IlqrArgs {
   int lds_work;                  // start of the Riccati / line-search scratch (elements)
   int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
   int cost_diag;                 // 1: Q, R, F of every cost block are diagonal -> O(n) objective
+  int cost_affine;               // 1: some cost block has an affine part (mlp_tile.hpp: cost_block_stride)
   int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it
                                  //    (cost.py:195, goal ignored); 1: (F+F')(x_N - goal)
   T dt, u_threshold, ls_cost_threshold;
   T alphas[kIlqrMaxLs];          // step sizes discount**j, computed on the host like the reference
-  const T* costs_par;            // [n_costs][cost_stride]: Q R F goal
+  const T* costs_par;            // [n_costs][cost_stride]: Q R F goal lin lint c0 c1
   const int* cost_idx;           // [B]
   const T* ubounds;              // lo[nu] hi[nu]
   T* states;                     // [B][H+1][nx]  nominal trajectory
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   const int tid = threadIdx.x, p = blockIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   if (args.active[p] == 0) return;
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
   T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
   T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   T* xbar = Wr + wk.xbar; T* ubar = Wr + wk.ubar; T* cpar = Wr + wk.cpar; T* scal = Wr + wk.scal;
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
+  const T* clin = goal + no; const T* clint = clin + no;     // affine part of the stage / terminal cost
   for (int i = tid; i < cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * cost_stride + i];
   __syncthreads();
@@ -228,7 +230,10 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
     if (a < no)
       for (int b = 0; b < no; ++b)
         s += (Fm[a * no + b] + Fm[b * no + a]) * (st[(size_t)H * nx + b] - (args.term_goal ? goal[b] : T(0)));
-    v[a] = s;     // term_goal == 0: no goal subtraction -- the reference's terminal gradient quirk
+    // term_goal == 0: no goal subtraction -- the reference's terminal gradient quirk, term by term in
+    // a sum (sum_cost.py:49-54 over cost.py:195), so the affine part only enters with term_goal
+    if (a < no && args.term_goal) s += clint[a];
+    v[a] = s;
   }
   if (tid == 0) scal[8] = T(0);
   __syncthreads();
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
       T cc = T(0);
       if (c < no) {
         for (int b = 0; b < no; ++b) cc += (Qm[c * no + b] + Qm[b * no + c]) * (xbar[b] - goal[b]);
+        cc += clin[c];
       } else if (c >= nx) {
         const int cj = c - nx;
         for (int j = 0; j < nu; ++j) cc += (Rm[cj * nu + j] + Rm[j * nu + cj]) * ubar[j];
@@ -435,7 +441,7 @@ __host__ __device__ constexpr RicLds make_ric_lds(int nx, int nu, int no) {
   r.cq = o; o += 2 * n;
   r.xbar = o; o += nx;
   r.ubar = o; o += nu;
-  r.goal = o; o += no;
+  r.goal = o; o += 3 * no;           // goal | lin | lint
   r.scal = o; o += 4;
   r.total = (o + 3) / 4 * 4;
   return r;
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   const int i16 = lane & 15, q = lane >> 4;
   const int nx = mlp.nx, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   if (args.active[p] == 0) return;
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const RicLds R = make_ric_lds(nx, nu, no);
   T* V = Wr + R.V; T* Jm = Wr + R.J; T* VJ = Wr + R.VJ; T* Qt = Wr + R.Qt; T* SB = Wr + R.SB;
   T* CQ = Wr + R.CQ; T* CR = Wr + R.CR; T* Fs = Wr + R.Fm; T* cq = Wr + R.cq;
@@ -567,7 +573,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
     const int a = i / nu, b = i - a * nu;
     CR[i] = cpar[no * no + a * nu + b] + cpar[no * no + b * nu + a];
   }
-  for (int i = tid; i < no; i += NTHR) goal[i] = cpar[2 * no * no + nu * nu + i];
+  for (int i = tid; i < 3 * no; i += NTHR) goal[i] = cpar[2 * no * no + nu * nu + i];   // goal | lin | lint
+  const T* clin = goal + no; const T* clint = clin + no;
   __syncthreads();
   for (int i = tid; i < no * no; i += NTHR) {           // V_H = F + F' on the observed block
     const int a = i / no, b = i - a * no;
@@ -576,6 +583,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   for (int a = tid; a < no; a += NTHR) {                // v_H (term_goal == 0: the reference's quirk)
     T s = T(0);
     for (int b = 0; b < no; ++b) s += Fs[a * no + b] * (st[(size_t)H * nx + b] - (args.term_goal ? goal[b] : T(0)));
+    if (args.term_goal) s += clint[a];
     VJ[a * ldJ + n] = s;
   }
   // J_t = [jx | ju], xbar_t, ubar_t: loaded one step ahead into registers by the side threads
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
       cc += __shfl_xor(cc, 1);
       cc += __shfl_xor(cc, 2);
       cc += __shfl_xor(cc, 4);
-      if (part == 0 && c < n) cq[buf * n + c] = cc * dt;
+      if (part == 0 && c < n) cq[buf * n + c] = (c < no ? cc + clin[c] : cc) * dt;
     }
   };
   if (sid >= 0) { fetch_step(H - 1); commit_step(); }
@@ -831,7 +839,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   const int tid = threadIdx.x, p = blockIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   const int xs_ = L.xu_stride;
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
   T* Wr = lds + (SH::kStatic ? L.extra : args.lds_work);
   T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
@@ -842,6 +850,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   int* piv = reinterpret_cast<int*>(Wr + wk.piv);
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
+  const T* clin = goal + no; const T* clint = clin + no;     // affine part of the stage / terminal cost
   T* xu = lds + L.xu;
 
   if (args.mode == 1 && args.active[p] == 0) {
@@ -922,7 +931,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     commit_ls();
     __syncthreads();
   }
-  const bool cdiag = args.cost_diag != 0;
+  const bool cdiag = args.cost_diag != 0, caff = args.cost_affine != 0;
   for (int t = 0; t < H; ++t) {
     AMPC_IPROBE_STEP(args.mode == 1 && t == H / 2);
     AMPC_IMARK(40);
@@ -959,6 +968,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     // objective: dt * (stage costs)
     obj_part += args.dt * (quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, cdiag) +
                            quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, cdiag));
+    if (caff) obj_part += args.dt * affine_rows<T>(clin, xu + m * xs_, goal, no, r, TPS, clint[no]);
     AMPC_IMARK(43);
     if constexpr (DYN == 0) {
       net.run(mlp, L, lds);
@@ -990,6 +1000,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   if (args.mode == 1 && m < rows)
     for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
   obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, cdiag);
+  if (caff) obj_part += affine_rows<T>(clint, xu + m * xs_, goal, no, r, TPS, clint[no + 1]);
 #pragma unroll
   for (int off = TPS / 2; off > 0; off >>= 1) obj_part += __shfl_xor(obj_part, off);
   if (r == 0) lsobj[m] = obj_part;

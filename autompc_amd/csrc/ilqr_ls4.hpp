@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
   const int Lh = RES ? 2 : mlp.n_hidden, nxp = mlp.nxp, tiles = nxp / 16, ks0 = mlp.k1p / 4;
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const Ls4Lds L = make_ls4_lds(nu, mlp.k1p, nxp, HP, Lh, RES, cost_stride);
   T* xu = lds + L.xu; T* part = lds + L.part; T* bias = lds + L.bias;
   T* cpar = lds + L.cpar; T* blo = lds + L.blo; T* bhi = lds + L.bhi; T* scal = lds + L.scal;
@@ -142,6 +142,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   const int xs = L.xs, as = L.as;
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
+  const T* clin = goal + no; const T* clint = clin + no;     // affine part of the stage / terminal cost
 
   if (args.mode == 1 && args.active[p] == 0) {
     if (tid == 0) args.refresh[p] = 0;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
   T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
   const int rows = args.mode == 0 ? 1 : args.ls_n;
-  const bool cdiag = args.cost_diag != 0;
+  const bool cdiag = args.cost_diag != 0, caff = args.cost_affine != 0;
   // Wave w owns row w of the tile between time steps: it adds the network output to its state,
   // evaluates the control law (ilqr.py:196-205) -- no workgroup barrier in between -- and
   // accumulates the row's stage cost.  Control law: `parts` lanes per control, interleaved over
@@ -444,6 +445,10 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
           if (t < H) obj_part += args.dt * (quad_rows<T>(Qm, xt, goal, no, 0, 1, cdiag) +
                                             quad_rows<T>(Rm, usrc + (size_t)t * nu, nullptr, nu, 0, 1, cdiag));
           else obj_part += quad_rows<T>(Fm, xt, goal, no, 0, 1, cdiag);
+          if (caff) {
+            if (t < H) obj_part += args.dt * affine_rows<T>(clin, xt, goal, no, 0, 1, clint[no]);
+            else obj_part += affine_rows<T>(clint, xt, goal, no, 0, 1, clint[no + 1]);
+          }
         }
     }
 #pragma unroll

@@ -242,6 +242,21 @@ __device__ __forceinline__ void lds_barrier() {
 __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline int round_up(int a, int m) { return (a + m - 1) / m * m; }
 
+// Layout of one cost block (ampc_set_affine_quad_costs; one block per controller / tuning candidate):
+//   Q[no*no] R[nu*nu] F[no*no] goal[no] lin[no] lint[no] c0 c1
+// stage cost   (x-goal)'Q(x-goal) + lin'(x-goal) + c0 + u'Ru      (dt-scaled in iLQR, not in MPPI)
+// terminal     (x-goal)'F(x-goal) + lint'(x-goal) + c1
+// A sum of quadratic terms with DIFFERENT goals (SumCost._sum_results, sum_cost.py:49-54, e.g.
+// QuadCostFactory + GaussRegFactory, gauss_reg_factory.py:37-45) is such a form about the first
+// term's goal; for a single QuadCost / a same-goal sum lin = lint = c0 = c1 = 0.
+__host__ __device__ constexpr int cost_block_stride(int no, int nu) {
+  return (2 * no * no + nu * nu + 3 * no + 2 + 3) / 4 * 4;
+}
+__host__ __device__ constexpr int cost_off_goal(int no, int nu) { return 2 * no * no + nu * nu; }
+__host__ __device__ constexpr int cost_off_lin(int no, int nu) { return 2 * no * no + nu * nu + no; }
+__host__ __device__ constexpr int cost_off_lint(int no, int nu) { return 2 * no * no + nu * nu + 2 * no; }
+__host__ __device__ constexpr int cost_off_c(int no, int nu) { return 2 * no * no + nu * nu + 3 * no; }
+
 // (constexpr on plain integers: the shape-specialised kernels evaluate it at compile time, the host
 // at plan build -- both must agree, see StaticShape below)
 // Row stride of the output-layer partials [W][M][.]: nxp in f64; nxp + 4 in f32, where a wave's
@@ -987,6 +1002,16 @@ __device__ __forceinline__ T quad_rows(const T* __restrict__ Mx, const T* __rest
       acc += (v[i] - (g ? g[i] : T(0))) * s;
     }
   }
+  return acc;
+}
+
+// The affine part of a cost block over the same rows: sum_i lin_i (v_i - g_i), plus the constant on
+// the helper thread r == 0.
+template <typename T>
+__device__ __forceinline__ T affine_rows(const T* __restrict__ lin, const T* __restrict__ v,
+                                         const T* __restrict__ g, int n, int r, int tps, T c) {
+  T acc = r == 0 ? c : T(0);
+  for (int i = r; i < n; i += tps) acc += lin[i] * (v[i] - g[i]);
   return acc;
 }
 

@@ -41,9 +41,11 @@ template <typename T> struct MppiArgs {
   MlpDev<T> mlp;
   TileLds lds;
   int lds_aseq, lds_cost;       // extra LDS regions: shifted act sequence, cost block + bounds
-  int obs_dim, cost_stride;     // cost block = Q[no*no] R[nu*nu] F[no*no] goal[no]
+  int obs_dim, cost_stride;     // cost block = Q R F goal lin lint c0 c1 (mlp_tile.hpp: cost_block_stride)
   int term_mode, max_h;
   int cost_diag;                // 1: every Q, R, F is diagonal -> O(n) stage cost
+  int cost_affine;              // 1: some block has a non-zero affine part (sum of quadratics with
+                                //    different goals, sum_cost.py:49-54)
   int lds_eps;                  // >= 0: clipped noise of the tile is kept in LDS ([max_h][M][nu]) and
                                 //       the softmin update is fused (tile partials + combine kernel)
   int lds_red;                  // small reduction scratch: [M] costs, [M] weights
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   const int tid = threadIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int xs_ = L.xu_stride;
-  const bool diag = args.cost_diag != 0;
+  const bool diag = args.cost_diag != 0, affine = args.cost_affine != 0;
   // cost block stride and the fixed-position LDS regions behind the tile map (plan_build lays
   // them out in this order: cost block + bounds, shifted sequence, [clipped noise, reduction])
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const int lds_cost = SH::kStatic ? L.extra : args.lds_cost;
   const int lds_aseq = SH::kStatic ? round_up(L.extra + cost_stride + 3 * SH::nu, 4) : args.lds_aseq;
 
@@ -112,6 +114,8 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   const T* Rm = Qm + no * no;
   const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
+  const T* lin = goal + no;                 // affine part of the stage cost, about `goal`
+  const T* lint = lin + no;                 // ... of the terminal cost
   const T* blo = cpar + cost_stride;
   const T* bhi = blo + nu;
   const T* bsc = bhi + nu;
@@ -186,16 +190,23 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   // Diagonal costs are accumulated where the values are produced (actions / state update), so
   // the time loop has no separate cost phase; the stage cost of x_0 is added here.
   if (diag) c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, true);
+  // affine part: lin'(x_t - goal) is added where the quadratic part is; the constant c0 is charged
+  // for the H stage costs at once
+  if (affine) {
+    if (diag) c_part += affine_rows<T>(lin, xu + m * xs_, goal, no, r, TPS, T(0));
+    if (r == 0) c_part += T(H) * lint[no];
+  }
 
   AMPC_PROBE_KERNEL_BEGIN(net.probe);
   // the (at most ceil(nx / TPS)) state columns this thread updates: goal and diagonal Q weight
   constexpr int XPT = ((WIDE ? 64 : 32) + TPS - 1) / TPS;
-  T qd_r[XPT], gl_r[XPT];
+  T qd_r[XPT], gl_r[XPT], ql_r[XPT];
 #pragma unroll
   for (int e = 0; e < XPT; ++e) {
     const int i = r + e * TPS;
     qd_r[e] = (diag && i < no) ? Qm[i * no + i] : T(0);
     gl_r[e] = i < no ? goal[i] : T(0);
+    ql_r[e] = (diag && i < no) ? lin[i] : T(0);       // (zero without an affine part)
   }
   for (int t = 0; t < H; ++t) {
     AMPC_PROBE_STEP(net.probe, t == 5);
@@ -204,6 +215,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     if (!diag && !Probe::no_cost) {
       c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false);
       c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false);
+      if (affine) c_part += affine_rows<T>(lin, xu + m * xs_, goal, no, r, TPS, T(0));
     }
     AMPC_MARK(1);
     // ---- dynamics: x <- x + net'([x,u]) -------------------------------------------------------
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
         xu[m * xs_ + i] = xn;
         if (diag && i < no && t + 1 < H) {     // stage cost of x_{t+1} (x_H only pays the terminal cost)
           const T d = xn - gl_r[e];
-          c_part += qd_r[e] * d * d;
+          c_part += (qd_r[e] * d + ql_r[e]) * d;     // (x-g) q (x-g) + lin (x-g): two FMAs either way
         }
       }
     }
@@ -232,6 +244,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   AMPC_PROBE_KERNEL_END();
   // ---- epilogue: terminal cost, reduce the TPS partials, write ---------------------------------
   T term = quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, diag);
+  if (affine) term += affine_rows<T>(lint, xu + m * xs_, goal, no, r, TPS, lint[no + 1]);
   T c = c_part + pr.lam_over_sigma * ca_part;
   if (args.term_mode == 1) c += term;
 #pragma unroll

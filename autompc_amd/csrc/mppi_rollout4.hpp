@@ -73,13 +73,14 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int nxp = mlp.nxp, tiles = nxp / 16, ks0 = mlp.k1p / 4;
-  const int cost_stride = SH::kStatic ? round_up(2 * SH::no * SH::no + SH::nu * SH::nu + SH::no, 4) : args.cost_stride;
-  const bool diag = args.cost_diag != 0;
+  const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
+  const bool diag = args.cost_diag != 0, affine = args.cost_affine != 0;
   const Q4Lds L = make_q4_lds(nu, mlp.k1p, nxp, HP, NH, cost_stride, args.max_h);
   const int xs = L.xs, as = L.as;
   T* xu = lds + L.xu + (FULL ? w * 4 * xs : 0); T* part = lds + L.part; T* bias = lds + L.bias; T* cpar = lds + L.cpar;
   T* aseq = lds + L.aseq; T* el = lds + L.eps;
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu; const T* goal = Fm + no * no;
+  const T* lin = goal + no; const T* lint = lin + no;      // affine part (stage / terminal), c0 c1 behind
   const T* blo = cpar + cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
 
   const int p = args.tile_prob[blockIdx.x];
@@ -189,12 +190,18 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
     xu[m * xs + nx + r] = ul[m * nu + r];
   }
   if (diag) c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, true);     // stage cost of x_0
+  if (affine) {                                  // lin'(x_0 - goal); the constant for all H stage costs
+    if (diag) c_part += affine_rows<T>(lin, xu + m * xs, goal, no, r, 64, T(0));
+    if (r == 0) c_part += T(H) * lint[no];
+  }
 
   const int arow = lane & 3, ak = lane >> 4, drow = lane >> 4, dcol = lane & 15;
   // per-lane constants of the state update: diagonal Q weight, goal, output bias of the lane's columns
   const T qd_r = (diag && r < no) ? Qm[r * no + r] : T(0), gl_r = r < no ? goal[r] : T(0);
   const T qd0 = (diag && dcol < no) ? Qm[dcol * no + dcol] : T(0), gl0 = dcol < no ? goal[dcol] : T(0);
   const T qd1 = (diag && 16 + dcol < no) ? Qm[(16 + dcol) * no + 16 + dcol] : T(0);
+  const T ql_r = (diag && r < no) ? lin[r] : T(0), ql0 = (diag && dcol < no) ? lin[dcol] : T(0);
+  const T ql1 = (diag && 16 + dcol < no) ? lin[16 + dcol] : T(0);
   const T gl1 = 16 + dcol < no ? goal[16 + dcol] : T(0);
   const T ob0 = bias[NH * HP + dcol], ob1 = tiles > 1 ? bias[NH * HP + 16 + dcol] : T(0);
   T xr0 = dcol < nx ? xu[drow * xs + dcol] : T(0), xr1 = 16 + dcol < nx ? xu[drow * xs + 16 + dcol] : T(0);
@@ -210,7 +217,10 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
     AMPC_MARK(0);
     if (BAR_A) lds_barrier();                    // state and controls of step t are in xu
     AMPC_MARK(1);
-    if (!diag) c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, false);
+    if (!diag) {
+      c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, false);
+      if (affine) c_part += affine_rows<T>(lin, xu + m * xs, goal, no, r, 64, T(0));
+    }
     // ---- layer 0
     T* ain = lds + L.act0;
     {
@@ -291,12 +301,12 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
       if (dcol < nx) {
         xr0 += fold(o0) + ob0;
         xu[drow * xs + dcol] = xr0;
-        if (diag && drow == w && dcol < no && t + 1 < H) { const T d = xr0 - gl0; c_part += qd0 * d * d; }
+        if (diag && drow == w && dcol < no && t + 1 < H) { const T d = xr0 - gl0; c_part += (qd0 * d + ql0) * d; }
       }
       if (tiles > 1 && 16 + dcol < nx) {
         xr1 += fold(o1) + ob1;
         xu[drow * xs + 16 + dcol] = xr1;
-        if (diag && drow == w && 16 + dcol < no && t + 1 < H) { const T d = xr1 - gl1; c_part += qd1 * d * d; }
+        if (diag && drow == w && 16 + dcol < no && t + 1 < H) { const T d = xr1 - gl1; c_part += (qd1 * d + ql1) * d; }
       }
     } else {
       T o0[NA], o1[NA];
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
         xu[m * xs + r] = xn;
         if (diag && r < no && t + 1 < H) {       // stage cost of x_{t+1} (x_H only pays the terminal cost)
           const T d = xn - gl_r;
-          c_part += qd_r * d * d;
+          c_part += (qd_r * d + ql_r) * d;
         }
       }
     }
@@ -337,6 +347,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
 
   // ---- epilogue: terminal cost, reduce the 64 partials of the row, write -----------------------
   T term = quad_rows<T>(Fm, xu + m * xs, goal, no, r, 64, diag);
+  if (affine) term += affine_rows<T>(lint, xu + m * xs, goal, no, r, 64, lint[no + 1]);
   T c = c_part + pr.lam_over_sigma * ca_part;
   if (args.term_mode == 1) c += term;
 #pragma unroll

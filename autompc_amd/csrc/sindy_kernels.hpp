@@ -301,6 +301,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   __syncthreads();
   const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
   const T* goal = Fm + no * no;
+  const T* lin = goal + no; const T* lint = lin + no;       // affine part (all zero for one QuadCost)
   const T* blo = cpar + args.cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
   for (int i = 0; i < nx; ++i) v[i * BS] = args.x0[p * nx + i];
   const T* eps_row = args.eps + pr.eps_off + (size_t)(valid ? n : 0) * H * nu;
@@ -321,8 +322,9 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
     for (int i = 0; i < no; ++i) {
       T s = T(0);
       for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (v[j * BS] - goal[j]);
-      c += (v[i * BS] - goal[i]) * s;
+      c += (v[i * BS] - goal[i]) * (s + lin[i]);
     }
+    c += lint[no];
     for (int i = 0; i < nu; ++i) {
       T s = T(0);
       for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[(nx + j) * BS];
@@ -335,8 +337,9 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   for (int i = 0; i < no; ++i) {
     T s = T(0);
     for (int j = 0; j < no; ++j) s += Fm[i * no + j] * (v[j * BS] - goal[j]);
-    term += (v[i * BS] - goal[i]) * s;
+    term += (v[i * BS] - goal[i]) * (s + lint[i]);
   }
+  term += lint[no + 1];
   c += pr.lam_over_sigma * ca;
   if (args.term_mode == 1) c += term;
   if (valid) {

@@ -19,7 +19,7 @@ backend is "nccl"; 8 bytes per candidate, latency-bound).
 import numpy as np
 
 from .. import _lib
-from ..control.mppi import _quad_cost_blocks
+from ..costs.blocks import quad_sum_block, is_quad_sum, stack_blocks
 from ..costs.terms import cost_terms
 
 
@@ -41,11 +41,12 @@ def score_trajectories(cost, obs, ctrls):
     observation.  Quadratic costs are scored in closed form; anything else (threshold costs)
     falls back to the cost object's own per-step interface."""
     B = obs.shape[0]
-    if getattr(cost, "is_quad", False):
-        Q, R, F = cost.get_cost_matrices()
-        d = obs - cost.get_goal()
-        s = np.einsum("bti,ij,btj->b", d, Q, d) + np.einsum("bti,ij,btj->b", ctrls, R, ctrls)
-        return s + np.einsum("bi,ij,bj->b", d[:, -1], F, d[:, -1])
+    if is_quad_sum(cost):          # (also a sum of quadratics with different goals: costs/blocks.py)
+        k = quad_sum_block(cost, obs.shape[2], ctrls.shape[2])
+        d = obs - k["goal"]
+        s = (np.einsum("bti,ij,btj->b", d, k["Q"], d) + np.einsum("bti,i->b", d, k["lin"])
+             + obs.shape[1] * k["consts"][0] + np.einsum("bti,ij,btj->b", ctrls, k["R"], ctrls))
+        return s + np.einsum("bi,ij,bj->b", d[:, -1], k["F"], d[:, -1]) + d[:, -1] @ k["lin_term"] + k["consts"][1]
     out = np.zeros(B)
     for b in range(B):
         for t in range(obs.shape[1]):
@@ -54,12 +55,43 @@ def score_trajectories(cost, obs, ctrls):
     return out
 
 
+def _first_goal(cost, obs_dim):
+    """Goal of the first quadratic term of a (nested) sum of quadratics (read structurally: the
+    reference's SumCost.get_goal returns a cost object, sum_cost.py:45-47)."""
+    c = cost
+    while getattr(c, "costs", None) is not None and not callable(c.costs):
+        c = c.costs[0]
+    return np.asarray(c.get_goal(), dtype=np.float64).reshape(obs_dim).copy()
+
+
+def candidate_cost_blocks(candidates, goal, obs_dim, ctrl_dim):
+    """Stacked device cost blocks of a batch of candidates (Handle.set_cost_blocks) and their common
+    ``terminal_goal`` flag.  A candidate gives its controller cost either as QuadCostFactory does
+    (quad_cost_factory.py:64-95) -- ``Q``, ``R``, ``F`` diagonals or matrices about the task's goal --
+    or as a cost OBJECT under ``"cost"``: a QuadCost or any sum of QuadCosts, shared goal or not,
+    e.g. what ``QuadCostFactory + GaussRegFactory`` produce (gauss_reg_factory.py:37-45,
+    sum_cost.py:49-54)."""
+    no, nu = int(obs_dim), int(ctrl_dim)
+    blocks = []
+    for c in candidates:
+        if c.get("cost") is not None:
+            blocks.append(quad_sum_block(c["cost"], no, nu))
+        else:
+            blocks.append({"Q": _as_matrix(c["Q"], no), "R": _as_matrix(c["R"], nu), "F": _as_matrix(c["F"], no),
+                           "goal": goal, "lin": np.zeros(no), "lin_term": np.zeros(no), "consts": np.zeros(2),
+                           "terminal_goal": False})
+    tg = {bool(b["terminal_goal"]) for b in blocks}
+    if len(tg) > 1:
+        raise TypeError("the candidates of one batch must agree on strict_reference")
+    return stack_blocks(blocks), tg.pop()
+
+
 def _task_goal(cost, obs_dim):
     """Goal the candidates' quadratic costs are centred on: the task cost's goal (as
     QuadCostFactory takes it, quad_cost_factory.py:64-66); for a sum without a shared goal the
     first term that has one; the origin if none has."""
-    if getattr(cost, "is_quad", False):
-        return _quad_cost_blocks(cost)[3]
+    if is_quad_sum(cost):
+        return _first_goal(cost, obs_dim)
     for c in [cost] + list(getattr(cost, "costs", [])):
         try:
             g = np.asarray(c.get_goal(), dtype=np.float64)
@@ -199,10 +231,8 @@ class CandidateEvaluator:
         h = _lib.Handle(self.device, self.precision)
         opened.append(h)
         self.model.stage_into(h)
-        Q = np.stack([_as_matrix(c["Q"], no) for c in candidates])
-        R = np.stack([_as_matrix(c["R"], nu) for c in candidates])
-        F = np.stack([_as_matrix(c["F"], no) for c in candidates])
-        h.set_quad_costs(Q, R, F, np.tile(self.goal, (B, 1)))
+        blocks, _ = candidate_cost_blocks(candidates, self.goal, no, nu)
+        h.set_cost_blocks(**blocks)
         h.set_ctrl_bounds(self.umin, self.umax)
         sur = None
         if self.surrogate is not self.model:
@@ -449,14 +479,12 @@ class IlqrCandidateEvaluator:
             h = _lib.Handle(self.device, self.precision)
             opened.append(h)
             self.model.stage_into(h)
-            h.set_quad_costs(np.stack([_as_matrix(candidates[i]["Q"], no) for i in idx]),
-                             np.stack([_as_matrix(candidates[i]["R"], nu) for i in idx]),
-                             np.stack([_as_matrix(candidates[i]["F"], no) for i in idx]),
-                             np.tile(self.goal, (len(idx), 1)))
+            blocks, term_goal = candidate_cost_blocks([candidates[i] for i in idx], self.goal, no, nu)
+            h.set_cost_blocks(**blocks)
             if self.bounded:
                 h.set_ctrl_bounds(self.umin, self.umax)
             plan = _lib.IlqrPlan(h, len(idx), H, self.system.dt, cost_index=np.arange(len(idx)),
-                                 clip_to_bounds=self.bounded)
+                                 clip_to_bounds=self.bounded, terminal_goal=term_goal)
             opened.append(plan)
             plans[H] = (plan, np.array(idx))
         obs = np.full((B, n_ctl + 1, nx), np.nan)

@@ -37,7 +37,7 @@ enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU
 enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 
 const char* ampc_last_error(void);
-int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy */
+int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -128,6 +128,21 @@ int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, const doubl
  * n_costs blocks (one per tuning candidate), each Q[no][no], R[nu][nu], F[no][no], goal[no]. */
 int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
                         const double* R, const double* F, const double* goal);
+/* A sum of quadratic terms (SumCost._sum_results, sum_cost.py:49-54, over quad_cost.py:7-51) whose
+ * goals differ -- what QuadCostFactory + GaussRegFactory produce (gauss_reg_factory.py:37-45: goal =
+ * mean of the data; sum_cost_factory.py) and what the reference's MPPI / iLQR evaluate term by term
+ * through Cost.eval_* (mppi.py:73-82, ilqr.py:124-129,159-174).  About the first term's goal g the
+ * sum is an affine-quadratic form, per block:
+ *   stage     (x-g)'Q(x-g) + lin'(x-g) + consts[0] + u'Ru          Q = sum Q_k, R = sum R_k,
+ *   terminal  (x-g)'F(x-g) + lin_term'(x-g) + consts[1]            F = sum F_k,
+ *   lin = sum (Q_k+Q_k')(g-g_k),  consts[0] = sum (g-g_k)'Q_k(g-g_k)   (lin_term, consts[1]: with F_k)
+ * lin [n_costs][obs_dim], lin_term [n_costs][obs_dim], consts [n_costs][2]; any of the three may be
+ * NULL (zeros: ampc_set_quad_costs).  iLQR's stage gradient is (Q+Q')(x-g) + lin; its terminal
+ * gradient is (F+F')x as the reference computes it term by term (cost.py:195: no goal, hence no
+ * lin_term), or (F+F')(x-g) + lin_term under ampc_ilqr_plan_set_terminal_goal(1). */
+int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                               const double* R, const double* F, const double* goal,
+                               const double* lin, const double* lin_term, const double* consts);
 /* Task.get_ctrl_bounds (task.py:257-267): lo[nu], hi[nu] (MPPI requires finite bounds,
  * mppi.py:100-102; iLQR clips only if bounded, ilqr.py:62-64). */
 int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi);

@@ -52,11 +52,66 @@ class QuadCostOracle:
     def ctrl_cost_batch(self, ctrls):
         return np.einsum("ni,ij,nj->n", ctrls, self.R, ctrls)
 
+    def term_cost_batch(self, obs):
+        d = obs - self.goal
+        return np.einsum("ni,ij,nj->n", d, self.F, d)
+
     def traj_cost(self, obs, ctrls):
         """Cost.__call__ (cost.py:27-41): sum over ALL rows of obs and ctrl cost
         (the last row's ctrl is the zero row ``simulate`` appends) + terminal."""
         return (self.obs_cost_batch(obs).sum() + self.ctrl_cost_batch(ctrls).sum()
                 + self.eval_term_obs_cost(obs[-1]))
+
+
+class SumCostOracle:
+    """Sum of quadratic terms -- SumCost._sum_results (sum_cost.py:49-54): every ``eval_*`` call is
+    fanned out to the terms IN ORDER and the results (scalars, or tuples entry by entry) are added
+    with Python's ``sum``.  The goals of the terms may differ (QuadCostFactory + GaussRegFactory,
+    gauss_reg_factory.py:37-45); the terminal ``_hess`` of every term ignores that term's goal
+    (cost.py:195,208-211), so the sum's does too."""
+
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+    @classmethod
+    def from_arrays(cls, Qs, Rs, Fs, goals):
+        return cls([QuadCostOracle(q, r, f, g) for q, r, f, g in zip(Qs, Rs, Fs, goals)])
+
+    def _fan(self, attr, arg):
+        res = [getattr(t, attr)(arg) for t in self.terms]
+        if isinstance(res[0], tuple):
+            return tuple(sum(v) for v in zip(*res))
+        return sum(res)
+
+    def eval_obs_cost(self, obs):
+        return self._fan("eval_obs_cost", obs)
+
+    def eval_ctrl_cost(self, ctrl):
+        return self._fan("eval_ctrl_cost", ctrl)
+
+    def eval_term_obs_cost(self, obs):
+        return self._fan("eval_term_obs_cost", obs)
+
+    def eval_obs_cost_hess(self, obs):
+        return self._fan("eval_obs_cost_hess", obs)
+
+    def eval_ctrl_cost_hess(self, ctrl):
+        return self._fan("eval_ctrl_cost_hess", ctrl)
+
+    def eval_term_obs_cost_hess(self, obs):
+        return self._fan("eval_term_obs_cost_hess", obs)
+
+    def obs_cost_batch(self, obs):
+        return sum(t.obs_cost_batch(obs) for t in self.terms)
+
+    def ctrl_cost_batch(self, ctrls):
+        return sum(t.ctrl_cost_batch(ctrls) for t in self.terms)
+
+    def term_cost_batch(self, obs):
+        return sum(t.term_cost_batch(obs) for t in self.terms)
+
+    def traj_cost(self, obs, ctrls):
+        return sum(t.traj_cost(obs, ctrls) for t in self.terms)
 
 
 def score_terms(kinds, params, obs, ctrls, obs_dim=None):

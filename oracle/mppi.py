@@ -85,8 +85,7 @@ class MPPIOracle:
             action_cost += self.lmda / self.sigma * np.einsum("ij,ij->i", actions, eps[i])
             path = self.model.pred_batch(path, scaled)
         if self.per_particle_terminal:
-            d = path[:, :self.obs_dim] - self.cost.goal
-            costs += np.einsum("ni,ij,nj->n", d, self.cost.F, d)
+            costs += self.cost.term_cost_batch(path[:, :self.obs_dim])
         else:
             costs += self.cost.eval_term_obs_cost(path[-1, :self.obs_dim])
         costs += action_cost

@@ -427,6 +427,220 @@ def gen_evalcfg():
     save("loop_evalcfg_ilqr", num_steps=T, H=12, dt=0.05, **out, **common)
 
 
+# ---------------------------------------------------------- sums of quadratic costs
+def _term_arrays(cost):
+    """Per-term Q, R, F, goal of a (sum of) QuadCost(s), in the sum's order."""
+    terms = cost.costs if hasattr(cost, "costs") else [cost]
+    mats = [t.get_cost_matrices() for t in terms]
+    return dict(Qs=np.stack([m[0] for m in mats]), Rs=np.stack([m[1] for m in mats]),
+                Fs=np.stack([m[2] for m in mats]), goals=np.stack([np.asarray(t.get_goal(), dtype=float) for t in terms]))
+
+
+def sum_cost_of(system, kind, seed, task_goal=None):
+    """Controller costs that are sums of quadratics, built by the reference's own classes:
+      gauss    QuadCostFactory(cfg) + GaussRegFactory(cfg)  -- the factories themselves called with
+               dict configurations, combined as SumCostFactory.__call__ does (sum_cost_factory.py:45-53:
+               ``sum(costs, SumCost(system, []))``); goal of the second term = mean of the data
+               (gauss_reg_factory.py:37-45), of the first = the task's goal
+      dense    two dense, non-symmetric QuadCosts with different goals, both with a terminal part
+      three    three terms, two of them sharing a goal
+      samegoal two terms with the SAME goal: the reference's SumCost is then ``is_quad`` and its
+               get_goal() returns a cost OBJECT (sum_cost.py:45-47)"""
+    from autompc.costs import SumCost
+    from autompc.costs.quad_cost_factory import QuadCostFactory
+    from autompc.costs.gauss_reg_factory import GaussRegFactory
+    no, nu = system.obs_dim, system.ctrl_dim
+    rng = np.random.default_rng(seed)
+    if kind == "gauss":
+        task = Task(system)
+        goal = rng.normal(scale=0.2, size=no) if task_goal is None else task_goal
+        task.set_cost(QuadCost(system, np.eye(no), np.eye(nu), np.eye(no), goal=goal))
+        cfg = {}
+        for n in system.observations:
+            cfg[n + "_Q"] = float(10 ** rng.uniform(-1, 1.5))
+            cfg[n + "_F"] = float(10 ** rng.uniform(-1, 1.5))
+        for n in system.controls:
+            cfg[n + "_R"] = float(10 ** rng.uniform(-3, -1))
+        trajs = []
+        for k in range(5):
+            tr = ampc.zeros(system, 30)
+            tr.obs[:] = rng.normal(scale=0.4, size=(30, no)) @ (np.eye(no) + 0.3 * rng.normal(size=(no, no))) \
+                + rng.normal(scale=0.3, size=no)
+            trajs.append(tr)
+        c1 = QuadCostFactory(system)(cfg, task, trajs)
+        c2 = GaussRegFactory(system)({"reg_weight": float(10 ** rng.uniform(-2, -0.5))}, task, trajs)
+        return sum([c1, c2], SumCost(system, []))
+
+    def dense(goal_scale):
+        A, B = rng.normal(size=(no, no)), rng.normal(size=(no, no))
+        Q = A @ A.T / no + 0.1 * rng.normal(size=(no, no))
+        F = B @ B.T / no + 0.05 * rng.normal(size=(no, no))
+        R = np.diag(rng.uniform(0.01, 0.1, size=nu)) + 0.004 * rng.normal(size=(nu, nu))
+        return QuadCost(system, Q, R, F, goal=rng.normal(scale=goal_scale, size=no))
+    if kind == "dense":
+        return dense(0.2) + dense(0.5)
+    if kind == "three":
+        a, b = dense(0.3), dense(0.3)
+        c = QuadCost(system, np.diag(rng.uniform(0.1, 1, size=no)), 0.02 * np.eye(nu), None, goal=a.get_goal())
+        return a + b + c
+    if kind == "samegoal":
+        a = dense(0.3)
+        b = QuadCost(system, np.diag(rng.uniform(0.1, 1, size=no)), 0.02 * np.eye(nu), np.eye(no), goal=a.get_goal())
+        return a + b
+    raise ValueError(kind)
+
+
+def gen_sumcost():
+    from autompc.costs import SumCost
+    # -- the nine eval_* entry points of sums (sum_cost.py:49-82) ---------------------------------
+    system = make_system(5, 3)
+    rng = np.random.default_rng(2024)
+    out = {}
+    for kind in ("gauss", "dense", "three", "samegoal"):
+        cost = sum_cost_of(system, kind, 700 + len(kind))
+        assert isinstance(cost, SumCost)
+        obs, ctrl = rng.normal(size=5), rng.normal(size=3)
+        o, c, t = cost.eval_obs_cost_hess(obs), cost.eval_ctrl_cost_hess(ctrl), cost.eval_term_obs_cost_hess(obs)
+        traj = ampc.zeros(system, 7)
+        traj.obs[:] = rng.normal(size=(7, 5))
+        traj.ctrls[:] = rng.normal(size=(7, 3))
+        arrs = _term_arrays(cost)
+        out.update({kind + "_" + k: v for k, v in arrs.items()})
+        out.update({kind + "_obs": obs, kind + "_ctrl": ctrl, kind + "_is_quad": bool(cost.is_quad),
+                    kind + "_obs_cost": cost.eval_obs_cost(obs), kind + "_ctrl_cost": cost.eval_ctrl_cost(ctrl),
+                    kind + "_term_cost": cost.eval_term_obs_cost(obs),
+                    kind + "_obs_c": o[0], kind + "_obs_j": o[1], kind + "_obs_h": o[2],
+                    kind + "_ctrl_c": c[0], kind + "_ctrl_j": c[1], kind + "_ctrl_h": c[2],
+                    kind + "_term_c": t[0], kind + "_term_j": t[1], kind + "_term_h": t[2],
+                    kind + "_traj_obs": traj.obs, kind + "_traj_ctrls": traj.ctrls, kind + "_traj_cost": cost(traj)})
+    save("cost_sum", **out)
+
+    # -- MPPI (nu = 1) with such costs: mppi.py:73-82 evaluates them term by term ----------------
+    cases = [
+        # tag, nx, hidden, act, mlpseed, N, H, sigma, lmda, bounds, costkind, npseed
+        ("gauss", 2, [64, 64], "relu", 61, 512, 20, 1.0, 1.0, (-2.0, 2.0), "gauss", 11),
+        ("dense", 4, [32, 32], "tanh", 62, 300, 15, 0.6, 0.3, (-1.0, 1.5), "dense", 12),
+        ("hc_gauss", 17, [256, 256], "relu", 63, 256, 20, 1.0, 1.0, (-1.0, 1.0), "gauss", 13),
+        ("samegoal", 3, [48, 48], "tanh", 64, 200, 12, 0.8, 0.5, (-1.0, 1.0), "samegoal", 14),
+    ]
+    for tag, nx, hidden, act, mseed, N, H, sigma, lmda, bnd, ckind, npseed in cases:
+        system = make_system(nx, 1)
+        model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+        cost = sum_cost_of(system, ckind, mseed + 300)
+        task = Task(system)
+        task.set_cost(cost)
+        task.set_ctrl_bound("u0", bnd[0], bnd[1])
+        np.random.seed(npseed)
+        ctl = quiet(MPPI, system, task, model, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+        out = {"act0": ctl.act_sequence.copy()}
+        obs = np.random.default_rng(npseed + 99).uniform(-0.1, 0.1, size=nx)
+        constate = np.concatenate([obs, np.zeros(1)])
+        n_runs = 3
+        for r in range(n_runs):
+            cap = {}
+            orig_update = ctl.update
+
+            def spy(costs, eps, cap=cap, orig=orig_update):
+                cap["costs"] = costs.copy()
+                cap["eps"] = eps.copy()
+                return orig(costs, eps)
+            ctl.update = spy
+            u, constate = ctl.run(constate, obs)
+            ctl.update = orig_update
+            out["x0_%d" % r] = obs.copy()
+            out["costs_%d" % r] = cap["costs"]
+            out["eps_sub_%d" % r] = cap["eps"][:, ::16, :].copy()
+            out["act_%d" % r] = ctl.act_sequence.copy()
+            out["u_%d" % r] = u.copy()
+            out["newstate_%d" % r] = constate.copy()
+            obs = model.pred(obs, u)
+        save("mppi_sumcost_" + tag, nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed,
+             plain_norm=True, wsum=weight_checksum(p), N=N, H=H, sigma=sigma, lmda=lmda,
+             bounds=np.array(bnd), np_seed=npseed, n_runs=n_runs, is_quad=bool(cost.is_quad),
+             **_term_arrays(cost), **out)
+
+    # -- iLQR with such costs: ilqr.py:124-129 (objective), :159-174 (gradients / Hessians) -------
+    icases = [
+        # tag, nx, nu, hidden, act, mseed, H, bounds, costkind, x0scale
+        ("p64_gauss", 2, 1, [64, 64], "tanh", 71, 20, None, "gauss", 0.3),
+        ("p64_dense_bounded", 2, 1, [64, 64], "tanh", 71, 20, (-0.4, 0.4), "dense", 0.3),
+        ("hc6_gauss", 17, 6, [256, 256], "relu", 72, 50, None, "gauss", 0.1),
+        ("hc6_three_bounded", 17, 6, [256, 256], "tanh", 73, 50, (-0.25, 0.25), "three", 0.1),
+        ("q3_samegoal", 3, 2, [48, 48], "tanh", 74, 15, None, "samegoal", 0.3),
+    ]
+    for tag, nx, nu, hidden, act, mseed, H, bnd, ckind, x0s in icases:
+        system = make_system(nx, nu, dt=0.05)
+        model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+        cost = sum_cost_of(system, ckind, mseed + 400)
+        task = Task(system)
+        task.set_cost(cost)
+        if bnd is not None:
+            task.set_ctrl_bounds(np.full(nu, bnd[0]), np.full(nu, bnd[1]))
+        ctl = IterativeLQR(system, task, model, H)
+        x0 = np.random.default_rng(mseed + 77).uniform(-x0s, x0s, size=nx)
+        calls = {"n": 0}
+        orig = model.pred_diff_batch
+
+        def counting(states, ctrls, orig=orig, calls=calls):
+            calls["n"] += 1
+            return orig(states, ctrls)
+        model.pred_diff_batch = counting
+        conv, states, ctrls, Ks, ks = quiet(ctl.compute_ilqr_default, x0, np.zeros((H, nu)), silent=True)
+        n_refresh = calls["n"]
+        u, newstate = quiet(ctl.run, np.concatenate([x0, np.zeros(nu)]), x0)
+        model.pred_diff_batch = orig
+        save("ilqr_sumcost_" + tag, n_refresh=n_refresh, kind="mlp", nx=nx, nu=nu, hidden=np.array(hidden), activation=act,
+             mlp_seed=mseed, plain_norm=True, H=H, bounded=bnd is not None,
+             bounds=np.array(bnd if bnd else (0.0, 0.0)), dt=0.05, x0=x0, converged=conv, states=states,
+             ctrls=ctrls, Ks=Ks, ks=ks, u=u, newstate=newstate, wsum=weight_checksum(p),
+             is_quad=bool(cost.is_quad), **_term_arrays(cost))
+
+    # -- eval_cfg's call shape (pipeline_tuner.py:213-258) with a QuadCostFactory + GaussRegFactory
+    #    controller cost; the TASK cost that scores the episode stays the task's own ---------------
+    nx, hidden, act, mseed = 3, [48, 48], "tanh", 51
+    system = make_system(nx, 1, dt=0.05)
+    model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+    task_cost = make_cost(system, "dense", 600)
+    init = np.array([0.25, -0.15, 0.1])
+    ctl_cost = sum_cost_of(system, "gauss", 910, task_goal=task_cost.get_goal())
+    Q, R, F = task_cost.get_cost_matrices()
+
+    def eval_cfg(make_controller, task):
+        controller = make_controller()
+        controller.reset()
+        traj = quiet(simulate, controller, task.get_init_obs(), task.term_cond, sim_model=model,
+                     max_steps=task.get_num_steps(), silent=True)
+        return dict(surr_obs=traj.obs, surr_ctrls=traj.ctrls, surr_cost=task.get_cost()(traj),
+                    ctl_cost_of_traj=ctl_cost(traj))
+
+    def tasks(T, bounded):
+        task = Task(system)                 # what the tuner scores with
+        task.set_cost(task_cost)
+        ctask = Task(system)                # what the pipeline hands the controller (pipeline.py:156-160)
+        ctask.set_cost(ctl_cost)
+        for t in (task, ctask):
+            if bounded:
+                t.set_ctrl_bound("u0", -1.0, 1.0)
+            t.set_init_obs(init)
+            t.set_num_steps(T)
+        return task, ctask
+    common = dict(nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed, wsum=weight_checksum(p),
+                  Q=Q, R=R, F=F, goal=task_cost.get_goal(), init=init, **_term_arrays(ctl_cost))
+    T = 13
+    task, ctask = tasks(T, True)
+    hyper = dict(horizon=9, num_path=96, sigma=0.7, lmda=0.6)
+    np.random.seed(16)
+    out = eval_cfg(lambda: quiet(MPPI, system, ctask, model, **hyper), task)
+    assert len(out["surr_obs"]) == T
+    save("loop_evalcfg_sumcost", np_seed=16, num_steps=T, N=hyper["num_path"], H=hyper["horizon"],
+         sigma=hyper["sigma"], lmda=hyper["lmda"], bounds=np.array([-1.0, 1.0]), **out, **common)
+    T = 10
+    task, ctask = tasks(T, False)
+    out = eval_cfg(lambda: IterativeLQR(system, ctask, model, 12), task)
+    assert len(out["surr_obs"]) == T
+    save("loop_evalcfg_sumcost_ilqr", num_steps=T, H=12, dt=0.05, **out, **common)
+
+
 # ------------------------------------------------------------------- score terms
 def gen_cost_terms():
     """Cost.__call__ of threshold / box / summed costs on a batch of trajectories."""
@@ -738,7 +952,7 @@ def gen_linear_wide():
 
 
 GENERATORS = {"linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
-              "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms}
+              "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):

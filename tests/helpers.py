@@ -4,7 +4,7 @@ import numpy as np
 
 from autompc_amd import System
 from oracle import mlp as omlp
-from oracle.costs import QuadCostOracle
+from oracle.costs import QuadCostOracle, SumCostOracle
 
 
 def make_system(nx, nu, dt=0.05):
@@ -36,7 +36,23 @@ def check_weights(p, g):
 
 
 def cost_from_golden(g):
+    """The fixture's controller cost for the oracle: one QuadCost, or -- fixtures that store per-term
+    arrays Qs / Rs / Fs / goals (gen_golden.gen_sumcost) -- the sum of quadratic terms."""
+    if "Qs" in g:
+        return SumCostOracle.from_arrays(g["Qs"], g["Rs"], g["Fs"], g["goals"])
     return QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"])
+
+
+def hip_cost_from_golden(system, g):
+    """The same cost as product objects (autompc_amd.QuadCost, summed with ``+``)."""
+    from autompc_amd import QuadCost
+    if "Qs" in g:
+        terms = [QuadCost(system, q, r, f, goal=gl) for q, r, f, gl in zip(g["Qs"], g["Rs"], g["Fs"], g["goals"])]
+        cost = terms[0]
+        for t in terms[1:]:
+            cost = cost + t
+        return cost
+    return QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"])
 
 
 def rel_err(a, b):

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden
-from helpers import check_weights, golden_params, make_system, rel_err
+from helpers import check_weights, golden_params, hip_cost_from_golden, make_system, rel_err
 from oracle import mlp as omlp
 from oracle.costs import QuadCostOracle
 from oracle.ilqr import ILQROracle
@@ -34,7 +34,7 @@ def _hip_ilqr(p, nx, nu, Q, R, F, goal, H, dt, bounds, precision="f64", **kw):
     m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
     m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
     task = Task(system)
-    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    task.set_cost(Q(system) if callable(Q) else QuadCost(system, Q, R, F, goal=goal))   # Q: or a cost builder
     if bounds is not None:
         task.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
     return IterativeLQR(system, task, m, H, **kw)
@@ -47,7 +47,8 @@ def test_ilqr_matches_reference_golden(name):
     p = golden_params(nx, nu, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
     check_weights(p, g)
     bounds = (g["bounds"][0], g["bounds"][1]) if bool(g["bounded"]) else None
-    ctl = _hip_ilqr(p, nx, nu, g["Q"], g["R"], g["F"], g["goal"], H, float(g["dt"]), bounds)
+    # (ilqr_sumcost_*: sums of quadratic terms with different goals, ilqr.py:124-129,159-174)
+    ctl = _hip_ilqr(p, nx, nu, lambda sy: hip_cost_from_golden(sy, g), None, None, None, H, float(g["dt"]), bounds)
     conv, states, ctrls, Ks, ks = ctl.compute_ilqr_default(g["x0"], np.zeros((H, nu)))
     assert conv == bool(g["converged"])
     # iLQR amplifies rounding through up to 50 Riccati sweeps and 50 discrete line-search

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, golden
-from helpers import check_weights, cost_from_golden, golden_params, make_system, rel_err
+from helpers import check_weights, cost_from_golden, golden_params, hip_cost_from_golden, make_system, rel_err
 from oracle import mlp as omlp
 from oracle.costs import QuadCostOracle
 from oracle.mlp import MLPOracle
@@ -29,7 +29,7 @@ def _hip_stack(p, nx, nu, Q, R, F, goal, bounds, precision="f64", **mppi_kw):
     m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
     m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
     task = Task(system)
-    task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+    task.set_cost(Q(system) if callable(Q) else QuadCost(system, Q, R, F, goal=goal))   # Q: or a cost builder
     task.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
     return system, m, task
 
@@ -41,7 +41,8 @@ def test_mppi_matches_reference_golden(name):
     nx = int(g["nx"])
     p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], bool(g["plain_norm"]))
     check_weights(p, g)
-    system, model, task = _hip_stack(p, nx, 1, g["Q"], g["R"], g["F"], g["goal"], g["bounds"])
+    # (mppi_sumcost_*: sums of quadratic terms with different goals, mppi.py:73-82 over sum_cost.py:49-54)
+    system, model, task = _hip_stack(p, nx, 1, lambda sy: hip_cost_from_golden(sy, g), None, None, None, g["bounds"])
     np.random.seed(int(g["np_seed"]))
     ctl = MPPI(system, task, model, horizon=int(g["H"]), num_path=int(g["N"]),
                sigma=float(g["sigma"]), lmda=float(g["lmda"]))

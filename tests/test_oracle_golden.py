@@ -222,3 +222,52 @@ def test_evalcfg_ilqr_matches_reference():
     assert len(obs) == int(g["num_steps"])
     assert rel_err(obs, g["surr_obs"]) < 1e-6 and rel_err(ctrls, g["surr_ctrls"]) < 1e-6
     assert abs(s - g["surr_cost"]) < 1e-6 * abs(g["surr_cost"])
+
+
+# ---- sums of quadratic costs (sum_cost.py:49-54; gen_golden.gen_sumcost) --------------------------
+from oracle.costs import SumCostOracle        # noqa: E402
+
+
+@pytest.mark.parametrize("kind", ["gauss", "dense", "three", "samegoal"])
+def test_sumcost_matches_reference(kind):
+    """cost_sum.npz: the reference's SumCost of QuadCosts -- QuadCostFactory + GaussRegFactory's
+    (goal of the second term = mean of the data), dense terms with different goals, three terms,
+    and a same-goal sum -- through all its eval_* entry points and Cost.__call__."""
+    g = golden("cost_sum")
+    k = lambda name: g[kind + "_" + name]                    # noqa: E731
+    c = SumCostOracle.from_arrays(k("Qs"), k("Rs"), k("Fs"), k("goals"))
+    assert bool(k("is_quad")) == (kind == "samegoal")       # sum_cost.py:84-93
+    obs, ctrl = k("obs"), k("ctrl")
+    assert abs(c.eval_obs_cost(obs) - k("obs_cost")) < 1e-12 * max(1.0, abs(k("obs_cost")))
+    assert abs(c.eval_ctrl_cost(ctrl) - k("ctrl_cost")) < 1e-12
+    assert abs(c.eval_term_obs_cost(obs) - k("term_cost")) < 1e-12 * max(1.0, abs(k("term_cost")))
+    for got, key in zip(c.eval_obs_cost_hess(obs), ("obs_c", "obs_j", "obs_h")):
+        np.testing.assert_allclose(got, k(key), rtol=1e-13, atol=1e-12)
+    for got, key in zip(c.eval_ctrl_cost_hess(ctrl), ("ctrl_c", "ctrl_j", "ctrl_h")):
+        np.testing.assert_allclose(got, k(key), rtol=1e-13, atol=1e-12)
+    for got, key in zip(c.eval_term_obs_cost_hess(obs), ("term_c", "term_j", "term_h")):
+        np.testing.assert_allclose(got, k(key), rtol=1e-13, atol=1e-12)   # every term ignores its goal
+    assert abs(c.traj_cost(k("traj_obs"), k("traj_ctrls")) - k("traj_cost")) < 1e-11 * abs(k("traj_cost"))
+
+
+def test_evalcfg_sumcost_matches_reference():
+    """eval_cfg's call shape with a QuadCostFactory + GaussRegFactory CONTROLLER cost (the pipeline
+    hands the controller a task carrying the factory's cost, pipeline.py:156-160) while the episode
+    is scored with the task's own cost: MPPI and iLQR."""
+    g = golden("loop_evalcfg_sumcost")
+    system, model, ctl_cost = _evalcfg_setup(g)
+    task_cost = QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"])
+    np.random.seed(int(g["np_seed"]))
+    ctl = MPPIOracle(model, ctl_cost, np.array([g["bounds"]]), horizon=int(g["H"]), num_path=int(g["N"]),
+                     sigma=float(g["sigma"]), lmda=float(g["lmda"]))
+    s, obs, ctrls = eval_cfg_episode(ctl, g["init"], model, int(g["num_steps"]), task_cost.traj_cost)
+    assert rel_err(obs, g["surr_obs"]) < 1e-8 and rel_err(ctrls, g["surr_ctrls"]) < 1e-8
+    assert abs(s - g["surr_cost"]) < 1e-8 * abs(g["surr_cost"])
+    assert abs(ctl_cost.traj_cost(obs, ctrls) - g["ctl_cost_of_traj"]) < 1e-8 * abs(g["ctl_cost_of_traj"])
+    g = golden("loop_evalcfg_sumcost_ilqr")
+    system, model, ctl_cost = _evalcfg_setup(g)
+    ctl = ILQROracle(model, ctl_cost, float(g["dt"]), int(g["H"]))
+    ctl.state_dim = int(g["nx"]) + 1
+    s, obs, ctrls = eval_cfg_episode(ctl, g["init"], model, int(g["num_steps"]), task_cost.traj_cost)
+    assert rel_err(obs, g["surr_obs"]) < 1e-6 and rel_err(ctrls, g["surr_ctrls"]) < 1e-6
+    assert abs(s - g["surr_cost"]) < 1e-6 * abs(g["surr_cost"])
