@@ -136,6 +136,10 @@ class ARX(_LinearModel):
     def state_to_obs(self, state):
         return state[0:self.system.obs_dim]
 
+    # update_state shifts the OLD state (arx.py:113-127): a controller must hand it the state it was
+    # given, whole (control/ilqr.py: traj_to_state)
+    update_state_reads_state = True
+
     def update_state(self, state, new_ctrl, new_obs):
         # shift the history with the model itself, then overwrite the prediction with the
         # measured observation (arx.py:94-99)

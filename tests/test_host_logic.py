@@ -278,3 +278,25 @@ def test_evaluator_rejects_horizon_above_cap():
     cand = dict(horizon=21, sigma=1.0, lmda=1.0, num_path=16, Q=[1.0], R=[1.0], F=[1.0])
     with pytest.raises(ValueError, match="horizon_cap"):
         ev.evaluate([cand])
+
+
+def test_ilqr_traj_to_state_default_is_the_references_bare_model_state():
+    """ilqr.py:96-98 returns model.traj_to_state(traj); run() strips ctrl_dim entries off it anyway
+    (:278).  Default = that, for every model whose update_state ignores the old state; ARX
+    (update_state shifts the old state, arx.py:113-127) gets model state + last control -- the only
+    layout it can be simulated with; strict_reference forces either."""
+    from autompc_amd import ARX, IterativeLQR, zeros
+    system, task, model = _stack()
+    traj = zeros(system, 3)
+    traj.obs[:] = np.arange(9.0).reshape(3, 3)
+    traj.ctrls[:] = [[0.1, 0.2], [0.3, 0.4], [0.5, 0.6]]
+    np.testing.assert_array_equal(IterativeLQR(system, task, model, 5).traj_to_state(traj), [6, 7, 8])
+    np.testing.assert_array_equal(IterativeLQR(system, task, model, 5, strict_reference=True).traj_to_state(traj), [6, 7, 8])
+    np.testing.assert_array_equal(IterativeLQR(system, task, model, 5, strict_reference=False).traj_to_state(traj),
+                                  [6, 7, 8, 0.5, 0.6])
+    arx = ARX(system, history=2)
+    arx.A, arx.B = np.zeros((arx.state_dim, arx.state_dim)), np.zeros((arx.state_dim, 2))
+    auto = IterativeLQR(system, task, arx, 5).traj_to_state(traj)
+    assert auto.shape == (arx.state_dim + 2,) and list(auto[-2:]) == [0.5, 0.6]
+    bare = IterativeLQR(system, task, arx, 5, strict_reference=True).traj_to_state(traj)
+    np.testing.assert_array_equal(bare, auto[:-2])
