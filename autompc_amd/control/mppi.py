@@ -39,7 +39,13 @@ class _ActSequence(np.ndarray):
     """The host copy of a controller's warm-start sequence, handed out by ``MPPI.act_sequence``:
     a plain writable array (the reference exposes a plain attribute that callers edit in place,
     e.g. ``ctl.act_sequence[:] = 0``) that tells its controller when it was written to, so the
-    edit reaches the device copy before the next solve."""
+    edit reaches the device copy before the next solve.
+
+    A view may be HELD across ``run()`` calls (in the reference the attribute is one array mutated in
+    place, so a held reference stays current).  Here the live copy moves to the device; a write
+    through a view whose memory is no longer the current sequence first brings that memory up to date
+    (one download), then applies -- it never resurrects the pre-``run()`` sequence.  Reads through a
+    held view are NOT refreshed: read ``ctl.act_sequence`` again."""
 
     def __new__(cls, array, owner):
         obj = np.asarray(array).view(cls)
@@ -49,10 +55,28 @@ class _ActSequence(np.ndarray):
     def __array_finalize__(self, obj):
         self._owner = getattr(obj, "_owner", None)
 
+    @staticmethod
+    def _root(a):
+        """The array that owns the memory `a` views."""
+        while isinstance(getattr(a, "base", None), np.ndarray):
+            a = a.base
+        return a
+
     def __setitem__(self, key, value):
+        o = self._owner
+        if o is not None:
+            root = self._root(self)
+            if root is not self._root(o._act_host) or not (o._act_dirty or o._act_synced):
+                cur = o._current_sequence()
+                if root.size != cur.size or not root.flags.c_contiguous:
+                    raise RuntimeError("stale act_sequence view: read ctl.act_sequence again")
+                mine = root.reshape(cur.shape)           # (a view: the held array's own memory)
+                if root is not self._root(cur):
+                    mine[...] = cur
+                o._act_host, o._act_synced = mine, True
         super().__setitem__(key, value)
-        if self._owner is not None:
-            self._owner._act_dirty = True
+        if o is not None:
+            o._act_dirty = True
 
     def __reduce__(self):                      # pickles / deep-copies as a plain array
         return np.asarray(self).copy().__reduce__()
@@ -96,6 +120,7 @@ class MPPI(Controller):
     def _init_sequence(self):
         self._act_host = np.random.normal(scale=self._scale, size=(self.H, self.dim_ctrl))
         self._act_dirty = True        # host copy is newer than the device copy
+        self._act_synced = False      # host copy equals the device copy (set by a download)
         self.cur_step = 0
 
     def _device(self):
@@ -105,9 +130,7 @@ class MPPI(Controller):
             # warm start moves with it
             st = self._handle.jit_status()[0]
             if st == 2:
-                if not self._act_dirty:
-                    a, _, _, _ = self._plan.download(act_seq=True, u=False)
-                    self._act_host = a.reshape(self.H, self.dim_ctrl)
+                self._current_sequence()
                 self._plan.close()
                 self._plan = None
             self._jit_pending = st == 1
@@ -127,10 +150,9 @@ class MPPI(Controller):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        if self._plan is not None and not self._act_dirty:
-            state["_act_host"] = self.act_sequence.copy()
+        state["_act_host"] = np.array(self._current_sequence())
         state["_handle"] = state["_plan"] = None
-        state["_act_dirty"] = True
+        state["_act_dirty"], state["_act_synced"] = True, False
         return state
 
     @property
@@ -142,15 +164,20 @@ class MPPI(Controller):
         ``ctl.act_sequence[0] += d``) marks the host copy as newer and it is uploaded before the
         next solve.  Writes that bypass ``__setitem__`` (``np.copyto``, ufunc ``out=``) are not
         seen; assign through the setter for those."""
-        if self._plan is not None and not self._act_dirty:
+        return _ActSequence(self._current_sequence(), self)
+
+    def _current_sequence(self):
+        """The live sequence as a host array (downloaded when the device copy is the newer one)."""
+        if self._plan is not None and not self._act_dirty and not self._act_synced:
             a, _, _, _ = self._plan.download(act_seq=True, u=False)
             self._act_host = a.reshape(self.H, self.dim_ctrl)
-        return _ActSequence(self._act_host, self)
+            self._act_synced = True
+        return self._act_host
 
     @act_sequence.setter
     def act_sequence(self, value):
         self._act_host = np.array(value, dtype=np.float64).reshape(self.H, self.dim_ctrl)
-        self._act_dirty = True
+        self._act_dirty, self._act_synced = True, False
 
     def reset(self):
         self._init_sequence()
@@ -193,7 +220,7 @@ class MPPI(Controller):
             a, u, costs, eps_out = plan.download(costs=True, eps_out=True)
             self.last_costs = costs
             self.last_eps = eps_out.reshape(self.H, self.num_path, nu)
-            self._act_host = a.reshape(self.H, nu)
+            self._act_host, self._act_synced = a.reshape(self.H, nu), True
         else:
             # the hot call: everything of this control step in one library call (ampc_mppi_run)
             if mode == "numpy_host":
@@ -209,7 +236,7 @@ class MPPI(Controller):
                     u = plan.run(x0, act)
             else:
                 u = plan.run(x0, act, philox=(self.seed, self.cur_step))
-            self._act_dirty = False
+            self._act_dirty = self._act_synced = False
         self.cur_step += 1
         ret_action = u[0].copy()
         return ret_action, np.concatenate([x0, ret_action])

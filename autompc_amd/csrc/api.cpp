@@ -1645,6 +1645,7 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   if (rc == 0 && score && scores)
     rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, h->obs_dim, *score, scores);
   (void)hipStreamSynchronize(h->stream);
+  p->step_offset = 0;      // one-shot: ampc_mppi_plan_set_step_offset names the NEXT closed loop's first step
   return rc;
 }
 

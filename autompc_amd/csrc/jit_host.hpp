@@ -11,11 +11,14 @@
 //   plan creation     plugin present (or just finished) -> dlopen, check ampc_jit_info against the
 //                     model, plan->jit = plugin, plan->static_shape = 0;  otherwise the DynShape
 //                     kernels run (1.1-1.9x slower) and the next plan looks again
+//   ampc_jit_status   reaps a finished build: a controller that polls it switches over by itself
 //   ampc_jit_wait     block until the build of the handle's shape has finished (tools / tests)
 //
 // <cache> = $AMPC_JIT_CACHE or <package>/jit_cache (in-tree: it travels with the package).  The key
-// holds precision + shape, the file name also a hash of every source the plugin is compiled from,
-// so a plugin is never used with other headers than the ones this library was built from.
+// holds precision + shape, the file name also a hash of every source the plugin is compiled from
+// and of `hipcc --version`, so a plugin is never used with other headers or another compiler /
+// ROCm release than the ones at hand.  Processes that want the same plugin at the same time (the
+// ranks of a torch.distributed job) share ONE build through a lock directory in the cache.
 // AMPC_JIT=0 disables all of it.  Same arithmetic in the same order as DynShape: results are
 // bit-identical (tests/test_gpu_jit.py).
 #pragma once
@@ -24,6 +27,8 @@
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+
+#include <signal.h>
 
 #include <fstream>
 #include <map>
@@ -133,67 +138,155 @@ inline bool load(Entry& e, const ampc_handle* h, size_t tsize) {
   return true;
 }
 
+// Identity of the compiler the plugin would be built with: FNV-1a of `hipcc --version` (the ROCm /
+// clang version line), part of the plugin's file name -- a cache directory that outlives a ROCm
+// upgrade never hands a code object built by the old compiler to the new runtime.
+inline const std::string& compiler_id() {
+  static const std::string id = [] {
+    uint64_t x = 1469598103934665603ull;
+    int fd[2];
+    if (pipe(fd) == 0) {                                // `hipcc --version`, no shell in between
+      posix_spawn_file_actions_t fa;
+      posix_spawn_file_actions_init(&fa);
+      posix_spawn_file_actions_adddup2(&fa, fd[1], 1);
+      posix_spawn_file_actions_addclose(&fa, fd[0]);
+      const std::string cc = hipcc_path();
+      const char* argv[] = {cc.c_str(), "--version", nullptr};
+      pid_t pid = -1;
+      const int rc = posix_spawnp(&pid, cc.c_str(), &fa, nullptr, (char* const*)argv, environ);
+      posix_spawn_file_actions_destroy(&fa);
+      close(fd[1]);
+      if (rc == 0) {
+        char buf[512];
+        ssize_t n;
+        while ((n = read(fd[0], buf, sizeof(buf))) > 0)
+          for (ssize_t i = 0; i < n; ++i) { x ^= (unsigned char)buf[i]; x *= 1099511628211ull; }
+        int st = 0;
+        (void)waitpid(pid, &st, 0);
+      }
+      close(fd[0]);
+    }
+    char out[16];
+    std::snprintf(out, sizeof(out), "%08x", (unsigned)(x ^ (x >> 32)));
+    return std::string(out);
+  }();
+  return id;
+}
+
+// The build script.  Every path reaches it through the ENVIRONMENT (AMPC_J_*), never pasted into the
+// text, so quotes or spaces in $AMPC_JIT_CACHE / the package path cannot break it.  One builder per
+// plugin file across processes (eight torch.distributed ranks staging the same model): the lock is a
+// directory next to the plugin (mkdir is atomic) holding the builder's pid; the others wait for the
+// plugin to appear, and take over if the builder has died.  A failed build leaves <plugin>.failed.
+inline const char* build_script() {
+  return R"SH(exec > "$AMPC_J_LOG" 2>&1
+LOCK="$AMPC_J_SO.lock"
+mine=0
+take() { mkdir "$LOCK" 2>/dev/null && echo $$ > "$LOCK/pid" && mine=1; }
+trap '[ $mine = 1 ] && rm -rf "$LOCK"' EXIT
+take
+i=0
+while [ $mine = 0 ] && [ ! -f "$AMPC_J_SO" ] && [ ! -f "$AMPC_J_SO.failed" ] && [ $i -lt 3000 ]; do
+  p=$(cat "$LOCK/pid" 2>/dev/null)
+  if [ -n "$p" ] && ! kill -0 "$p" 2>/dev/null; then rm -rf "$LOCK"; fi     # the builder died: take over
+  take || { sleep 0.1; i=$((i+1)); }
+done
+[ -f "$AMPC_J_SO" ] && exit 0
+[ $mine = 1 ] || exit 4
+rm -f "$AMPC_J_SO.failed"
+mkdir -p "$AMPC_J_TMP" && cd "$AMPC_J_TMP" || { touch "$AMPC_J_SO.failed"; exit 1; }
+for u in launch_mppi launch_mlp launch_ilqr jit_plugin; do
+  "$AMPC_J_CC" -x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-pass-failed \
+    -I "$AMPC_J_INC" $AMPC_J_DEFS -c "$AMPC_J_SRC/$u.cpp" -o $u.o &
+done
+wait
+if [ -f launch_mppi.o -a -f launch_mlp.o -a -f launch_ilqr.o -a -f jit_plugin.o ] &&
+   "$AMPC_J_CC" --offload-arch=gfx950 -shared -fPIC launch_mppi.o launch_mlp.o launch_ilqr.o jit_plugin.o -o plugin.so &&
+   mv plugin.so "$AMPC_J_SO"; then
+  cd / && rm -rf "$AMPC_J_TMP"
+  exit 0
+fi
+touch "$AMPC_J_SO.failed"
+exit 2
+)SH";
+}
+
 template <typename T> inline void start_build(Entry& e, const ampc_handle* h, const std::string& key) {
   const std::string dir = cache_dir(), src = package_dir() + "/csrc", inc = package_dir() + "/../include";
   ::mkdir(dir.c_str(), 0755);
   const std::string tmp = dir + "/build_" + key + "_" + std::to_string((long)getpid());
-  std::ostringstream sh;
-  const std::string cc = hipcc_path();
-  sh << "mkdir -p '" << tmp << "' && cd '" << tmp << "' || exit 1\n";
-  std::ostringstream fl;
-  fl << "-x hip --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-pass-failed -I '" << inc
-     << "' -DAMPC_JIT_PLUGIN -DAMPC_T=" << (sizeof(T) == 8 ? "double -DAMPC_T_IS_F64=1" : "float")
-     << " -DAMPC_JIT_NX=" << h->nx << " -DAMPC_JIT_NU=" << h->nu << " -DAMPC_JIT_NO=" << h->obs_dim
-     << " -DAMPC_JIT_NH=" << h->n_hidden << " -DAMPC_JIT_HPAD=" << h->hpad;
-  for (const char* u : {"launch_mppi", "launch_mlp", "launch_ilqr", "jit_plugin"})
-    sh << "'" << cc << "' " << fl.str() << " -c '" << src << "/" << u << ".cpp' -o " << u << ".o &\n";
-  sh << "wait\n"
-     << "test -f launch_mppi.o -a -f launch_mlp.o -a -f launch_ilqr.o -a -f jit_plugin.o || exit 2\n"
-     << "'" << cc << "' --offload-arch=gfx950 -shared -fPIC launch_mppi.o launch_mlp.o launch_ilqr.o jit_plugin.o"
-     << " -o plugin.so || exit 3\n"
-     << "mv plugin.so '" << e.so << "' && cd / && rm -rf '" << tmp << "'\n";
-  e.log = dir + "/shape_" + key + ".log";
-  const std::string script = "exec > '" + e.log + "' 2>&1\n" + sh.str();
-  const char* argv[] = {"/bin/sh", "-c", script.c_str(), nullptr};
+  std::ostringstream defs;         // (no paths in here: plain -D words, split by the shell on purpose)
+  defs << "-DAMPC_JIT_PLUGIN -DAMPC_T=" << (sizeof(T) == 8 ? "double -DAMPC_T_IS_F64=1" : "float")
+       << " -DAMPC_JIT_NX=" << h->nx << " -DAMPC_JIT_NU=" << h->nu << " -DAMPC_JIT_NO=" << h->obs_dim
+       << " -DAMPC_JIT_NH=" << h->n_hidden << " -DAMPC_JIT_HPAD=" << h->hpad;
+  e.log = dir + "/shape_" + key + "_" + std::to_string((long)getpid()) + ".log";
+  std::vector<std::string> env;
+  for (char** p = environ; p && *p; ++p) env.emplace_back(*p);
+  env.push_back("AMPC_J_LOG=" + e.log);
+  env.push_back("AMPC_J_SO=" + e.so);
+  env.push_back("AMPC_J_TMP=" + tmp);
+  env.push_back("AMPC_J_SRC=" + src);
+  env.push_back("AMPC_J_INC=" + inc);
+  env.push_back("AMPC_J_CC=" + hipcc_path());
+  env.push_back("AMPC_J_DEFS=" + defs.str());
+  std::vector<char*> envp;
+  for (std::string& v : env) envp.push_back(&v[0]);
+  envp.push_back(nullptr);
+  const char* argv[] = {"/bin/sh", "-c", build_script(), nullptr};
   pid_t pid = -1;
-  if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, environ) != 0) {
+  if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, envp.data()) != 0) {
     e.state = -1; e.log = "posix_spawn(/bin/sh) failed"; return;
   }
   e.pid = pid;
   e.state = 1;
 }
 
-// reap a finished build; `block`: wait for it
-inline void poll(Entry& e, const ampc_handle* h, size_t tsize, bool block) {
+// Reap a finished build (never blocks).  The child may not be ours to wait for any more -- the
+// process forked after the spawn, or runs with SIGCHLD ignored: waitpid then fails with ECHILD -- so
+// the verdict always comes from the files the script leaves: the plugin, or <plugin>.failed.
+inline void poll(Entry& e, const ampc_handle* h, size_t tsize) {
   if (e.state != 1) return;
   int st = 0;
-  const pid_t r = waitpid(e.pid, &st, block ? 0 : WNOHANG);
+  const pid_t r = waitpid(e.pid, &st, WNOHANG);
   if (r == 0) return;                                   // still running
+  if (r < 0 && !exists(e.so) && !exists(e.so + ".failed")) {
+    if (::kill(e.pid, 0) == 0) return;                  // not our child, but alive: keep waiting
+  }
   if (exists(e.so)) { load(e, h, tsize); return; }
   e.state = -1;
   e.log = "build failed, see " + e.log;
 }
 
-// plugin for the handle's staged shape, or nullptr (not eligible / still building / failed)
+// plugin for the handle's staged shape, or nullptr (not eligible / still building / failed).
+// block: wait for a running build -- polling with the table's mutex RELEASED in between, so other
+// threads keep creating plans and staging handles meanwhile.
 template <typename T> inline const JitPlugin* get(const ampc_handle* h, bool block = false) {
   if (!eligible(h)) return nullptr;
-  std::lock_guard<std::mutex> g(mu());
   const std::string key = key_of<T>(h);
-  Entry& e = table()[key];
-  if (e.state == 0) {
-    e.so = cache_dir() + "/shape_" + key + "_" + source_hash() + ".so";
-    if (exists(e.so)) load(e, h, sizeof(T));
-    else start_build<T>(e, h, key);
+  for (;;) {
+    {
+      std::lock_guard<std::mutex> g(mu());
+      Entry& e = table()[key];
+      if (e.state == 0) {
+        e.so = cache_dir() + "/shape_" + key + "_" + source_hash() + "_" + compiler_id() + ".so";
+        if (exists(e.so)) load(e, h, sizeof(T));
+        else start_build<T>(e, h, key);
+      }
+      poll(e, h, sizeof(T));
+      if (e.state != 1 || !block) return e.state == 2 ? &e.plug : nullptr;
+    }
+    usleep(20000);
   }
-  poll(e, h, sizeof(T), block);
-  return e.state == 2 ? &e.plug : nullptr;
 }
 
+// state of the handle's shape; reaps a finished build, so a long-lived controller that only ever asks
+// ampc_jit_status (the drop-in classes do, once per run()) sees 1 -> 2 and switches over
 template <typename T> inline int status(const ampc_handle* h, std::string* msg) {
   if (!eligible(h)) return 0;
   std::lock_guard<std::mutex> g(mu());
   auto it = table().find(key_of<T>(h));
   if (it == table().end()) return 0;
+  poll(it->second, h, sizeof(T));
   if (msg) *msg = it->second.state == 2 ? it->second.so : it->second.log;
   return it->second.state;
 }

@@ -271,7 +271,7 @@ int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate, const doubl
  * is run in several segments -- simulate() with a user termination condition
  * (utils/simulation.py:62-63, tasks/task.py:92-101) evaluated on the host between segments, each
  * segment starting from the state the previous one ended in -- thereby consumes exactly the noise
- * the unsegmented episode would. */
+ * the unsegmented episode would.  One-shot: the closed loop that consumes the offset resets it to 0. */
 int ampc_mppi_plan_set_step_offset(ampc_mppi_plan* p, uint64_t first_step);
 
 /* ---- trajectory scoring --------------------------------------------------------------------

@@ -226,3 +226,91 @@ def test_single_hidden_layer_specialised_rollout_next_to_other_kernels(monkeypat
             np.random.set_state(st)
             ctl.run(cs, obs, return_details=True)
             assert rel_err(ctl.last_costs, orc.last_costs) < 1e-9, (mt, rep)
+
+
+def test_long_lived_controller_switches_over_without_jit_wait(monkeypatch, tmp_path):
+    """nobody calls ampc_jit_wait in production.  A controller that just keeps calling
+    run() must move to the compiled kernels by itself once the background build has finished
+    (ampc_jit_status reaps the build), with unchanged results, and the hipcc child must not stay a
+    zombie."""
+    import os
+    import time
+    from autompc_amd import MLP, MPPI, QuadCost, Task
+    from helpers import make_system
+    monkeypatch.delenv("AMPC_QUAD", raising=False)
+    monkeypatch.setenv("AMPC_JIT", "1")
+    monkeypatch.setenv("AMPC_JIT_CACHE", str(tmp_path))
+    nx, nu = 11, 3                     # (a shape no other test of this module compiles: the table is per process)
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [80, 80], "tanh", seed=8)
+    m = MLP(system, n_hidden_layers=2, hidden_size_1=80, hidden_size_2=80, nonlintype="tanh")
+    m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), np.eye(nx)))
+    task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    np.random.seed(1)                  # (the warm start is drawn from numpy's global stream)
+    ctl = MPPI(system, task, m, horizon=8, num_path=2048, noise="device")
+    cs, obs = np.zeros(nx + nu), np.full(nx, 0.1)
+    u0, _ = ctl.run(cs, obs)
+    assert ctl._plan.kernel_kind() in (0, 3) and ctl._handle.jit_status()[0] == 1      # run-time shape; still building
+    t0, kind = time.time(), 0
+    while time.time() - t0 < 120:
+        ctl.run(cs, obs)
+        kind = ctl._plan.kernel_kind()
+        if kind == 2:
+            break
+        time.sleep(0.05)
+    assert kind == 2, "the controller never switched to the compiled kernels"
+    # same numbers from the compiled kernels (fresh controller, same Philox stream)
+    np.random.seed(1)
+    ctl2 = MPPI(system, task, m, horizon=8, num_path=2048, noise="device")
+    u2, _ = ctl2.run(cs, obs)
+    assert ctl2._plan.kernel_kind() == 2
+    np.testing.assert_array_equal(u2, u0)
+    # no zombie child left behind
+    me = os.getpid()
+    zombies = []
+    for pid in os.listdir("/proc"):
+        if pid.isdigit():
+            try:
+                f = open("/proc/%s/stat" % pid).read().rsplit(")", 1)[1].split()
+            except OSError:
+                continue
+            if f[0] == "Z" and int(f[1]) == me:
+                zombies.append(pid)
+    assert not zombies
+
+
+def test_processes_wanting_the_same_plugin_share_one_build(tmp_path):
+    """the ranks of a torch.distributed job stage the same model at the same time.
+    They must share ONE hipcc build (lock directory in the cache) instead of racing eight compiles:
+    three processes started together all end up with the plugin, and only one build log shows
+    compiler invocations."""
+    import glob
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from autompc_amd import _lib
+from oracle import mlp as omlp
+p = omlp.random_params(9, 2, [90, 90], "relu", seed=1)
+h = _lib.Handle(0, "f64")
+h.set_mlp(9, 2, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+h.set_quad_costs(np.eye(9), np.eye(2), np.eye(9), np.zeros(9))
+h.jit_wait()
+print("STATUS", h.jit_status()[0])
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMPC_JIT="1", AMPC_JIT_CACHE=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for _ in range(3)]
+    outs = [pr.communicate(timeout=300)[0].decode() for pr in procs]
+    for o in outs:
+        assert "STATUS 2" in o, o
+    assert len(glob.glob(str(tmp_path / "shape_*.so"))) == 1
+    assert not glob.glob(str(tmp_path / "*.lock")) and not glob.glob(str(tmp_path / "build_*"))
+    # exactly one of the three scripts compiled; the others waited for its result
+    built = [f for f in glob.glob(str(tmp_path / "shape_*.log")) if os.path.getsize(f) >= 0]
+    assert len(built) == 3

@@ -335,3 +335,40 @@ def test_shape_specialised_kernel_equals_the_general_kernel(shape, precision, mo
         np.testing.assert_array_equal(a, b)
     # and both agree with the oracle on the first problem's costs of the second solve
     assert np.all(np.isfinite(out["1"][2]))
+
+
+def test_a_view_held_across_run_never_resurrects_the_old_sequence():
+    """the reference's act_sequence is ONE array mutated in place, so a reference kept
+    across run() calls stays current.  Here the live copy moves to the device: a write through a view
+    taken before run() must land on the CURRENT sequence (the device's warm start), not re-upload the
+    pre-run one."""
+    from autompc_amd import MPPI
+    nx = 2
+    p = omlp.random_params(nx, 1, [64, 64], "relu", seed=2)
+    system, model, task = _hip_stack(p, nx, 1, np.eye(nx), 0.01 * np.eye(1), np.eye(nx), np.zeros(nx), (-1, 1))
+    np.random.seed(5)
+    ctl = MPPI(system, task, model, horizon=5, num_path=64)
+    held = ctl.act_sequence                       # before any solve
+    row = held[2]                                 # a sub-view of it
+    before = np.asarray(held).copy()
+    ctl.run(np.zeros(3), np.zeros(2))
+    ctl.run(np.zeros(3), np.full(2, 0.05))
+    live = np.asarray(ctl.act_sequence).copy()    # what the device holds now
+    assert not np.array_equal(live, before)
+    held[0, 0] = 0.5                              # write through the stale view
+    expect = live.copy()
+    expect[0, 0] = 0.5
+    np.testing.assert_array_equal(np.asarray(ctl.act_sequence), expect)
+    np.testing.assert_array_equal(np.asarray(held), expect)          # its memory was brought up to date
+    row[0] = -0.25                                # and through the stale sub-view: no second refresh
+    expect[2, 0] = -0.25
+    np.testing.assert_array_equal(np.asarray(ctl.act_sequence), expect)
+    # the next solve starts from exactly that sequence
+    np.random.seed(9)
+    u1, _ = ctl.run(np.zeros(3), np.full(2, 0.1))
+    np.random.seed(5)
+    ctl2 = MPPI(system, task, model, horizon=5, num_path=64)
+    ctl2.act_sequence = expect
+    np.random.seed(9)
+    u2, _ = ctl2.run(np.zeros(3), np.full(2, 0.1))
+    np.testing.assert_array_equal(u1, u2)
