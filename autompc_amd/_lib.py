@@ -86,6 +86,8 @@ SIGNATURES = {
     "ampc_ilqr_plan_timing": (c_int, [c_void_p, _dp, _ip]),
     "ampc_ilqr_plan_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
+    "ampc_ilqr_solve_queue": (c_int, [c_void_p, c_int, _dp, _dp, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
+                                      _dp]),
 }
 
 
@@ -618,4 +620,27 @@ class IlqrPlan:
                                        dptr(out["states"]), dptr(out["ctrls"]), dptr(out["Ks"]),
                                        dptr(out["ks"]), iptr(out["converged"]), iptr(out["iters"]),
                                        iptr(out["status"]), dptr(out["objective"])))
+        return out
+
+    def solve_queue(self, x0, uguess=None, cost_index=None, max_iter=50, gains=True, trajectories=True):
+        """P problems streamed through the plan's B slots (ampc_ilqr_solve_queue): a slot whose problem
+        is finished takes the next one at the following iteration boundary, on the device.  x0 [P, nx];
+        uguess [P, H, nu] or None (zeros); cost_index [P] or None (block 0).  Per-problem results are
+        bit-identical to one-problem solves.  gains / trajectories = False skip those downloads."""
+        nx, nu, H = self.handle.nx, self.handle.nu, self.H
+        x0 = as_f64(x0).reshape(-1, nx)
+        P = x0.shape[0]
+        ug = None if uguess is None else as_f64(uguess).reshape(P, H, nu)
+        ci = None if cost_index is None else np.ascontiguousarray(np.broadcast_to(
+            np.asarray(cost_index, dtype=np.int32), (P,)))
+        out = {"converged": np.zeros(P, dtype=np.int32), "iters": np.zeros(P, dtype=np.int32),
+               "status": np.zeros(P, dtype=np.int32), "objective": np.empty(P)}
+        if trajectories:
+            out["states"], out["ctrls"] = np.empty((P, H + 1, nx)), np.empty((P, H, nu))
+        if gains:
+            out["Ks"], out["ks"] = np.empty((P, H, nu, nx)), np.empty((P, H, nu))
+        check(self.lib.ampc_ilqr_solve_queue(self._p, P, dptr(x0), dptr(ug), iptr(ci), int(max_iter),
+                                             dptr(out.get("states")), dptr(out.get("ctrls")), dptr(out.get("Ks")),
+                                             dptr(out.get("ks")), iptr(out["converged"]), iptr(out["iters"]),
+                                             iptr(out["status"]), dptr(out["objective"])))
         return out

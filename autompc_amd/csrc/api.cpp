@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 104; }   // 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
+extern "C" int ampc_version(void) { return 105; }   // 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1302,6 +1302,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   p->use_ls4 = env_int("AMPC_LS4", 1) != 0;
   p->use_mfma_sweep = env_int("AMPC_RICCATI", 1) != 0;
   p->par_passes = env_int("AMPC_LS4_PAR", 1) != 0;
+  p->ls_split = env_int("AMPC_LS4_SPLIT", 0) != 0;
   p->static_shape = -1;
   p->jit = nullptr;
   if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
@@ -1330,8 +1331,8 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(p->ls_states.reserve((size_t)B * p->ls_n * (H + 1) * nx * e));
   HIP_OK(p->ls_ctrls.reserve((size_t)B * p->ls_n * H * nu * e));
   HIP_OK(p->obj.reserve((size_t)B * e));
-  HIP_OK(p->flags.reserve((size_t)7 * B * sizeof(int)));
-  HIP_OK(hipMemset(p->flags.p, 0, (size_t)7 * B * sizeof(int)));
+  HIP_OK(p->flags.reserve((size_t)8 * B * sizeof(int)));
+  HIP_OK(hipMemset(p->flags.p, 0, (size_t)8 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
   if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
@@ -1411,7 +1412,9 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
-                    &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric};
+                    &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric,
+                    &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
+                    &p->q_obj, &p->q_flags};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->poll_host) (void)hipHostFree(p->poll_host);
@@ -1437,11 +1440,10 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   if (int rc = ilqr_launch_iter<T>(p, 0)) return rc;        // rollout of the guess + objective
   if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
   std::vector<int> flags(7 * B);
-  HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)B * sizeof(int), h->stream));
-  if (!p->poll_host) {
-    HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * B * sizeof(int), hipHostMallocDefault));
+  HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)3 * B * sizeof(int), h->stream));   // ls_rows, ls_count, ls_pass
+  if (!p->poll_host) HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * B * sizeof(int), hipHostMallocDefault));
+  if (!p->poll_ev[0])
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
-  }
   // Iterations are queued in batches of kPoll; the `active` flags of a batch are copied out behind
   // it and inspected only after the NEXT batch has been queued, so the stream never drains while the
   // host decides.  Iterations queued past convergence are no-ops (retired problems exit at once).
@@ -1516,6 +1518,151 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
   return p->h->precision == AMPC_F64
              ? ilqr_solve_impl<double>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective)
              : ilqr_solve_impl<float>(p, x0, uguess, max_iter, states, ctrls, Ks, ks, converged, iters, status, objective);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Continuous batching: P problems through the plan's B slots (ilqr_queue_refill_kernel)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, const double* uguess,
+                                 const int* cost_index, int max_iter, double* states, double* ctrls,
+                                 double* Ks, double* ks, int* converged, int* iters, int* status,
+                                 double* objective) {
+  ampc_handle* h = p->h;
+  const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
+  const size_t e = sizeof(T);
+  HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
+  HIP_OK(p->q_x0.reserve((size_t)P * nx * e));
+  HIP_OK(p->q_u.reserve((size_t)P * H * nu * e));
+  HIP_OK(p->q_cost.reserve((size_t)P * sizeof(int)));
+  HIP_OK(p->q_states.reserve((size_t)P * (H + 1) * nx * e));
+  HIP_OK(p->q_ctrls.reserve((size_t)P * H * nu * e));
+  HIP_OK(p->q_Ks.reserve((size_t)P * H * nu * nx * e));
+  HIP_OK(p->q_ks.reserve((size_t)P * H * nu * e));
+  HIP_OK(p->q_obj.reserve((size_t)P * e));
+  HIP_OK(p->q_flags.reserve((size_t)4 * P * sizeof(int)));
+  std::vector<int> ctl(2 + 2 * B, 0), cost(P, 0);
+  for (int b = 0; b < B; ++b) { ctl[2 + b] = -1; ctl[2 + B + b] = 1; }       // no problem; mode "iterate"
+  if (cost_index) std::memcpy(cost.data(), cost_index, (size_t)P * sizeof(int));
+  HIP_OK(hipMemcpyAsync(p->q_ctl.p, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(p->q_cost.p, cost.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(upload_converted<T>(p->q_x0.p, x0, (size_t)P * nx, h->stream));
+  if (uguess) HIP_OK(upload_converted<T>(p->q_u.p, uguess, (size_t)P * H * nu, h->stream));
+  else HIP_OK(hipMemsetAsync(p->q_u.p, 0, (size_t)P * H * nu * e, h->stream));
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)8 * B * sizeof(int), h->stream));     // every slot idle
+  HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  const int npoll = B + 2;
+  if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+  HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * npoll * sizeof(int), hipHostMallocDefault));
+  if (!p->poll_ev[0])
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
+  struct Guard {
+    ampc_ilqr_plan* p;
+    ~Guard() { p->queue_on = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+  } guard{p};
+  p->queue_on = true;
+  p->queue_max_iter = max_iter;
+  p->active_hint = B;
+  IlqrQueue<T> q;
+  q.P = P; q.B = B; q.H = H; q.nx = nx; q.nu = nu;
+  q.ctl = (int*)p->q_ctl.p; q.slot_prob = q.ctl + 2;
+  q.x0 = (const T*)p->q_x0.p; q.uguess = (const T*)p->q_u.p; q.cost = (const int*)p->q_cost.p;
+  q.cost_idx = (int*)p->d_cost_idx.p;
+  q.out_states = (T*)p->q_states.p; q.out_ctrls = (T*)p->q_ctrls.p; q.out_Ks = (T*)p->q_Ks.p;
+  q.out_ks = (T*)p->q_ks.p; q.out_obj = (T*)p->q_obj.p; q.out_flags = (int*)p->q_flags.p;
+  // An iteration = refill + sweep + line search (or the guess's rollout, per slot) + Jacobian refresh.
+  // The queue's counters and the slots' `active` flags are copied out behind every batch of kPoll
+  // iterations and read after the NEXT batch has been queued (the stream never drains); everything
+  // is done when P problems have been harvested.  Upper bound on the iterations: every problem takes
+  // at most max_iter + 1 slot-iterations (+1: the rollout of its guess).
+  constexpr int kPoll = 4;
+  const long long bound = ((long long)(P + B - 1) / B) * (max_iter + 2LL) + (long long)P + 4 * kPoll;
+  long long it = 0;
+  int batch = 0, pending = -1;
+  bool done = false;
+  const size_t ev_first = p->ev_used / 5;
+  while (!done && it < bound) {
+    for (int k = 0; k < kPoll; ++k) {
+      IlqrArgs<T> a = make_ilqr_args<T>(p, 1);
+      hipLaunchKernelGGL(ilqr_queue_refill_kernel<T>, dim3(B), dim3(256), 0, h->stream, a, q);
+      HIP_OK(hipGetLastError());
+      if (p->timing) {
+        if (p->ev_used + 5 > p->ev.size())
+          for (int i = 0; i < 5; ++i) {
+            hipEvent_t x;
+            HIP_OK(hipEventCreate(&x));
+            p->ev.push_back(x);
+          }
+        p->ev_cur = &p->ev[p->ev_used];
+        p->ev_used += 5;
+      }
+      int rc = ilqr_launch_iter<T>(p, 1);
+      if (rc == 0) rc = ilqr_refresh_jacobians<T>(p);
+      p->ev_cur = nullptr;
+      if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+    }
+    it += kPoll;
+    const int slot = batch & 1;
+    int* ph = p->poll_host + (size_t)slot * npoll;
+    HIP_OK(hipMemcpyAsync(ph, (const int*)p->flags.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(ph + B, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
+    if (pending >= 0) {
+      const int* pp = p->poll_host + (size_t)(pending & 1) * npoll;
+      HIP_OK(hipEventSynchronize(p->poll_ev[pending & 1]));
+      int live = 0;
+      for (int b = 0; b < B; ++b) live += pp[b] != 0;
+      // while the queue still holds problems every slot is (about to be) busy
+      p->active_hint = pp[B] < P ? B : std::max(live, 1);
+      if (pp[B + 1] >= P) done = true;
+    }
+    pending = batch++;
+  }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  p->last_queue_launches = it;
+  p->last_iterations = (int)std::min<long long>(it, 1 << 30);
+  int fin[2] = {0, 0};
+  HIP_OK(hipMemcpy(fin, p->q_ctl.p, sizeof(fin), hipMemcpyDeviceToHost));
+  if (fin[1] < P) return fail("ampc_ilqr_solve_queue: internal: the queue did not drain");
+  std::vector<int> fl((size_t)4 * P);
+  HIP_OK(hipMemcpy(fl.data(), p->q_flags.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost));
+  p->last_ls_rows = 0;
+  p->last_effective = (int)std::min<long long>(it, 1 << 30);
+  for (int j = 0; j < P; ++j) {
+    if (converged) converged[j] = fl[4 * j];
+    if (iters) iters[j] = fl[4 * j + 1];
+    if (status) status[j] = fl[4 * j + 2];
+    p->last_ls_rows += fl[4 * j + 3];
+  }
+  if (p->timing) p->ev_live.resize(p->ev_used / 5, 1);
+  (void)ev_first;
+  if (states) HIP_OK(download_converted<T>(states, p->q_states.p, (size_t)P * (H + 1) * nx, h->stream));
+  if (ctrls) HIP_OK(download_converted<T>(ctrls, p->q_ctrls.p, (size_t)P * H * nu, h->stream));
+  if (Ks) HIP_OK(download_converted<T>(Ks, p->q_Ks.p, (size_t)P * H * nu * nx, h->stream));
+  if (ks) HIP_OK(download_converted<T>(ks, p->q_ks.p, (size_t)P * H * nu, h->stream));
+  if (objective) HIP_OK(download_converted<T>(objective, p->q_obj.p, (size_t)P, h->stream));
+  // leave the plan as ampc_ilqr_solve expects it: the slots' cost blocks as given at plan creation
+  HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
+                                     const int* cost_index, int max_iter, double* states, double* ctrls,
+                                     double* Ks, double* ks, int* converged, int* iters, int* status,
+                                     double* objective) {
+  REQUIRE(p && x0, "ampc_ilqr_solve_queue: NULL argument");
+  REQUIRE(n_problems >= 1, "ampc_ilqr_solve_queue: n_problems < 1");
+  REQUIRE(max_iter >= 1, "ampc_ilqr_solve_queue: max_iter < 1");
+  if (cost_index)
+    for (int j = 0; j < n_problems; ++j)
+      REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_solve_queue: bad cost_index");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, max_iter, states, ctrls, Ks, ks,
+                                             converged, iters, status, objective)
+             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, max_iter, states, ctrls, Ks, ks,
+                                            converged, iters, status, objective);
 }
 
 // ---------------------------------------------------------------------------------------------

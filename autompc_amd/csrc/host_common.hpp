@@ -361,8 +361,9 @@ struct ampc_ilqr_plan {
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
-  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B] ls_count[B]
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B] ls_count[B] ls_pass[B]
   int use_ls4 = 1, use_mfma_sweep = 1, par_passes = 1;   // (AMPC_LS4_PAR = 0: passes one after the other)
+  int ls_split = 0;          // (AMPC_LS4_SPLIT = 1: large batches search in two launches, ilqr_ls4.hpp; measured: no gain)
   int unused_ = 0;   // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
   TileLds L{};
   int lds_work = 0, lds_xn = 0;
@@ -384,8 +385,14 @@ struct ampc_ilqr_plan {
                                         // search run side by side on the idle CUs
   // convergence polling: the `active` flags of one batch of iterations are copied to pinned host
   // memory behind that batch and read while the NEXT batch is already queued
-  int* poll_host = nullptr;     // [2][B] pinned
+  int* poll_host = nullptr;     // [2][B + 2] pinned (queue mode: + the queue's two counters)
   hipEvent_t poll_ev[2] = {nullptr, nullptr};
+  // continuous batching (ampc_ilqr_solve_queue): P problems stream through the B slots
+  bool queue_on = false;        // kernels read the per-slot mode and the per-problem iteration cap
+  int queue_max_iter = 0;
+  DevBuf q_ctl;                 // ints: [0] next, [1] harvested, then slot_prob[B], slot_mode[B]
+  DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
+  long long last_queue_launches = 0;   // iterations launched by the last queue solve
 };
 
 template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int mode) {
@@ -411,8 +418,12 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.obj = (T*)p->obj.p;
   int* f = (int*)p->flags.p;
   a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
-  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B; a.ls_count = f + 6 * p->B;
+  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B; a.ls_count = f + 6 * p->B; a.ls_pass = f + 7 * p->B;
   a.ric = (T*)p->ric.p;
+  if (p->queue_on) {
+    a.slot_mode = (int*)p->q_ctl.p + 2 + p->B;
+    a.max_iter = p->queue_max_iter;
+  }
   return a;
 }
 

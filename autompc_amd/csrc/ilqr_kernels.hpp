@@ -45,6 +45,13 @@ template <typename T> struct IlqrArgs {
   int H, obs_dim, cost_stride, bounded, ls_n, mode;   // mode 0: initial rollout, 1: iteration
   int cost_diag;                 // 1: Q, R, F of every cost block are diagonal -> O(n) objective
   int cost_affine;               // 1: some cost block has an affine part (mlp_tile.hpp: cost_block_stride)
+  int max_iter;                  // > 0: a problem is retired once it has done this many iterations (the
+                                 //      queue's per-problem cap; 0: the host loop counts)
+  int ls_split;                  // four-row line search in two launches (ilqr_ls4.hpp): 0 no, 1 first launch
+                                 // (pass 0 for every problem), 2 second (the other passes side by side, for
+  int* ls_pass;                  // the problems the first left undecided: ls_pass[p] = 1)
+  int* slot_mode;                // queue mode (ampc_ilqr_solve_queue): per slot 0 = roll out the guess of the
+                                 // problem just loaded, 1 = iterate; nullptr: `mode` for every problem
   int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it
                                  //    (cost.py:195, goal ignored); 1: (F+F')(x_N - goal)
   T dt, u_threshold, ls_cost_threshold;
@@ -828,6 +835,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
 // thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
 template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
+  const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   // nothing resident: the kernel is launched once per iteration and runs only H steps, so filling
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   const T* clin = goal + no; const T* clint = clin + no;     // affine part of the stage / terminal cost
   T* xu = lds + L.xu;
 
-  if (args.mode == 1 && args.active[p] == 0) {
+  if (mode == 1 && args.active[p] == 0) {
     if (tid == 0) args.refresh[p] = 0;
     return;
   }
@@ -879,7 +887,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
 
   // (backward Riccati sweep: ilqr_riccati_kernel above, launched just before this kernel)
-  if (args.mode == 1) {
+  if (mode == 1) {
     const T* rin = args.ric + (size_t)p * kRicStride;
     if (rin[3] != T(0)) return;     // singular Quu: the sweep already retired this problem
     if (tid == 0) { scal[0] = rin[0]; scal[1] = rin[1]; scal[2] = rin[2]; }
@@ -889,7 +897,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // =========================== forward rollout(s) (ilqr.py:141-149, 196-205) ===================
   AMPC_IMARK_ALWAYS(31);
   if constexpr (DYN == 0) net.init(mlp);
-  const int rows = args.mode == 0 ? 1 : args.ls_n;
+  const int rows = mode == 0 ? 1 : args.ls_n;
   const int m = tid / TPS, r = tid % TPS;        // row-in-tile, helper index (same wave)
   T obj_part = T(0);
   const T alpha = args.alphas[m];
@@ -926,20 +934,20 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     if (tid < nu) { kv[tid] = kvr; ubar[tid] = ubr; }
     if (tid < nx) xbar[tid] = xbr;
   };
-  if (args.mode == 1) {
+  if (mode == 1) {
     fetch_ls(0);
     commit_ls();
     __syncthreads();
   }
   const bool cdiag = args.cost_diag != 0, caff = args.cost_affine != 0;
   for (int t = 0; t < H; ++t) {
-    AMPC_IPROBE_STEP(args.mode == 1 && t == H / 2);
+    AMPC_IPROBE_STEP(mode == 1 && t == H / 2);
     AMPC_IMARK(40);
-    if (args.mode == 1 && t + 1 < H) fetch_ls(t + 1);
+    if (mode == 1 && t + 1 < H) fetch_ls(t + 1);
     // controls for this step
     for (int a = r; a < nu; a += TPS) {
       T u;
-      if (args.mode == 0) {
+      if (mode == 0) {
         u = ct[(size_t)t * nu + a];
       } else {
         // four partial sums over interleaved b: the LDS reads of a whole group are in flight
@@ -960,7 +968,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       }
       xu[m * xs_ + nx + a] = u;
     }
-    if (args.mode == 1 && m < rows)
+    if (mode == 1 && m < rows)
       for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
     AMPC_IMARK(41);
     lds_barrier();
@@ -976,7 +984,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       for (int a = r; a < nx; a += TPS) {
         const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
         xu[m * xs_ + a] = xn;
-        if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+        if (mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
       }
     } else {
       T* xnext = lds + args.lds_xn;
@@ -987,17 +995,17 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       for (int a = r; a < nx; a += TPS) {
         const T xn = xnext[m * nx + a];
         xu[m * xs_ + a] = xn;
-        if (args.mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+        if (mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
       }
     }
     // every thread passed the barrier above after its last read of K, k, ubar, xbar
     AMPC_IMARK(45);
-    if (args.mode == 1 && t + 1 < H) commit_ls();
+    if (mode == 1 && t + 1 < H) commit_ls();
     lds_barrier();
     AMPC_IMARK(46);
   }
   AMPC_IMARK_ALWAYS(32);
-  if (args.mode == 1 && m < rows)
+  if (mode == 1 && m < rows)
     for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
   obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, cdiag);
   if (caff) obj_part += affine_rows<T>(clint, xu + m * xs_, goal, no, r, TPS, clint[no + 1]);
@@ -1006,11 +1014,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   if (r == 0) lsobj[m] = obj_part;
   __syncthreads();
 
-  if (args.mode == 0) {
+  if (mode == 0) {
     if (tid == 0) {
       args.obj[p] = lsobj[0];
       args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
-      args.refresh[p] = 1;
+      args.refresh[p] = 1; args.ls_rows[p] = 0;
+      if (args.slot_mode) args.slot_mode[p] = 1;
     }
     return;
   }
@@ -1062,7 +1071,64 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     args.obj[p] = scal[3];
     args.refresh[p] = success;
     if (conv) { args.converged[p] = 1; args.active[p] = 0; }
+    else if (args.max_iter > 0 && args.iters[p] >= args.max_iter) args.active[p] = 0;
   }
+}
+
+// ---- continuous batching (ampc_ilqr_solve_queue) ---------------------------------------------------
+// P problems stream through the plan's B slots.  Once per iteration, ahead of the sweep, every idle
+// slot (active == 0) hands the finished problem's results to its output row and takes the next
+// unsolved problem from the queue: x0 / guess / cost block into the slot, slot_mode = 0 -- the
+// line-search launch of this iteration rolls the guess out instead (what ampc_ilqr_solve does before
+// its first iteration), the Jacobian launch refreshes it, and from the next iteration on the slot
+// iterates with everybody else.  No host round trip; a problem's arithmetic is the one-problem solve's.
+template <typename T> struct IlqrQueue {
+  int P, B, H, nx, nu;
+  int* ctl;                  // [0] next problem to hand out, [1] problems harvested
+  int* slot_prob;            // [B] problem in the slot, -1: none
+  const T* x0;               // [P][nx]
+  const T* uguess;           // [P][H][nu]
+  const int* cost;           // [P] cost block of the problem
+  int* cost_idx;             // [B] the plan's per-slot cost block (read by every kernel)
+  T* out_states; T* out_ctrls; T* out_Ks; T* out_ks; T* out_obj;      // [P] rows
+  int* out_flags;            // [P][4] converged, iters, status, candidate rows
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T> args, const IlqrQueue<T> q) {
+  __shared__ int next_s;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (args.active[p] != 0 || args.slot_mode[p] == 0) return;      // running, or loaded and not yet started
+  const int H = q.H, nx = q.nx, nu = q.nu;
+  T* st = args.states + (size_t)p * (H + 1) * nx;
+  T* ct = args.ctrls + (size_t)p * H * nu;
+  const int j = q.slot_prob[p];
+  if (j >= 0) {                                        // harvest
+    for (int i = tid; i < (H + 1) * nx; i += 256) q.out_states[(size_t)j * (H + 1) * nx + i] = st[i];
+    for (int i = tid; i < H * nu; i += 256) q.out_ctrls[(size_t)j * H * nu + i] = ct[i];
+    for (int i = tid; i < H * nu * nx; i += 256) q.out_Ks[(size_t)j * H * nu * nx + i] = args.Ks[(size_t)p * H * nu * nx + i];
+    for (int i = tid; i < H * nu; i += 256) q.out_ks[(size_t)j * H * nu + i] = args.ks[(size_t)p * H * nu + i];
+    if (tid == 0) {
+      q.out_obj[j] = args.obj[p];
+      q.out_flags[4 * j] = args.converged[p]; q.out_flags[4 * j + 1] = args.iters[p];
+      q.out_flags[4 * j + 2] = args.status[p]; q.out_flags[4 * j + 3] = args.ls_rows[p];
+    }
+  }
+  if (tid == 0) {
+    int n = q.ctl[0] < q.P ? atomicAdd(&q.ctl[0], 1) : q.P;
+    if (n >= q.P) n = -1;
+    next_s = n;
+    q.slot_prob[p] = n;
+    if (n >= 0) {
+      q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0;
+    }
+    if (j >= 0) { __threadfence(); atomicAdd(&q.ctl[1], 1); }
+  }
+  __syncthreads();
+  const int n = next_s;
+  if (n < 0) return;
+  for (int i = tid; i < nx; i += 256) st[i] = q.x0[(size_t)n * nx + i];
+  for (int i = tid; i < H * nu; i += 256) ct[i] = q.uguess[(size_t)n * H * nu + i];
 }
 
 }  // namespace ampc

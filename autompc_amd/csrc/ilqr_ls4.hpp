@@ -113,6 +113,10 @@ __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int 
 
 template <int NT, bool RES, typename SH = DynShape>
 __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<double> args) {
+  const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
+  if (mode == 0 && blockIdx.y > 0) return;       // (side-by-side passes: a slot rolling out its guess has one)
+  // second launch of a split line search (below): only problems the first launch left undecided
+  if (args.ls_split == 2 && args.ls_pass[blockIdx.x] == 0) return;
   using T = double;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
@@ -144,11 +148,11 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   const T* goal = Fm + no * no;
   const T* clin = goal + no; const T* clint = clin + no;     // affine part of the stage / terminal cost
 
-  if (args.mode == 1 && args.active[p] == 0) {
+  if (mode == 1 && args.active[p] == 0) {
     if (tid == 0) args.refresh[p] = 0;
     return;
   }
-  if (args.mode == 1 && args.ric[(size_t)p * kRicStride + 3] != T(0)) return;   // singular Quu: retired by the sweep
+  if (mode == 1 && args.ric[(size_t)p * kRicStride + 3] != T(0)) return;   // singular Quu: retired by the sweep
 
   for (int l = 0; l < Lh; ++l)
     for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.b[l][i];
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     blo[i] = args.bounded ? args.ubounds[i] : T(0);
     bhi[i] = args.bounded ? args.ubounds[nu + i] : T(0);
   }
-  if (tid == 0 && args.mode == 1) {
+  if (tid == 0 && mode == 1) {
     const T* rin = args.ric + (size_t)p * kRicStride;
     scal[0] = rin[0]; scal[1] = rin[1]; scal[2] = rin[2];
   }
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   const T* kg = args.ks + (size_t)p * H * nu;
   T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
   T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
-  const int rows = args.mode == 0 ? 1 : args.ls_n;
+  const int rows = mode == 0 ? 1 : args.ls_n;
   const bool cdiag = args.cost_diag != 0, caff = args.cost_affine != 0;
   // Wave w owns row w of the tile between time steps: it adds the network output to its state,
   // evaluates the control law (ilqr.py:196-205) -- no workgroup barrier in between -- and
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   constexpr int KPL = 8;                             // entries per lane: nx <= 32 = 4 * 8
   T kreg[KPL], xbreg[KPL], kvr = T(0), ubr = T(0);
   auto fetch_law = [&](int t) {
-    if (args.mode == 1) {
+    if (mode == 1) {
 #pragma unroll
       for (int i = 0; i < KPL; ++i) {
         const int b = cpart + parts * i;
@@ -268,8 +272,20 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   // small batches, idle CUs -- each pass on its own workgroup (blockIdx.y), all at once; the last
   // workgroup to finish then runs the reference's acceptance loop over all of them.
   const int npass = (rows + ROWS - 1) / ROWS;
-  const bool par = args.mode == 1 && args.par_passes != 0;
-  const int pass0 = par ? (int)blockIdx.y : 0, pass1 = par ? (int)blockIdx.y + 1 : npass;
+  // Split line search (args.ls_split; many problems per launch): the problems of a launch run in
+  // lock-step, and most line searches are decided by their first four step sizes -- a launch that ran
+  // all three passes back to back would keep every decided problem's CU idle while the few undecided
+  // ones work through passes two and three.  So launch 1 rolls out pass 0 for everybody and runs the
+  // acceptance loop over it; a problem it leaves undecided parks its four objectives in `ric` and raises
+  // ls_pass[p]; launch 2 (grid.y = npass - 1, everybody else exits at once) rolls out the REMAINING
+  // passes side by side on the now idle CUs, and the last of them to arrive runs the reference's
+  // acceptance loop over all candidates.  Same decisions, same arithmetic as the passes in sequence.
+  const int split = mode == 1 ? args.ls_split : 0;
+  const bool par = mode == 1 && (args.par_passes != 0 || split == 2);
+  const int par_first = split == 2 ? 1 : 0;                   // first pass the side-by-side launch covers
+  T* gstate = args.ric + (size_t)p * kRicStride + 4;          // [16] candidate objectives
+  const int pass0 = par ? (int)blockIdx.y + par_first : 0;
+  const int pass1 = par ? pass0 + 1 : (split == 1 ? 1 : npass);
   for (int pass = pass0; pass < pass1; ++pass) {
     const int jw = ROWS * pass + w;                  // the candidate this wave's row carries
     const bool livew = jw < rows;
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     if (lane < nx) xu[w * xs + lane] = st[lane];
     fetch_law(0);
     for (int t = 0; t <= H; ++t) {
-      AMPC_IPROBE_STEP(args.mode == 1 && pass == 0 && t == H / 2);
+      AMPC_IPROBE_STEP(mode == 1 && pass == 0 && t == H / 2);
       AMPC_IMARK(40);
       // ---- between steps, on row w: x_t = x_{t-1} + net output, then u_t
       if (t > 0 && lane < nx) {
@@ -287,13 +303,13 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
         for (int ww = 0; ww < W; ++ww) s += part[(ww * ROWS + w) * nxp + lane];
         const T xn = xu[w * xs + lane] + s;
         xu[w * xs + lane] = xn;
-        if (args.mode == 0 && w == 0) stw[(size_t)t * nx + lane] = xn;
+        if (mode == 0 && w == 0) stw[(size_t)t * nx + lane] = xn;
       }
-      if (args.mode == 1 && livew && lane < nx) lss[((size_t)jw * (H + 1) + t) * nx + lane] = xu[w * xs + lane];
+      if (mode == 1 && livew && lane < nx) lss[((size_t)jw * (H + 1) + t) * nx + lane] = xu[w * xs + lane];
       if (t == H) break;
       {
         T u;
-        if (args.mode == 0) {
+        if (mode == 0) {
           u = ubr;
         } else {
           T f = T(0);
@@ -307,7 +323,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
           if (args.bounded && ca < nu) { u = u < blo[ca] ? blo[ca] : u; u = u > bhi[ca] ? bhi[ca] : u; }
         }
         if (ca < nu && cpart == 0) {
-          if (args.mode == 1 && livew) lsc[((size_t)jw * H + t) * nu + ca] = u;
+          if (mode == 1 && livew) lsc[((size_t)jw * H + t) * nu + ca] = u;
           xu[w * xs + nx + ca] = u;
         }
         if (t + 1 < H) fetch_law(t + 1);
@@ -437,8 +453,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     // trajectory, one time step per lane -- kept off the serial chain of the rollout above
     __syncthreads();                                 // (orders this workgroup's trajectory stores)
     {
-      const T* xsrc = args.mode == 0 ? stw : lss + (size_t)jw * (H + 1) * nx;
-      const T* usrc = args.mode == 0 ? ctw : lsc + (size_t)jw * H * nu;
+      const T* xsrc = mode == 0 ? stw : lss + (size_t)jw * (H + 1) * nx;
+      const T* usrc = mode == 0 ? ctw : lsc + (size_t)jw * H * nu;
       if (livew)
         for (int t = lane; t <= H; t += 64) {
           const T* xt = xsrc + (size_t)t * nx;
@@ -456,11 +472,12 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     if (lane == 0) lsobj[ROWS * pass + w] = obj_part;
     __syncthreads();
 
-    if (args.mode == 0) {
+    if (mode == 0) {
       if (tid == 0) {
         args.obj[p] = lsobj[0];
         args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
-        args.refresh[p] = 1;
+        args.refresh[p] = 1; args.ls_rows[p] = 0; args.ls_count[p] = 0;
+        if (args.slot_mode) args.slot_mode[p] = 1;
       }
       return;
     }
@@ -472,9 +489,9 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
       __syncthreads();
       if (tid == 0) piv[4] = atomicAdd(&args.ls_count[p], 1);
       __syncthreads();
-      if (piv[4] != npass - 1) return;
+      if (piv[4] != npass - par_first - 1) return;
       __threadfence();
-      if (tid == 0) args.ls_count[p] = 0;
+      if (tid == 0) { args.ls_count[p] = 0; if (split == 2) args.ls_pass[p] = 0; }
       if (tid < kIlqrMaxLs) lsobj[tid] = tid < rows ? __builtin_nontemporal_load(gobj + tid) : T(0);
       __syncthreads();
     }
@@ -496,6 +513,11 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     }
     __syncthreads();
     if (piv[3]) break;
+    if (split == 1 && npass > 1) {               // undecided, more step sizes to try: the second launch
+      if (tid < ROWS) gstate[tid] = lsobj[tid];
+      if (tid == 0) { args.ls_pass[p] = 1; args.refresh[p] = 0; }
+      return;
+    }
   }
 
   // =========================== acceptance (ilqr.py:234-261) ====================================
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     args.obj[p] = scal[3];
     args.refresh[p] = success;
     if (conv) { args.converged[p] = 1; args.active[p] = 0; }
+    else if (args.max_iter > 0 && args.iters[p] >= args.max_iter) args.active[p] = 0;
   }
 }
 

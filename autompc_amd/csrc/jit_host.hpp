@@ -44,6 +44,7 @@ namespace jit {
 struct Entry {
   int state = 0;            // 0 unknown, 1 building, 2 ready, -1 failed
   pid_t pid = -1;
+  bool reaped = false;       // the build's process has been waited for (or is not ours to wait for)
   std::string so, log;
   JitPlugin plug;
   int info[8] = {0};
@@ -244,17 +245,30 @@ template <typename T> inline void start_build(Entry& e, const ampc_handle* h, co
 // Reap a finished build (never blocks).  The child may not be ours to wait for any more -- the
 // process forked after the spawn, or runs with SIGCHLD ignored: waitpid then fails with ECHILD -- so
 // the verdict always comes from the files the script leaves: the plugin, or <plugin>.failed.
-inline void poll(Entry& e, const ampc_handle* h, size_t tsize) {
-  if (e.state != 1) return;
+inline bool child_gone(Entry& e) {
+  if (e.reaped) return true;
   int st = 0;
   const pid_t r = waitpid(e.pid, &st, WNOHANG);
-  if (r == 0) return;                                   // still running
-  if (r < 0 && !exists(e.so) && !exists(e.so + ".failed")) {
-    if (::kill(e.pid, 0) == 0) return;                  // not our child, but alive: keep waiting
-  }
+  if (r == 0) return false;                             // still running
+  if (r < 0 && !exists(e.so) && !exists(e.so + ".failed") && ::kill(e.pid, 0) == 0)
+    return false;                                       // not our child, but alive: keep waiting
+  e.reaped = true;
+  return true;
+}
+
+inline void poll(Entry& e, const ampc_handle* h, size_t tsize) {
+  if (e.state != 1 || !child_gone(e)) return;
   if (exists(e.so)) { load(e, h, tsize); return; }
   e.state = -1;
   e.log = "build failed, see " + e.log;
+}
+
+// Finished builds of OTHER shapes (a model that was staged and dropped before its plugin was ready)
+// are reaped whenever anybody asks about any shape, so no build stays a zombie for the life of the
+// process; their plugins are loaded when their own shape is next asked for.
+inline void reap_all() {
+  for (auto& kv : table())
+    if (kv.second.state == 1) (void)child_gone(kv.second);
 }
 
 // plugin for the handle's staged shape, or nullptr (not eligible / still building / failed).
@@ -273,6 +287,7 @@ template <typename T> inline const JitPlugin* get(const ampc_handle* h, bool blo
         else start_build<T>(e, h, key);
       }
       poll(e, h, sizeof(T));
+      reap_all();
       if (e.state != 1 || !block) return e.state == 2 ? &e.plug : nullptr;
     }
     usleep(20000);
@@ -287,6 +302,7 @@ template <typename T> inline int status(const ampc_handle* h, std::string* msg) 
   auto it = table().find(key_of<T>(h));
   if (it == table().end()) return 0;
   poll(it->second, h, sizeof(T));
+  reap_all();
   if (msg) *msg = it->second.state == 2 ? it->second.so : it->second.log;
   return it->second.state;
 }

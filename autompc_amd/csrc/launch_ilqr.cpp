@@ -94,40 +94,52 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       // (retired problems' workgroups exit at once, so what has to fit is the ACTIVE problems' passes)
       const int live = (p->active_hint > 0 && p->active_hint < p->B) ? p->active_hint : p->B;
       a.par_passes = (mode == 1 && p->par_passes && live * npass <= h->n_cus) ? 1 : 0;
-      const dim3 grid(p->B, a.par_passes ? npass : 1);
-      if (p->static_shape >= 0) {
-        // (the activation is a compile-time constant for relu AND tanh here: with the run-time
-        //  switch the epilogue keeps all five activations' temporaries alive and the kernel falls
-        //  off its register budget -- spills inside the time loop, 2x slower)
+      // many problems: the line search in two launches -- pass 0 for everybody, then the remaining
+      // passes side by side for the problems it left undecided (ilqr_ls4.hpp)
+      const bool split = mode == 1 && !a.par_passes && p->ls_split && npass > 1;
+      auto launch_ls = [&](const dim3 grid, const IlqrArgs<T>& a) -> int {
+        if (p->static_shape >= 0) {
+          // (the activation is a compile-time constant for relu AND tanh here: with the run-time
+          //  switch the epilogue keeps all five activations' temporaries alive and the kernel falls
+          //  off its register budget -- spills inside the time loop, 2x slower)
 #define AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, ACTV)                                            \
-        case (ID) * 8 + ((ACTV) < 0 ? 7 : (ACTV)): {                                               \
-          using SH = StaticShape<NX, NU, NO, NH, HPAD, ACTV>;                                      \
-          auto k = ilqr_ls4_kernel<HPAD / 64, NH == 2, SH>; HIP_OK(allow_lds(k, lb));              \
-          hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
+          case (ID) * 8 + ((ACTV) < 0 ? 7 : (ACTV)): {                                               \
+            using SH = StaticShape<NX, NU, NO, NH, HPAD, ACTV>;                                      \
+            auto k = ilqr_ls4_kernel<HPAD / 64, NH == 2, SH>; HIP_OK(allow_lds(k, lb));              \
+            hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
 #define AMPC_LS4_ONE(ID, NX, NU, NO, NH, HPAD)                                                    \
-        AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 0) AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 1)    \
-        AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, -1)
-        switch (p->static_shape * 8 + ((h->act == 0 || h->act == 1) ? h->act : 7)) {
-          AMPC_STATIC_SHAPES(AMPC_LS4_ONE)
-          default: return fail("internal: unknown static shape");
-        }
+          AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 0) AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 1)    \
+          AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, -1)
+          switch (p->static_shape * 8 + ((h->act == 0 || h->act == 1) ? h->act : 7)) {
+            AMPC_STATIC_SHAPES(AMPC_LS4_ONE)
+            default: return fail("internal: unknown static shape");
+          }
 #undef AMPC_LS4_ONE
 #undef AMPC_LS4_SHAPE
-      } else {
+        } else {
 #ifdef AMPC_JIT_PLUGIN
-        return fail("shape plugin entered without its static shape");
+          return fail("shape plugin entered without its static shape");
 #else
 #define AMPC_LS4_CASE(NTV, RESV)                                                               \
-        case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
-          HIP_OK(allow_lds(k, lb));                                                            \
-          hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
-        switch ((h->hpad / 64) * 2 + (res ? 1 : 0)) {
-          AMPC_LS4_CASE(1, 0) AMPC_LS4_CASE(1, 1) AMPC_LS4_CASE(2, 0) AMPC_LS4_CASE(2, 1)
-          AMPC_LS4_CASE(3, 0) AMPC_LS4_CASE(3, 1) AMPC_LS4_CASE(4, 0) AMPC_LS4_CASE(4, 1)
-          default: return fail("internal: unsupported hidden width for the four-row line search");
-        }
+          case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
+            HIP_OK(allow_lds(k, lb));                                                            \
+            hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
+          switch ((h->hpad / 64) * 2 + (res ? 1 : 0)) {
+            AMPC_LS4_CASE(1, 0) AMPC_LS4_CASE(1, 1) AMPC_LS4_CASE(2, 0) AMPC_LS4_CASE(2, 1)
+            AMPC_LS4_CASE(3, 0) AMPC_LS4_CASE(3, 1) AMPC_LS4_CASE(4, 0) AMPC_LS4_CASE(4, 1)
+            default: return fail("internal: unsupported hidden width for the four-row line search");
+          }
 #undef AMPC_LS4_CASE
 #endif
+        }
+        return 0;
+      };
+      a.ls_split = split ? 1 : 0;
+      if (int rc = launch_ls(dim3(p->B, a.par_passes ? npass : 1), a)) return rc;
+      if (split) {
+        HIP_OK(hipGetLastError());
+        a.ls_split = 2;
+        if (int rc = launch_ls(dim3(p->B, npass - 1), a)) return rc;
       }
       HIP_OK(hipGetLastError());
       if (e) HIP_OK(hipEventRecord(e[2], h->stream));

@@ -336,6 +336,23 @@ int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess, i
                     double* states, double* ctrls, double* Ks, double* ks, int* converged,
                     int* iters, int* status, double* objective);
 
+/* Continuous batching: n_problems independent problems streamed through the plan's B slots.
+ * ampc_ilqr_solve runs a batch for as long as its slowest problem; here a slot whose problem has
+ * converged, failed or used up max_iter iterations takes the next unsolved problem at the following
+ * iteration boundary -- on the device, with no host round trip (the finished problem's results go to
+ * its output row, the new problem's guess is rolled out by the same launch that line-searches the
+ * other slots) -- so every slot stays busy until the queue is empty.  Each problem's arithmetic is
+ * exactly that of a one-problem ampc_ilqr_solve (IterativeLQR.compute_ilqr_default, ilqr.py:100-265):
+ * results are bit-identical to it, whatever shares the plan.  What the tuner's candidate evaluator
+ * feeds (one problem per candidate and control step, ilqr.py:267-295) and what bench.py's c4 times.
+ *   x0 [n][nx];  uguess [n][H][nu] or NULL (zeros: IterativeLQR.run's guess, ilqr.py:280-281);
+ *   cost_index [n] or NULL (block 0);  outputs as ampc_ilqr_solve, [n] rows, any may be NULL.
+ * The plan's horizon, dt, bounds mode and terminal-gradient mode apply to every problem. */
+int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
+                          const int* cost_index, int max_iter, double* states, double* ctrls,
+                          double* Ks, double* ks, int* converged, int* iters, int* status,
+                          double* objective);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,95 @@
+"""Continuous batching of iLQR problems (ampc_ilqr_solve_queue): P problems streamed through B slots,
+refilled on the device, must give every problem exactly what a one-problem ampc_ilqr_solve gives it
+(IterativeLQR.compute_ilqr_default, ilqr.py:100-265).  Needs MI355X."""
+import numpy as np
+import pytest
+
+from oracle import mlp as omlp
+from oracle.costs import QuadCostOracle
+from oracle.ilqr import ILQROracle
+from oracle.mlp import MLPOracle
+from helpers import make_system
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("states", "ctrls", "Ks", "ks", "converged", "iters", "status", "objective")
+
+
+def _setup(nx, nu, hidden, act, C, seed, bounds=None, precision="f64"):
+    from autompc_amd import _lib
+    p = omlp.random_params(nx, nu, hidden, act, seed=seed)
+    rng = np.random.default_rng(seed)
+    Q = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(C)])
+    R = np.stack([np.diag(rng.uniform(0.05, 0.2, size=nu)) for _ in range(C)])
+    F = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(C)])
+    goal = rng.normal(scale=0.05, size=(C, nx))
+    h = _lib.Handle(0, precision)
+    h.set_mlp(nx, nu, p["weights"], p["biases"], act, p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+    h.set_quad_costs(Q, R, F, goal)
+    if bounds is not None:
+        h.set_ctrl_bounds(np.full(nu, bounds[0]), np.full(nu, bounds[1]))
+    return p, h, (Q, R, F, goal)
+
+
+@pytest.mark.parametrize("case", [
+    # nx, nu, hidden, act, H, B, P, bounds, max_iter
+    (17, 6, [256, 256], "relu", 50, 6, 20, (-0.25, 0.25), 50),      # BASELINE config 4 shape: MFMA sweep + four-row search
+    (17, 6, [256, 256], "tanh", 20, 4, 9, None, 12),                # the per-problem iteration cap bites
+    (5, 2, [64, 48], "tanh", 15, 8, 3, None, 50),                   # fewer problems than slots; run-time shapes
+    (40, 3, [64], "tanh", 10, 3, 7, None, 30),                      # wide states: general sweep + sixteen-row search
+])
+def test_queue_equals_one_problem_solves(case):
+    from autompc_amd import _lib
+    nx, nu, hidden, act, H, B, P, bounds, max_iter = case
+    C = 5
+    p, h, _ = _setup(nx, nu, hidden, act, C, seed=nx + H, bounds=bounds)
+    rng = np.random.default_rng(P)
+    x0 = rng.uniform(-0.2, 0.2, size=(P, nx))
+    ug = np.zeros((P, H, nu))
+    ug[::2] = rng.uniform(-0.05, 0.05, size=ug[::2].shape)          # some problems start from a non-zero guess
+    ci = rng.integers(0, C, size=P).astype(np.int32)
+    plan = _lib.IlqrPlan(h, B, H, 0.05, cost_index=np.zeros(B, dtype=np.int32), clip_to_bounds=bounds is not None)
+    got = plan.solve_queue(x0, ug, ci, max_iter=max_iter)
+    assert got["iters"].max() <= max_iter
+    one = _lib.IlqrPlan(h, 1, H, 0.05, cost_index=np.zeros(1, dtype=np.int32), clip_to_bounds=bounds is not None)
+    for j in range(P):
+        one.close()
+        one = _lib.IlqrPlan(h, 1, H, 0.05, cost_index=ci[j:j + 1], clip_to_bounds=bounds is not None)
+        ref = one.solve(x0[j], ug[j], max_iter=max_iter)
+        for k in KEYS:
+            np.testing.assert_array_equal(got[k][j], ref[k][0], err_msg="problem %d, %s" % (j, k))
+    # the plan is an ordinary plan again afterwards, and a second queue run gives the same answers
+    again = plan.solve_queue(x0, ug, ci, max_iter=max_iter)
+    for k in KEYS:
+        np.testing.assert_array_equal(again[k], got[k])
+    ordinary = plan.solve(x0[:B] if P >= B else np.tile(x0[:1], (B, 1)), np.zeros((B, H, nu)), max_iter=3)
+    assert ordinary["iters"].max() <= 3
+    assert plan.stats()["candidate_rows"] > 0
+
+
+def test_queue_against_the_oracle_and_failure_isolation():
+    """Queue results against independent oracle solves, with a singular problem in the middle of the
+    queue: it reports status 1 (the reference's LinAlgError) and nobody else notices."""
+    from autompc_amd import _lib
+    nx, nu, H, B, P = 4, 2, 12, 3, 8
+    p, h, (Q, R, F, goal) = _setup(nx, nu, [64, 64], "tanh", 2, seed=3)
+    # cost block 1: R = 0 on a model... keep the model, make Quu singular through R = 0 and F = Q = 0
+    Q2, R2, F2 = Q.copy(), R.copy(), F.copy()
+    Q2[1], R2[1], F2[1] = 0.0, 0.0, 0.0
+    h.set_quad_costs(Q2, R2, F2, goal)
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-0.3, 0.3, size=(P, nx))
+    ci = np.zeros(P, dtype=np.int32)
+    ci[3] = 1
+    plan = _lib.IlqrPlan(h, B, H, 0.05)
+    got = plan.solve_queue(x0, None, ci, max_iter=50)
+    assert got["status"][3] == 1 and (np.delete(got["status"], 3) == 0).all()
+    system = make_system(nx, nu, dt=0.05)
+    for j in range(P):
+        if j == 3:
+            continue
+        orc = ILQROracle(MLPOracle(system, p), QuadCostOracle(Q2[0], R2[0], F2[0], goal[0]), 0.05, H)
+        conv, st, ct, Ks, ks = orc.solve(x0[j], np.zeros((H, nu)))
+        assert bool(got["converged"][j]) == conv and int(got["iters"][j]) == orc.n_iter
+        assert np.max(np.abs(got["states"][j] - st)) < 1e-6 * max(1.0, np.max(np.abs(st)))
+        assert abs(got["objective"][j] - orc.final_obj) < 1e-8 * max(1.0, abs(orc.final_obj))
