@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
-PROFILE_TAG = "r03"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r04"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
 
 
 def parse():
@@ -52,19 +52,18 @@ def parse():
                          "resident: one numpy-drawn noise set uploaded before timing and reused")
     ap.add_argument("--batch", type=int, default=0,
                     help="independent problems per step per GPU (default: 1 solve; c4 256; c5 64)")
-    ap.add_argument("--groups", type=int, default=1,
-                    help="c4: split the batch over this many handles / streams driven by as many host "
-                         "threads (the latency-bound sweep and line search of one group overlap the "
-                         "Jacobian chain of another)")
     ap.add_argument("--tile-rows", type=int, default=32, choices=[16, 32, 64],
                     help="c5: samples per rollout workgroup of the candidate evaluator")
-    ap.add_argument("--preheat", type=float, default=0.6,
+    ap.add_argument("--preheat", type=float, default=1.0,
                     help="seconds of untimed solves before the warm-up steps, so that short runs "
                          "(--steps 20) are timed at the settled clock like long ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32 fast-mode side report")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0,
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="time budget of EACH cpu_baseline leg (all cores, one thread)")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="default line: the timed window of --steps solves is repeated this many times "
+                         "(value = the first window, as the contract says; repeat_windows = median / min / max)")
     return ap.parse_args()
 
 
@@ -160,7 +159,7 @@ def cpu_baseline_mppi(workload, spec, budget_s):
                             "pred_batch per step + the reference's per-particle Python cost loop)" % workload)
 
 
-def cpu_baseline_ilqr(system, spec, x0s, budget_s):
+def cpu_baseline_ilqr(system, spec, x0s, budget_s, bounded=False):
     from oracle.costs import QuadCostOracle
     from oracle.ilqr import ILQROracle
     from oracle.mlp import MLPOracle, make_params
@@ -169,14 +168,15 @@ def cpu_baseline_ilqr(system, spec, x0s, budget_s):
     om = MLPOracle(system, make_params(p["weights"], p["biases"], "relu", p["xu_means"],
                                        p["xu_std"], p["dy_means"], p["dy_std"]))
     orc = ILQROracle(om, QuadCostOracle(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx)),
-                     system.dt, 50)
+                     system.dt, 50, ubounds=(np.full(nu, -0.25), np.full(nu, 0.25)) if bounded else None)
     k = {"i": 0}
 
     def run_once():
         orc.solve(x0s[k["i"] % len(x0s)], np.zeros((50, nu)))
         k["i"] += 1
     return _baseline_record(_timed_legs(run_once, budget_s),
-                            "HalfCheetah iLQR H=50 solves from the bench's initial states (oracle: numpy f64)")
+                            "HalfCheetah iLQR H=50 solves from the bench's initial states%s (oracle: numpy f64)"
+                            % (", controls clipped to +-0.25" if bounded else ""))
 
 
 def cpu_baseline_c5(system, spec, cands, budget_s, n_ctl=16):
@@ -331,7 +331,8 @@ def timed_loop(R, step, steps, warmup, preheat_s, before_timed=None):
 # ----------------------------------------------------------------------------------------------
 # c4 / c5
 # ----------------------------------------------------------------------------------------------
-def secondary_workload(args, R):
+def secondary_workload(args, R, emit=True):
+    """c4 / c5 as the workload of the line (emit) or as a sub-record of the default line (returned)."""
     from autompc_amd import _lib
     from autompc_amd.synthetic import make_workload
     system, task, model, spec = make_workload("c3", precision=args.precision, device=R.local_rank)
@@ -345,100 +346,104 @@ def secondary_workload(args, R):
     roof = None
 
     if args.workload == "c4":
-        import threading
-        G = max(1, min(args.groups, B))
+        # Headline c4 = the CONVERGING problem set (controls clipped to +-0.25: the reference's bounded
+        # golden problem, tests/golden/ilqr_hc6_relu_bounded.npz; clipping in the forward pass,
+        # ilqr.py:62-64, 203-204): P independent problems streamed through B slots with continuous
+        # batching (ampc_ilqr_solve_queue) -- a slot whose problem has converged takes the next one at
+        # the following iteration boundary, on the device.  One step = P complete solves.
         Q, Rm, F = task.get_cost().get_cost_matrices()
+        P = 4 * B
         rng = np.random.default_rng(rank)
-        x0 = rng.uniform(-0.1, 0.1, size=(B, nx))
-        ug = np.zeros((B, 50, nu))
-        bounds_g = [(g * B // G, (g + 1) * B // G) for g in range(G)]
-        handles, plans = [], []
-        for g, (lo, hi) in enumerate(bounds_g):
-            # group 0 on torch's current stream (the one the bench synchronises), the others on
-            # streams of their own
-            hg = _lib.Handle(R.local_rank, args.precision,
-                             stream=R.torch.cuda.current_stream().cuda_stream if g == 0 else None)
-            model.stage_into(hg)
-            hg.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
-            handles.append(hg)
-            plans.append(_lib.IlqrPlan(hg, hi - lo, 50, system.dt))
-        h, plan = handles[0], plans[0]
-        iters, conv = [], []
+        x0 = rng.uniform(-0.1, 0.1, size=(max(P, 4096), nx))
+        stream = R.torch.cuda.current_stream().cuda_stream
 
-        rows = []
-
-        def solve_group(g, res):
-            lo, hi = bounds_g[g]
-            res[g] = plans[g].solve(x0[lo:hi], ug[lo:hi], max_iter=50)   # (ctypes releases the GIL)
+        def make(bounded):
+            hh = _lib.Handle(R.local_rank, args.precision, stream=stream)
+            model.stage_into(hh)
+            hh.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
+            if bounded:
+                hh.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
+            return hh, _lib.IlqrPlan(hh, B, 50, system.dt, clip_to_bounds=bounded)
+        h, plan = make(True)
+        last = {}
 
         def step(i):
-            res = [None] * G
-            if G == 1:
-                solve_group(0, res)
-            else:
-                th = [threading.Thread(target=solve_group, args=(g, res)) for g in range(G)]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-            if i >= warm:
-                iters.append(float(np.mean(np.concatenate([r["iters"] for r in res]))))
-                conv.append(float(np.mean(np.concatenate([r["converged"] for r in res]))))
-                rows.append(sum(pl.stats()["candidate_rows"] for pl in plans) / float(B))
-        label = ("c4: HalfCheetah MLP 2x256, iLQR horizon 50, %d independent problems per step per GPU"
-                 "%s" % (B, "" if G == 1 else " in %d groups on %d streams" % (G, G)))
-        unit_per_step = B
+            last["out"] = plan.solve_queue(x0[:P], max_iter=50, gains=False, trajectories=False)
+            if i >= 0:
+                last.setdefault("rows", []).append(plan.stats()["candidate_rows"])
+                last.setdefault("launched", []).append(plan.stats()["iterations"])
+        label = ("c4: HalfCheetah MLP 2x256, iLQR horizon 50, controls clipped to +-0.25 (converging set): %d "
+                 "independent problems per step per GPU streamed through %d slots (continuous batching)" % (P, B))
+        unit_per_step = P
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
         elapsed, n_pre = timed_loop(R, step, steps, warm, min(args.preheat, 0.3),
                                     before_timed=lambda: plan.set_timing(True))
         kt = plan.timing()
-        # the same problems with the controls bounded to +-0.25 (the reference's bounded golden problem,
-        # tests/golden/ilqr_hc6_relu_bounded.npz: clipping in the forward pass, ilqr.py:62-64, 203-204):
-        # these solves CONVERGE well inside the 50-iteration cap, the unbounded ones above never do
-        variant = None
+        plan.set_timing(False)
+        ob = last["out"]
+        sub = {}
         if not args.no_extras:
-            hb = _lib.Handle(R.local_rank, args.precision, stream=R.torch.cuda.current_stream().cuda_stream)
-            model.stage_into(hb)
-            hb.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
-            hb.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
-            pb = _lib.IlqrPlan(hb, B, 50, system.dt, clip_to_bounds=True)
-            pb.solve(x0, ug, max_iter=50)
-            R.sync_all()
-            tb = time.perf_counter()
-            ob = pb.solve(x0, ug, max_iter=50)
-            R.sync_all()
-            eb = R.max_over_ranks(time.perf_counter() - tb)
-            variant = {"workload": "the same %d problems with controls clipped to +-0.25 (bounded golden problem)" % B,
-                       "value": world * B / eb, "unit": "solves/s", "ms_per_step": 1e3 * eb,
-                       "mean_iterations_per_solve": float(ob["iters"].mean()),
-                       "converged_fraction": float(ob["converged"].mean()),
-                       "max_iterations": int(ob["iters"].max())}
-            pb.close()
-            hb.close()
+            def once(fn):
+                fn()
+                R.sync_all()
+                t0 = time.perf_counter()
+                o = fn()
+                R.sync_all()
+                return o, R.max_over_ranks(time.perf_counter() - t0)
+            # a long stream: the drain of the last (non-converging, 50-iteration) problems amortised
+            o, e = once(lambda: plan.solve_queue(x0[:4096], max_iter=50, gains=False, trajectories=False))
+            sub["stream_4096"] = {"workload": "the same set, 4096 problems through %d slots" % B,
+                                  "value": world * 4096 / e, "unit": "solves/s", "ms": 1e3 * e,
+                                  "converged_fraction": float(o["converged"].mean()),
+                                  "mean_iterations_per_solve": float(o["iters"].mean())}
+            # the same P problems as lock-step batches of B (ampc_ilqr_solve: a batch lasts as long as
+            # its slowest problem) -- what round 3 measured
+
+            def batches():
+                res = [plan.solve(x0[lo:lo + B], np.zeros((B, 50, nu)), max_iter=50) for lo in range(0, P, B)]
+                return {k: np.concatenate([r[k] for r in res]) for k in ("converged", "iters")}
+            o, e = once(batches)
+            sub["lockstep_batches"] = {"workload": "the same %d problems as %d lock-step batches of %d" % (P, P // B, B),
+                                       "value": world * P / e, "unit": "solves/s", "ms": 1e3 * e,
+                                       "converged_fraction": float(o["converged"].mean())}
+            # the unbounded problems of rounds 1-3: none converges within the reference's 50 iterations
+            hu, pu = make(False)
+            o, e = once(lambda: pu.solve(x0[:B], np.zeros((B, 50, nu)), max_iter=50))
+            sub["capped_variant"] = {"workload": "%d UNBOUNDED problems (never converge: 50-iteration capped solves)" % B,
+                                     "value": world * B / e, "unit": "solves/s", "ms": 1e3 * e,
+                                     "converged_fraction": float(o["converged"].mean()),
+                                     "mean_iterations_per_solve": float(o["iters"].mean())}
+            pu.close()
+            hu.close()
         if rank == 0:
-            # work of one solve of one problem: per iteration the Jacobian chain over H rows
-            # and the forward pass of the accepted trajectory; the line search as EXECUTED -- candidate
-            # rows rolled out (four per pass; the reference rolls out all ten step sizes every
-            # iteration, ilqr.py:196-205, the same arithmetic per row)
-            it = float(np.mean(iters))
-            ls_rows = float(np.mean(rows))
+            # work of one solve: per iteration the Jacobian chain over H rows and the forward
+            # pass of the accepted trajectory; the line search as EXECUTED -- candidate rows rolled out
+            # (four per pass; the reference rolls out all ten step sizes every iteration,
+            # ilqr.py:196-205, the same arithmetic per row); + the rollout of the guess
+            it = float(ob["iters"].mean())
+            ls_rows = float(np.mean(last["rows"])) / P
             hid = sum(a * b for a, b in zip(spec["hidden"], spec["hidden"][1:]))
             jac = 50 * 2 * nx * (hid + spec["hidden"][0] * (nx + nu))
             row = 50 * 2 * mlp_macs
-            per_solve = it * (jac + row) + ls_rows * row
-            ls = ls_rows / it * row                      # line-search flops of one problem-iteration
+            per_solve = (it + 1) * (jac + row) + ls_rows * row
+            extra["problems_per_step"] = P
+            extra["slots"] = B
             extra["mean_iterations_per_solve"] = it
-            extra["converged_fraction"] = float(np.mean(conv))
+            extra["converged_fraction"] = float(ob["converged"].mean())
             extra["iteration_cap"] = 50
-            if variant is not None:
-                extra["converging_variant"] = variant
+            extra["iterations_launched_per_step"] = float(np.mean(last["launched"]))
+            extra["ideal_iterations_per_step"] = P * (it + 1) / B
             extra["mean_line_search_rows_per_iteration"] = ls_rows / it
-            extra["algorithmic_tflops"] = world * steps * B * per_solve / elapsed / 1e12
-            extra["reference_work_tflops"] = world * steps * B * it * (jac + 11 * row) / elapsed / 1e12
+            extra["algorithmic_tflops"] = world * steps * P * per_solve / elapsed / 1e12
+            extra["reference_work_tflops"] = world * steps * P * ((it + 1) * (jac + row) + it * 10 * row) / elapsed / 1e12
+            extra.update(sub)
             if kt and kt.get("launches"):
-                n = nx + nu
-                cand = {"jacobian": (B * jac, "mlp_jacobian_kernel"), "iter": (B * ls, "ilqr_ls4_kernel"),
-                        "riccati": (B * 50 * 2.0 * (2 * nx * nx * n + nx * n * n), "ilqr_riccati_mfma_kernel")}
+                # per launch over the B slots; the busy fraction of the slots varies (drain), so the
+                # per-launch work is averaged over the launches of the timed steps
+                n_l = max(kt["launches"], 1)
+                jac_fl = steps * P * (it + 1) * jac / n_l
+                ls_fl = steps * P * ls_rows * row / n_l
+                cand = {"jacobian": (jac_fl, "mlp_jacobian_kernel"), "iter": (ls_fl, "ilqr_ls4_kernel")}
                 dom = max(cand, key=lambda k: kt.get(k + "_ms", 0.0))
                 fl, kname = cand[dom]
                 ach = fl / (kt[dom + "_ms"] * 1e-3) / 1e12
@@ -449,8 +454,12 @@ def secondary_workload(args, R):
                         "per_iteration_kernel_ms": {k: kt.get(k + "_ms") for k in
                                                     ("riccati", "iter", "forward", "jacobian")},
                         "iterations_timed": kt["launches"], "algorithmic_flops_per_launch": fl,
-                        "note": "the kernel with the largest share of an iteration; one launch covers all "
-                                "%d problems; whole-iteration rate in algorithmic_tflops" % B}
+                        "other_kernel": {k: {"achieved": cand[k][0] / (kt[k + "_ms"] * 1e-3) / 1e12,
+                                             "frac": cand[k][0] / (kt[k + "_ms"] * 1e-3) / 1e12 / peak}
+                                         for k in cand if k != dom},
+                        "note": "the kernel with the largest share of an iteration; one launch covers the %d "
+                                "slots (work averaged over the timed launches, drain included); whole-solve "
+                                "rate in algorithmic_tflops" % B}
     else:
         from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
         task.set_num_steps(200)
@@ -504,11 +513,14 @@ def secondary_workload(args, R):
                "roofline": roof, **extra}
         if not args.no_cpu_baseline and world == 1:
             if args.workload == "c4":
-                out["cpu_baseline"] = cpu_baseline_ilqr(system, spec, x0, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline_ilqr(system, spec, x0, args.cpu_seconds, bounded=True)
             else:
                 out["cpu_baseline"] = cpu_baseline_c5(system, spec, cands, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        if emit:
+            print(json.dumps(out))
+        return out
+    return None
 
 
 def c5_sharded_record(args, R, per_gpu=64, probes=4):
@@ -574,8 +586,8 @@ def main():
     from autompc_amd.synthetic import make_workload
     batch = args.batch if args.batch > 0 else 1
 
-    def build_plan(precision, nb):
-        system, task, model, spec = make_workload(args.workload, precision=precision,
+    def build_plan(precision, nb, workload=None):
+        system, task, model, spec = make_workload(workload or args.workload, precision=precision,
                                                   device=R.local_rank, seed=0)
         stream = R.torch.cuda.current_stream().cuda_stream
         h = _lib.Handle(R.local_rank, precision, stream=stream)
@@ -588,9 +600,11 @@ def main():
         plan = _lib.MppiPlan(h, [N] * nb, [H] * nb, [1.0] * nb, [1.0] * nb)
         return h, plan, task, spec
 
-    def timed_run(precision, steps, warmup, preheat_s):
-        """pre-heat + W untimed + K timed solves, bracketed by barrier + synchronize; max over ranks."""
-        h, plan, task, spec = build_plan(precision, batch)
+    def timed_run(precision, steps, warmup, preheat_s, workload=None, windows=1):
+        """pre-heat + W untimed + K timed solves, bracketed by barrier + synchronize; max over ranks.
+        windows > 1: the timed window is repeated (same plan, noise stream running on); the first
+        window is the one returned as `elapsed`, all of them in `rates`."""
+        h, plan, task, spec = build_plan(precision, batch, workload)
         nx, nu, N, H = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"]
         rng = np.random.default_rng(1000 + rank)
         x0 = np.tile(spec.get("x0", task.get_init_obs()), (batch, 1))
@@ -612,12 +626,81 @@ def main():
                                     before_timed=lambda: plan.set_timing(True))
         kt = plan.timing()
         plan.set_timing(False)
+        rates = [world * steps * batch / elapsed]
+        for wdw in range(1, windows):
+            ew, _ = timed_loop(R, lambda i: step(i + wdw * steps), steps, 0, 0.0)
+            rates.append(world * steps * batch / ew)
         _, u, _, _ = plan.download(act_seq=False, u=True)
         if not np.all(np.isfinite(u)):
             raise RuntimeError("non-finite control returned by the solve")
         plan.close()
         h.close()
+        spec = dict(spec, window_rates=rates)
         return elapsed, kt, info, spec, n_pre
+
+    def mppi_record(workload, steps, warmup):
+        """A compact record of another MPPI configuration (sub-record of the default line)."""
+        e, k, inf, sp, _ = timed_run(args.precision, steps, warmup, 0.2, workload=workload)
+        ach = inf["flops"] / (k["rollout_ms"] * 1e-3) / 1e12
+        pk = PEAK_TFLOPS[args.precision]
+        return {"workload": "%s: %s" % (workload, sp["label"]), "value": world * steps * batch / e, "unit": "solves/s",
+                "ms_per_step": 1e3 * e / steps, "steps": steps,
+                "roofline": {"bound": "mfma", "achieved": ach, "peak": pk, "unit": "TFLOP/s", "frac": ach / pk,
+                             "traffic": None,
+                             "kernel": "mppi_rollout4_kernel" if inf["samples_per_wg"] == 4 else "mppi_rollout_kernel",
+                             "kernel_ms": k["rollout_ms"], "update_kernel_ms": k["update_ms"],
+                             "launches_timed": k["count"], "algorithmic_flops_per_launch": inf["flops"],
+                             "workgroups": inf["workgroups"], "samples_per_workgroup": inf["samples_per_wg"],
+                             "note": "latency-bound: %d workgroups of %d samples, %d dependent steps"
+                                     % (inf["workgroups"], inf["samples_per_wg"], sp["horizon"])}}
+
+    def dropin_record():
+        """What a user's simulate() loop sees: Controller.run() itself, host arrays in, host control out
+        (one library call + one synchronisation per control step), in the parity-graded default noise
+        mode (numpy's legacy stream, generated on the device) and with device Philox noise; and
+        IterativeLQR.run() (a full re-solve from a zero guess, ilqr.py:267-295) on H = 50 problems."""
+        from autompc_amd import MPPI, IterativeLQR, Task, zeros
+        rec = {}
+        for name in ("c3", "c2"):
+            system, task, model, sp = make_workload(name, precision="f64", device=R.local_rank, seed=0)
+            for noise in ("numpy", "device"):
+                np.random.seed(0)
+                ctl = MPPI(system, task, model, horizon=sp["horizon"], num_path=sp["num_path"], sigma=1.0,
+                           lmda=1.0, noise=noise)
+                obs = task.get_init_obs()
+                one = zeros(system, 1)
+                one.obs[0, :] = obs
+                cs = ctl.traj_to_state(one)
+                for _ in range(30):
+                    u, cs = ctl.run(cs, obs)
+                n = 400 if name == "c3" else 1500
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    u, cs = ctl.run(cs, obs)
+                dt = time.perf_counter() - t0
+                rec["%s_mppi_run_noise_%s" % (name, noise)] = {"calls_per_s": n / dt, "ms_per_call": 1e3 * dt / n,
+                                                               "calls": n}
+        system, task, model, sp = make_workload("c3", precision="f64", device=R.local_rank, seed=0)
+        nu_ = sp["nu"]
+        for tag, bnd in (("free", None), ("bounded_0.25", 0.25)):
+            t2 = Task(system)
+            t2.set_cost(task.get_cost())
+            if bnd is not None:
+                t2.set_ctrl_bounds(np.full(nu_, -bnd), np.full(nu_, bnd))
+            ctl = IterativeLQR(system, t2, model, 50)
+            obs = task.get_init_obs()
+            cs = np.concatenate([obs, np.zeros(nu_)])
+            ctl.run(cs, obs)
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctl.run(cs, obs)
+            dt = time.perf_counter() - t0
+            rec["c4_ilqr_run_%s" % tag] = {"ms_per_call": 1e3 * dt / reps, "iterations": int(ctl.last_iters),
+                                           "calls": reps}
+        rec["note"] = ("Controller.run(): host arrays in, host control out; noise 'numpy' = the reference's own "
+                       "draw (bit-identical stream, generated on the device), the mode parity is graded in")
+        return rec
 
     def f32_vs_f64_parity():
         """One solve of the same problem, same numpy-drawn noise, in both precisions: the max
@@ -638,7 +721,9 @@ def main():
         return {"cost_rel_err": rel(res["f32"][1], res["f64"][1]),
                 "act_sequence_rel_err": rel(res["f32"][0], res["f64"][0]), "tolerance": 1e-4}
 
-    elapsed, kt, info, spec, n_pre = timed_run(args.precision, args.steps, args.warmup, args.preheat)
+    default_line = world == 1 and args.workload == "c3" and args.precision == "f64" and not args.no_extras
+    elapsed, kt, info, spec, n_pre = timed_run(args.precision, args.steps, args.warmup, args.preheat,
+                                               windows=max(1, args.repeats) if default_line else 1)
     nx, nu, N, H, B = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"], batch
     sharded = None
     if world > 1 and args.workload == "c3" and not args.no_extras:
@@ -677,6 +762,11 @@ def main():
                          "algorithmic_bytes_per_launch": info["bytes"],
                          "workgroups": info["workgroups"], "samples_per_workgroup": info["samples_per_wg"]},
         }
+        if len(spec["window_rates"]) > 1:
+            wr = np.array(spec["window_rates"])
+            out["repeat_windows"] = {"windows": len(wr), "steps_each": args.steps, "unit": "solves/s",
+                                     "median": float(np.median(wr)), "min": float(wr.min()), "max": float(wr.max()),
+                                     "note": "value = the first window; the same window repeated back to back"}
         if sharded is not None:
             out["c5_sharded"] = sharded
         if world == 1 and args.precision == "f64" and not args.no_extras:
@@ -689,6 +779,19 @@ def main():
                                     "kernel_ms": k32["rollout_ms"], "achieved_tflops": a32,
                                     "frac_of_f32_mfma_peak": a32 / PEAK_TFLOPS["f32"],
                                     "vs_f64_solve": f32_vs_f64_parity()}
+        if default_line:
+            # the other BASELINE configurations and the user-visible call rates, measured inside the
+            # same driver-timed process; full records: --workload c2 / c4 / c5
+            sub = argparse.Namespace(**vars(args))
+            sub.no_cpu_baseline, sub.no_extras, sub.batch = True, False, 0
+            recs = {"c2": mppi_record("c2", 400, 40)}
+            for wl, st in (("c4", 3), ("c5", 2)):
+                sub.workload, sub.steps, sub.warmup, sub.preheat = wl, st, 1, 0.0
+                r = secondary_workload(sub, R, emit=False)
+                recs[wl] = {k: v for k, v in r.items()
+                            if k not in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "preheat_steps")}
+            recs["dropin"] = dropin_record()
+            out["sub_records"] = recs
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_mppi(args.workload, spec, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session for the record: parity tests, smoke, every bench line, rocprofv3 summaries.
-# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r03
+# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -17,8 +17,7 @@ b c3_f64_batch8 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline
 b arx_f64 --workload arx --cpu-seconds 10
 b c1_sindy_f64 --workload c1 --cpu-seconds 10
 b c4_ilqr_f64 --workload c4 --steps 3 --warmup 1
-b c4_ilqr_f64_b1024 --workload c4 --batch 1024 --steps 2 --warmup 1 --no-cpu-baseline
-b c4_ilqr_f64_b1024_groups4 --workload c4 --batch 1024 --groups 4 --steps 2 --warmup 1 --no-cpu-baseline
+b c4_ilqr_f64_b512 --workload c4 --batch 512 --steps 2 --warmup 1 --no-cpu-baseline
 b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 # launcher plumbing: `bench.py --gpus 2` starts its own two ranks; both mapped onto this box's one
 # GPU (gloo for the barriers / all-gather; RCCL refuses two ranks on one device).  Not a performance number.
@@ -27,6 +26,9 @@ AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
 timeout 600 python tools/jit_rate.py > $OUT/jit_rate.log 2>&1
+timeout 300 python tools/c4_queue_rate.py 1024 256 > $OUT/c4_queue_rate.log 2>&1
+timeout 300 python tools/c4_queue_rate.py 8192 256 512 >> $OUT/c4_queue_rate.log 2>&1
+timeout 300 python tools/c4_queue_groups.py 4096 512 1 2 >> $OUT/c4_queue_rate.log 2>&1
 timeout 900 python tools/fuzz_gpu.py 400 31 > $OUT/fuzz_gpu.log 2>&1
 timeout 900 python tools/fuzz_gpu.py 400 32 >> $OUT/fuzz_gpu.log 2>&1
 timeout 120 python tools/validate_glibc_log.py > $OUT/glibc_log.log 2>&1
