@@ -63,6 +63,7 @@ SIGNATURES = {
                                         POINTER(c_uint32), _ip, _ip, _dp]),
     "ampc_mppi_plan_set_geometry": (c_int, [c_void_p, c_int, c_int]),
     "ampc_mppi_plan_set_step_offset": (c_int, [c_void_p, c_uint64]),
+    "ampc_mppi_plan_set_state_lift": (c_int, [c_void_p, c_int, _ip, _dp]),
     "ampc_mppi_solve": (c_int, [c_void_p]),
     "ampc_mppi_download": (c_int, [c_void_p, _dp, _dp, _dp, _dp]),
     "ampc_mppi_set_x0_dev": (c_int, [c_void_p, c_void_p]),
@@ -503,10 +504,25 @@ class MppiPlan:
     def set_x0_dev(self, ptr):
         check(self.lib.ampc_mppi_set_x0_dev(self._p, c_void_p(ptr)))
 
+    def set_state_lift(self, kinds, params):
+        """The controller model rebuilds its state from every observation (Koopman): x0 = the basis
+        functions (kind 0 identity, 1 power, 2 sin, 3 cos; parameter) applied to the observation.  The
+        closed loop then carries the simulation model's state: init_obs and the recorded rows have the
+        SURROGATE's state width."""
+        kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        params = as_f64(params)
+        check(self.lib.ampc_mppi_plan_set_state_lift(self._p, len(kinds), iptr(kinds), dptr(params)))
+        self._lift = len(kinds) > 0
+
+    def _loop_width(self, surrogate):
+        if getattr(self, "_lift", False):
+            return (surrogate if surrogate is not None else self.handle).nx
+        return self.handle.nx
+
     def closed_loop(self, init_obs, n_steps, seed=0, eps_all=None, surrogate=None):
         """simulate() for every problem of the plan, device resident.  Returns
         (traj_obs [B, n_steps+1, nx], traj_ctrls [B, n_steps+1, nu])."""
-        nx, nu = self.handle.nx, self.handle.nu
+        nx, nu = self._loop_width(surrogate), self.handle.nu
         init_obs = self._flat(init_obs, self.B * nx, "init_obs")
         eps_all = self._flat(eps_all, n_steps * self.sum_nhnu, "eps_all")
         obs = np.empty((self.B, n_steps + 1, nx))
@@ -520,7 +536,7 @@ class MppiPlan:
                            return_trajectories=False):
         """closed_loop + cost(traj) on the device (eval_cfg's simulate + score,
         pipeline_tuner.py:222-233); only the B scores come back unless return_trajectories."""
-        nx, nu = self.handle.nx, self.handle.nu
+        nx, nu = self._loop_width(surrogate), self.handle.nu
         init_obs = self._flat(init_obs, self.B * nx, "init_obs")
         eps_all = self._flat(eps_all, n_steps * self.sum_nhnu, "eps_all")
         kinds = np.ascontiguousarray(terms[0], dtype=np.int32)

@@ -116,7 +116,7 @@ static void handle_release(ampc_handle* h) {
 static void handle_free(ampc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->model_buf, &h->sindy_int, &h->sindy_flt, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
+  DevBuf* bufs[] = {&h->model_buf, &h->lin_buf, &h->sindy_int, &h->sindy_flt, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
                     &h->s_ctrls,   &h->s_out,      &h->s_dz,     &h->s_jx,       &h->s_ju};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -356,7 +356,40 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
   if (rc) return rc;
   h->has_mlp = true;
   h->has_sindy = false;
+  h->has_lin = false;
   jit_kick(h);            // (needs obs_dim: if the cost is set later, ampc_set_quad_costs starts it)
+  return 0;
+}
+
+// Wide linear model (65 .. 256 states; AMPC_LINEAR_WIDE = 1: any size): [A | B] packed in MFMA
+// fragment order for linear_kernels.hpp, plus a plain copy.
+constexpr int kLinMaxNx = 256;
+static int set_linear_wide(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
+  HIP_OK(hipSetDevice(h->device));
+  const int k = nx + nu, nxp = round_up(nx, 16), kp = round_up(k, 4), ntile = nxp / 16, ksn = kp / 4;
+  std::vector<double> buf((size_t)ntile * ksn * 64 + (size_t)nx * k, 0.0);
+  auto Mat = [&](int row, int col) -> double {
+    if (row >= nx || col >= k) return 0.0;
+    return col < nx ? A[(size_t)row * nx + col] : B[(size_t)row * nu + (col - nx)];
+  };
+  for (int nt = 0; nt < ntile; ++nt)
+    for (int ks = 0; ks < ksn; ++ks)
+      for (int l = 0; l < 64; ++l)
+        buf[((size_t)nt * ksn + ks) * 64 + l] = Mat(16 * nt + (l & 15), 4 * ks + (l >> 4));
+  double* plain = buf.data() + (size_t)ntile * ksn * 64;
+  for (int r = 0; r < nx; ++r)
+    for (int c = 0; c < k; ++c) plain[(size_t)r * k + c] = Mat(r, c);
+  HIP_OK(h->lin_buf.reserve(buf.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (nx != h->nx || nu != h->nu) { h->n_costs = 0; h->obs_dim = 0; h->has_bounds = false; }   // other dimensions
+  h->nx = nx; h->nu = nu; h->l_nxp = nxp; h->l_kp = kp;
+  h->n_hidden = 0; h->act = 4; h->hpad = 0;
+  std::memset(&h->md, 0, sizeof(h->md));
+  std::memset(&h->mf, 0, sizeof(h->mf));
+  h->md.nx = h->mf.nx = nx; h->md.nu = h->mf.nu = nu; h->md.kin = h->mf.kin = nx + nu;
+  h->has_lin = true; h->has_mlp = false; h->has_sindy = false;
   return 0;
 }
 
@@ -366,8 +399,9 @@ extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const 
 // linear models too.  Multiplying by the identity output layer is exact; A - I rounds once.
 extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
   REQUIRE(h && A && B, "ampc_set_linear: NULL argument");
-  REQUIRE(nx >= 1 && nx <= 64, "ampc_set_linear: state dim must be in 1..64");
+  REQUIRE(nx >= 1 && nx <= kLinMaxNx, "ampc_set_linear: state dim must be in 1..256");
   REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_linear: ctrl dim must be in 1..16");
+  if (nx > 64 || env_int("AMPC_LINEAR_WIDE", 0) != 0) return set_linear_wide(h, nx, nu, A, B);
   const int kin = nx + nu;
   std::vector<double> w0((size_t)nx * kin), w1((size_t)nx * nx, 0.0), b0(nx, 0.0);
   for (int i = 0; i < nx; ++i) {
@@ -461,10 +495,45 @@ extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const doub
   return 0;
 }
 
+// Model.pred_batch / pred_diff_batch of a wide linear model (linear_kernels.hpp)
+template <typename T>
+static int lin_pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out, double* jx,
+                         double* ju, int n) {
+  const int nx = h->nx, nu = h->nu;
+  const LinDev<T> m = lin_of<T>(h);
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const size_t lb = (size_t)16 * lin_xs(m.kp, (int)sizeof(T)) * sizeof(T);
+  HIP_OK(allow_lds(linear_forward_kernel<T>, lb));
+  hipLaunchKernelGGL(linear_forward_kernel<T>, dim3((n + 15) / 16), dim3(64 * kLinW), lb, h->stream, m,
+                     (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
+  HIP_OK(hipGetLastError());
+  if (jx) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    hipLaunchKernelGGL(linear_jacobian_kernel<T>, dim3(1024), dim3(256), 0, h->stream, m, (T*)h->s_jx.p,
+                       (T*)h->s_ju.p, n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
 extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
                                    double* out, int n) {
   REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
-  if (h->has_sindy) return ampc_sindy_pred_batch(h, states, ctrls, out, n);   // wide linear models
+  if (h->has_sindy) return ampc_sindy_pred_batch(h, states, ctrls, out, n);
+  if (h->has_lin) {
+    if (n <= 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    return h->precision == AMPC_F64 ? lin_pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                    : lin_pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+  }
   REQUIRE(h->has_mlp, "ampc_mlp_pred_batch: no model set");
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(h->device));
@@ -476,6 +545,12 @@ extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, co
                                         double* out, double* jx, double* ju, int n) {
   REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
   if (h->has_sindy) return ampc_sindy_pred_diff_batch(h, states, ctrls, out, jx, ju, n);
+  if (h->has_lin) {
+    if (n <= 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    return h->precision == AMPC_F64 ? lin_pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                    : lin_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
+  }
   REQUIRE(h->has_mlp, "ampc_mlp_pred_diff_batch: no model set");
   if (n <= 0) return 0;
   HIP_OK(hipSetDevice(h->device));
@@ -492,6 +567,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   // a rollout's time is its per-step latency, and a four-row step costs a quarter of the matrix
   // pipe.  AMPC_QUAD: -1 automatic, 0 never, 1 whenever the shape is supported.
   p->quad = false;
+  p->eps_inline = false;
   if (sizeof(T) == 8 && h->has_mlp && q4_supported(m.hpad, m.n_hidden, m.nxp, m.k1p)) {
     long long tiles16 = 0;
     for (int b = 0; b < p->B; ++b) tiles16 += (p->N[b] + 15) / 16;
@@ -508,6 +584,9 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     p->mt = 0;
   } else if (h->has_sindy) {
     p->mt = 4;
+  } else if (h->has_lin) {
+    REQUIRE(p->forced_mt <= 1, "ampc_mppi_plan_set_geometry: wide linear models roll out in 16-row tiles");
+    p->mt = 1;
   } else {
     p->mt = choose_mt<T>(h, m, p->sum_n, extra, p->forced_mt);
     // a caller that fixed the tile height relies on it (summation orders, hence bit-identical
@@ -529,6 +608,10 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   } else if (h->has_sindy) {
     std::memset(&p->L, 0, sizeof(p->L));
     p->L.extra = (2 * nx + nu + h->s_ntab) * 64;   // per-thread columns: [x|u], next x, value table
+  } else if (h->has_lin) {
+    std::memset(&p->L, 0, sizeof(p->L));
+    p->L.xu_stride = lin_xs(h->l_kp, (int)sizeof(T));
+    p->L.extra = lin_lds_base(h->l_kp, (int)sizeof(T));         // [x | u] twice (ping-pong)
   } else {
     p->L = tile_lds_for<T>(h, m, M, extra);
   }
@@ -560,7 +643,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     int sid = static_shape_of<T>(h, m);
     if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;
     p->static_shape = sid;
-  } else if (!h->has_sindy && !p->quad && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
+  } else if (!h->has_sindy && !h->has_lin && !p->quad && p->mt <= 2 && env_int("AMPC_STATIC", 1) != 0) {
     int sid = static_shape_of<T>(h, m);
     if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;      // run-time compiled shape
     const int lv = sid >= 0 ? lds_variant_of<T>(m, p->L, M, h->nw) : -1;
@@ -662,7 +745,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
-  DevBuf* bufs[] = {&p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
+  DevBuf* bufs[] = {&p->lift_prog, &p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
@@ -687,7 +770,10 @@ static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* a
   ampc_handle* h = p->h;
   if (x0) HIP_OK(upload_converted<T>(p->x0.p, x0, (size_t)p->B * h->nx, h->stream));
   if (act_seq) HIP_OK(upload_converted<T>(p->act[p->cur].p, act_seq, (size_t)p->sum_hnu, h->stream));
-  if (eps) HIP_OK(upload_converted<T>(p->eps.p, eps, (size_t)p->sum_nhnu, h->stream));
+  if (eps) {
+    HIP_OK(upload_converted<T>(p->eps.p, eps, (size_t)p->sum_nhnu, h->stream));
+    p->eps_inline = false;
+  }
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -703,6 +789,12 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
   const int nu = h->nu;
+  // The four-row rollout (small problems: a solve is a few tens of microseconds, a launch is five)
+  // forms this noise in its own prologue -- the same values, element by element -- so nothing is
+  // launched here; the buffer keeps whatever it held (AMPC_INLINE_NOISE = 0: always generate it).
+  p->eps_inline = p->quad && env_int("AMPC_INLINE_NOISE", 1) != 0;
+  p->eps_seed = seed; p->eps_stream = stream;
+  if (p->eps_inline) return 0;
   long long max_pairs = 0;
   for (int b = 0; b < p->B; ++b) {
     const long long pairs = ((long long)p->N[b] * p->H[b] * nu + 1) / 2;
@@ -901,6 +993,7 @@ static int legacy_blocks_for(int start_pos, long long n_att) {
 template <typename T>
 static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
                           LegacyDraw* d) {
+  p->eps_inline = false;          // (this draw fills the plan's noise buffer)
   ampc_handle* h = p->h;
   const long long n = p->sum_nhnu;
   const int shift = has_gauss ? 1 : 0;
@@ -1232,8 +1325,8 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
   if (samples_per_wg) *samples_per_wg = p->tile_m;
   // Algorithmic work: per sample-step 2*sum(in*out) MLP flops plus the quadratic
   // stage cost; bytes = noise in + clipped noise out + costs + weights once.
-  double macs = h->has_sindy ? (double)h->s_nfeat * h->nx : 0.0;
-  for (int l = 0; !h->has_sindy && l <= h->n_hidden; ++l) {
+  double macs = h->has_sindy ? (double)h->s_nfeat * h->nx : (h->has_lin ? (double)h->nx * (h->nx + h->nu) : 0.0);
+  for (int l = 0; h->has_mlp && l <= h->n_hidden; ++l) {
     const int in = l == 0 ? h->nx + h->nu : h->hidden[l - 1];
     const int out = l == h->n_hidden ? h->nx : h->hidden[l];
     macs += (double)in * out;
@@ -1347,6 +1440,8 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   REQUIRE(h->nx + h->nu + 1 <= 64,
           "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
+  REQUIRE(!h->has_lin, "ampc_ilqr_plan_create: iLQR plans take model states up to 64 (the Riccati workspace lives "
+                       "in LDS); wide linear models (65..256 states) run MPPI and the closed loop");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
   HIP_OK(hipSetDevice(h->device));
@@ -1756,18 +1851,32 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
                             double* scores = nullptr) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
-  ScopedBuf d_obs, d_ctl, d_next;
-  HIP_OK(d_obs.reserve((size_t)B * T1 * nx * sizeof(T)));
+  // With a state lift (Koopman controller model) the simulation model's state is carried separately:
+  // simulate() advances simstate = sim_model.pred(simstate, u) and hands the controller only the
+  // observation simstate[:obs_dim], from which update_state re-lifts (simulation.py:52-58,
+  // koopman.py:166-168).  snx = width of the carried state = width of the recorded rows.
+  const bool lift = p->lift_n > 0;
+  const int snx = lift ? sur->nx : nx;
+  ScopedBuf d_obs, d_ctl, d_next, d_sim;
+  HIP_OK(d_obs.reserve((size_t)B * T1 * snx * sizeof(T)));
   HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
-  HIP_OK(d_next.reserve((size_t)B * nx * sizeof(T)));
+  HIP_OK(d_next.reserve((size_t)B * snx * sizeof(T)));
+  if (lift) HIP_OK(d_sim.reserve((size_t)B * snx * sizeof(T)));
+  void* state = lift ? d_sim.p : p->x0.p;             // what the surrogate advances
   HIP_OK(hipMemsetAsync(d_ctl.p, 0, (size_t)B * T1 * nu * sizeof(T), h->stream));
-  HIP_OK(upload_converted<T>(p->x0.p, init_obs, (size_t)B * nx, h->stream));
+  HIP_OK(upload_converted<T>(state, init_obs, (size_t)B * snx, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   // traj_obs[:, 0, :] = init_obs
-  HIP_OK(hipMemcpy2DAsync(d_obs.p, (size_t)T1 * nx * sizeof(T), p->x0.p, (size_t)nx * sizeof(T),
-                          (size_t)nx * sizeof(T), B, hipMemcpyDeviceToDevice, h->stream));
+  HIP_OK(hipMemcpy2DAsync(d_obs.p, (size_t)T1 * snx * sizeof(T), state, (size_t)snx * sizeof(T),
+                          (size_t)snx * sizeof(T), B, hipMemcpyDeviceToDevice, h->stream));
   int rc = 0;
   for (int s = 0; s < n_steps && rc == 0; ++s) {
+    if (lift) {
+      const int n = B * nx;
+      hipLaunchKernelGGL(state_lift_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const T*)d_sim.p,
+                         (T*)p->x0.p, (const T*)p->lift_prog.p, B, snx, h->obs_dim, p->lift_n);
+      HIP_OK(hipGetLastError());
+    }
     if (eps_all) {
       rc = mppi_upload_impl<T>(p, nullptr, nullptr, eps_all + (size_t)s * p->sum_nhnu);
     } else {
@@ -1777,23 +1886,57 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
     rc = mppi_solve_impl<T>(p);
     if (rc) break;
     // x_next = surrogate.pred(x, u)
-    rc = surrogate_step<T>(h, sur, p->x0.p, p->u_out.p, d_next.p, B);
+    rc = surrogate_step<T>(h, sur, state, p->u_out.p, d_next.p, B);
     if (rc) break;
-    const int n = B * (nx > nu ? nx : nu);
+    const int n = B * (snx > nu ? snx : nu);
     hipLaunchKernelGGL(closed_loop_record_kernel<T>, dim3((n + 255) / 256), dim3(256), 0, h->stream,
-                       (const T*)d_next.p, (const T*)p->u_out.p, (T*)p->x0.p, (T*)d_obs.p,
-                       (T*)d_ctl.p, B, nx, nu, T1, s);
+                       (const T*)d_next.p, (const T*)p->u_out.p, (T*)state, (T*)d_obs.p,
+                       (T*)d_ctl.p, B, snx, nu, T1, s);
     HIP_OK(hipGetLastError());
   }
   if (rc == 0) {
-    if (traj_obs) rc = download_converted<T>(traj_obs, d_obs.p, (size_t)B * T1 * nx, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
+    if (traj_obs) rc = download_converted<T>(traj_obs, d_obs.p, (size_t)B * T1 * snx, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
     if (rc == 0 && traj_ctrls) rc = download_converted<T>(traj_ctrls, d_ctl.p, (size_t)B * T1 * nu, h->stream) == hipSuccess ? 0 : fail("closed loop: download failed");
   }
   if (rc == 0 && score && scores)
-    rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, nx, nu, h->obs_dim, *score, scores);
+    rc = score_device<T>(h, d_obs.p, d_ctl.p, B, T1, snx, nu, h->obs_dim, *score, scores);
   (void)hipStreamSynchronize(h->stream);
   p->step_offset = 0;      // one-shot: ampc_mppi_plan_set_step_offset names the NEXT closed loop's first step
   return rc;
+}
+
+// Which surrogate a plan's closed loop accepts: the controller model's dimensions -- or, with a state
+// lift, any model with the same controls whose state starts with the observation.
+static int closed_loop_check(const ampc_mppi_plan* p, const ampc_handle* sur, const char* who) {
+  const bool ok = sur->has_model() && sur->nu == p->h->nu &&
+                  (p->lift_n > 0 ? sur->nx >= p->h->obs_dim : sur->nx == p->h->nx);
+  if (!ok) return fail(std::string(who) + ": surrogate model must have the controller model's dimensions (with a "
+                                          "state lift: its controls, and a state that starts with the observation)");
+  if (sur->precision != p->h->precision || sur->device != p->h->device)
+    return fail(std::string(who) + ": surrogate must share the plan's device and precision");
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_set_state_lift(ampc_mppi_plan* p, int n_basis, const int* kinds, const double* params) {
+  REQUIRE(p, "ampc_mppi_plan_set_state_lift: NULL plan");
+  if (n_basis <= 0) { p->lift_n = 0; return 0; }
+  REQUIRE(kinds && params, "ampc_mppi_plan_set_state_lift: NULL argument");
+  REQUIRE(p->h->obs_dim >= 1 && n_basis * p->h->obs_dim == p->h->nx,
+          "ampc_mppi_plan_set_state_lift: n_basis * obs_dim must be the model's state dimension");
+  std::vector<double> prog(2 * (size_t)n_basis);
+  for (int k = 0; k < n_basis; ++k) {
+    REQUIRE(kinds[k] >= 0 && kinds[k] <= 3, "ampc_mppi_plan_set_state_lift: kind must be 0 identity, 1 power, 2 sin, 3 cos");
+    REQUIRE(kinds[k] != 1 || (params[k] >= 0 && params[k] <= 64 && params[k] == std::floor(params[k])),
+            "ampc_mppi_plan_set_state_lift: powers must be integers in 0..64");
+    prog[2 * k] = kinds[k]; prog[2 * k + 1] = params[k];
+  }
+  HIP_OK(hipSetDevice(p->h->device));
+  HIP_OK(p->lift_prog.reserve(prog.size() * p->h->esz()));
+  if (p->h->precision == AMPC_F64) HIP_OK(upload_converted<double>(p->lift_prog.p, prog.data(), prog.size(), p->h->stream));
+  else HIP_OK(upload_converted<float>(p->lift_prog.p, prog.data(), prog.size(), p->h->stream));
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  p->lift_n = n_basis;
+  return 0;
 }
 
 extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
@@ -1802,10 +1945,7 @@ extern "C" int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate,
   REQUIRE(p && init_obs, "ampc_mppi_closed_loop: NULL argument");
   REQUIRE(n_steps >= 1, "ampc_mppi_closed_loop: n_steps < 1");
   ampc_handle* sur = surrogate ? surrogate : p->h;
-  REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
-          "ampc_mppi_closed_loop: surrogate model must have the controller model's dimensions");
-  REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
-          "ampc_mppi_closed_loop: surrogate must share the plan's device and precision");
+  if (int rc = closed_loop_check(p, sur, "ampc_mppi_closed_loop")) return rc;
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
              ? closed_loop_impl<double>(p, sur, init_obs, n_steps, seed, eps_all, traj_obs, traj_ctrls)
@@ -1820,10 +1960,7 @@ extern "C" int ampc_mppi_closed_loop_scored(ampc_mppi_plan* p, ampc_handle* surr
   REQUIRE(p && init_obs && scores, "ampc_mppi_closed_loop_scored: NULL argument");
   REQUIRE(n_steps >= 1, "ampc_mppi_closed_loop_scored: n_steps < 1");
   ampc_handle* sur = surrogate ? surrogate : p->h;
-  REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
-          "ampc_mppi_closed_loop_scored: surrogate model must have the controller model's dimensions");
-  REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
-          "ampc_mppi_closed_loop_scored: surrogate must share the plan's device and precision");
+  if (int rc = closed_loop_check(p, sur, "ampc_mppi_closed_loop_scored")) return rc;
   ScoreSpec sp;
   sp.n_terms = n_terms; sp.kinds = kinds; sp.params = params;
   std::vector<int> offs;
@@ -1973,6 +2110,7 @@ extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const 
   h->n_hidden = 0;
   h->has_sindy = true;
   h->has_mlp = false;
+  h->has_lin = false;
   return 0;
 }
 

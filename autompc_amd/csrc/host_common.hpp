@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "mlp_kernels.hpp"
+#include "linear_kernels.hpp"
 #include "ilqr_kernels.hpp"
 #include "ilqr_ls4.hpp"
 #include "mppi_kernels.hpp"
@@ -121,7 +122,10 @@ struct ampc_handle {
   // model (host copy, double) ---------------------------------------------------------------
   bool has_mlp = false;
   bool has_sindy = false;         // SINDy feature-library dynamics instead of an MLP
-  bool has_model() const { return has_mlp || has_sindy; }
+  bool has_lin = false;           // wide linear model (65..256 states): linear_kernels.hpp
+  int l_nxp = 0, l_kp = 0;
+  DevBuf lin_buf;                 // fragments of [A | B], then the plain row-major copy
+  bool has_model() const { return has_mlp || has_sindy || has_lin; }
   int s_nfeat = 0, s_continuous = 0, s_strict = 1, s_ntrig = 0, s_npow = 0, s_ntab = 0, s_nmon = 0, s_npool = 0;
   double s_dt = 0.0;
   DevBuf sindy_int, sindy_flt;    // kind|a0|a1 (int), par|xi (T)
@@ -156,6 +160,14 @@ template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
   if (h->s_ntab == 0) return 0;
   const size_t b = sindy_prog_elems(h->nx, h->s_nfeat, h->s_ntrig, h->s_npow, h->s_nmon, h->s_npool, sizeof(T)) * sizeof(T);
   return b <= (size_t)kSindyStageBytes ? b + 2 * sizeof(T) : 0;
+}
+
+template <typename T> static LinDev<T> lin_of(const ampc_handle* h) {
+  LinDev<T> m;
+  m.nx = h->nx; m.nu = h->nu; m.nxp = h->l_nxp; m.kp = h->l_kp; m.ntile = h->l_nxp / 16; m.ksn = h->l_kp / 4;
+  m.wf = (const T*)h->lin_buf.p;
+  m.plain = m.wf + (size_t)m.ntile * m.ksn * 64;
+  return m;
 }
 
 template <typename T> static SindyDev<T> sindy_of(const ampc_handle* h) {
@@ -268,6 +280,10 @@ struct ampc_mppi_plan {
   int forced_mt = 0;    // ampc_mppi_plan_set_geometry: tile height fixed by the caller (0 = automatic)
   bool forced_quad = false;   // ... to the four-row kernel (tile_rows = 4)
   bool quad = false;    // the four-row rollout kernel runs (mppi_rollout4.hpp); mt is 0 then
+  bool eps_inline = false;    // the plan's noise is Philox(eps_seed, eps_stream), formed inside the four-row rollout
+  uint64_t eps_seed = 0, eps_stream = 0;
+  int lift_n = 0;             // ampc_mppi_plan_set_state_lift: basis functions of the controller model's lift
+  DevBuf lift_prog;           // [lift_n][2] (kind, parameter) in compute precision
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
   void* pin_x0 = nullptr;     // ampc_mppi_run: pinned staging of x0 in / controls out (compute precision)
   void* pin_u = nullptr;
@@ -332,6 +348,8 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.lds_eps = p->lds_eps;
   a.lds_red = p->lds_red;
   a.write_eps_out = (p->keep_eps_out || p->lds_eps < 0) ? 1 : 0;
+  a.eps_inline = (p->eps_inline && p->quad) ? 1 : 0;
+  a.eps_seed = p->eps_seed; a.eps_stream = p->eps_stream;
   a.hnu_stride = p->max_h * h->nu;
   a.tile_stat = (T*)p->tile_stat.p;
   a.tile_part = (T*)p->tile_part.p;

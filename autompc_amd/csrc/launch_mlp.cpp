@@ -157,6 +157,15 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
 // x_next[b] = surrogate.pred(x[b], u[b]) for B rows, all device pointers, enqueued on h's stream.
 template <typename T>
 int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u, void* x_next, int B) {
+  if (sur->has_lin) {
+    const LinDev<T> lm = lin_of<T>(sur);
+    const size_t lb = (size_t)16 * lin_xs(lm.kp, (int)sizeof(T)) * sizeof(T);
+    HIP_OK(allow_lds(linear_forward_kernel<T>, lb));
+    hipLaunchKernelGGL(linear_forward_kernel<T>, dim3((B + 15) / 16), dim3(64 * kLinW), lb, h->stream, lm,
+                       (const T*)x, (const T*)u, (T*)x_next, B);
+    HIP_OK(hipGetLastError());
+    return 0;
+  }
   if (sur->has_sindy) {
     const SindyDev<T> sd = sindy_of<T>(sur);
     const size_t lb = (size_t)(2 * sur->nx + sur->nu + sur->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(sur);

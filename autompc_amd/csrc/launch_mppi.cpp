@@ -68,7 +68,11 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
     if (sizeof(T) != 8) return fail("internal: four-row rollout in f32");      // (launched above)
   } else
 #ifndef AMPC_JIT_PLUGIN
-  if (h->has_sindy) {
+  if (h->has_lin) {               // wide linear model (linear_kernels.hpp)
+    HIP_OK(allow_lds(linear_rollout_kernel<T>, p->lds_bytes));
+    hipLaunchKernelGGL(linear_rollout_kernel<T>, dim3(p->n_tiles), dim3(64 * kLinW), p->lds_bytes, h->stream, a,
+                       lin_of<T>(h));
+  } else if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);
     const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
                       sindy_stage_bytes<T>(h);

@@ -50,6 +50,8 @@ template <typename T> struct MppiArgs {
                                 //       the softmin update is fused (tile partials + combine kernel)
   int lds_red;                  // small reduction scratch: [M] costs, [M] weights
   int write_eps_out;            // materialise the clipped noise in HBM (needed only for download)
+  int eps_inline;               // four-row rollout: 1 = the noise is Philox(eps_seed, eps_stream, noise id),
+  unsigned long long eps_seed, eps_stream;   // formed in the kernel's prologue (no generator launch, no buffer)
   int hnu_stride;               // max_h * nu: row length of tile_part
   const T* costs_par;           // [n_costs][cost_stride]
   const T* bounds;              // lo[nu] hi[nu] scale[nu]   (lo, hi already divided by scale)
@@ -474,6 +476,32 @@ __global__ void closed_loop_record_kernel(const T* __restrict__ x_next, const T*
     const int p = i / nu, c = i - p * nu;
     traj_ctrls[((size_t)p * T1 + step) * nu + c] = u[i];
   }
+}
+
+// Controller state of a lifted model from the simulated observation (ampc_mppi_plan_set_state_lift):
+// Koopman.update_state (koopman.py:166-168) rebuilds the model state from EVERY new observation,
+//   x0 = [f_0(o_0 .. o_{no-1}), f_1(o_0 ..), ...]   (basis-major, koopman.py:105-122)
+// with f_k one of  0 identity  1 o ** p (integer p)  2 sin(p o)  3 cos(p o);  prog[k] = (kind, p).
+// sim [B][snx]: the simulation model's state, whose first `no` entries are the observation.
+template <typename T>
+__global__ void state_lift_kernel(const T* __restrict__ sim, T* __restrict__ x0, const T* __restrict__ prog,
+                                  int B, int snx, int no, int n_basis) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n_basis * no) return;
+  const int b = i / (n_basis * no), e = i - b * n_basis * no, f = e / no, j = e - f * no;
+  const T o = sim[(size_t)b * snx + j];
+  const int kind = (int)prog[2 * f];
+  const T par = prog[2 * f + 1];
+  T v = o;
+  if (kind == 1) {
+    v = T(1);
+    for (int k = 0; k < (int)par; ++k) v *= o;
+  } else if (kind == 2) {
+    v = sin(par * o);
+  } else if (kind == 3) {
+    v = cos(par * o);
+  }
+  x0[(size_t)b * (n_basis * no) + e] = v;
 }
 
 }  // namespace ampc

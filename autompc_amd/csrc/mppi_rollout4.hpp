@@ -19,6 +19,7 @@
 // rollout (NT = 1: 12 + 16 (NH-1) + 8 values per lane), activations go through LDS ([4][hpad+1]).
 #pragma once
 #include "mppi_kernels.hpp"
+#include "rng_kernels.hpp"
 
 namespace ampc {
 
@@ -134,7 +135,18 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   const int n = first + m;
   const bool valid = n < N;
   const T* eps_row = args.eps + pr.eps_off + (size_t)(valid ? n : 0) * H * nu;
-  const T e_first = (valid && lane < H * nu) ? eps_row[lane] : T(0);   // (in flight during the staging below)
+  // The row's noise: read from the plan's buffer (numpy's stream, uploaded or generated there), or --
+  // device Philox noise -- formed right here: value e of the problem's draw is a pure function of
+  // (seed, stream, noise id, e) (rng_kernels.hpp), so the generator's launch and the HBM round trip of
+  // the buffer go (the stream position is the same element index the generator kernel would have used).
+  const bool inl = args.eps_inline != 0;
+  auto noise = [&](int i) -> T {
+    if (!valid) return T(0);
+    if (inl) return philox_normal_elem<T>(pr.sqrt_sigma, args.eps_seed, args.eps_stream, pr.noise_id,
+                                          (long long)n * H * nu + i);
+    return eps_row[i];
+  };
+  const T e_first = lane < H * nu ? noise(lane) : T(0);   // (in flight during the staging below)
 
   // ---- prologue: constants, shifted sequence, initial state ---------------------------------
   for (int l = 0; l < NH; ++l)
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   for (int i = lane; i < H * nu; i += 64) {
     const int t = i / nu, j = i - t * nu;
     const T a = aseq[i];
-    T A = (i < 64 ? e_first : (valid ? eps_row[i] : T(0))) + a;
+    T A = (i < 64 ? e_first : noise(i)) + a;
     A = A < blo[j] ? blo[j] : A;                 // by comparison: a NaN poisons the cost as in numpy
     A = A > bhi[j] ? bhi[j] : A;
     const T ec = A - a;

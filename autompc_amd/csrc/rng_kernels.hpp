@@ -66,6 +66,29 @@ __device__ __forceinline__ void philox_normal_pair(T* __restrict__ out, long lon
   if (e0 + 1 < count) out[e0 + 1] = (T)(rad * s) * scale;
 }
 
+// One element of the same stream (value e of a problem's draw): what philox_normal_pair stores at
+// out[e], recomputed by whoever needs it -- the four-row rollout forms its noise in its prologue
+// instead of reading a buffer another launch filled (mppi_rollout4.hpp).  Bit-identical to the pair
+// form: the same block, the same radius, the cosine (even e) or sine (odd e) branch.
+template <typename T>
+__device__ __forceinline__ T philox_normal_elem(T scale, uint64_t seed, uint64_t stream, uint32_t id, long long e) {
+  const long long pair = e >> 1;
+  Philox4 c;
+  c.v[0] = (uint32_t)pair;
+  c.v[1] = (uint32_t)(((uint64_t)pair >> 32) & 0xffu) | (uint32_t)((stream >> 32) << 8);
+  c.v[2] = (uint32_t)stream;
+  c.v[3] = id;
+  const Philox4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint64_t a = ((uint64_t)r.v[0] << 32) | r.v[1];
+  const uint64_t b = ((uint64_t)r.v[2] << 32) | r.v[3];
+  const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+  const double rad = sqrt(-2.0 * log(u1));
+  double s, cth;
+  sincospi(2.0 * u2, &s, &cth);
+  return (T)(rad * ((e & 1) ? s : cth)) * scale;
+}
+
 // The noise of every problem of a plan in one launch: grid.y * grid.z covers the problems; problem
 // b draws N_b*H_b*nu values of std sqrt(sigma_b) keyed by (seed, stream, noise_id_b).
 template <typename T>

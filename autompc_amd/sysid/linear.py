@@ -13,7 +13,9 @@ iLQR solve built on them go through the C ABI (``ampc_set_linear``), where the p
 staged as a one-hidden-layer identity-activation network so that the MFMA rollout, Jacobian and
 iLQR kernels serve it unchanged.  Model states of up to 32 entries use two 16-column output tiles;
 33..64 entries (long histories, large lifts) use the four-tile variant of the same kernels (hidden
-width -- here the padded model state -- of at most 64).
+width -- here the padded model state -- of at most 64).  65..256 entries (ARX with history 3..10 on
+HalfCheetah is 66..235 states) run on a dedicated K-tiled MFMA kernel family
+(csrc/linear_kernels.hpp): prediction, Jacobians, MPPI and the closed loop; iLQR is refused there.
 """
 import numpy as np
 
@@ -251,6 +253,14 @@ class Koopman(_LinearModel):
             iu = np.triu_indices(n, k=1)
             lifted = np.concatenate([lifted, lifted[..., iu[0]] * lifted[..., iu[1]]], axis=-1)
         return lifted
+
+    def device_lift(self):
+        """(kinds, params) of the basis for the device closed loop (ampc_mppi_plan_set_state_lift), or
+        None when the lift has product terms (not expressible there)."""
+        if self.product_terms:
+            return None
+        return (np.array([k for k, _ in self.basis], dtype=np.int32),
+                np.array([p for _, p in self.basis], dtype=np.float64))
 
     def _transform_observations(self, observations):
         return self._apply_basis(np.asarray(observations))

@@ -164,14 +164,20 @@ class CandidateEvaluator:
         # The device loop hands the surrogate's predicted STATE to the next solve.  That is
         # simulate()'s loop (controller.run -> model.update_state(state, u, obs), simulation.py:52-58)
         # exactly when the model state is the observation (MLP, SINDy), or when controller and
-        # surrogate are one model whose update_state reproduces its own prediction (ARX).
-        if model.state_dim != system.obs_dim:
+        # surrogate are one model whose update_state reproduces its own prediction (ARX).  A model
+        # that REBUILDS its state from every observation (Koopman's lift, koopman.py:166-168) hands the
+        # device its basis functions instead (device_lift): the loop then carries the surrogate's own
+        # state and re-lifts the observation before every solve (ampc_mppi_plan_set_state_lift).
+        self._lift = model.device_lift() if hasattr(model, "device_lift") else None
+        if model.state_dim != system.obs_dim and self._lift is None:
             if not (getattr(model, "device_closed_loop", False) and self.surrogate is model):
                 raise TypeError(
                     "%s keeps a model state that is not the observation and rebuilds it from every new "
-                    "observation (update_state): the device-resident closed loop cannot represent that; "
+                    "observation (update_state) in a way the device-resident closed loop cannot represent; "
                     "score such candidates with simulate() and the drop-in controller"
                     % type(model).__name__)
+        # width of the state the loop carries and records
+        self._snx = self.surrogate.state_dim if self._lift is not None else model.state_dim
         self.precision, self.device = precision, device
         b = task.get_ctrl_bounds()
         self.umin, self.umax = b[:, 0].copy(), b[:, 1].copy()
@@ -249,13 +255,15 @@ class CandidateEvaluator:
                              [float(candidates[i]["lmda"]) for i in which], cost_index=np.asarray(which))
         opened.append(plan)
         plan.set_geometry(self.tile_rows, self.horizon_cap)
+        if self._lift is not None:
+            plan.set_state_lift(*self._lift)
         plan.set_noise_ids(np.asarray(noise_ids)[which])
         plan.upload(act_seq=act_seq)
         return plan
 
     def _evaluate(self, candidates, n_steps, seed, init_obs, eps_all, act_init, return_trajectories,
                   index_offset, opened, timing=None):
-        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        nx, nu, no = self._snx, self.system.ctrl_dim, self.system.obs_dim
         B = len(candidates)
         if n_steps is not None:
             n_ctl, term_cond = int(n_steps), None
@@ -281,12 +289,13 @@ class CandidateEvaluator:
         if timing is not None:            # Python interface from the downloaded trajectories
             timing["control_steps"] = n_ctl
         init_obs = np.asarray(init_obs, dtype=np.float64)
-        if init_obs.shape == (nx,):
+        carried = self.surrogate if self._lift is not None else self.model
+        if init_obs.shape == (nx,) and nx != no:
             state0 = init_obs
-        else:                            # the model state of the one-row trajectory simulate() starts from
+        else:                            # the state of the one-row trajectory simulate() starts from (simulation.py:44-47)
             from ..trajectory import Trajectory
-            state0 = self.model.traj_to_state(Trajectory(self.system, 1, init_obs[None, :no].copy(),
-                                                         np.zeros((1, nu))))
+            state0 = carried.traj_to_state(Trajectory(self.system, 1, init_obs[None, :no].copy(),
+                                                      np.zeros((1, nu))))
         x0 = np.tile(state0, (B, 1))
         if term_cond is not None:
             return self._evaluate_segmented(candidates, h, sur, x0, n_ctl, term_cond, seed, eps_all,
@@ -325,7 +334,7 @@ class CandidateEvaluator:
         a few steps past its end and dropping it from the batch at the next segment boundary leaves
         every row it keeps bit-identical to an unsegmented run."""
         from ..trajectory import Trajectory
-        nx, nu, no = self.model.state_dim, self.system.ctrl_dim, self.system.obs_dim
+        nx, nu, no = self._snx, self.system.ctrl_dim, self.system.obs_dim
         B = len(candidates)
         Hs = np.array([int(c["horizon"]) for c in candidates])
         a_off = np.concatenate([[0], np.cumsum(Hs * nu)])

@@ -88,9 +88,12 @@ int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr_plan* ilqr
  * points below (ampc_mlp_pred_batch / _pred_diff_batch, whose Jacobians are then A and B) and
  * every solver serve it unchanged.  Costs see the first obs_dim state entries
  * (mppi.py:73-82, ilqr.py:124-128).
- * nx <= 64.  Above 32 states (long-history ARX, large Koopman lifts; e.g. ARX with history 2 on
+ * Up to 64 states: above 32 (long-history ARX, large Koopman lifts; e.g. ARX with history 2 on
  * HalfCheetah: 41) the MFMA tile carries three or four output column tiles; iLQR plans need
- * nx + nu <= 63 (the augmented Quu system lives in one wave). */
+ * nx + nu <= 63 (the augmented Quu system lives in one wave).
+ * 65 .. 256 states (ARX history 3..10 on HalfCheetah: 66..235, arx.py:27,37-45): a dedicated
+ * K-tiled MFMA kernel family (csrc/linear_kernels.hpp) serves ampc_mlp_pred_batch /
+ * _pred_diff_batch, MPPI plans and the closed loop; iLQR plans are refused there. */
 int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B);
 
 /* Model.pred_batch (model.py:109-130, mlp.py:229-236): out[n][nx]. */
@@ -273,6 +276,18 @@ int ampc_mppi_closed_loop(ampc_mppi_plan* p, ampc_handle* surrogate, const doubl
  * segment starting from the state the previous one ended in -- thereby consumes exactly the noise
  * the unsegmented episode would.  One-shot: the closed loop that consumes the offset resets it to 0. */
 int ampc_mppi_plan_set_step_offset(ampc_mppi_plan* p, uint64_t first_step);
+/* Controller models whose state is REBUILT from every observation -- autompc.sysid.Koopman:
+ * update_state(state, ctrl, obs) = lift(obs) (koopman.py:166-168), state = the basis functions applied
+ * to the observation, basis-major [f_0(o_0..o_{no-1}), f_1(..), ...] (koopman.py:105-122) -- in the
+ * device closed loop.  simulate() (utils/simulation.py:44-58) advances the SIMULATION model's state
+ * with its own prediction and hands the controller only the observation (the first obs_dim entries);
+ * with a lift set, ampc_mppi_closed_loop[_scored] does the same: init_obs is then the simulation
+ * model's initial state [B][surrogate nx], every solve starts from x0 = lift(observation), and the
+ * recorded rows traj_obs are [B][n_steps+1][surrogate nx].  The surrogate only has to share the
+ * controls and start its state with the observation.
+ *   kinds[k]: 0 identity, 1 o ** params[k] (integer power), 2 sin(params[k] o), 3 cos(params[k] o);
+ *   n_basis * obs_dim must equal the controller model's state dimension;  n_basis = 0 removes the lift. */
+int ampc_mppi_plan_set_state_lift(ampc_mppi_plan* p, int n_basis, const int* kinds, const double* params);
 
 /* ---- trajectory scoring --------------------------------------------------------------------
  * Cost.__call__ (costs/cost.py:27-41) for n_traj finished trajectories of n_rows rows each:

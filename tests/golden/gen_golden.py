@@ -951,8 +951,90 @@ def gen_linear_wide():
          ilqr_converged=conv, ilqr_states=st, ilqr_ctrls=ct, ilqr_Ks=Ks, ilqr_ks=ks)
 
 
+# ------------------------------------------- wide linear models (65..256 states) + lifted closed loop
+def gen_linear_wide2():
+    """ARX with history 10 (the top of the reference's range, arx.py:27,37-45) on a HalfCheetah-sized
+    system (18 observations, 6 controls): 10*18 + 9*6 + 1 = 235 model states -- fit, state construction,
+    prediction, Jacobians.  The same history on 18 observations / ONE control (190 states) additionally
+    runs the reference's MPPI through simulate() (the reference's MPPI needs ctrl_dim 1, mppi.py:21-24).
+    Only the dense rows of [A | B] are stored (the other rows are the history shift, arx.py:121-148)."""
+    from autompc.sysid.arx import ARX
+    for tag, nu in (("arx10_hc", 6), ("arx10_nu1", 1)):
+        system = make_system(18, nu)
+        trajs = linear_train_trajs(system, n_traj=10, T=70, seed=77 + nu)
+        model = quiet(ARX, system, history=10)
+        quiet(model.train, trajs)
+        ns = model.state_dim
+        assert ns == 10 * 18 + 9 * nu + 1
+        rng = np.random.default_rng(5 + nu)
+        states = model.traj_to_states(trajs[1])[12:36].copy()
+        ctrls = rng.uniform(-1, 1, size=(24, nu))
+        d0 = model.pred_diff(states[0], ctrls[0])
+        A, B = model.A, model.B
+        probe = rng.integers(0, ns, size=(64, 2))
+        out = dict(coeffs=np.concatenate([A[:18], B[:18]], axis=1), state_dim=ns,
+                   A_probe_idx=probe, A_probe=A[probe[:, 0], probe[:, 1]], A_sum=A.sum(), A_abs_sum=np.abs(A).sum(),
+                   B_abs_sum=np.abs(B).sum(), A_diff0_equal=bool(np.array_equal(d0[1], A)),
+                   state_prefix12=model.traj_to_state(trajs[0][:12]), state_prefix1=model.traj_to_state(trajs[0][:1]),
+                   pb_states=states, pb_ctrls=ctrls, pred_batch=model.pred_batch(states, ctrls),
+                   pred0=model.pred(states[0], ctrls[0]), diff0_pred=d0[0])
+        if nu == 1:
+            cost = make_cost(system, "dense", 1234)
+            Q, R, F = cost.get_cost_matrices()
+            task = Task(system)
+            task.set_cost(cost)
+            task.set_ctrl_bound("u0", -1.0, 1.0)
+            init = np.random.default_rng(3).uniform(-0.4, 0.4, size=18)
+            np.random.seed(31)
+            ctl = quiet(MPPI, system, task, model, horizon=8, num_path=96, sigma=0.6, lmda=0.7)
+            out["mppi_act0"] = ctl.act_sequence.copy()
+            tr = quiet(simulate, ctl, init, sim_model=model, max_steps=6, silent=True)
+            out.update(mppi_obs=tr.obs, mppi_ctrls=tr.ctrls, mppi_score=cost(tr), Q=Q, R=R, F=F,
+                       goal=cost.get_goal(), init=init, np_seed=31, N=96, H=8, sigma=0.6, lmda=0.7)
+        save("linear_" + tag, train_obs=np.stack([t.obs for t in trajs]),
+             train_ctrls=np.stack([t.ctrls for t in trajs]), **out)
+
+
+def gen_evalcfg_koopman():
+    """eval_cfg's call shape (pipeline_tuner.py:213-258) with the reference's MPPI on its Koopman model
+    (poly + trig basis): the controller re-lifts every observation (koopman.py:166-168) while
+    simulate() advances the lifted simulation state with the model's own prediction
+    (simulation.py:52-58) -- the two differ, which is what the device loop has to reproduce.  A second
+    episode simulates on an MLP surrogate (state = observation) with the same Koopman controller."""
+    from autompc.sysid.koopman import Koopman
+    system = make_system(3, 1)
+    trajs = linear_train_trajs(system)
+    model = quiet(Koopman, system, method="lstsq", poly_basis="true", poly_degree=3, trig_basis="true",
+                  trig_freq=2, product_terms="false")
+    quiet(model.train, trajs)
+    sur, p = ref_mlp(system, [48, 48], "tanh", 51, plain_norm=True)
+    cost = make_cost(system, "dense", 700)
+    Q, R, F = cost.get_cost_matrices()
+    init = np.array([0.35, -0.25, 0.2])
+    T = 12
+    task = Task(system)
+    task.set_cost(cost)
+    task.set_ctrl_bound("u0", -1.0, 1.0)
+    task.set_init_obs(init)
+    task.set_num_steps(T)
+    hyper = dict(horizon=8, num_path=64, sigma=0.6, lmda=0.7)
+    out = {}
+    for tag, sim_model, seed in (("self", model, 41), ("mlp", sur, 42)):
+        np.random.seed(seed)
+        ctl = quiet(MPPI, system, task, model, **hyper)
+        ctl.reset()
+        tr = quiet(simulate, ctl, task.get_init_obs(), task.term_cond, sim_model=sim_model,
+                   max_steps=task.get_num_steps(), silent=True)
+        assert len(tr) == T
+        out.update({tag + "_obs": tr.obs, tag + "_ctrls": tr.ctrls, tag + "_cost": cost(tr), tag + "_np_seed": seed})
+    save("loop_evalcfg_koopman", A=model.A, B=model.B, state_dim=model.state_dim, Q=Q, R=R, F=F,
+         goal=cost.get_goal(), init=init, num_steps=T, N=64, H=8, sigma=0.6, lmda=0.7,
+         bounds=np.array([-1.0, 1.0]), mlp_seed=51, hidden=np.array([48, 48]), activation="tanh",
+         wsum=weight_checksum(p), **out)
+
+
 GENERATORS = {"linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
-              "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost}
+              "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost, "linear_wide2": gen_linear_wide2, "evalcfg_koopman": gen_evalcfg_koopman}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(GENERATORS)):

@@ -140,3 +140,40 @@ def test_automatic_choice_and_refusals(monkeypatch):
     plan = _lib.MppiPlan(h32, [256], [10], [1.0], [1.0])
     assert plan.info()["samples_per_wg"] >= 16                    # (f64 only)
     plan.close(); h32.close()
+
+
+@pytest.mark.parametrize("nx,nu,hidden,N,H", [(2, 1, [64, 64], 1024, 30), (5, 3, [64, 48], 333, 11), (11, 4, [100], 50, 7)])
+def test_noise_formed_inside_the_rollout_equals_the_generator_kernel(nx, nu, hidden, N, H, monkeypatch):
+    """Device Philox noise on a four-row plan is formed in the rollout's prologue (no generator
+    launch, no buffer round trip): every value must be the one philox_normal_batch_kernel writes --
+    costs, clipped noise, updated sequence and control bit for bit, for odd element counts and ragged
+    tiles, across consecutive streams, and when a solve is repeated on the same noise."""
+    from autompc_amd import _lib
+    system, p, h, _ = _handle(nx, nu, hidden, "tanh", False)
+    rng = np.random.default_rng(N)
+    x0, act = rng.uniform(-0.2, 0.2, size=nx), rng.normal(size=H * nu)
+    outs = {}
+    for inline in ("0", "1"):
+        monkeypatch.setenv("AMPC_INLINE_NOISE", inline)
+        plan = _lib.MppiPlan(h, N, H, 0.8, 0.6)
+        plan.set_geometry(4, 0)
+        plan.set_noise_ids(np.array([7], dtype=np.uint32))
+        plan.upload(x0=x0, act_seq=act)
+        res = []
+        for stream in (0, 1, 2 ** 33 + 5):
+            plan.generate_eps(11, stream)
+            plan.solve()
+            res.append(plan.download(costs=True, eps_out=True))
+        plan.solve()                                   # again on the same noise: the stream did not move
+        res.append(plan.download(costs=True, eps_out=True))
+        u = plan.run(x0, act, philox=(11, 3))          # the drop-in classes' one-call form
+        res.append((u,))
+        assert plan.kernel_kind() in (1, 3)
+        outs[inline] = res
+        plan.close()
+    for a, b in zip(outs["0"], outs["1"]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    # and the repeated solve saw the same noise as the one before it (same clipped noise where unclipped)
+    np.testing.assert_array_equal(outs["1"][3][3] != 0, outs["1"][2][3] != 0)
+    h.close()

@@ -42,7 +42,7 @@ python - <<PY
 import json,glob
 for f in sorted(glob.glob("$OUT/bench_*.json")):
     try:
-        d=json.load(open(f)); r=d["roofline"] or {"kernel_ms":0,"achieved":0,"frac":0}
+        d=json.loads(open(f).read().strip().splitlines()[-1]); r=d["roofline"] or {"kernel_ms":0,"achieved":0,"frac":0}
         print("%-32s n_gpus=%d value=%9.1f ms/step=%8.3f kernel_ms=%.4f TF=%.1f frac=%.3f cpu=%s" % (f.split("/")[-1], d["n_gpus"], d["value"], d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"], d.get("cpu_baseline",{}).get("value")))
     except Exception as e: print(f, "failed", e)
 PY
