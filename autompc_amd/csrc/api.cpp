@@ -1437,11 +1437,11 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
+  REQUIRE(!h->has_lin, "ampc_ilqr_plan_create: iLQR plans take model states up to 64 (the Riccati workspace lives "
+                       "in LDS); wide linear models (65..256 states) run MPPI and the closed loop");
   REQUIRE(h->nx + h->nu + 1 <= 64,
           "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
-  REQUIRE(!h->has_lin, "ampc_ilqr_plan_create: iLQR plans take model states up to 64 (the Riccati workspace lives "
-                       "in LDS); wide linear models (65..256 states) run MPPI and the closed loop");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
   HIP_OK(hipSetDevice(h->device));

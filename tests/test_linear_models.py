@@ -205,8 +205,8 @@ def test_device_mppi_closed_loop_matches_reference(tag):
 @pytest.mark.gpu
 def test_candidate_evaluator_on_arx_matches_reference_simulate():
     """The reference's simulate() with MPPI on its fitted ARX model (history 3: the model state is
-    the stacked history, not the observation) replayed through the device-resident evaluator;
-    Koopman, whose controller state is re-lifted from every observation, is refused."""
+    the stacked history, not the observation) replayed through the device-resident evaluator; and
+    on its Koopman models, whose controller state is re-lifted from every observation."""
     from autompc_amd.tuning import CandidateEvaluator
     g = golden("linear_arx3")
     system, m = _host_model("arx3", g)
@@ -223,11 +223,22 @@ def test_candidate_evaluator_on_arx_matches_reference_simulate():
     assert obs.shape[2] == m.state_dim
     assert rel_err(obs[0][:, :3], g["mppi_obs"]) < 1e-8 and rel_err(ctrls[0], g["mppi_ctrls"]) < 1e-8
     assert abs(scores[0] - g["mppi_score"]) < 1e-7 * abs(g["mppi_score"])
-    gk = golden("linear_koop_full")
-    systemk, mk = _host_model("koop_full", gk)
-    mk.set_parameters({"A": gk["A"], "B": gk["B"]})
-    with pytest.raises(TypeError, match="update_state"):
-        CandidateEvaluator(systemk, _task(systemk, gk, True), mk)
+    # Koopman re-lifts its state from every observation (koopman.py:166-168): the device loop's state
+    # lift (round 4; refused before) against the reference's simulate() on both fitted Koopman models
+    for tag in ("koop_full", "koop_lasso"):
+        gk = golden("linear_" + tag)
+        systemk, mk = _host_model(tag, gk)
+        mk.set_parameters({"A": gk["A"], "B": gk["B"]})
+        np.random.seed(int(gk["np_seed"]))
+        act0 = np.random.normal(scale=scale, size=(H, 1))
+        eps = np.stack([np.random.normal(scale=scale, size=(N, H, 1)) for _ in range(T)])
+        evk = CandidateEvaluator(systemk, _task(systemk, gk, True), mk)
+        cand = dict(horizon=H, sigma=float(gk["sigma"]), lmda=float(gk["lmda"]), num_path=N, Q=gk["Q"], R=gk["R"], F=gk["F"])
+        scores, obs, ctrls = evk.evaluate([cand], n_steps=T, init_obs=gk["init"], eps_all=eps, act_init=act0,
+                                          return_trajectories=True)
+        assert obs.shape[2] == mk.state_dim
+        assert rel_err(obs[0][:, :3], gk["mppi_obs"]) < 1e-8 and rel_err(ctrls[0], gk["mppi_ctrls"]) < 1e-8
+        assert abs(scores[0] - gk["mppi_score"]) < 1e-7 * abs(gk["mppi_score"])
 
 
 @pytest.mark.gpu
@@ -322,7 +333,8 @@ def test_device_rejects_oversized_linear_state():
     from autompc_amd import _lib
     h = _lib.Handle(0, "f64")
     with pytest.raises(_lib.AmpcError):
-        h.set_linear(np.eye(65), np.zeros((65, 1)))
+        h.set_linear(np.eye(257), np.zeros((257, 1)))        # (65..256: csrc/linear_kernels.hpp, test_linear_wide.py)
+    h.set_linear(np.eye(65), np.zeros((65, 1)))
     h.close()
 
 
