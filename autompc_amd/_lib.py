@@ -87,6 +87,8 @@ SIGNATURES = {
     "ampc_ilqr_plan_timing": (c_int, [c_void_p, _dp, _ip]),
     "ampc_ilqr_plan_stats": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve": (c_int, [c_void_p, _dp, _dp, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip, _dp]),
+    "ampc_ilqr_closed_loop": (c_int, [c_void_p, c_void_p, c_int, _dp, _ip, c_int, c_int, _dp, _dp, _ip, _ip,
+                                      POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve_queue": (c_int, [c_void_p, c_int, _dp, _dp, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
                                       _dp]),
 }
@@ -636,6 +638,24 @@ class IlqrPlan:
                                        dptr(out["states"]), dptr(out["ctrls"]), dptr(out["Ks"]),
                                        dptr(out["ks"]), iptr(out["converged"]), iptr(out["iters"]),
                                        iptr(out["status"]), dptr(out["objective"])))
+        return out
+
+    def closed_loop(self, init_obs, n_steps, cost_index=None, max_iter=50, surrogate=None):
+        """simulate() with IterativeLQR controllers for C episodes, device resident (ampc_ilqr_closed_loop):
+        init_obs [C, nx]; returns dict(obs [C, n_steps+1, nx], ctrls [C, n_steps+1, nu], failed [C],
+        steps [C], iterations [C])."""
+        nx, nu = self.handle.nx, self.handle.nu
+        init_obs = as_f64(init_obs).reshape(-1, nx)
+        C = init_obs.shape[0]
+        ci = None if cost_index is None else np.ascontiguousarray(np.broadcast_to(
+            np.asarray(cost_index, dtype=np.int32), (C,)))
+        out = {"obs": np.empty((C, n_steps + 1, nx)), "ctrls": np.empty((C, n_steps + 1, nu)),
+               "failed": np.zeros(C, dtype=np.int32), "steps": np.zeros(C, dtype=np.int32),
+               "iterations": np.zeros(C, dtype=np.int64)}
+        check(self.lib.ampc_ilqr_closed_loop(
+            self._p, surrogate._h if surrogate is not None else None, C, dptr(init_obs), iptr(ci), int(n_steps),
+            int(max_iter), dptr(out["obs"]), dptr(out["ctrls"]), iptr(out["failed"]), iptr(out["steps"]),
+            out["iterations"].ctypes.data_as(POINTER(ctypes.c_longlong))))
         return out
 
     def solve_queue(self, x0, uguess=None, cost_index=None, max_iter=50, gains=True, trajectories=True):

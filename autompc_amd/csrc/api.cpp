@@ -693,6 +693,15 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   HIP_OK(p->u_out.reserve((size_t)p->B * nu * sizeof(T)));
   HIP_OK(p->tile_stat.reserve((size_t)p->n_tiles * 2 * sizeof(T)));
   HIP_OK(p->tile_part.reserve((size_t)p->n_tiles * p->max_h * nu * sizeof(T)));
+  HIP_OK(p->tile_done.reserve((size_t)p->B * sizeof(int)));
+  HIP_OK(hipMemset(p->tile_done.p, 0, (size_t)p->B * sizeof(int)));
+  // AMPC_FUSED_COMBINE = 1 (experiment, off: measured slower): four-row plans finish the update inside the rollout launch
+  {
+    int max_tiles = 0;
+    for (int b = 0; b < p->B; ++b) max_tiles = std::max(max_tiles, (p->N[b] + M - 1) / M);
+    p->fused_combine = p->quad && p->lds_eps >= 0 && env_int("AMPC_FUSED_COMBINE", 0) != 0 &&
+                       (size_t)(2 * max_tiles + 256) * sizeof(T) <= p->lds_bytes;
+  }
   HIP_OK(hipMemset(p->x0.p, 0, (size_t)p->B * nx * sizeof(T)));
   return 0;
 }
@@ -746,7 +755,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->lift_prog, &p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
-                    &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part,
+                    &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part, &p->tile_done,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
                     &p->lg_win, &p->lg_logtab, &p->lg_gather};
@@ -1509,7 +1518,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
                     &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric,
                     &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
-                    &p->q_obj, &p->q_flags};
+                    &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->poll_host) (void)hipHostFree(p->poll_host);
@@ -1758,6 +1767,124 @@ extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const do
                                              converged, iters, status, objective)
              : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, max_iter, states, ctrls, Ks, ks,
                                             converged, iters, status, objective);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident closed loops of iLQR controllers (ilqr_chain_*_kernel)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, const double* init_obs,
+                                 const int* cost_index, int n_steps, int max_iter, double* traj_obs,
+                                 double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
+  ampc_handle* h = p->h;
+  const int nx = h->nx, nu = h->nu, B = p->B, H = p->H, T1 = n_steps + 1;
+  const size_t e = sizeof(T);
+  // ints: ctl[2] | slot_mode[B] (where make_ilqr_args expects it: q_ctl + 2 + B) ...
+  HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
+  HIP_OK(p->c_ints.reserve((size_t)(2 * B + 3 * C) * sizeof(int)));      // need[B] slot_chain[B] chain_t[C] chain_fail[C] cost[C]
+  HIP_OK(p->c_iters.reserve((size_t)C * sizeof(long long)));
+  HIP_OK(p->c_stage.reserve((size_t)B * (2 * nx + nu) * e));
+  HIP_OK(p->c_obs.reserve((size_t)C * T1 * nx * e));
+  HIP_OK(p->c_ctl.reserve((size_t)C * T1 * nu * e));
+  HIP_OK(p->q_x0.reserve((size_t)C * nx * e));
+  std::vector<int> ctl(2 + 2 * B, 0), ci(2 * B + 3 * C, 0);
+  for (int b = 0; b < B; ++b) { ctl[2 + b] = -1; ctl[2 + B + b] = 1; ci[B + b] = -1; }
+  if (cost_index) std::memcpy(ci.data() + 2 * B + 2 * C, cost_index, (size_t)C * sizeof(int));
+  HIP_OK(hipMemcpyAsync(p->q_ctl.p, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemcpyAsync(p->c_ints.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIP_OK(hipMemsetAsync(p->c_iters.p, 0, (size_t)C * sizeof(long long), h->stream));
+  HIP_OK(hipMemsetAsync(p->c_obs.p, 0, (size_t)C * T1 * nx * e, h->stream));
+  HIP_OK(hipMemsetAsync(p->c_ctl.p, 0, (size_t)C * T1 * nu * e, h->stream));
+  HIP_OK(hipMemsetAsync(p->c_stage.p, 0, (size_t)B * (2 * nx + nu) * e, h->stream));
+  HIP_OK(upload_converted<T>(p->q_x0.p, init_obs, (size_t)C * nx, h->stream));
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)8 * B * sizeof(int), h->stream));
+  HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+  HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * 2 * sizeof(int), hipHostMallocDefault));
+  if (!p->poll_ev[0])
+    for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
+  struct Guard {
+    ampc_ilqr_plan* p;
+    ~Guard() { p->queue_on = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+  } guard{p};
+  p->queue_on = true;
+  p->queue_max_iter = max_iter;
+  p->active_hint = B;
+  IlqrChains<T> q;
+  q.C = C; q.B = B; q.H = H; q.nx = nx; q.nu = nu; q.n_steps = n_steps; q.max_iter = max_iter;
+  q.ctl = (int*)p->q_ctl.p;
+  int* ints = (int*)p->c_ints.p;
+  q.need = ints; q.slot_chain = ints + B; q.chain_t = ints + 2 * B; q.chain_fail = ints + 2 * B + C;
+  q.cost = ints + 2 * B + 2 * C;
+  q.chain_iters = (long long*)p->c_iters.p;
+  q.x0 = (const T*)p->q_x0.p; q.cost_idx = (int*)p->d_cost_idx.p;
+  q.stage_x = (T*)p->c_stage.p; q.stage_u = q.stage_x + (size_t)B * nx; q.stage_next = q.stage_u + (size_t)B * nu;
+  q.traj_obs = (T*)p->c_obs.p; q.traj_ctrls = (T*)p->c_ctl.p;
+  // Upper bound on the plan iterations: every control step of every chain takes at most max_iter + 2.
+  constexpr int kPoll = 4;
+  const long long bound = ((long long)(C + B - 1) / B) * n_steps * (max_iter + 2LL) + (long long)C + 4 * kPoll;
+  long long it = 0;
+  int batch = 0, pending = -1;
+  bool done = false;
+  while (!done && it < bound) {
+    for (int k = 0; k < kPoll; ++k) {
+      IlqrArgs<T> a = make_ilqr_args<T>(p, 1);
+      hipLaunchKernelGGL(ilqr_chain_pre_kernel<T>, dim3(B), dim3(64), 0, h->stream, a, q);
+      HIP_OK(hipGetLastError());
+      if (int rc = surrogate_step<T>(h, sur, q.stage_x, q.stage_u, q.stage_next, B)) return rc;
+      hipLaunchKernelGGL(ilqr_chain_post_kernel<T>, dim3(B), dim3(256), 0, h->stream, a, q);
+      HIP_OK(hipGetLastError());
+      int rc = ilqr_launch_iter<T>(p, 1);
+      if (rc == 0) rc = ilqr_refresh_jacobians<T>(p);
+      if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
+    }
+    it += kPoll;
+    const int slot = batch & 1;
+    HIP_OK(hipMemcpyAsync(p->poll_host + 2 * slot, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
+    if (pending >= 0) {
+      HIP_OK(hipEventSynchronize(p->poll_ev[pending & 1]));
+      if (p->poll_host[2 * (pending & 1) + 1] >= C) done = true;
+    }
+    pending = batch++;
+  }
+  HIP_OK(hipStreamSynchronize(h->stream));
+  p->last_queue_launches = it;
+  p->last_iterations = (int)std::min<long long>(it, 1 << 30);
+  int fin[2] = {0, 0};
+  HIP_OK(hipMemcpy(fin, p->q_ctl.p, sizeof(fin), hipMemcpyDeviceToHost));
+  if (fin[1] < C) return fail("ampc_ilqr_closed_loop: internal: the chains did not finish");
+  std::vector<int> back((size_t)2 * B + 3 * C);
+  HIP_OK(hipMemcpy(back.data(), p->c_ints.p, back.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (steps_done) std::memcpy(steps_done, back.data() + 2 * B, (size_t)C * sizeof(int));
+  if (failed) std::memcpy(failed, back.data() + 2 * B + C, (size_t)C * sizeof(int));
+  if (iterations) HIP_OK(hipMemcpy(iterations, p->c_iters.p, (size_t)C * sizeof(long long), hipMemcpyDeviceToHost));
+  if (traj_obs) HIP_OK(download_converted<T>(traj_obs, p->c_obs.p, (size_t)C * T1 * nx, h->stream));
+  if (traj_ctrls) HIP_OK(download_converted<T>(traj_ctrls, p->c_ctl.p, (size_t)C * T1 * nu, h->stream));
+  HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
+                                     const int* cost_index, int n_steps, int max_iter, double* traj_obs,
+                                     double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
+  REQUIRE(p && init_obs, "ampc_ilqr_closed_loop: NULL argument");
+  REQUIRE(n_chains >= 1 && n_steps >= 1 && max_iter >= 1, "ampc_ilqr_closed_loop: n_chains, n_steps, max_iter must be >= 1");
+  ampc_handle* sur = surrogate ? surrogate : p->h;
+  REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
+          "ampc_ilqr_closed_loop: surrogate model must have the controller model's dimensions");
+  REQUIRE(sur->precision == p->h->precision && sur->device == p->h->device,
+          "ampc_ilqr_closed_loop: surrogate must share the plan's device and precision");
+  if (cost_index)
+    for (int j = 0; j < n_chains; ++j)
+      REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_closed_loop: bad cost_index");
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? ilqr_closed_loop_impl<double>(p, sur, n_chains, init_obs, cost_index, n_steps, max_iter, traj_obs,
+                                             traj_ctrls, failed, steps_done, iterations)
+             : ilqr_closed_loop_impl<float>(p, sur, n_chains, init_obs, cost_index, n_steps, max_iter, traj_obs,
+                                            traj_ctrls, failed, steps_done, iterations);
 }
 
 // ---------------------------------------------------------------------------------------------

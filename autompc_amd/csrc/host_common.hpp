@@ -296,7 +296,8 @@ struct ampc_mppi_plan {
   std::vector<double> sigma, lmda;
   std::vector<long long> eps_off, epso_off, cost_off;
   long long sum_n = 0, sum_hnu = 0, sum_nhnu = 0;
-  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part;
+  DevBuf probs, tile_prob, x0, act[2], eps, eps_out, costs, term_last, u_out, tile_stat, tile_part, tile_done;
+  bool fused_combine = false;   // the four-row rollout's last workgroup finishes the update (no combine launch)
   // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
   // call is generated speculatively on a side stream (it only depends on the generator state this
   // call leaves behind) and used if the next call indeed starts from that state.
@@ -353,6 +354,8 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.hnu_stride = p->max_h * h->nu;
   a.tile_stat = (T*)p->tile_stat.p;
   a.tile_part = (T*)p->tile_part.p;
+  a.tile_done = (int*)p->tile_done.p;
+  a.fused_combine = p->fused_combine ? 1 : 0;
   a.costs_par = (const T*)h->cost_buf.p;
   a.bounds = (const T*)h->bounds_buf.p;
   a.probs = (const MppiProblem<T>*)p->probs.p;
@@ -410,6 +413,7 @@ struct ampc_ilqr_plan {
   int queue_max_iter = 0;
   DevBuf q_ctl;                 // ints: [0] next, [1] harvested, then slot_prob[B], slot_mode[B]
   DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
+  DevBuf c_ints, c_iters, c_stage, c_obs, c_ctl;   // ampc_ilqr_closed_loop: chain bookkeeping, staged rows, trajectories
   long long last_queue_launches = 0;   // iterations launched by the last queue solve
 };
 

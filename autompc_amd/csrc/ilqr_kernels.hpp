@@ -1131,4 +1131,92 @@ __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T
   for (int i = tid; i < H * nu; i += 256) ct[i] = q.uguess[(size_t)n * H * nu + i];
 }
 
+// ---- device-resident closed loops of iLQR controllers (ampc_ilqr_closed_loop) ------------------------------
+// simulate() with an IterativeLQR controller (utils/simulation.py:44-63, ilqr.py:267-295): every control
+// step is a full solve from a zero guess, u = ubar_0 (+ K_0 (x - xbar_0) with x = xbar_0), then
+// x <- surrogate.pred(x, u).  C such episodes ("chains") stream through the plan's B slots: a slot keeps
+// its chain -- solve, surrogate step, next solve -- until the episode ends, then takes the next chain.
+// Per iteration of the plan:   pre (this kernel)  ->  surrogate step over the B staged rows  ->  post.
+template <typename T> struct IlqrChains {
+  int C, B, H, nx, nu, n_steps, max_iter;
+  int* ctl;                  // [0] next chain to hand out, [1] chains finished
+  int* slot_chain;           // [B] chain in the slot, -1: none
+  int* need;                 // [B] 0 nothing, 1 step the surrogate and continue, 2 chain failed, 3 wants a chain
+  int* chain_t;              // [C] control steps done
+  int* chain_fail;           // [C] status of the solve that ended the chain early (1: singular Quu), else 0
+  long long* chain_iters;    // [C] iLQR iterations over the episode
+  const T* x0;               // [C][nx]
+  const int* cost;           // [C]
+  int* cost_idx;             // [B]
+  T* stage_x; T* stage_u; T* stage_next;     // [B][nx], [B][nu], [B][nx]
+  T* traj_obs;               // [C][n_steps+1][nx]
+  T* traj_ctrls;             // [C][n_steps+1][nu]  (row n_steps stays zero, as simulate() appends it)
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void ilqr_chain_pre_kernel(const IlqrArgs<T> args, const IlqrChains<T> q) {
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) q.need[p] = 0;
+  if (args.active[p] != 0 || args.slot_mode[p] == 0) return;        // solving, or loaded and not yet started
+  const int c = q.slot_chain[p];
+  if (c < 0) { if (tid == 0) q.need[p] = 3; return; }
+  if (tid == 0) q.chain_iters[c] += args.iters[p];
+  if (args.status[p] == 1) {                    // singular Quu -- the reference's LinAlgError: the episode ends
+    if (tid == 0) { q.chain_fail[c] = 1; q.need[p] = 2; }
+    return;
+  }
+  const T* st = args.states + (size_t)p * (q.H + 1) * q.nx;
+  const T* ct = args.ctrls + (size_t)p * q.H * q.nu;
+  for (int i = tid; i < q.nx; i += 64) q.stage_x[(size_t)p * q.nx + i] = st[i];
+  for (int i = tid; i < q.nu; i += 64) q.stage_u[(size_t)p * q.nu + i] = ct[i];
+  if (tid == 0) q.need[p] = 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ilqr_chain_post_kernel(const IlqrArgs<T> args, const IlqrChains<T> q) {
+  __shared__ int next_s;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const int need = q.need[p];
+  if (need == 0) return;
+  const int H = q.H, nx = q.nx, nu = q.nu, T1 = q.n_steps + 1;
+  T* st = args.states + (size_t)p * (H + 1) * nx;
+  T* ct = args.ctrls + (size_t)p * H * nu;
+  int c = q.slot_chain[p];
+  bool finished = need == 2;
+  if (need == 1) {
+    const int t = q.chain_t[c];
+    for (int i = tid; i < nu; i += 256) q.traj_ctrls[((size_t)c * T1 + t) * nu + i] = q.stage_u[(size_t)p * nu + i];
+    for (int i = tid; i < nx; i += 256) {
+      const T v = q.stage_next[(size_t)p * nx + i];
+      q.traj_obs[((size_t)c * T1 + t + 1) * nx + i] = v;
+      st[i] = v;                                  // the next solve of this chain starts here ...
+    }
+    __syncthreads();
+    if (tid == 0) q.chain_t[c] = t + 1;
+    if (t + 1 < q.n_steps) {                      // ... from a zero guess (ilqr.py:280-281)
+      for (int i = tid; i < H * nu; i += 256) ct[i] = T(0);
+      if (tid == 0) { args.slot_mode[p] = 0; args.refresh[p] = 0; }
+      return;
+    }
+    finished = true;
+  }
+  if (tid == 0) {
+    if (finished) { __threadfence(); atomicAdd(&q.ctl[1], 1); }
+    int n = q.ctl[0] < q.C ? atomicAdd(&q.ctl[0], 1) : q.C;
+    if (n >= q.C) n = -1;
+    next_s = n;
+    q.slot_chain[p] = n;
+    if (n >= 0) { q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0; q.chain_t[n] = 0; }
+  }
+  __syncthreads();
+  const int n = next_s;
+  if (n < 0) return;
+  for (int i = tid; i < nx; i += 256) {
+    const T v = q.x0[(size_t)n * nx + i];
+    st[i] = v;
+    q.traj_obs[(size_t)n * T1 * nx + i] = v;
+  }
+  for (int i = tid; i < H * nu; i += 256) ct[i] = T(0);
+}
+
 }  // namespace ampc

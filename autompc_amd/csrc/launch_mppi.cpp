@@ -119,7 +119,9 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
 #endif
   }
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
-  if (p->lds_eps >= 0) {
+  if (p->fused_combine && p->quad) {
+    // (the rollout's last workgroup per problem finished the update: mppi_kernels.hpp)
+  } else if (p->lds_eps >= 0) {
     hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
                        p->tile_m);
   } else {

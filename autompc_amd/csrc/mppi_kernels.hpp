@@ -67,11 +67,98 @@ template <typename T> struct MppiArgs {
   T* u_out;                     // [B][nu] first action * scale (written by the update kernel)
   T* tile_stat;                 // [n_tiles][2]  fused update: tile min cost, tile weight sum
   T* tile_part;                 // [n_tiles][hnu_stride]  fused update: sum_m S_m eps[t][m][j]
+  int* tile_done;               // [B] tickets: the four-row rollout's last workgroup of a problem finishes the
+                                // softmin update itself (fused_combine; no combine launch)
+  int fused_combine;
 };
 
 template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch);
 template <typename T> __device__ __forceinline__ T wave_sum(T v);
+
+
+// ---- finishing the softmin update inside the rollout launch (small problems) -------------------------
+// A solve of a small problem is a few tens of microseconds; the dependent combine launch is seven of
+// them.  So the LAST workgroup of a problem to publish its tile partials finishes the update itself.
+// Cross-workgroup visibility WITHOUT agent-scope fences (a release fence is an L2 write-back on this
+// eight-L2 part: measured 28 -> 61 us per c2 rollout in round 3):
+//   * every published value is stored with an agent-scope atomic store: the AMDGPU memory model lowers it
+//     to a store with sc1 = 1, which is written THROUGH the XCD's L2 to memory;
+//   * each thread then waits for its own stores (s_waitcnt vmcnt(0): a write-through store is
+//     acknowledged once it has left the L2 towards memory), the workgroup meets at a barrier, and one
+//     thread takes a ticket with an agent-scope atomic add (performed at the memory side, where all
+//     XCDs' atomics meet): a ticket value of tiles - 1 therefore happens after every other workgroup's
+//     stores have been written through;
+//   * the winner reads the published values with agent-scope atomic loads (sc1 = 1: they bypass its own
+//     L2, which may hold stale lines of these addresses from the previous solve).
+// No other data crosses workgroups.  tools/stress_fused_combine.py repeats one solve 2*10^5 times and
+// checks that the result never changes (0 differences on c2 and the ARX workload).
+// MEASURED (round 4): correct, but SLOWER than the combine launch it replaces -- every hop of the
+// protocol (write-through acknowledgement, ticket, two rounds of bypassing loads) is a round trip to
+// memory, not to an L2: the c2 rollout goes from 27.7 to 46.6 us where the combine launch costs 7.4.
+// Off by default (AMPC_FUSED_COMBINE=1 enables it); kept as the measured answer to "fuse the combine".
+template <typename T> __device__ __forceinline__ void st_agent(T* p, T v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ T ld_agent(const T* p) {
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by every thread of a workgroup after its tile's partials were published with st_agent.
+// Returns for all but the problem's last workgroup; that one computes a[t] += sum_w P_w[t] / sum_w s_w
+// with every tile rescaled to the global minimum (mppi.py:110-118) -- tiles in index order, so the
+// result does not depend on which workgroup happens to be last.  scratch: 2 * tiles + NTHR values of LDS.
+template <typename T, int NTHR>
+__device__ __forceinline__ void finish_update_if_last(const MppiArgs<T>& args, const MppiProblem<T>& pr, int p,
+                                                      int tile_m, T* scratch) {
+  __shared__ int ticket_s;
+  const int tid = threadIdx.x, nu = args.mlp.nu, H = pr.H;
+  const int tiles = (pr.N + tile_m - 1) / tile_m;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's published values are through
+  __syncthreads();
+  if (tid == 0) ticket_s = __hip_atomic_fetch_add(&args.tile_done[p], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket_s != tiles - 1) return;
+  if (tid == 0) __hip_atomic_store(&args.tile_done[p], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const T* st = args.tile_stat + 2 * (size_t)pr.tile0;
+  T* sc = scratch;                       // [tiles] tile minima, then tile weights
+  T* ss = scratch + tiles;               // [tiles] tile weight sums
+  T* part = ss + tiles;                  // [NTHR] partial sums of the second phase
+  for (int i = tid; i < tiles; i += NTHR) { sc[i] = ld_agent(st + 2 * i); ss[i] = ld_agent(st + 2 * i + 1); }
+  __syncthreads();
+  T vmin = T(INFINITY);
+  for (int i = 0; i < tiles; ++i) vmin = sc[i] < vmin ? sc[i] : vmin;
+  __syncthreads();
+  for (int i = tid; i < tiles; i += NTHR)
+    sc[i] = (sc[i] < T(INFINITY)) ? exp(pr.neg_inv_lambda * (sc[i] - vmin)) : T(0);   // all-inf tile: weight 0
+  __syncthreads();
+  T ssum = T(0);
+  for (int i = 0; i < tiles; ++i) ssum += sc[i] * ss[i];
+  // sum_w scale_w P_w[t][j]: the tiles of an element are dealt to NG thread groups (all their loads in
+  // flight together), the groups' partial sums are added in group order -- a fixed order either way
+  const T* tp = args.tile_part + (size_t)pr.tile0 * args.hnu_stride;
+  const int E = H * nu;
+  for (int e0 = 0; e0 < E; e0 += NTHR) {
+    const int ne = (E - e0) < NTHR ? (E - e0) : NTHR;        // elements of this round
+    const int NG = NTHR / ne;                                // thread groups per element
+    const int g = tid / ne, e = e0 + tid - g * ne;
+    T acc = T(0);
+    if (g < NG)
+      for (int i = g; i < tiles; i += NG) acc += sc[i] * ld_agent(tp + (size_t)i * args.hnu_stride + e);
+    __syncthreads();
+    if (g < NG) part[tid] = acc;
+    __syncthreads();
+    if (tid < ne) {
+      T tot = T(0);
+      for (int k = 0; k < NG; ++k) tot += part[k * ne + tid];
+      const int ee = e0 + tid, t = ee / nu, j = ee - t * nu;
+      const int ts = (t + 1 < H) ? t + 1 : H - 1;
+      const T a_new = args.act_in[pr.a_off + ts * nu + j] + tot / ssum;
+      args.act_out[pr.a_off + ee] = a_new;
+      if (t == 0) args.u_out[p * nu + j] = a_new * args.bounds[2 * nu + j];
+    }
+  }
+}
 
 // SH: DynShape (everything read from `args` at run time) or a StaticShape (shapes.hpp) whose
 // dimensions, strides and LDS offsets are compile-time constants -- see mlp_tile.hpp.

@@ -385,18 +385,22 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
     sred[tid] = (first + tid < N && !dead_tile) ? exp(pr.neg_inv_lambda * (cred[tid] - mw)) : T(0);
   __syncthreads();
   T* tp = args.tile_part + (size_t)blockIdx.x * args.hnu_stride;
+  const bool fuse = args.fused_combine != 0;
   for (int e = tid; e < H * nu; e += NTHR) {
     const int t = e / nu, j = e - t * nu;
     T s = T(0);
     for (int i = 0; i < ROWS; ++i) s += sred[i] * el[(t * ROWS + i) * nu + j];
-    tp[e] = s;
+    if (fuse) st_agent(tp + e, s);
+    else tp[e] = s;
   }
   if (tid == 0) {
     T ss = T(0);
     for (int i = 0; i < ROWS; ++i) ss += sred[i];
-    args.tile_stat[2 * blockIdx.x] = mw;
-    args.tile_stat[2 * blockIdx.x + 1] = ss;
+    if (fuse) { st_agent(args.tile_stat + 2 * blockIdx.x, mw); st_agent(args.tile_stat + 2 * blockIdx.x + 1, ss); }
+    else { args.tile_stat[2 * blockIdx.x] = mw; args.tile_stat[2 * blockIdx.x + 1] = ss; }
   }
+  // the problem's last workgroup finishes the softmin update (mppi_kernels.hpp: no combine launch)
+  if (fuse) finish_update_if_last<T, NTHR>(args, pr, p, ROWS, lds);
 }
 
 }  // namespace ampc

@@ -434,7 +434,12 @@ class IlqrCandidateEvaluator:
     own cost block) followed by one batched surrogate step.  Everything is deterministic: a
     candidate's score does not depend on the batch it is in or on the rank that evaluates it."""
 
-    def __init__(self, system, task, model, surrogate=None, precision="f64", device=0):
+    def __init__(self, system, task, model, surrogate=None, precision="f64", device=0, device_resident=True,
+                 max_slots=256):
+        """device_resident: episodes of known length run entirely on the device (ampc_ilqr_closed_loop;
+        a user termination condition is asked on the host, one batched solve per control step);
+        max_slots: problems solved side by side (one workgroup each)."""
+        self.device_resident, self.max_slots = bool(device_resident), int(max_slots)
         if not hasattr(model, "stage_into"):
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         if precision != "f64":
@@ -484,6 +489,7 @@ class IlqrCandidateEvaluator:
         opened.append(sur)
         self.surrogate.stage_into(sur)
         plans = {}
+        device_loop = term_cond is None and n_ctl >= 1 and self.device_resident
         for H, idx in groups.items():
             h = _lib.Handle(self.device, self.precision)
             opened.append(h)
@@ -492,7 +498,8 @@ class IlqrCandidateEvaluator:
             h.set_cost_blocks(**blocks)
             if self.bounded:
                 h.set_ctrl_bounds(self.umin, self.umax)
-            plan = _lib.IlqrPlan(h, len(idx), H, self.system.dt, cost_index=np.arange(len(idx)),
+            slots = min(len(idx), self.max_slots) if device_loop else len(idx)
+            plan = _lib.IlqrPlan(h, slots, H, self.system.dt, cost_index=np.arange(slots),
                                  clip_to_bounds=self.bounded, terminal_goal=term_goal)
             opened.append(plan)
             plans[H] = (plan, np.array(idx))
@@ -502,7 +509,22 @@ class IlqrCandidateEvaluator:
         lengths = np.full(B, n_ctl + 1)
         failed = np.zeros(B, dtype=bool)          # singular Quu: the reference's LinAlgError -> inf
         alive = np.ones(B, dtype=bool)
-        for t in range(n_ctl):
+        if device_loop:
+            # The episode length is known up front: every candidate's whole episode runs on the device
+            # (ampc_ilqr_closed_loop) -- solve, surrogate step, next solve without a host round trip, the
+            # candidates of a horizon group streaming through the plan's slots.
+            self.last_iterations = np.zeros(B, dtype=np.int64)
+            for H, (plan, idx) in plans.items():
+                out = plan.closed_loop(np.tile(np.asarray(init_obs, dtype=np.float64), (len(idx), 1)), n_ctl,
+                                       cost_index=np.arange(len(idx)), max_iter=max_iter, surrogate=sur)
+                bad = out["failed"] != 0
+                failed[idx[bad]] = True
+                obs[idx], ctl[idx] = out["obs"], out["ctrls"]
+                self.last_iterations[idx] = out["iterations"]
+            n_ctl_host = 0
+        else:
+            n_ctl_host = n_ctl
+        for t in range(n_ctl_host):
             if not alive.any():
                 break
             for H, (plan, idx) in plans.items():

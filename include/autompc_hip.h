@@ -368,6 +368,21 @@ int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, c
                           double* Ks, double* ks, int* converged, int* iters, int* status,
                           double* objective);
 
+/* simulate() with IterativeLQR controllers, device resident (utils/simulation.py:44-63 as eval_cfg drives it,
+ * pipeline_tuner.py:222-231; IterativeLQR.run, ilqr.py:267-295: every control step is a full solve from a zero
+ * guess, u = ubar_0, then obs <- surrogate.pred(obs, u)).  n_chains episodes of n_steps control steps stream
+ * through the plan's B slots: a slot keeps its episode -- solve, surrogate step, next solve, with no host round
+ * trip -- until it ends, then takes the next episode; slots whose solve has converged do not wait for the
+ * others (continuous batching as in ampc_ilqr_solve_queue).  The model state must be the observation.
+ *   init_obs [n][nx];  cost_index [n] or NULL (block 0);  surrogate: NULL = the plan's own model;
+ *   traj_obs [n][n_steps+1][nx], traj_ctrls [n][n_steps+1][nu] (last control row zero, as simulate() returns);
+ *   failed [n]: 1 = a solve hit a singular Quu (the reference's LinAlgError, which eval_cfg scores inf,
+ *   pipeline_tuner.py:236-239) -- the episode stops there, steps_done [n] tells after how many control steps;
+ *   iterations [n]: iLQR iterations over the episode.  Any output may be NULL. */
+int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
+                          const int* cost_index, int n_steps, int max_iter, double* traj_obs,
+                          double* traj_ctrls, int* failed, int* steps_done, long long* iterations);
+
 #ifdef __cplusplus
 }
 #endif

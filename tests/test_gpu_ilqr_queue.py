@@ -93,3 +93,54 @@ def test_queue_against_the_oracle_and_failure_isolation():
         assert bool(got["converged"][j]) == conv and int(got["iters"][j]) == orc.n_iter
         assert np.max(np.abs(got["states"][j] - st)) < 1e-6 * max(1.0, np.max(np.abs(st)))
         assert abs(got["objective"][j] - orc.final_obj) < 1e-8 * max(1.0, abs(orc.final_obj))
+
+
+def test_device_resident_ilqr_episodes_equal_the_host_loop():
+    """ampc_ilqr_closed_loop: whole episodes (solve -> surrogate step -> next solve) on the device, the
+    candidates streaming through fewer slots than there are candidates, against the per-control-step
+    host loop (one batched solve + one surrogate step per step) and host simulate() + the drop-in
+    controller; a candidate whose Quu is singular stops with `failed` and scores inf."""
+    from autompc_amd import MLP, IterativeLQR, QuadCost, Task, simulate
+    from autompc_amd.tuning import IlqrCandidateEvaluator, random_ilqr_candidates
+    nx, nu, T = 4, 2, 9
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, [64, 48], "tanh", seed=21)
+
+    def model_of(pp):
+        m = MLP(system, n_hidden_layers=2, hidden_size_1=64, hidden_size_2=48, nonlintype="tanh")
+        m.weights, m.biases = [w.copy() for w in pp["weights"]], [b.copy() for b in pp["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = pp["xu_means"], pp["xu_std"], pp["dy_means"], pp["dy_std"]
+        return m
+    model = model_of(p)
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), 2.0 * np.eye(nx)))
+    task.set_ctrl_bounds(-0.6 * np.ones(nu), 0.6 * np.ones(nu))
+    task.set_init_obs(np.array([0.3, -0.2, 0.25, 0.1]))
+    task.set_num_steps(T)
+    cands = random_ilqr_candidates(system, 10, seed=4)
+    for c in cands:
+        c["Q"], c["R"], c["F"] = c["Q"] ** 0.3, c["R"] ** 0.3, c["F"] ** 0.3
+        c["horizon"] = 8 if c["horizon"] % 2 else 12                 # two horizon groups of several candidates
+    dev = IlqrCandidateEvaluator(system, task, model, max_slots=3)   # fewer slots than candidates per group
+    host = IlqrCandidateEvaluator(system, task, model, device_resident=False)
+    sd, od, cd = dev.evaluate(cands, return_trajectories=True)
+    sh, oh, ch = host.evaluate(cands, return_trajectories=True)
+    assert dev.last_iterations.min() >= T - 1
+    np.testing.assert_allclose(od, oh, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(cd, ch, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(sd, sh, rtol=1e-12)
+    c = cands[3]
+    t1 = Task(system)
+    t1.set_cost(QuadCost(system, np.diag(c["Q"]), np.diag(c["R"]), np.diag(c["F"])))
+    t1.set_ctrl_bounds(-0.6 * np.ones(nu), 0.6 * np.ones(nu))
+    ctl = IterativeLQR(system, t1, model, c["horizon"])
+    traj = simulate(ctl, task.get_init_obs(), task.term_cond, sim_model=model, max_steps=T)
+    assert np.max(np.abs(od[3] - traj.obs)) < 1e-9 and np.max(np.abs(cd[3] - traj.ctrls)) < 1e-9
+    # singular Quu in the middle of the queue
+    p2 = {k: ([w.copy() for w in v] if isinstance(v, list) else v) for k, v in p.items()}
+    p2["weights"][0][:, nx:] = 0.0
+    ev2 = IlqrCandidateEvaluator(system, task, model_of(p2), max_slots=2)
+    good = dict(horizon=8, Q=np.ones(nx), R=0.1 * np.ones(nu), F=np.ones(nx))
+    sing = dict(horizon=8, Q=np.ones(nx), R=np.zeros(nu), F=np.ones(nx))
+    s2 = ev2.evaluate([good, sing, good, good])
+    assert np.isinf(s2[1]) and np.all(np.isfinite(np.delete(s2, 1))) and s2[0] == s2[2] == s2[3]

@@ -6,10 +6,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["AMPC_LIB"] = os.path.join(ROOT, "variants", sys.argv[1] if len(sys.argv) > 1 else "lib_wavetime.so")
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f64"          # python tools/wavetime.py lib_wavetime.so f32
 from autompc_amd import _lib
 from autompc_amd.synthetic import make_workload
-system, task, model, spec = make_workload("c3", precision="f64")
-h = _lib.Handle(0, "f64")
+system, task, model, spec = make_workload("c3", precision=PREC)
+h = _lib.Handle(0, PREC)
 model.stage_into(h)
 Q, R, F = task.get_cost().get_cost_matrices()
 h.set_quad_costs(Q, R, F, task.get_cost().get_goal())
