@@ -429,17 +429,22 @@ class IlqrCandidateEvaluator:
     singular ``Quu`` (the reference's ``LinAlgError``, ilqr.py:179) scores ``inf`` (:236-239).
 
     ``IterativeLQR.run`` re-solves from a zero guess at every control step (ilqr.py:267-295 with the
-    default ``reuse_feedback``), so a control step of the batch is ONE batched device solve
-    (``ampc_ilqr_solve``: every candidate of a horizon group is a problem of the plan, each with its
-    own cost block) followed by one batched surrogate step.  Everything is deterministic: a
-    candidate's score does not depend on the batch it is in or on the rank that evaluates it."""
+    default ``reuse_feedback``).  Episodes of known length (the task only carries a step count) run
+    entirely on the device (``ampc_ilqr_closed_loop``): the candidates of a horizon group stream
+    through the plan's slots, each slot carrying one candidate's episode -- solve, surrogate step,
+    next solve -- without a host round trip and without waiting for the other slots' solves.  With a
+    user termination condition (asked on the host after every step) a control step of the batch is
+    one batched device solve (``ampc_ilqr_solve``) followed by one batched surrogate step.  Either
+    way everything is deterministic: a candidate's score does not depend on the batch it is in or
+    on the rank that evaluates it."""
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0, device_resident=True,
-                 max_slots=256):
+                 max_slots=256, max_threads=32):
         """device_resident: episodes of known length run entirely on the device (ampc_ilqr_closed_loop;
         a user termination condition is asked on the host, one batched solve per control step);
-        max_slots: problems solved side by side (one workgroup each)."""
-        self.device_resident, self.max_slots = bool(device_resident), int(max_slots)
+        max_slots: problems solved side by side per horizon group (one workgroup each); max_threads:
+        horizon groups evaluated concurrently (one plan, stream and host thread each)."""
+        self.device_resident, self.max_slots, self.max_threads = bool(device_resident), int(max_slots), max(1, int(max_threads))
         if not hasattr(model, "stage_into"):
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         if precision != "f64":
@@ -513,10 +518,25 @@ class IlqrCandidateEvaluator:
             # The episode length is known up front: every candidate's whole episode runs on the device
             # (ampc_ilqr_closed_loop) -- solve, surrogate step, next solve without a host round trip, the
             # candidates of a horizon group streaming through the plan's slots.
+            # Horizon groups are independent plans on handles (streams) of their own: they run side by
+            # side, one host thread each (the library call releases the GIL) -- a group of three
+            # candidates occupies three compute units, and the reference's horizon range 5..25 makes up
+            # to 21 groups.
             self.last_iterations = np.zeros(B, dtype=np.int64)
-            for H, (plan, idx) in plans.items():
-                out = plan.closed_loop(np.tile(np.asarray(init_obs, dtype=np.float64), (len(idx), 1)), n_ctl,
-                                       cost_index=np.arange(len(idx)), max_iter=max_iter, surrogate=sur)
+            x0 = np.asarray(init_obs, dtype=np.float64)
+
+            def run_group(item):
+                plan, idx = item
+                return idx, plan.closed_loop(np.tile(x0, (len(idx), 1)), n_ctl, cost_index=np.arange(len(idx)),
+                                             max_iter=max_iter, surrogate=sur)
+            items = list(plans.values())
+            if len(items) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(len(items), self.max_threads)) as pool:
+                    results = list(pool.map(run_group, items))
+            else:
+                results = [run_group(items[0])]
+            for idx, out in results:
                 bad = out["failed"] != 0
                 failed[idx[bad]] = True
                 obs[idx], ctl[idx] = out["obs"], out["ctrls"]
