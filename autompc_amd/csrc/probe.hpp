@@ -169,6 +169,13 @@ __device__ long long g_phase_marks[64];
     HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_wave_marks), 8 * 16 * sizeof(long long)));   \
     return 0;                                                                                       \
   }
+#elif defined(AMPC_X_WAVETIME)      /* the f32 translation unit: its own copy of the marks */
+#define AMPC_PROBE_HOST_MPPI                                                                        \
+  extern "C" int ampc_x_wave_marks_f32(long long* out) {                                            \
+    HIP_OK(hipDeviceSynchronize());                                                                 \
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_wave_marks), 8 * 16 * sizeof(long long)));   \
+    return 0;                                                                                       \
+  }
 #elif defined(AMPC_X_PHASETIME) && defined(AMPC_T_IS_F64)
 #define AMPC_PROBE_HOST_MPPI                                                                        \
   extern "C" int ampc_x_phase_marks(long long* out) {                                               \

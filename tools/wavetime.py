@@ -25,8 +25,9 @@ for i in range(30):
 h.synchronize()
 marks = (ctypes.c_longlong * 128)()
 lib = _lib.load()
-lib.ampc_x_wave_marks.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
-lib.ampc_x_wave_marks(marks)
+fn = lib.ampc_x_wave_marks if PREC == "f64" else lib.ampc_x_wave_marks_f32      # (one copy of the marks per translation unit)
+fn.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
+fn(marks)
 m = np.array(marks[:], dtype=np.int64).reshape(8, 16)
 order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 9, 12, 10, 11]
 names = {0: "step start", 1: "dense cost done", 2: "L0 mma issued", 3: "epi0 done", 4: "L1 mma issued (+bar inside)",
