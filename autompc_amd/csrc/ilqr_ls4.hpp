@@ -556,6 +556,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     args.refresh[p] = success;
     if (conv) { args.converged[p] = 1; args.active[p] = 0; }
     else if (args.max_iter > 0 && args.iters[p] >= args.max_iter) args.active[p] = 0;
+    if (args.active[p] == 0) args.refresh[p] = 0;       // retired: nobody reads its Jacobians again
   }
 }
 

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from autompc_amd import MLP, MPPI, IterativeLQR, QuadCost, System, Task
 from oracle import mlp as omlp
-from oracle.costs import QuadCostOracle
+from oracle.costs import QuadCostOracle, SumCostOracle
 from oracle.ilqr import ILQROracle
 from oracle.mlp import MLPOracle
 from oracle.mppi import MPPIOracle
@@ -70,8 +70,23 @@ def main():
             R = np.diag(rng.uniform(0.01, 0.1, size=nu))
             F = np.diag(rng.uniform(0.5, 2.0, size=nx))
             goal = rng.normal(scale=0.1, size=nx)
+            # a third of the cases: a SUM of quadratic terms with different goals (sum_cost.py:49-54) -- one
+            # affine-quadratic block on the device, the term-by-term fan-out in the oracle
+            hip_cost, orc_cost = QuadCost(system, Q, R, F, goal=goal), QuadCostOracle(Q, R, F, goal)
+            if rng.random() < 0.35:
+                terms = [(Q, R, F, goal)]
+                for _ in range(int(rng.integers(1, 3))):
+                    Wq = rng.normal(size=(nx, nx))
+                    terms.append((Wq @ Wq.T / nx * float(rng.uniform(0.05, 0.5)) if rng.random() < 0.5
+                                  else np.diag(rng.uniform(0.05, 0.5, size=nx)), np.diag(rng.uniform(0.0, 0.05, size=nu)),
+                                  np.diag(rng.uniform(0.0, 0.5, size=nx)), rng.normal(scale=0.3, size=nx)))
+                hip_cost = QuadCost(system, *terms[0][:3], goal=terms[0][3])
+                for t_ in terms[1:]:
+                    hip_cost = hip_cost + QuadCost(system, *t_[:3], goal=t_[3])
+                orc_cost = SumCostOracle.from_arrays(*zip(*terms))
+                tag += " sumcost%d" % len(terms)
             task = Task(system)
-            task.set_cost(QuadCost(system, Q, R, F, goal=goal))
+            task.set_cost(hip_cost)
             lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
             task.set_ctrl_bounds(np.full(nu, lo), np.full(nu, hi))
             N, H = int(rng.choice([17, 64, 100, 300])), int(rng.integers(2, 20))   # (H = 1 raises in the reference: a[-2])
@@ -79,7 +94,7 @@ def main():
             seed = int(rng.integers(1 << 30))
             omodel = MLPOracle(system, p)
             np.random.seed(seed)
-            orc = MPPIOracle(omodel, QuadCostOracle(Q, R, F, goal), np.tile([lo, hi], (nu, 1)),
+            orc = MPPIOracle(omodel, orc_cost, np.tile([lo, hi], (nu, 1)),
                              horizon=H, num_path=N, sigma=sigma, lmda=lmda)
             np.random.seed(seed)
             ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
@@ -116,19 +131,31 @@ def main():
             if prec == "f64" and case % 3 == 0 and nx + nu <= 45:
                 Hh = int(rng.integers(3, 15))
                 t2 = Task(system)
-                t2.set_cost(QuadCost(system, Q, R, F, goal=goal))
+                t2.set_cost(hip_cost)
                 il = IterativeLQR(system, t2, m, Hh)
                 if use_jit:
                     il._device()
                     il._handle.jit_wait()
                 n_it = int(rng.integers(1, 7))
-                oil = ILQROracle(omodel, QuadCostOracle(Q, R, F, goal), system.dt, Hh, max_iter=n_it)
+                oil = ILQROracle(omodel, orc_cost, system.dt, Hh, max_iter=n_it)
                 r1 = il._device().solve(obs[None, :], np.zeros((1, Hh, nu)), n_it)
                 co, so, uo2, Ko, ko = oil.solve(obs, np.zeros((Hh, nu)))
                 ei = max(rel(r1["states"][0], so), rel(r1["Ks"][0], Ko))
                 worst["ilqr"] = max(worst["ilqr"], ei / 1e-6)
                 if ei > 1e-6:
                     bad.append((tag + " H=%d" % Hh, "ilqr", ei, 0.0))
+                # the same solve as problem 2 of 5 streamed through a two-slot queue: bit-identical
+                if case % 2 == 0:
+                    from autompc_amd import _lib
+                    xs = np.stack([obs + 0.01 * k for k in (-2, -1, 0, 1, 2)])
+                    qp = _lib.IlqrPlan(il._handle, 2, Hh, system.dt, clip_to_bounds=False,
+                                       terminal_goal=il._terminal_goal)
+                    rq = qp.solve_queue(xs, max_iter=n_it)
+                    qp.close()
+                    same = all(np.array_equal(rq[k][2], r1[k][0]) for k in ("states", "ctrls", "Ks", "ks", "iters"))
+                    worst["ilqr_queue"] = max(worst.get("ilqr_queue", 0.0), 0.0 if same else 1e9)
+                    if not same:
+                        bad.append((tag + " H=%d" % Hh, "ilqr queue differs from the one-problem solve", 0.0, 0.0))
         except Exception as ex:          # noqa: BLE001 -- report and continue
             bad.append((tag, "exception", repr(ex)[:200], 0.0))
     # ---- linear models, closed loop and device scoring ------------------------------------------
@@ -141,9 +168,11 @@ def main():
     os.environ["AMPC_MT"] = "0"
     for case in range(max(4, n_cases // 10)):
         ns, nu = int(rng.integers(1, 65)), int(rng.integers(1, 9))     # 33..64: the four-output-tile path
+        if case % 3 == 2:
+            ns = int(rng.integers(65, 257))                              # 65..256: csrc/linear_kernels.hpp
         if ns <= 32 and ns + nu > 48:
             nu = 48 - ns
-        no = int(rng.integers(1, ns + 1))
+        no = int(rng.integers(1, min(ns, 64) + 1))
         system = System(["x%d" % i for i in range(no)], ["u%d" % i for i in range(nu)], dt=0.05)
         S = rng.normal(size=(ns, ns))
         A = np.eye(ns) * 0.9 + 0.1 * (S - S.T) / max(1.0, np.sqrt(ns))
