@@ -84,10 +84,13 @@ def cpu_model_name():
 def _timed_legs(run_once, budget_s, min_all=3, target=20):
     """Two legs -- all host cores, then one thread -- each: one untimed call, then consecutive timed
     calls until `target` of them or `budget_s` seconds (at least min_all / 1).  Per-call times ->
-    median, p10, p90."""
+    median, p10, p90.  (torch's intra-op pool follows the same limit.)"""
+    import torch
     from threadpoolctl import threadpool_limits
     legs = {}
+    torch_default = torch.get_num_threads()
     for name, limit, lo in (("all_cores", None, min_all), ("one_thread", 1, 1)):
+        torch.set_num_threads(limit if limit else torch_default)
         with threadpool_limits(limits=limit if limit else os.cpu_count()):
             run_once()
             times, t_start = [], time.perf_counter()
@@ -99,19 +102,32 @@ def _timed_legs(run_once, budget_s, min_all=3, target=20):
         legs[name] = {"value": float(1.0 / np.median(t)), "unit": "solves/s", "solves": len(times),
                       "median_s": float(np.median(t)), "p10_s": float(np.percentile(t, 10)),
                       "p90_s": float(np.percentile(t, 90)), "threads": limit or os.cpu_count()}
+    torch.set_num_threads(torch_default)
     return legs
 
 
-def _baseline_record(legs, sample):
-    # the FASTER of the two legs is the baseline (on a many-core host the tiny per-step GEMMs of
-    # this path run slower on all cores than on one); both legs are reported in full
-    best = max(legs.values(), key=lambda leg: leg["value"])
-    return {"value": best["value"], "unit": "solves/s", "cores": best["threads"], "kind": "port",
-            "cpu": cpu_model_name(), "host_cores": os.cpu_count(),
-            "sample": "%s; all-core leg %d solves, one-thread leg %d solves; value = 1 / median solve "
-                      "time of the faster leg (%d thread(s))"
-                      % (sample, legs["all_cores"]["solves"], legs["one_thread"]["solves"], best["threads"]),
-            "all_cores": legs["all_cores"], "one_thread": legs["one_thread"]}
+def _baseline_record(legs, sample, torch_legs=None):
+    # the FASTEST leg is the baseline (on a many-core host the tiny per-step GEMMs of this path run
+    # slower on all cores than on one); all legs are reported in full.  torch_legs: the same workload with
+    # the model evaluated the way the reference does it (oracle.mlp.MLPOracleTorch: torch f64 nn.Linear on
+    # the CPU, numpy <-> torch copies and per-column normalisation loops per call, mlp.py:20-30,219-236) --
+    # SURVEY.md section 8d's protocol; the numpy restatement is the faster one, so the ratio is conservative
+    every = dict(legs)
+    if torch_legs:
+        every.update({"torch_" + k: v for k, v in torch_legs.items()})
+    best = max(every.values(), key=lambda leg: leg["value"])
+    rec = {"value": best["value"], "unit": "solves/s", "cores": best["threads"], "kind": "port",
+           "cpu": cpu_model_name(), "host_cores": os.cpu_count(),
+           "sample": "%s; all-core leg %d solves, one-thread leg %d solves; value = 1 / median solve "
+                     "time of the fastest leg (%d thread(s))"
+                     % (sample, legs["all_cores"]["solves"], legs["one_thread"]["solves"], best["threads"]),
+           "all_cores": legs["all_cores"], "one_thread": legs["one_thread"]}
+    if torch_legs:
+        rec["reference_call_structure"] = {
+            "note": "model evaluated as the reference does (torch f64 nn.Linear on the CPU, numpy <-> torch copies, "
+                    "per-column normalisation loops: mlp.py:20-30, 219-236)",
+            "all_cores": torch_legs["all_cores"], "one_thread": torch_legs["one_thread"]}
+    return rec
 
 
 def cpu_baseline_mppi(workload, spec, budget_s):
@@ -154,9 +170,19 @@ def cpu_baseline_mppi(workload, spec, budget_s):
 
     def run_once():
         _, state["cs"] = ctl.run(state["cs"], x0)
-    return _baseline_record(_timed_legs(run_once, budget_s),
+    legs = _timed_legs(run_once, budget_s)
+    torch_legs = None
+    if "sindy" not in spec and "linear" not in spec:
+        from oracle.mlp import MLPOracleTorch
+        np.random.seed(0)
+        ctl = MPPIOracle(MLPOracleTorch(system, model.params), cost, bnd, horizon=spec["horizon"],
+                         num_path=spec["num_path"], sigma=1.0, lmda=1.0, strict_reference=True)
+        state["cs"] = cs
+        torch_legs = _timed_legs(run_once, budget_s / 2, min_all=2, target=10)
+    return _baseline_record(legs,
                             "consecutive %s MPPI solves feeding back the controller state (oracle: numpy f64 "
-                            "pred_batch per step + the reference's per-particle Python cost loop)" % workload)
+                            "pred_batch per step + the reference's per-particle Python cost loop)" % workload,
+                            torch_legs)
 
 
 def cpu_baseline_ilqr(system, spec, x0s, budget_s, bounded=False):
@@ -396,6 +422,35 @@ def secondary_workload(args, R, emit=True):
                                   "value": world * 4096 / e, "unit": "solves/s", "ms": 1e3 * e,
                                   "converged_fraction": float(o["converged"].mean()),
                                   "mean_iterations_per_solve": float(o["iters"].mean())}
+            # two independent queues of B slots each (own handle / stream / host thread): the kernels of one
+            # fill the compute units the other's lock-step launches leave idle (decided line searches,
+            # retired slots)
+            import threading
+            h2 = _lib.Handle(R.local_rank, args.precision)          # (a stream of its own)
+            model.stage_into(h2)
+            h2.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
+            h2.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
+            plan2 = _lib.IlqrPlan(h2, B, 50, system.dt, clip_to_bounds=True)
+
+            def two_queues():
+                res = [None, None]
+
+                def run(k, pl, xs):
+                    res[k] = pl.solve_queue(xs, max_iter=50, gains=False, trajectories=False)
+                th = [threading.Thread(target=run, args=(0, plan, x0[:2048])),
+                      threading.Thread(target=run, args=(1, plan2, x0[2048:4096]))]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                h2.synchronize()
+                return {k: np.concatenate([r[k] for r in res]) for k in ("converged", "iters")}
+            o, e = once(two_queues)
+            sub["two_queues_4096"] = {"workload": "4096 problems through two queues of %d slots on two streams" % B,
+                                      "value": world * 4096 / e, "unit": "solves/s", "ms": 1e3 * e,
+                                      "converged_fraction": float(o["converged"].mean())}
+            plan2.close()
+            h2.close()
             # the same P problems as lock-step batches of B (ampc_ilqr_solve: a batch lasts as long as
             # its slowest problem) -- what round 3 measured
 

@@ -139,3 +139,73 @@ class MLPOracle:
 
     def pred_diff_batch(self, states, ctrls):
         return pred_diff_batch(self.params, states, ctrls)
+
+
+class MLPOracleTorch(MLPOracle):
+    """The same model with the reference's own CALL STRUCTURE (for the CPU baseline's timing, SURVEY.md
+    section 8d): torch f64 ``nn.Linear`` layers on the CPU, a numpy -> torch -> numpy copy per call and
+    the column-by-column Python normalisation loops (mlp.py:20-30 transform_input / transform_output,
+    :55-59 ForwardNet.forward, :219-236 pred / pred_batch), Jacobians by autograd over an obs_dim-fold
+    repeated batch (mlp.py:238-305).  Same values as the numpy restatement to rounding
+    (tests/test_oracle_golden.py)."""
+
+    def __init__(self, system, params):
+        super().__init__(system, params)
+        import torch
+        self._torch = torch
+        self._W = [torch.from_numpy(np.ascontiguousarray(w)) for w in params["weights"]]
+        self._b = [torch.from_numpy(np.ascontiguousarray(b)) for b in params["biases"]]
+        self._act = {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "selu": torch.selu}[
+            params["activation"]]
+
+    @staticmethod
+    def _transform_input(means, std, XU):                 # mlp.py:20-24
+        cols = []
+        for i in range(XU.shape[1]):
+            cols.append((XU[:, i] - means[i]) / std[i])
+        return np.vstack(cols).T
+
+    @staticmethod
+    def _transform_output(means, std, XU):                # mlp.py:26-30
+        cols = []
+        for i in range(XU.shape[1]):
+            cols.append((XU[:, i] * std[i]) + means[i])
+        return np.vstack(cols).T
+
+    def _forward(self, x):                                # mlp.py:55-59
+        F = self._torch.nn.functional
+        for W, b in zip(self._W[:-1], self._b[:-1]):
+            x = self._act(F.linear(x, W, b))
+        return F.linear(x, self._W[-1], self._b[-1])
+
+    def pred_batch(self, states, ctrls):                  # mlp.py:229-236
+        p = self.params
+        X = np.concatenate([states, ctrls], axis=1)
+        Xt = self._transform_input(p["xu_means"], p["xu_std"], X)
+        with self._torch.no_grad():
+            yout = self._forward(self._torch.from_numpy(Xt)).cpu().numpy()
+        dy = self._transform_output(p["dy_means"], p["dy_std"], yout).flatten()
+        return states + dy.reshape((states.shape[0], self.state_dim))
+
+    def pred(self, state, ctrl):                          # mlp.py:219-227
+        return self.pred_batch(state[None, :], ctrl[None, :])[0]
+
+    def pred_diff_batch(self, states, ctrls):             # mlp.py:281-305
+        torch, p = self._torch, self.params
+        X = np.concatenate([states, ctrls], axis=1)
+        Xt = self._transform_input(p["xu_means"], p["xu_std"], X)
+        n, m = states.shape[1], states.shape[0]
+        T = torch.from_numpy(Xt).repeat(n, 1, 1).permute(1, 0, 2).flatten(0, 1)
+        T.requires_grad_(True)
+        predy = self._forward(T)
+        predy.backward(torch.eye(n, dtype=predy.dtype).repeat(m, 1), retain_graph=True)
+        predy = predy.reshape((m, n, n))
+        jac = T.grad.cpu().data.numpy().reshape((m, n, T.shape[-1]))
+        jac = jac / np.tile(p["xu_std"], (m, n, 1)) * np.tile(p["dy_std"], (m, 1))[:, :, np.newaxis]
+        out = predy[:, 0, :].cpu().data.numpy()
+        dy = self._transform_output(p["dy_means"], p["dy_std"], out)
+        return states + dy, jac[:, :, :n] + np.tile(np.eye(n), (m, 1, 1)), jac[:, :, n:]
+
+    def pred_diff(self, state, ctrl):                     # mlp.py:238-279 (same values as the batch form)
+        o, a, b = self.pred_diff_batch(state[None, :], ctrl[None, :])
+        return o[0], a[0], b[0]

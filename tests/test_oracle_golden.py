@@ -271,3 +271,18 @@ def test_evalcfg_sumcost_matches_reference():
     s, obs, ctrls = eval_cfg_episode(ctl, g["init"], model, int(g["num_steps"]), task_cost.traj_cost)
     assert rel_err(obs, g["surr_obs"]) < 1e-6 and rel_err(ctrls, g["surr_ctrls"]) < 1e-6
     assert abs(s - g["surr_cost"]) < 1e-6 * abs(g["surr_cost"])
+
+
+@pytest.mark.parametrize("name", ["mlp_hc6_relu", "mlp_cp3_selu", "mlp_deep4_tanh", "mlp_odd1_sigmoid"])
+def test_torch_structured_oracle_matches_reference(name):
+    """MLPOracleTorch -- the reference's own call structure (torch f64 nn.Linear, per-column
+    normalisation loops, autograd Jacobians), used by bench.py's CPU baseline -- against the same goldens."""
+    from oracle.mlp import MLPOracleTorch
+    g = golden(name)
+    nx, nu = int(g["nx"]), int(g["nu"])
+    p = golden_params(nx, nu, g["hidden"], g["activation"], g["seed"])
+    m = MLPOracleTorch(make_system(nx, nu), p)
+    assert rel_err(m.pred_batch(g["states"], g["ctrls"]), g["pred_batch"]) < 1e-11
+    o, jx, ju = m.pred_diff_batch(g["states"], g["ctrls"])
+    assert rel_err(o, g["diff_pred"]) < 1e-11 and rel_err(jx, g["diff_jx"]) < 1e-10 and rel_err(ju, g["diff_ju"]) < 1e-10
+    assert rel_err(m.pred(g["states"][0], g["ctrls"][0]), g["pred0"]) < 1e-11
