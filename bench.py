@@ -81,7 +81,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def _timed_legs(run_once, budget_s, min_all=3, target=20):
+def _timed_legs(run_once, budget_s, min_all=3, target=20, only=None):
     """Two legs -- all host cores, then one thread -- each: one untimed call, then consecutive timed
     calls until `target` of them or `budget_s` seconds (at least min_all / 1).  Per-call times ->
     median, p10, p90.  (torch's intra-op pool follows the same limit.)"""
@@ -90,11 +90,17 @@ def _timed_legs(run_once, budget_s, min_all=3, target=20):
     legs = {}
     torch_default = torch.get_num_threads()
     for name, limit, lo in (("all_cores", None, min_all), ("one_thread", 1, 1)):
+        if only and name not in only:
+            continue
         torch.set_num_threads(limit if limit else torch_default)
         with threadpool_limits(limits=limit if limit else os.cpu_count()):
+            t0 = time.perf_counter()
             run_once()
+            first = time.perf_counter() - t0
             times, t_start = [], time.perf_counter()
-            while len(times) < target and (len(times) < lo or time.perf_counter() - t_start < budget_s):
+            if first > budget_s:              # one call already exceeds the leg's budget: it is the sample
+                times, lo = [first], 0
+            while len(times) < target and (len(times) < lo or time.perf_counter() - t_start < budget_s) and lo > 0:
                 t0 = time.perf_counter()
                 run_once()
                 times.append(time.perf_counter() - t0)
@@ -123,10 +129,9 @@ def _baseline_record(legs, sample, torch_legs=None):
                      % (sample, legs["all_cores"]["solves"], legs["one_thread"]["solves"], best["threads"]),
            "all_cores": legs["all_cores"], "one_thread": legs["one_thread"]}
     if torch_legs:
-        rec["reference_call_structure"] = {
-            "note": "model evaluated as the reference does (torch f64 nn.Linear on the CPU, numpy <-> torch copies, "
-                    "per-column normalisation loops: mlp.py:20-30, 219-236)",
-            "all_cores": torch_legs["all_cores"], "one_thread": torch_legs["one_thread"]}
+        rec["reference_call_structure"] = dict(
+            note="model evaluated as the reference does (torch f64 nn.Linear on the CPU, numpy <-> torch copies, "
+                 "per-column normalisation loops: mlp.py:20-30, 219-236)", **torch_legs)
     return rec
 
 
@@ -178,7 +183,9 @@ def cpu_baseline_mppi(workload, spec, budget_s):
         ctl = MPPIOracle(MLPOracleTorch(system, model.params), cost, bnd, horizon=spec["horizon"],
                          num_path=spec["num_path"], sigma=1.0, lmda=1.0, strict_reference=True)
         state["cs"] = cs
-        torch_legs = _timed_legs(run_once, budget_s / 2, min_all=2, target=10)
+        # (one thread only: on all 256 hardware threads torch's tiny f64 GEMMs take 24 s per c3 solve --
+        #  0.041 solves/s, measured once in round 4 -- which would be most of this bench's run time)
+        torch_legs = _timed_legs(run_once, budget_s / 2, target=10, only=("one_thread",))
     return _baseline_record(legs,
                             "consecutive %s MPPI solves feeding back the controller state (oracle: numpy f64 "
                             "pred_batch per step + the reference's per-particle Python cost loop)" % workload,
