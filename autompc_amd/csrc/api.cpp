@@ -133,6 +133,17 @@ extern "C" int ampc_precision(const ampc_handle* h) { return h ? h->precision : 
 
 // ---------------------------------------------------------------------------------------------
 // weight packing (host, double) -- layouts documented in mlp_tile.hpp
+// Which line-search kernel the next launches of a many-problem plan take (ampc_ilqr_plan::ls_rb): the
+// four-row kernel's launch lasts as many passes as its slowest search, the twelve-row kernel's about 2.4
+// passes' time whatever the searches need -- twelve rows once some active slot's last search needed a
+// third pass.  (A speed heuristic only: both kernels give the same results bit for bit.)
+static int ls_rb_from_poll(const int* active, const int* need, int B) {
+  int most = 0;
+  for (int b = 0; b < B; ++b)
+    if (active[b] != 0 && need[b] > most) most = need[b];
+  return most >= 3 ? 3 : 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // B[k][n] supplied by a functor; N-split over W waves, NT tiles per wave.
 // own_first: wave w's stream starts at k-group w (8 k-steps per group) and wraps around -- the
@@ -1405,6 +1416,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   p->use_mfma_sweep = env_int("AMPC_RICCATI", 1) != 0;
   p->par_passes = env_int("AMPC_LS4_PAR", 1) != 0;
   p->ls_split = env_int("AMPC_LS4_SPLIT", 0) != 0;
+  { const int rb = env_int("AMPC_LS4_RB", 0); p->ls_rb = (rb == 1 || rb == 3) ? rb : 0; }
   p->static_shape = -1;
   p->jit = nullptr;
   if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
@@ -1433,8 +1445,8 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(p->ls_states.reserve((size_t)B * p->ls_n * (H + 1) * nx * e));
   HIP_OK(p->ls_ctrls.reserve((size_t)B * p->ls_n * H * nu * e));
   HIP_OK(p->obj.reserve((size_t)B * e));
-  HIP_OK(p->flags.reserve((size_t)8 * B * sizeof(int)));
-  HIP_OK(hipMemset(p->flags.p, 0, (size_t)8 * B * sizeof(int)));
+  HIP_OK(p->flags.reserve((size_t)9 * B * sizeof(int)));
+  HIP_OK(hipMemset(p->flags.p, 0, (size_t)9 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
   if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
@@ -1544,8 +1556,9 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
   if (int rc = ilqr_launch_iter<T>(p, 0)) return rc;        // rollout of the guess + objective
   if (int rc = ilqr_refresh_jacobians<T>(p)) return rc;
   std::vector<int> flags(7 * B);
-  HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)3 * B * sizeof(int), h->stream));   // ls_rows, ls_count, ls_pass
-  if (!p->poll_host) HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * B * sizeof(int), hipHostMallocDefault));
+  HIP_OK(hipMemsetAsync((int*)p->flags.p + 5 * B, 0, (size_t)4 * B * sizeof(int), h->stream));   // ls_rows, ls_count, ls_pass, ls_need
+  p->ls_rb_now = 1;
+  if (!p->poll_host) HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)4 * B * sizeof(int), hipHostMallocDefault));
   if (!p->poll_ev[0])
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
   // Iterations are queued in batches of kPoll; the `active` flags of a batch are copied out behind
@@ -1578,14 +1591,18 @@ static int ilqr_solve_impl(ampc_ilqr_plan* p, const double* x0, const double* ug
     }
     it += n;
     const int slot = batch & 1;
-    HIP_OK(hipMemcpyAsync(p->poll_host + (size_t)slot * B, (const int*)p->flags.p + B, (size_t)B * sizeof(int),
+    HIP_OK(hipMemcpyAsync(p->poll_host + (size_t)slot * 2 * B, (const int*)p->flags.p + B, (size_t)B * sizeof(int),
                           hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(p->poll_host + (size_t)slot * 2 * B + B, (const int*)p->flags.p + 8 * B,
+                          (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
     if (pending >= 0) {
       const int ps = pending & 1;
       HIP_OK(hipEventSynchronize(p->poll_ev[ps]));
+      const int* pa = p->poll_host + (size_t)ps * 2 * B;
       int live = 0;
-      for (int b = 0; b < B; ++b) live += p->poll_host[(size_t)ps * B + b] != 0;
+      for (int b = 0; b < B; ++b) live += pa[b] != 0;
+      p->ls_rb_now = ls_rb_from_poll(pa, pa + B, B);
       p->active_hint = live;          // (as of two batches ago: an upper bound of the current count)
       if (live == 0) done = true;
     }
@@ -1653,10 +1670,11 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   HIP_OK(upload_converted<T>(p->q_x0.p, x0, (size_t)P * nx, h->stream));
   if (uguess) HIP_OK(upload_converted<T>(p->q_u.p, uguess, (size_t)P * H * nu, h->stream));
   else HIP_OK(hipMemsetAsync(p->q_u.p, 0, (size_t)P * H * nu * e, h->stream));
-  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)8 * B * sizeof(int), h->stream));     // every slot idle
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)9 * B * sizeof(int), h->stream));     // every slot idle
   HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  const int npoll = B + 2;
+  const int npoll = 2 * B + 2;               // active[B], ls_need[B], the queue's two counters
+  p->ls_rb_now = 1;
   if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
   HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * npoll * sizeof(int), hipHostMallocDefault));
   if (!p->poll_ev[0])
@@ -1710,16 +1728,18 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
     const int slot = batch & 1;
     int* ph = p->poll_host + (size_t)slot * npoll;
     HIP_OK(hipMemcpyAsync(ph, (const int*)p->flags.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(ph + B, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(ph + B, (const int*)p->flags.p + 8 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(ph + 2 * B, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
     if (pending >= 0) {
       const int* pp = p->poll_host + (size_t)(pending & 1) * npoll;
       HIP_OK(hipEventSynchronize(p->poll_ev[pending & 1]));
       int live = 0;
       for (int b = 0; b < B; ++b) live += pp[b] != 0;
+      p->ls_rb_now = ls_rb_from_poll(pp, pp + B, B);
       // while the queue still holds problems every slot is (about to be) busy
-      p->active_hint = pp[B] < P ? B : std::max(live, 1);
-      if (pp[B + 1] >= P) done = true;
+      p->active_hint = pp[2 * B] < P ? B : std::max(live, 1);
+      if (pp[2 * B + 1] >= P) done = true;
     }
     pending = batch++;
   }
@@ -1797,7 +1817,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   HIP_OK(hipMemsetAsync(p->c_ctl.p, 0, (size_t)C * T1 * nu * e, h->stream));
   HIP_OK(hipMemsetAsync(p->c_stage.p, 0, (size_t)B * (2 * nx + nu) * e, h->stream));
   HIP_OK(upload_converted<T>(p->q_x0.p, init_obs, (size_t)C * nx, h->stream));
-  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)8 * B * sizeof(int), h->stream));
+  HIP_OK(hipMemsetAsync(p->flags.p, 0, (size_t)9 * B * sizeof(int), h->stream));
   HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
@@ -1811,6 +1831,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   p->queue_on = true;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
+  p->ls_rb_now = 3;     // (episodes: the slots' solves are at every stage at once -- some search always needs all step sizes)
   IlqrChains<T> q;
   q.C = C; q.B = B; q.H = H; q.nx = nx; q.nu = nu; q.n_steps = n_steps; q.max_iter = max_iter;
   q.ctl = (int*)p->q_ctl.p;

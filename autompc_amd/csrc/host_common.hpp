@@ -23,6 +23,7 @@
 #include "linear_kernels.hpp"
 #include "ilqr_kernels.hpp"
 #include "ilqr_ls4.hpp"
+#include "ilqr_lsw.hpp"
 #include "mppi_kernels.hpp"
 #include "mppi_rollout4.hpp"
 #include "rng_kernels.hpp"
@@ -382,10 +383,16 @@ struct ampc_ilqr_plan {
   double dt = 0, u_threshold = 1e-3, ls_discount = 0.2, ls_cost_threshold = 0.3;
   std::vector<int> cost_idx;
   DevBuf d_cost_idx, states, ctrls, jx, ju, Ks, ks, ls_states, ls_ctrls, obj, flags, dz, ric;
-  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B] ls_count[B] ls_pass[B]
+  // flags layout (ints): converged[B] active[B] iters[B] status[B] refresh[B] ls_rows[B] ls_count[B] ls_pass[B] ls_need[B]
   int use_ls4 = 1, use_mfma_sweep = 1, par_passes = 1;   // (AMPC_LS4_PAR = 0: passes one after the other)
   int ls_split = 0;          // (AMPC_LS4_SPLIT = 1: large batches search in two launches, ilqr_ls4.hpp; measured: no gain)
-  int unused_ = 0;   // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
+  // Line-search kernel when the passes are NOT side by side (many problems per launch, in lock-step):
+  // four-row passes (ilqr_ls4.hpp: a launch lasts as many passes as its slowest search needs) or all step
+  // sizes in one twelve-row pass (ilqr_lsw.hpp: 2.4 four-row passes' time whatever the searches need).
+  // ls_rb: 0 = chosen per poll from what the slots' last searches needed (ls_need: twelve rows as soon as
+  // some search needed a third pass), 1 / 3 = AMPC_LS4_RB forces one.  Same results either way.
+  int ls_rb = 0, ls_rb_now = 1;
+  // kernel choices, fixed at plan build (AMPC_LS4 / AMPC_RICCATI = 0: the general kernels)
   TileLds L{};
   int lds_work = 0, lds_xn = 0;
   size_t lds_bytes = 0;
@@ -440,7 +447,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.obj = (T*)p->obj.p;
   int* f = (int*)p->flags.p;
   a.converged = f; a.active = f + p->B; a.iters = f + 2 * p->B; a.status = f + 3 * p->B;
-  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B; a.ls_count = f + 6 * p->B; a.ls_pass = f + 7 * p->B;
+  a.refresh = f + 4 * p->B; a.ls_rows = f + 5 * p->B; a.ls_count = f + 6 * p->B; a.ls_pass = f + 7 * p->B; a.ls_need = f + 8 * p->B;
   a.ric = (T*)p->ric.p;
   if (p->queue_on) {
     a.slot_mode = (int*)p->q_ctl.p + 2 + p->B;

@@ -50,6 +50,8 @@ template <typename T> struct IlqrArgs {
   int ls_split;                  // four-row line search in two launches (ilqr_ls4.hpp): 0 no, 1 first launch
                                  // (pass 0 for every problem), 2 second (the other passes side by side, for
   int* ls_pass;                  // the problems the first left undecided: ls_pass[p] = 1)
+  int* ls_need;                  // [B] four-row passes the slot's LAST line search needed (1..): what the host
+                                 // picks the line-search kernel of the next launches from (ilqr_lsw.hpp)
   int* slot_mode;                // queue mode (ampc_ilqr_solve_queue): per slot 0 = roll out the guess of the
                                  // problem just loaded, 1 = iterate; nullptr: `mode` for every problem
   int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it

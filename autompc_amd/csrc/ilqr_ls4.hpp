@@ -83,20 +83,26 @@ struct Ls4Lds {
   int xu, xs, act0, act1, as, part, bias, cpar, blo, bhi, scal, lsobj, piv, hres, w0, total;
 };
 // hidden-layer residency split (k-steps per round of KSH/8 = 2 NT): registers, LDS, streamed
-__host__ __device__ constexpr int ls4_rpr(int NT) { return NT <= 2 ? 2 * NT : (NT == 4 ? 3 : 4); }
-__host__ __device__ constexpr int ls4_lpr(int NT) { return NT == 4 ? 1 : 0; }
+// (rb = row blocks of the tile: 1 here, 3 in ilqr_lsw.hpp, whose activations of 4 rb rows take the LDS
+//  the resident k-steps had)
+// (rb > 1, NT = 4: two k-steps per round -- the twelve-row tile's own working set needs the registers, and
+//  its MFMA time hides six streamed k-steps per round)
+__host__ __device__ constexpr int ls4_rpr(int NT, int rb = 1) {
+  return NT <= 2 ? 2 * NT : (NT == 4 ? (rb > 1 ? 1 : 3) : 4);
+}
+__host__ __device__ constexpr int ls4_lpr(int NT, int rb = 1) { return NT == 4 && rb == 1 ? 1 : 0; }
 // first-layer fragments in LDS instead of registers
 __host__ __device__ constexpr bool ls4_w0_lds(int NT) { return NT >= 3; }
 __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int hpad, int n_hidden, bool res,
-                                                  int cost_stride) {
-  const int NT = hpad / 64, W = kLs4W;
+                                                  int cost_stride, int rb = 1) {
+  const int NT = hpad / 64, W = kLs4W, rows = 4 * rb;
   Ls4Lds L{};
   int o = 0;
   L.xs = k1p + 1; L.as = hpad + 1;
-  L.xu = o; o += 4 * L.xs;
-  L.act0 = o; o += 4 * L.as;
-  L.act1 = o; o += 4 * L.as;
-  L.part = o; o += W * 4 * nxp;
+  L.xu = o; o += rows * L.xs;
+  L.act0 = o; o += rows * L.as;
+  L.act1 = o; o += rows * L.as;
+  L.part = o; o += W * rows * nxp;
   L.bias = o; o += n_hidden * hpad + nxp;
   L.cpar = o; o += cost_stride;
   L.blo = o; o += nu;
@@ -105,7 +111,7 @@ __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int 
   L.lsobj = o; o += 2 * kIlqrMaxLs;
   L.piv = o; o += 8;
   o = (o + 3) / 4 * 4;                               // 32-byte aligned fragment reads
-  L.hres = o; o += res ? W * 8 * ls4_lpr(NT) * 64 * NT : 0;
+  L.hres = o; o += res ? W * 8 * ls4_lpr(NT, rb) * 64 * NT : 0;
   L.w0 = o; o += ls4_w0_lds(NT) ? W * (k1p / 4) * 64 * NT : 0;
   L.total = (o + 3) / 4 * 4;
   return L;
@@ -534,6 +540,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     scal[3] = new_obj;
     args.iters[p] += 1;
     args.ls_rows[p] += par ? ROWS * npass : ROWS * (last / ROWS + 1);
+    args.ls_need[p] = last / 4 + 1;
   }
   __syncthreads();
   const int sel = piv[0], fail = piv[1], success = piv[2];

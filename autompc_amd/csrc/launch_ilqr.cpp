@@ -83,20 +83,32 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   if constexpr (sizeof(T) == 8) {
     // one hidden -> hidden layer: that layer partly resident on chip (registers + LDS)
     const bool res = h->n_hidden == 2;
-    const size_t lb = (p->use_ls4 && !h->has_sindy && h->nx <= 32)
+    const bool ls4_ok = p->use_ls4 && !h->has_sindy && h->nx <= 32;
+    size_t lb = ls4_ok
         ? (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res, h->cost_stride).total * sizeof(T)
         : 0;
     // (a wide first layer with many controls can push the resident LDS copies past 160 KB: those
     //  shapes take the general kernel below)
     if (lb > 0 && lb <= kLdsLimit) {
       // few problems: the passes of a line search side by side on otherwise idle CUs
-      const int npass = (p->ls_n + 3) / 4;
+      int npass = (p->ls_n + 3) / 4;
       // (retired problems' workgroups exit at once, so what has to fit is the ACTIVE problems' passes)
       const int live = (p->active_hint > 0 && p->active_hint < p->B) ? p->active_hint : p->B;
       a.par_passes = (mode == 1 && p->par_passes && live * npass <= h->n_cus) ? 1 : 0;
       // many problems: the line search in two launches -- pass 0 for everybody, then the remaining
       // passes side by side for the problems it left undecided (ilqr_ls4.hpp)
       const bool split = mode == 1 && !a.par_passes && p->ls_split && npass > 1;
+      // many problems in lock-step: all step sizes in one pass of a twelve-row tile (ilqr_lsw.hpp) once
+      // some search of the batch needs a third four-row pass (the launch lasts as long as its slowest
+      // search); the host picks from the slots' last searches (ls_need), see ampc_ilqr_plan::ls_rb.
+      // (A whole-batch rollout of the guess, mode 0 without per-slot modes, has one row per problem.)
+      int rb = 1;
+      const bool wide = p->ls_rb == 3 || (p->ls_rb == 0 && p->ls_rb_now == 3);
+      if (!a.par_passes && !split && wide && npass > 1 && (mode == 1 || a.slot_mode)) {
+        const size_t lb3 = (size_t)make_ls4_lds(h->nu, h->k1p, h->nxp, h->hpad, h->n_hidden, res, h->cost_stride, 3)
+                               .total * sizeof(T);
+        if (lb3 <= kLdsLimit) { rb = 3; lb = lb3; npass = (p->ls_n + 11) / 12; }
+      }
       auto launch_ls = [&](const dim3 grid, const IlqrArgs<T>& a) -> int {
         if (p->static_shape >= 0) {
           // (the activation is a compile-time constant for relu AND tanh here: with the run-time
@@ -105,7 +117,8 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
 #define AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, ACTV)                                            \
           case (ID) * 8 + ((ACTV) < 0 ? 7 : (ACTV)): {                                               \
             using SH = StaticShape<NX, NU, NO, NH, HPAD, ACTV>;                                      \
-            auto k = ilqr_ls4_kernel<HPAD / 64, NH == 2, SH>; HIP_OK(allow_lds(k, lb));              \
+            auto k = rb == 3 ? ilqr_lsw_kernel<HPAD / 64, NH == 2, SH, 3>                            \
+                             : ilqr_ls4_kernel<HPAD / 64, NH == 2, SH>; HIP_OK(allow_lds(k, lb));       \
             hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
 #define AMPC_LS4_ONE(ID, NX, NU, NO, NH, HPAD)                                                    \
           AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 0) AMPC_LS4_SHAPE(ID, NX, NU, NO, NH, HPAD, 1)    \
@@ -121,7 +134,8 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
           return fail("shape plugin entered without its static shape");
 #else
 #define AMPC_LS4_CASE(NTV, RESV)                                                               \
-          case (NTV) * 2 + (RESV): { auto k = ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;        \
+          case (NTV) * 2 + (RESV): { auto k = rb == 3 ? ilqr_lsw_kernel<NTV, (RESV) != 0, DynShape, 3>  \
+                                                      : ilqr_ls4_kernel<NTV, (RESV) != 0, DynShape>;    \
             HIP_OK(allow_lds(k, lb));                                                            \
             hipLaunchKernelGGL(k, grid, dim3(64 * kLs4W), lb, h->stream, a); } break;
           switch ((h->hpad / 64) * 2 + (res ? 1 : 0)) {

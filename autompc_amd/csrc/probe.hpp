@@ -15,6 +15,7 @@
 //   sg8          whole-group weight streaming in f64
 //   side_late    the caller's side work after the hidden layers instead of inside them
 //   no_cost      dense stage cost skipped
+//   lsw_global   twelve-row line search: per-step traffic as global_load / global_store, not raw buffer
 //   wave_time    per-wave s_memtime marks of one rollout step, kept in registers
 //   phase_time   per-phase s_memtime marks of workgroup 7 in a device array
 #pragma once
@@ -89,6 +90,11 @@ struct Probe {
 #else
   AMPC_PROBE_FLAG(no_cost, false);
 #endif
+#ifdef AMPC_X_LSWGLOBAL
+  AMPC_PROBE_FLAG(lsw_global, true);
+#else
+  AMPC_PROBE_FLAG(lsw_global, false);
+#endif
 #ifdef AMPC_X_WAVETIME
   AMPC_PROBE_FLAG(wave_time, true);
 #else
@@ -124,7 +130,7 @@ __device__ long long g_wave_marks[8 * 16];
       for (int i_ = 0; i_ < 16; ++i_) g_wave_marks[(threadIdx.x >> 6) * 16 + i_] = _xm[i_];      \
   } while (0)
 #elif defined(AMPC_X_PHASETIME)
-__device__ long long g_phase_marks[64];
+__device__ long long g_phase_marks[128];   // (64..: per-wave register marks of the twelve-row line search)
 #define AMPC_PROBE_LOCALS(pw) do { } while (0)
 #define AMPC_MARK(idx)                                                              \
   do {                                                                              \
@@ -152,15 +158,29 @@ __device__ long long g_phase_marks[64];
 
 // phase marks of the iLQR kernels (tools/phasetime_ilqr.py): only in the phase_time build
 #if defined(AMPC_X_PHASETIME) && !defined(AMPC_X_WAVETIME)
+// low-perturbation variant (ilqr_lsw.hpp): every wave keeps its marks of one time step in registers
+#define AMPC_LSW_MARK(pm, on, i) do { if (on) (pm)[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define AMPC_LSW_DUMP(pm, w, n)                                                                   \
+  do {                                                                                            \
+    if (blockIdx.x == 7 && (threadIdx.x & 63) == 0)                                               \
+      for (int i_ = 0; i_ < (n); ++i_) g_phase_marks[64 + (w) * 16 + i_] = (pm)[i_];              \
+  } while (0)
 #define AMPC_IMARK(idx) AMPC_MARK(idx)
 #define AMPC_IMARK_ALWAYS(idx) AMPC_MARK_ALWAYS(idx)
 #define AMPC_IPROBE_STEP(cond) AMPC_PROBE_STEP(0, cond)
 #else
+#define AMPC_LSW_MARK(pm, on, i) do { } while (0)
+#define AMPC_LSW_DUMP(pm, w, n) do { } while (0)
 #define AMPC_IMARK(idx) do { } while (0)
 #define AMPC_IMARK_ALWAYS(idx) do { } while (0)
 #define AMPC_IPROBE_STEP(cond) do { } while (0)
 #endif
 
+#if defined(AMPC_X_PHASETIME) && !defined(AMPC_X_WAVETIME)
+#define AMPC_NMARKS 128
+#else
+#define AMPC_NMARKS 64
+#endif
 // host-side read-back entry points of the experiment builds (expanded in launch_*.cpp)
 #if defined(AMPC_X_WAVETIME) && defined(AMPC_T_IS_F64)
 #define AMPC_PROBE_HOST_MPPI                                                                        \
@@ -180,7 +200,7 @@ __device__ long long g_phase_marks[64];
 #define AMPC_PROBE_HOST_MPPI                                                                        \
   extern "C" int ampc_x_phase_marks(long long* out) {                                               \
     HIP_OK(hipDeviceSynchronize());                                                                 \
-    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));      \
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), AMPC_NMARKS * sizeof(long long)));      \
     return 0;                                                                                       \
   }
 #else
@@ -190,7 +210,7 @@ __device__ long long g_phase_marks[64];
 #define AMPC_PROBE_HOST_ILQR                                                                        \
   extern "C" int ampc_x_phase_marks_ilqr(long long* out) {                                          \
     HIP_OK(hipDeviceSynchronize());                                                                 \
-    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), 64 * sizeof(long long)));      \
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(ampc::g_phase_marks), AMPC_NMARKS * sizeof(long long)));      \
     return 0;                                                                                       \
   }
 #else

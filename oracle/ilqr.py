@@ -144,7 +144,7 @@ class ILQROracle:
                 Jacs[:, :, nx:] = jus
                 new_obj = self._objective(new_states, new_ctrls)
             self.trace.append((float(obj), float(new_obj), -1 if best_idx is None else int(best_idx),
-                               bool(ls_success)))
+                               bool(ls_success), int(last)))
             if (not ls_success and new_obj > obj + 1e-3) or best_idx is None:
                 break
             du_norm = np.linalg.norm(new_ctrls - ctrls)

@@ -329,3 +329,58 @@ def test_f32_ilqr_is_outside_the_parity_mode():
         assert worst[name] < 2e-2
     assert worst["ilqr_hc6_relu_free"] < 1e-4
     print("f32 iLQR state deviation from the reference:", worst)
+
+
+@pytest.mark.parametrize("nx,nu,hidden,act,bounded,affine", [
+    (17, 6, [256, 256], "relu", True, False),     # BASELINE config 4's shape: static-shape kernels, LDS first layer
+    (17, 6, [256, 256], "tanh", False, True),     # tanh instantiation; a sum-of-quadratics (affine) cost block
+    (17, 6, [200, 256], "tanh", True, False),     # run-time shapes, padded hidden width
+    (5, 2, [128, 100], "sigmoid", True, False),   # hidden layer fully register-resident, 16-column output
+    (9, 3, [192, 150], "relu", True, False),      # 192-wide: registers + streamed
+    (17, 6, [256], "relu", True, False),          # no hidden -> hidden layer
+    (8, 8, [256, 256, 256], "tanh", False, False),  # every hidden layer streamed (four-group ring)
+    (32, 16, [128, 128, 128, 128], "relu", True, False),
+])
+def test_twelve_row_line_search_equals_the_four_row_passes(monkeypatch, nx, nu, hidden, act, bounded, affine):
+    """ilqr_lsw_kernel (all step sizes in ONE pass of a twelve-row tile: what many-problem launches take once
+    some search needs a third four-row pass) against ilqr_ls4_kernel (four at a time, passes in sequence):
+    a row's arithmetic does not depend on the tile, the acceptance loop is the same -- every output is
+    identical bit for bit, whichever kernel runs and however the plan switches between them."""
+    from autompc_amd import _lib
+    H, B, dt = 15, 6, 0.05
+    p = omlp.random_params(nx, nu, hidden, act, seed=nx * 5 + nu)
+    rng = np.random.default_rng(nx + 3 * len(hidden))
+    Q = np.stack([rng.uniform(0.5, 2.0) * np.eye(nx) for _ in range(B)])
+    R = np.stack([np.diag(rng.uniform(0.05, 0.2, size=nu)) for _ in range(B)])
+    F = np.stack([np.diag(rng.uniform(0.5, 2.0, size=nx)) for _ in range(B)])
+    goal = rng.normal(scale=0.05, size=(B, nx))
+    x0 = rng.uniform(-0.3, 0.3, size=(B, nx))
+    lin = rng.normal(scale=0.1, size=(B, nx))
+    monkeypatch.setenv("AMPC_LS4_PAR", "0")           # (few problems: passes side by side would pre-empt both)
+    outs = {}
+    for rb in ("1", "3", "0"):                        # forced four rows, forced twelve, chosen per poll
+        monkeypatch.setenv("AMPC_LS4_RB", rb)
+        h = _lib.Handle(0, "f64")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], act, p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        if affine:
+            h.set_cost_blocks(Q, R, F, goal, lin, 0.5 * lin, np.zeros((B, 2)))
+        else:
+            h.set_quad_costs(Q, R, F, goal)
+        if bounded:
+            h.set_ctrl_bounds(-0.4 * np.ones(nu), 0.5 * np.ones(nu))
+        plan = _lib.IlqrPlan(h, B, H, dt, cost_index=np.arange(B), clip_to_bounds=bounded)
+        out = plan.solve(x0, np.zeros((B, H, nu)), max_iter=25)
+        out["rows"] = plan.stats()["candidate_rows"]
+        q = plan.solve_queue(np.concatenate([x0, x0[::-1]]), max_iter=25, cost_index=np.r_[np.arange(B), np.arange(B)[::-1]])
+        outs[rb] = (out, q)
+        plan.close(); h.close()
+    a, qa = outs["1"]
+    total = int(a["iters"].sum())
+    for rb in ("3", "0"):
+        b, qb = outs[rb]
+        for k in ("states", "ctrls", "Ks", "ks", "objective", "iters", "converged", "status"):
+            assert np.array_equal(a[k], b[k]), (rb, k)
+            assert np.array_equal(qa[k], qb[k]), (rb, "queue", k)
+    assert outs["3"][0]["rows"] == 10 * total          # twelve-row tile: all ten step sizes, every iteration
+    assert 4 * total <= a["rows"] <= 12 * total
+    assert a["rows"] <= outs["0"][0]["rows"] <= 12 * total

@@ -21,7 +21,7 @@ plan.generate_eps(0, 0)
 for _ in range(3):
     plan.solve()
 h.synchronize()
-marks = (ctypes.c_longlong * 64)()
+marks = (ctypes.c_longlong * 128)()
 lib = _lib.load()
 lib.ampc_x_phase_marks.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks(marks)

@@ -17,7 +17,7 @@ plan = _lib.IlqrPlan(h, B, H, system.dt)
 x0 = np.tile(task.get_init_obs(), (B, 1)) + np.random.default_rng(0).uniform(-0.01, 0.01, size=(B, nx))
 plan.solve(x0, np.zeros((B, H, nu)), 5)
 h.synchronize()
-marks = (ctypes.c_longlong * 64)()
+marks = (ctypes.c_longlong * 128)()
 lib = _lib.load()
 lib.ampc_x_phase_marks_ilqr.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 lib.ampc_x_phase_marks_ilqr(marks)
