@@ -480,8 +480,8 @@ def secondary_workload(args, R, emit=True):
         if rank == 0:
             # work of one solve: per iteration the Jacobian chain over H rows and the forward
             # pass of the accepted trajectory; the line search as EXECUTED -- candidate rows rolled out
-            # (four per pass; the reference rolls out all ten step sizes every iteration,
-            # ilqr.py:196-205, the same arithmetic per row); + the rollout of the guess
+            # (four per pass, or all ten in one twelve-row pass; the reference rolls out all ten step
+            # sizes every iteration, ilqr.py:196-205, the same arithmetic per row); + the rollout of the guess
             it = float(ob["iters"].mean())
             ls_rows = float(np.mean(last["rows"])) / P
             hid = sum(a * b for a, b in zip(spec["hidden"], spec["hidden"][1:]))
@@ -505,7 +505,9 @@ def secondary_workload(args, R, emit=True):
                 n_l = max(kt["launches"], 1)
                 jac_fl = steps * P * (it + 1) * jac / n_l
                 ls_fl = steps * P * ls_rows * row / n_l
-                cand = {"jacobian": (jac_fl, "mlp_jacobian_kernel"), "iter": (ls_fl, "ilqr_ls4_kernel")}
+                # (line search: ilqr_lsw_kernel -- all step sizes in one twelve-row pass -- once some search of
+                #  the launch needs a third four-row pass, else ilqr_ls4_kernel; chosen by the plan per poll)
+                cand = {"jacobian": (jac_fl, "mlp_jacobian_kernel"), "iter": (ls_fl, "ilqr_lsw_kernel")}
                 dom = max(cand, key=lambda k: kt.get(k + "_ms", 0.0))
                 fl, kname = cand[dom]
                 ach = fl / (kt[dom + "_ms"] * 1e-3) / 1e12

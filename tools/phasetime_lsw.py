@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["AMPC_LIB"] = os.path.join(ROOT, "variants", "lib_phasetime.so")
 os.environ["AMPC_LS4_PAR"] = "0"
+os.environ["AMPC_LS4_RB"] = "3"
 from autompc_amd import _lib                                   # noqa: E402
 from autompc_amd.synthetic import make_workload                # noqa: E402
 
