@@ -393,6 +393,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
         // (the stream's scalar offsets are base + constant: left alone, the compiler forms all of them once,
         //  outside the time loop, parks them in vector lanes and pays a v_readlane + hazard nop per load;
         //  an opaque base keeps them as one s_add each, next to the load)
+        sl = (unsigned)__builtin_amdgcn_readfirstlane((int)sl);   // (wave-uniform by construction; a layer index
+        sn = (unsigned)__builtin_amdgcn_readfirstlane((int)sn);   //  that is a run-time loop variable hides it)
         asm volatile("" : "+s"(sl), "+s"(sn));
         T acc[RB][NT];
 #pragma unroll
@@ -514,25 +516,34 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
     // ---- objectives of this wave's rows (ilqr.py:141-149, 206): dt * stage costs + terminal cost, from the stored
     // trajectory, one time step per lane -- kept off the serial chain of the rollout above
     __syncthreads();                                 // (orders this workgroup's trajectory stores)
+    {
+      // (the rows' sums side by side, time step outermost: three independent chains of loads and FMAs)
+      T obj_part[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      T obj_part = T(0);
-      const T* xsrc = mode == 0 ? stw : lss + (size_t)jw[r] * (H + 1) * nx;
-      const T* usrc = mode == 0 ? ctw : lsc + (size_t)jw[r] * H * nu;
-      if (livew[r])
-        for (int t = lane; t <= H; t += 64) {
+      for (int r = 0; r < RB; ++r) obj_part[r] = T(0);
+      for (int t = lane; t <= H; t += 64) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          if (!livew[r]) continue;
+          const T* xsrc = mode == 0 ? stw : lss + (size_t)jw[r] * (H + 1) * nx;
+          const T* usrc = mode == 0 ? ctw : lsc + (size_t)jw[r] * H * nu;
           const T* xt = xsrc + (size_t)t * nx;
-          if (t < H) obj_part += args.dt * (quad_rows<T>(Qm, xt, goal, no, 0, 1, cdiag) +
-                                            quad_rows<T>(Rm, usrc + (size_t)t * nu, nullptr, nu, 0, 1, cdiag));
-          else obj_part += quad_rows<T>(Fm, xt, goal, no, 0, 1, cdiag);
+          if (t < H) obj_part[r] += args.dt * (quad_rows<T>(Qm, xt, goal, no, 0, 1, cdiag) +
+                                               quad_rows<T>(Rm, usrc + (size_t)t * nu, nullptr, nu, 0, 1, cdiag));
+          else obj_part[r] += quad_rows<T>(Fm, xt, goal, no, 0, 1, cdiag);
           if (caff) {
-            if (t < H) obj_part += args.dt * affine_rows<T>(clin, xt, goal, no, 0, 1, clint[no]);
-            else obj_part += affine_rows<T>(clint, xt, goal, no, 0, 1, clint[no + 1]);
+            if (t < H) obj_part[r] += args.dt * affine_rows<T>(clin, xt, goal, no, 0, 1, clint[no]);
+            else obj_part[r] += affine_rows<T>(clint, xt, goal, no, 0, 1, clint[no + 1]);
           }
         }
+      }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) obj_part += __shfl_xor(obj_part, off);
-      if (lane == 0) lsobj[ROWS * pass + 4 * r + w] = obj_part;
+      for (int r = 0; r < RB; ++r) {
+        T o = obj_part[r];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) o += __shfl_xor(o, off);
+        if (lane == 0) lsobj[ROWS * pass + 4 * r + w] = o;
+      }
     }
     __syncthreads();
     AMPC_LSW_MARK(pm, pm_k && pass == 0, 11);

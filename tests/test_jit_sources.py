@@ -38,3 +38,22 @@ def test_product_headers_read_no_experiment_flags():
     for name in os.listdir(CSRC):
         if name.endswith((".hpp", ".cpp")) and name != "probe.hpp":
             assert "AMPC_X_" not in open(os.path.join(CSRC, name)).read(), name
+
+
+def test_ilqr_plugin_unit_compiles_for_a_deep_unregistered_shape(tmp_path):
+    """The iLQR translation unit of a shape plugin, cross-compiled here the way csrc/jit_host.hpp does on
+    the user's box, for a shape whose hidden -> hidden layers run in a RUN-TIME layer loop (three hidden
+    layers, 192 wide): code generation problems of the line-search kernels that only show for such shapes
+    (a wave-uniform value the compiler can no longer prove uniform) must not wait for a GPU box to show."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("no hipcc here")
+    cmd = [hipcc, "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed",
+           "-I", os.path.join(ROOT, "include"), "-DAMPC_JIT_PLUGIN", "-DAMPC_T=double", "-DAMPC_T_IS_F64=1",
+           "-DAMPC_JIT_NX=12", "-DAMPC_JIT_NU=3", "-DAMPC_JIT_NO=12", "-DAMPC_JIT_NH=3", "-DAMPC_JIT_HPAD=192",
+           "-c", os.path.join(CSRC, "launch_ilqr.cpp"), "-o", str(tmp_path / "ilqr_plugin.o")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
