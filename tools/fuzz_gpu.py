@@ -42,6 +42,10 @@ def main():
         # (csrc/jit_host.hpp) and run on those; the rest stay on the run-time-shape kernels
         use_jit = rng.random() < 0.25
         os.environ["AMPC_JIT"] = "1" if use_jit else "0"
+        # the line search of the case's iLQR solves: four-row passes side by side (few problems), in sequence,
+        # all step sizes in one twelve-row pass (ilqr_lsw.hpp), or picked per poll -- one oracle for all
+        ls_par, ls_rb = str(rng.choice([0, 1])), str(rng.choice([0, 1, 3]))
+        os.environ["AMPC_LS4_PAR"], os.environ["AMPC_LS4_RB"] = ls_par, ls_rb
         system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
         p = omlp.random_params(nx, nu, hidden, act, seed=int(rng.integers(1 << 30)))
         p["xu_means"] = rng.normal(scale=0.2, size=nx + nu)
@@ -52,7 +56,8 @@ def main():
                 **{"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)})
         m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
         m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
-        tag = "case %d nx=%d nu=%d hidden=%s %s %s MT=%s jit=%d" % (case, nx, nu, hidden, act, prec, os.environ["AMPC_MT"], use_jit)
+        tag = "case %d nx=%d nu=%d hidden=%s %s %s MT=%s jit=%d ls=%s%s" % (case, nx, nu, hidden, act, prec, os.environ["AMPC_MT"], use_jit,
+                                                                             ls_par, ls_rb)
         try:
             n = int(rng.choice([1, 7, 16, 33, 200]))
             s, c = rng.normal(size=(n, nx)), rng.normal(size=(n, nu))
@@ -166,6 +171,8 @@ def main():
     from oracle.linear import LinearOracle
     worst.update({"lin_pred": 0.0, "lin_mppi": 0.0, "loop_score": 0.0})
     os.environ["AMPC_MT"] = "0"
+    os.environ.pop("AMPC_LS4_PAR", None)
+    os.environ.pop("AMPC_LS4_RB", None)
     for case in range(max(4, n_cases // 10)):
         ns, nu = int(rng.integers(1, 65)), int(rng.integers(1, 9))     # 33..64: the four-output-tile path
         if case % 3 == 2:
