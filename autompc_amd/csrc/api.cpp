@@ -1821,7 +1821,8 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
-  HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * 2 * sizeof(int), hipHostMallocDefault));
+  const int npoll = 2 * B + 2;               // active[B], ls_need[B], the chains' two counters
+  HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * npoll * sizeof(int), hipHostMallocDefault));
   if (!p->poll_ev[0])
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
   struct Guard {
@@ -1831,7 +1832,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   p->queue_on = true;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
-  p->ls_rb_now = 3;     // (episodes: the slots' solves are at every stage at once -- some search always needs all step sizes)
+  p->ls_rb_now = 1;
   IlqrChains<T> q;
   q.C = C; q.B = B; q.H = H; q.nx = nx; q.nu = nu; q.n_steps = n_steps; q.max_iter = max_iter;
   q.ctl = (int*)p->q_ctl.p;
@@ -1862,11 +1863,16 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
     }
     it += kPoll;
     const int slot = batch & 1;
-    HIP_OK(hipMemcpyAsync(p->poll_host + 2 * slot, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    int* ph = p->poll_host + (size_t)slot * npoll;
+    HIP_OK(hipMemcpyAsync(ph, (const int*)p->flags.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(ph + B, (const int*)p->flags.p + 8 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(ph + 2 * B, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
     if (pending >= 0) {
+      const int* pp = p->poll_host + (size_t)(pending & 1) * npoll;
       HIP_OK(hipEventSynchronize(p->poll_ev[pending & 1]));
-      if (p->poll_host[2 * (pending & 1) + 1] >= C) done = true;
+      p->ls_rb_now = ls_rb_from_poll(pp, pp + B, B);
+      if (pp[2 * B + 1] >= C) done = true;
     }
     pending = batch++;
   }
