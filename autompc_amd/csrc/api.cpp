@@ -765,7 +765,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (!p) return 0;
   (void)hipSetDevice(p->h->device);
   (void)hipStreamSynchronize(p->h->stream);
-  DevBuf* bufs[] = {&p->lift_prog, &p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps,
+  DevBuf* bufs[] = {&p->lift_prog, &p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps, &p->eps_next,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part, &p->tile_done,
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
@@ -793,6 +793,7 @@ static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* a
   if (eps) {
     HIP_OK(upload_converted<T>(p->eps.p, eps, (size_t)p->sum_nhnu, h->stream));
     p->eps_inline = false;
+    p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
   }
   HIP_OK(hipStreamSynchronize(h->stream));
   return 0;
@@ -813,8 +814,20 @@ template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t 
   // forms this noise in its own prologue -- the same values, element by element -- so nothing is
   // launched here; the buffer keeps whatever it held (AMPC_INLINE_NOISE = 0: always generate it).
   p->eps_inline = p->quad && env_int("AMPC_INLINE_NOISE", 1) != 0;
+  // streams drawn in sequence (s, s + 1, ...): from now on a solve's combine launch forms the next one's
+  // noise as well (eps_next, host_common.hpp), and a draw that was predicted is a swap of two pointers
+  const bool ahead_allowed = env_int("AMPC_NOISE_AHEAD", 1) != 0;
+  if (!ahead_allowed) p->ahead_on = false;
+  if (ahead_allowed && p->eps_from_generator && seed == p->eps_seed && stream == p->eps_stream + 1) p->ahead_on = true;
+  const bool hit = p->ahead_valid && p->ahead_seed == seed && p->ahead_stream == stream;
+  p->ahead_valid = false;
   p->eps_seed = seed; p->eps_stream = stream;
+  p->eps_from_generator = true;
   if (p->eps_inline) return 0;
+  if (hit) {
+    std::swap(p->eps, p->eps_next);
+    return 0;
+  }
   long long max_pairs = 0;
   for (int b = 0; b < p->B; ++b) {
     const long long pairs = ((long long)p->N[b] * p->H[b] * nu + 1) / 2;
@@ -1014,6 +1027,7 @@ template <typename T>
 static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
                           LegacyDraw* d) {
   p->eps_inline = false;          // (this draw fills the plan's noise buffer)
+  p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
   ampc_handle* h = p->h;
   const long long n = p->sum_nhnu;
   const int shift = has_gauss ? 1 : 0;
@@ -1218,6 +1232,7 @@ template <typename T> static int mppi_set_noise_ids_impl(ampc_mppi_plan* p) {
   HIP_OK(hipMemcpy(pr.data(), p->probs.p, pr.size() * sizeof(MppiProblem<T>), hipMemcpyDeviceToHost));
   for (int b = 0; b < p->B; ++b) pr[b].noise_id = p->noise_id[b];
   HIP_OK(hipMemcpy(p->probs.p, pr.data(), pr.size() * sizeof(MppiProblem<T>), hipMemcpyHostToDevice));
+  p->ahead_valid = false;          // (noise formed ahead carried the old ids)
   return 0;
 }
 

@@ -283,6 +283,15 @@ struct ampc_mppi_plan {
   bool quad = false;    // the four-row rollout kernel runs (mppi_rollout4.hpp); mt is 0 then
   bool eps_inline = false;    // the plan's noise is Philox(eps_seed, eps_stream), formed inside the four-row rollout
   uint64_t eps_seed = 0, eps_stream = 0;
+  // Noise one solve ahead (device Philox noise, sixteen-row plans): callers draw stream s, s + 1, s + 2, ...
+  // (MPPI.run(), bench.py), so once that pattern has been seen a solve's combine launch also forms the
+  // noise of stream + 1 into eps_next (extra workgroups of the same launch), and the next
+  // ampc_mppi_generate_eps(seed, stream + 1) swaps the buffers instead of launching the generator: one
+  // launch and its gap (~10 us) less per solve.  Anything that changes what the generator would produce
+  // (problems, noise ids, an uploaded buffer) drops the speculation.
+  DevBuf eps_next;
+  bool ahead_on = false, ahead_valid = false, eps_from_generator = false;
+  uint64_t ahead_seed = 0, ahead_stream = 0;
   int lift_n = 0;             // ampc_mppi_plan_set_state_lift: basis functions of the controller model's lift
   DevBuf lift_prog;           // [lift_n][2] (kind, parameter) in compute precision
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step

@@ -122,8 +122,27 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   if (p->fused_combine && p->quad) {
     // (the rollout's last workgroup per problem finished the update: mppi_kernels.hpp)
   } else if (p->lds_eps >= 0) {
-    hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(p->max_h, p->B), dim3(kWG), 0, h->stream, a,
-                       p->tile_m);
+    // (noise one solve ahead: extra blocks of this launch form the next stream index's noise, host_common.hpp)
+    NoiseAhead<T> ahead{nullptr, 0, 0};
+    unsigned gx = (unsigned)p->max_h;
+    p->ahead_valid = false;
+    if (p->ahead_on && p->eps_from_generator && !p->eps_inline && p->B <= 65535) {
+      long long max_pairs = 0;
+      for (int b = 0; b < p->B; ++b) {
+        const long long pairs = ((long long)p->N[b] * p->H[b] * h->nu + 1) / 2;
+        max_pairs = pairs > max_pairs ? pairs : max_pairs;
+      }
+      if (p->eps_next.reserve((size_t)p->sum_nhnu * sizeof(T)) == hipSuccess) {
+        ahead.eps = (T*)p->eps_next.p;
+        ahead.seed = p->eps_seed;
+        ahead.stream = p->eps_stream + 1;
+        gx += (unsigned)((max_pairs + kWG - 1) / kWG);
+        p->ahead_valid = true;
+        p->ahead_seed = ahead.seed;
+        p->ahead_stream = ahead.stream;
+      }
+    }
+    hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(gx, p->B), dim3(kWG), 0, h->stream, a, p->tile_m, ahead);
   } else {
     int maxn = 0;
     for (int n : p->N) maxn = n > maxn ? n : maxn;

@@ -15,6 +15,7 @@
 // for the softmin weights, then the weighted noise sum for that step.
 #pragma once
 #include "mlp_tile.hpp"
+#include <stdint.h>
 
 namespace ampc {
 
@@ -386,12 +387,31 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
 // tiles (its nu values of a tile row are contiguous), then one shuffle/LDS reduction per block.
 constexpr int kMaxNu = 16;
 
+// Noise one solve ahead (ampc_mppi_plan::eps_next): blocks x >= max_h of the same launch form problem p's
+// Philox noise of the NEXT stream index -- the generator kernel's values (philox_normal_batch_kernel), thread
+// for thread -- while blocks x < max_h finish this solve's update.
+// (rng_kernels.hpp, which includes this file for MppiProblem)
 template <typename T>
-__global__ __launch_bounds__(kWG) void mppi_combine_kernel(const MppiArgs<T> args, int tile_m) {
+__device__ __forceinline__ void philox_normal_pair(T* __restrict__ out, long long count, T scale, uint64_t seed,
+                                                   uint64_t stream, uint32_t id, long long pair);
+template <typename T> struct NoiseAhead {
+  T* eps;                        // nullptr: nothing to generate
+  unsigned long long seed, stream;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kWG) void mppi_combine_kernel(const MppiArgs<T> args, int tile_m,
+                                                           const NoiseAhead<T> ahead) {
   __shared__ T scratch[kWaves];
   __shared__ T red[kWaves][kMaxNu];
   const int p = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
   const MppiProblem<T> pr = args.probs[p];
+  if (t >= args.max_h) {
+    if (ahead.eps)
+      philox_normal_pair<T>(ahead.eps + pr.eps_off, (long long)pr.N * pr.H * args.mlp.nu, pr.sqrt_sigma, ahead.seed,
+                            ahead.stream, pr.noise_id, (long long)(t - args.max_h) * kWG + tid);
+    return;
+  }
   if (t >= pr.H) return;
   const int nu = args.mlp.nu, H = pr.H;
   const int tiles = (pr.N + tile_m - 1) / tile_m;

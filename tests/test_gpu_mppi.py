@@ -372,3 +372,50 @@ def test_a_view_held_across_run_never_resurrects_the_old_sequence():
     np.random.seed(9)
     u2, _ = ctl2.run(np.zeros(3), np.full(2, 0.1))
     np.testing.assert_array_equal(u1, u2)
+
+
+def test_noise_formed_one_solve_ahead_equals_the_generator_launch(monkeypatch):
+    """Streams drawn in sequence (s, s + 1, ...): the combine launch of a solve forms the next stream index's
+    Philox noise as well (ampc_mppi_plan::eps_next) and the predicted ampc_mppi_generate_eps is a pointer
+    swap.  Same values as the generator launch, whatever the call pattern: sequences, jumps, repeated
+    indices, changed noise ids, an uploaded buffer in between -- against AMPC_NOISE_AHEAD=0."""
+    from autompc_amd import _lib
+    nx, nu, H = 17, 6, 12
+    p = omlp.random_params(nx, nu, [256, 256], "relu", seed=3)
+    rng = np.random.default_rng(0)
+    x0 = rng.uniform(-0.1, 0.1, size=(2, nx))
+    upl = rng.normal(scale=0.3, size=(2 * 512 * H * nu))
+
+    def run(ahead):
+        monkeypatch.setenv("AMPC_NOISE_AHEAD", ahead)
+        h = _lib.Handle(0, "f64")
+        h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+        h.set_quad_costs(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+        h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+        plan = _lib.MppiPlan(h, [512, 512], [H, H], [0.09, 0.04], [1.0, 0.5])     # sixteen-row tiles (two problems)
+        plan.upload(x0, np.zeros(2 * H * nu))
+        out = []
+
+        def solve():
+            plan.solve()
+            a, u, _, e = plan.download(eps_out=True)
+            out.append((a.copy(), u.copy(), e.copy()))
+        for s in (5, 6, 7, 8, 8, 9, 20, 21, 22):              # sequence, a repeated index, a jump, a sequence again
+            plan.generate_eps(77, s)
+            solve()
+        plan.set_noise_ids(np.array([11, 3], dtype=np.uint32))   # the ids key the stream: speculation is dropped
+        for s in (23, 24):
+            plan.generate_eps(77, s)
+            solve()
+        plan.upload(None, None, upl)                          # caller's own noise in between
+        solve()
+        for s in (25, 26, 27):
+            plan.generate_eps(78 if s == 27 else 77, s)       # ... and a changed seed
+            solve()
+        plan.close(); h.close()
+        return out
+    a, b = run("1"), run("0")
+    assert len(a) == len(b) == 15
+    for i, (x, y) in enumerate(zip(a, b)):
+        for k in range(3):
+            assert np.array_equal(x[k], y[k]), (i, k)
