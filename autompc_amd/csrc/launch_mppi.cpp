@@ -74,10 +74,34 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
                        lin_of<T>(h));
   } else if (h->has_sindy) {
     const SindyDev<T> sm = sindy_of<T>(h);
-    const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
-                      sindy_stage_bytes<T>(h);
-    HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
-    hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
+    // features spread over sixteen lanes per sample (sindy_kernels.hpp) when the library is staged in LDS
+    // and has a product table and at most eight states; AMPC_SINDY_FP = 0: one thread per sample
+    const bool fp_allowed = env_int("AMPC_SINDY_FP", 1) != 0;
+    // lanes per sample: all 64 while that still leaves the chip waves to spare, else 32 / 16
+    const long long samples = (long long)p->n_tiles * 64;
+    int G = samples <= 2048 ? 64 : (samples <= 8192 ? 32 : 16);
+    { const int g = env_int("AMPC_SINDY_G", 0); if (g == 16 || g == 32 || g == 64) G = g; }
+    const int hcap = (p->max_h * h->nu + 3) / 4 * 4;
+    const size_t lbf = ((size_t)(64 / G) * (h->nx + h->nu + h->s_ntab + 2 * hcap) + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
+                       sindy_stage_bytes<T>(h);
+    if (fp_allowed && sm.stage && sm.n_tab > 0 && h->nx <= 8 && lbf <= kLdsLimit) {
+      const dim3 grid((unsigned)(p->n_tiles * G));
+      if (G == 64) {
+        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 64>, lbf));
+        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 64>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
+      } else if (G == 32) {
+        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 32>, lbf));
+        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 32>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
+      } else {
+        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 16>, lbf));
+        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 16>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
+      }
+    } else {
+      const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
+                        sindy_stage_bytes<T>(h);
+      HIP_OK(allow_lds(mppi_rollout_sindy_kernel<T>, lb));
+      hipLaunchKernelGGL(mppi_rollout_sindy_kernel<T>, dim3(p->n_tiles), dim3(64), lb, h->stream, a, sm);
+    }
   } else
 #endif
   if (p->static_shape >= 0) {

@@ -348,4 +348,160 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
   }
 }
 
+
+// The same rollout with the FEATURES spread over lanes (round 4; BASELINE config 1).  One thread per sample
+// leaves the machine idle on the small problems this model family is used for (CartPole: 256 samples = four
+// waves) and makes a time step a chain of ~55 dependent LDS round trips (36 k cycles).  Here G = 16 lanes
+// share a sample: lane g forms the table entries j = g, g + G, ... (one sin / cos pair each instead of five
+// in a row), then the features k = g, g + G, ... and their nx products with the coefficient column, and an
+// xor-butterfly over the G lanes leaves the sums in every lane; state, controls and cost are kept
+// redundantly by all lanes of the group (the same arithmetic, so they agree bit for bit) and only lane 0
+// stores.  Block b of the launch takes samples [64 (b / G) + 4 (b % G), + 4) -- sub-block b % G of the plan's
+// 64-sample tile b / G -- so the plan's tiling, offsets and update kernel are untouched.  A sample's sum over
+// the features is formed in a different order than mppi_rollout_sindy_kernel forms it (G partial sums, then
+// the butterfly): results agree to rounding (tests/test_gpu_sindy.py pins both to the reference's goldens).
+// Shapes it does not take (nx > 8, a table beyond kSindyMaxTab, programs that are not staged) keep the kernel
+// above.
+// Sum over the G lanes of a group, left in every lane: quad, half-row and row stages are DPP moves (no LDS
+// round trip), the 16- and 32-lane stages shuffles.
+template <int CTRL, typename T> __device__ __forceinline__ T sindy_dpp(T v) {
+  if constexpr (sizeof(T) == 8) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  } else {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+  }
+}
+template <int G, typename T> __device__ __forceinline__ T sindy_group_sum(T v) {
+  v += sindy_dpp<0xb1>(v);                         // quad_perm [1,0,3,2]
+  v += sindy_dpp<0x4e>(v);                         // quad_perm [2,3,0,1]
+  v += sindy_dpp<0x141>(v);                        // row_half_mirror
+  v += sindy_dpp<0x140>(v);                        // row_mirror: all 16 lanes of a row hold its sum
+  if constexpr (G >= 32) v += __shfl_xor(v, 16);
+  if constexpr (G >= 64) v += __shfl_xor(v, 32);
+  return v;
+}
+
+// (G lanes per sample: 16, 32 or 64 -- the fewer samples a plan has, the more lanes each can use; hcap =
+//  max_h * nu rounded up: a sample's noise row and the shifted action sequence are read into LDS once,
+//  ahead of the time loop, instead of a global-memory round trip per step on the chain)
+template <typename T, int G>
+__global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArgs<T> args, const SindyDev<T> mg,
+                                                                   const int hcap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* lds = reinterpret_cast<T*>(smem_raw);
+  constexpr int BS = 64, SPB = BS / G, NR = 8;
+  const int lane = threadIdx.x, nx = mg.nx, nu = mg.nu, nv = nx + nu, no = args.obs_dim, ntab = mg.n_tab;
+  // LDS: per sample v [nv], table [ntab], noise row [hcap], shifted actions [hcap]; then the shared cost
+  // block / bounds; then the staged program
+  const int per_s = nv + ntab + 2 * hcap;
+  T* cpar = lds + SPB * per_s;
+  const SindyDev<T> m = sindy_stage<T>(mg, cpar + args.cost_stride + 3 * nu + 1, lane, BS);
+  const int tile = blockIdx.x / G, sub = blockIdx.x - tile * G;
+  const int p = args.tile_prob[tile];
+  const MppiProblem<T> pr = args.probs[p];
+  const int sl = lane / G, g = lane - sl * G;               // sample of the block, lane of the group
+  const int n = (tile - pr.tile0) * BS + sub * SPB + sl;
+  const int H = pr.H, N = pr.N;
+  const bool valid = n < N;
+  T* v = lds + sl * per_s;                                   // this sample's x | u
+  T* tr = v + nv;                                            // ... and its table
+  T* er = tr + ntab;                                         // ... its noise row [H][nu]
+  T* ar = er + hcap;                                         // ... and a[min(t + 1, H - 1)][nu]
+  for (int i = lane; i < args.cost_stride; i += BS)
+    cpar[i] = args.costs_par[(size_t)pr.cost_idx * args.cost_stride + i];
+  for (int i = lane; i < 3 * nu; i += BS) cpar[args.cost_stride + i] = args.bounds[i];
+  for (int i = g; i < nx; i += G) v[i] = args.x0[p * nx + i];
+  if (g == 0) tr[ntab - 1] = T(1);
+  {
+    const T* eps_row = args.eps + pr.eps_off + (size_t)(n < pr.N ? n : 0) * pr.H * nu;
+    for (int e = g; e < pr.H * nu; e += G) {
+      const int t = e / nu, j = e - t * nu, ts = (t + 1 < pr.H) ? t + 1 : pr.H - 1;   // a[:-1] = a[1:]; a[-1] = a[-2]
+      er[e] = n < pr.N ? eps_row[e] : T(0);
+      ar[e] = args.act_in[pr.a_off + ts * nu + j];
+    }
+  }
+  __syncthreads();
+  const T* Qm = cpar; const T* Rm = Qm + no * no; const T* Fm = Rm + nu * nu;
+  const T* goal = Fm + no * no;
+  const T* lin = goal + no; const T* lint = lin + no;
+  const T* blo = cpar + args.cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
+  T* epso = args.eps_out + pr.epso_off;
+  T c = T(0), ca = T(0);
+  for (int t = 0; t < H; ++t) {
+    for (int j = 0; j < nu; ++j) {
+      const T a = ar[t * nu + j];
+      T A = er[t * nu + j] + a;
+      A = A < blo[j] ? blo[j] : A;
+      A = A > bhi[j] ? bhi[j] : A;
+      const T ec = A - a;
+      if (valid && g == 0) epso[((size_t)t * N + n) * nu + j] = ec;
+      ca += A * ec;
+      if (g == 0) v[nx + j] = A * bsc[j];
+    }
+    // (the group's lanes run in one wave: LDS accesses of a wave complete in order, no barrier needed)
+    // stage cost; diagonal blocks: the off-diagonal terms the dense loops add are exact zeros, skipped
+    const bool cdiag = args.cost_diag != 0;
+    for (int i = 0; i < no; ++i) {
+      T s = T(0);
+      if (cdiag) s = Qm[i * no + i] * (v[i] - goal[i]);
+      else
+        for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (v[j] - goal[j]);
+      c += (v[i] - goal[i]) * (s + lin[i]);
+    }
+    c += lint[no];
+    for (int i = 0; i < nu; ++i) {
+      T s = T(0);
+      if (cdiag) s = Rm[i * nu + i] * v[nx + i];
+      else
+        for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[nx + j];
+      c += v[nx + i] * s;
+    }
+    // ---- table entries of this lane
+    for (int j = g; j < m.n_trig; j += G) {
+      const T arg = m.tpar[j] * v[m.tvar[j]];
+      T sv, cv;
+      if constexpr (sizeof(T) == 8) sincos(arg, &sv, &cv);    // (one argument reduction for the pair)
+      else sincosf(arg, &sv, &cv);
+      tr[2 * j] = sv;
+      tr[2 * j + 1] = cv;
+    }
+    for (int j = g; j < m.n_pow; j += G) tr[2 * m.n_trig + j] = pow(v[m.pvar[j]], m.ppar[j]);
+    for (int j = g; j < m.n_mon; j += G)
+      tr[2 * m.n_trig + m.n_pow + j] = sindy_monomial<T>(m.mpool, m.moff[j], m.mcnt[j], v, 1);
+    // ---- features of this lane, times their coefficient column
+    T acc[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[i] = T(0);
+    for (int k = g; k < m.n_feat; k += G) {
+      const int ix = m.fx[k], iy = m.fy[k];
+      const T f = (ix >= 0 ? v[ix] : tr[-ix - 1]) * tr[iy];
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < nx) acc[i] += m.xi[i * m.n_feat + k] * f;
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i < nx) acc[i] = sindy_group_sum<G>(acc[i]);
+    // ---- next state (every lane holds the sums; lane i of the group stores element i)
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i < nx && g == i % G) v[i] = m.continuous ? v[i] + m.dt * acc[i] : acc[i];
+  }
+  T term = T(0);
+  for (int i = 0; i < no; ++i) {
+    T s = T(0);
+    for (int j = 0; j < no; ++j) s += Fm[i * no + j] * (v[j] - goal[j]);
+    term += (v[i] - goal[i]) * (s + lint[i]);
+  }
+  term += lint[no + 1];
+  c += pr.lam_over_sigma * ca;
+  if (args.term_mode == 1) c += term;
+  if (valid && g == 0) {
+    args.costs[pr.cost_off + n] = c;
+    if (n == N - 1) args.term_last[p] = term;
+  }
+}
+
 }  // namespace ampc
