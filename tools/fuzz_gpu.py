@@ -291,6 +291,39 @@ def main():
             worst["sindy_jac"] = max(worst["sindy_jac"], ej / (10 * tol))
             if e > tol or ej > 10 * tol:
                 bad.append((tag, "sindy pred/jac", e, ej))
+            # the MPPI rollout on this library (features over lanes, sindy_kernels.hpp) against the oracle's
+            # MPPI on the oracle's model: one control step from the same numpy noise
+            if prec == "f64" and mode == "discrete":
+                from autompc_amd import MPPI as SMPPI, QuadCost as SQuadCost, Task as STask
+                from oracle.costs import QuadCostOracle as SQuadCostOracle
+                from oracle.mppi import MPPIOracle as SMPPIOracle
+                Xs = Xi * 0.2                                  # (a contraction: the rollout stays finite)
+                m.set_coefficients(Xs)
+                orc2 = SINDyOracle(system, Xs, trig_freq=tf, trig_interaction=inter, poly_degree=pd, time_mode=mode,
+                                   strict_reference=strict, poly_cross_terms=cross)
+                S = rng.normal(size=(nx, nx))
+                Qc = np.diag(rng.uniform(0.5, 2.0, size=nx)) + (0.05 * (S + S.T) if rng.random() < 0.5 else 0.0)
+                Rc, Fc = np.diag(rng.uniform(0.01, 0.1, size=nu)), np.diag(rng.uniform(0.5, 2.0, size=nx))
+                task = STask(system)
+                task.set_cost(SQuadCost(system, Qc, Rc, Fc))
+                task.set_ctrl_bounds(np.full(nu, -1.0), np.full(nu, 1.0))
+                Hh, Np = int(rng.integers(3, 26)), int(rng.choice([64, 100, 256, 300]))
+                sd = int(rng.integers(1 << 30))
+                np.random.seed(sd)
+                ctl = SMPPI(system, task, m, horizon=Hh, num_path=Np, sigma=0.25, lmda=1.0)
+                np.random.seed(sd)
+                oc = SMPPIOracle(orc2, SQuadCostOracle(Qc, Rc, Fc, np.zeros(nx)), np.tile([-1.0, 1.0], (nu, 1)),
+                                horizon=Hh, num_path=Np, sigma=0.25, lmda=1.0)
+                obs = rng.normal(scale=0.3, size=nx)
+                cs = np.concatenate([obs, np.zeros(nu)])
+                st = np.random.get_state()
+                uo, _ = oc.run(cs, obs)
+                np.random.set_state(st)
+                uh, _ = ctl.run(cs, obs, return_details=True)
+                em = max(rel(ctl.last_costs, oc.last_costs), rel(ctl.act_sequence, oc.act_sequence), rel(uh, uo))
+                worst["sindy_mppi"] = max(worst.get("sindy_mppi", 0.0), em / 1e-9)
+                if not em <= 1e-9:
+                    bad.append((tag + " H=%d N=%d" % (Hh, Np), "sindy mppi", em, 0.0))
         except Exception as ex:      # noqa: BLE001
             bad.append((tag, "exception", repr(ex)[:200], 0.0))
     print("worst error / tolerance:", {k: float("%.3g" % v) for k, v in worst.items()})
