@@ -143,12 +143,11 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
 #endif
   }
   if (e) HIP_OK(hipEventRecord(e[1], h->stream));
-  if (p->fused_combine && p->quad) {
-    // (the rollout's last workgroup per problem finished the update: mppi_kernels.hpp)
-  } else if (p->lds_eps >= 0) {
-    // (noise one solve ahead: extra blocks of this launch form the next stream index's noise, host_common.hpp)
+  // Noise one solve ahead (host_common.hpp): extra blocks of the update / combine launch form the next stream
+  // index's noise; gx = blocks along x of that launch.
+  auto noise_ahead = [&](unsigned& gx) {
     NoiseAhead<T> ahead{nullptr, 0, 0};
-    unsigned gx = (unsigned)p->max_h;
+    gx = (unsigned)p->max_h;
     p->ahead_valid = false;
     if (p->ahead_on && p->eps_from_generator && !p->eps_inline && p->B <= 65535) {
       long long max_pairs = 0;
@@ -166,6 +165,14 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
         p->ahead_stream = ahead.stream;
       }
     }
+    return ahead;
+  };
+  if (p->fused_combine && p->quad) {
+    // (the rollout's last workgroup per problem finished the update: mppi_kernels.hpp)
+    p->ahead_valid = false;
+  } else if (p->lds_eps >= 0) {
+    unsigned gx = 0;
+    const NoiseAhead<T> ahead = noise_ahead(gx);
     hipLaunchKernelGGL(mppi_combine_kernel<T>, dim3(gx, p->B), dim3(kWG), 0, h->stream, a, p->tile_m, ahead);
   } else {
     int maxn = 0;
@@ -173,7 +180,9 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
     const size_t ub = ((size_t)(maxn <= kUpdateMaxN ? maxn : 0) + kWaves + kWG) * sizeof(T);
     auto uk = mppi_update_kernel<T>;
     HIP_OK(allow_lds(uk, ub));
-    hipLaunchKernelGGL(uk, dim3(p->max_h, p->B), dim3(kWG), ub, h->stream, a);
+    unsigned gx = 0;
+    const NoiseAhead<T> ahead = noise_ahead(gx);
+    hipLaunchKernelGGL(uk, dim3(gx, p->B), dim3(kWG), ub, h->stream, a, ahead);
   }
   if (e) HIP_OK(hipEventRecord(e[2], h->stream));
   HIP_OK(hipGetLastError());

@@ -493,11 +493,17 @@ template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch) {
 constexpr int kUpdateMaxN = 8192;   // weights kept in LDS up to this many samples (64 KB f64)
 
 template <typename T>
-__global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args) {
+__global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args, const NoiseAhead<T> ahead) {
   extern __shared__ __attribute__((aligned(16))) unsigned char upd_smem[];
   T* wts = reinterpret_cast<T*>(upd_smem);          // [min(N, kUpdateMaxN)] weights, then scratch
   const int p = blockIdx.y, t = blockIdx.x;
   const MppiProblem<T> pr = args.probs[p];
+  if (t >= args.max_h) {                            // (noise one solve ahead, as in mppi_combine_kernel)
+    if (ahead.eps)
+      philox_normal_pair<T>(ahead.eps + pr.eps_off, (long long)pr.N * pr.H * args.mlp.nu, pr.sqrt_sigma, ahead.seed,
+                            ahead.stream, pr.noise_id, (long long)(t - args.max_h) * kWG + threadIdx.x);
+    return;
+  }
   if (t >= pr.H) return;
   const int N = pr.N, nu = args.mlp.nu, tid = threadIdx.x;
   const bool cached = N <= kUpdateMaxN;
