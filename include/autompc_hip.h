@@ -177,7 +177,9 @@ int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const double* act_seq,
                      const double* eps);
 /* Fill the plan's noise buffer on the device: eps ~ N(0, sigma_p) from Philox4x32-10 keyed by
  * (seed, stream, noise id of the problem, element).  `stream` (< 2^56) is the caller's step
- * counter.  Statistically equivalent to, not bit-identical with, numpy's draw (mppi.py:21-24). */
+ * counter.  Statistically equivalent to, not bit-identical with, numpy's draw (mppi.py:21-24).
+ * Callers that draw stream, stream + 1, ... with one seed get the next draw formed by the previous solve's
+ * update launch (the same values; this call then only swaps two buffers) -- AMPC_NOISE_AHEAD=0 disables. */
 int ampc_mppi_generate_eps(ampc_mppi_plan* p, uint64_t seed, uint64_t stream);
 /* The reference's noise draw itself, on the device: fills the plan's noise buffer with what
  *   np.random.normal(scale=sqrt(sigma_p), size=(N_p, H_p, nu))          (mppi.py:16-24, :126)
@@ -340,7 +342,9 @@ int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations)
  * candidate rows the line searches rolled out, summed over the plan's problems.  The reference rolls out all ls_max_iter = 10 step
  * sizes in every iteration (ilqr.py:196-205) and then accepts the first that passes its test; the
  * f64 MLP path rolls them out four at a time and stops at the first accepted one (same decisions,
- * same results), so its row count is a multiple of 4 per iteration.  Either pointer may be NULL. */
+ * same results: a multiple of 4 rows per iteration) or -- many problems per launch, once some search
+ * needs a third four-row pass -- all of them in one pass of a twelve-row tile (ls_max_iter rows per
+ * iteration; same results again, csrc/ilqr_lsw.hpp).  Either pointer may be NULL. */
 int ampc_ilqr_plan_stats(ampc_ilqr_plan* p, long long* iterations, long long* candidate_rows);
 /* use_goal = 0 (default): the backward sweep is seeded with the terminal gradient exactly as the
  * reference computes it, (F + F') x_N -- Cost.eval_term_obs_cost_diff ignores the goal
