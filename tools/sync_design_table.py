@@ -36,7 +36,7 @@ rows = {
                      % (th(c2["value"]), c2["roofline"]["kernel_ms"], c2["roofline"]["achieved"], 100 * c2["roofline"]["frac"]),
     "| arx: MPPI": "| arx: MPPI 1024×30 on a 20-state ARX model (§8 f3; latency-bound) | f64 | %s | %.3f ms | %.1f | — |"
                    % (th(ax["value"]), ax["roofline"]["kernel_ms"], ax["roofline"]["achieved"]),
-    "| c1 CartPole": "| c1 CartPole SINDy MPPI 256×20 (scalar kernels, 4 single-wave workgroups: pure latency) | f64 | %s | %.3f ms | — | — |"
+    "| c1 CartPole": "| c1 CartPole SINDy MPPI 256×20 (a sample's features over 64 lanes, §4.5: 256 single-wave workgroups; latency-bound; one thread per sample: 3037) | f64 | %s | %.3f ms | — | — |"
                      % (th(c1["value"]), c1["roofline"]["kernel_ms"]),
     "| c4 HalfCheetah": "| c4 HalfCheetah iLQR H=50, 256 problems × 50 iterations | f64 | %s | — | %.1f (whole iteration) | %.0f %% |"
                         % (th(c4["value"]), c4["algorithmic_tflops"], 100 * c4["algorithmic_tflops"] / 78.6),
