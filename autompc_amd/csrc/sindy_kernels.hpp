@@ -68,12 +68,18 @@ __host__ __device__ inline size_t sindy_prog_elems(int nx, int n_feat, int n_tri
 // sindy_step is wave-uniform; from global memory each is a dependent scalar-load round trip per
 // feature, from LDS a broadcast read (measured 5x on the CartPole library).  Must be called by
 // all threads; ends with a barrier.  g.stage == 0 (program too large): returns g unchanged.
-template <typename T>
+// ALWAYS: the caller is only launched for staged programs (g.stage == 1) -- without the early return every
+// pointer of the result derives from the LDS array, so the compiler addresses the program with ds_read
+// instead of flat loads (a pointer that MAY be global is a flat pointer: ~5 x the latency per operand, and
+// every read counts against vmcnt as well).
+template <typename T, bool ALWAYS = false>
 __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area, int tid, int nthr);
 
-template <typename T>
+template <typename T, bool ALWAYS>
 __device__ __forceinline__ SindyDev<T> sindy_stage(const SindyDev<T>& g, T* area, int tid, int nthr) {
-  if (!g.stage) return g;
+  if constexpr (!ALWAYS) {
+    if (!g.stage) return g;
+  }
   const int nf = g.n_feat, nt = g.n_trig, np = g.n_pow, nx = g.nx;
   T* xi = area;
   T* tpar = xi + (size_t)nx * nf;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
   // block / bounds; then the staged program
   const int per_s = nv + ntab + 2 * hcap;
   T* cpar = lds + SPB * per_s;
-  const SindyDev<T> m = sindy_stage<T>(mg, cpar + args.cost_stride + 3 * nu + 1, lane, BS);
+  const SindyDev<T> m = sindy_stage<T, true>(mg, cpar + args.cost_stride + 3 * nu + 1, lane, BS);
   const int tile = blockIdx.x / G, sub = blockIdx.x - tile * G;
   const int p = args.tile_prob[tile];
   const MppiProblem<T> pr = args.probs[p];
@@ -428,6 +434,37 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
   const T* lin = goal + no; const T* lint = lin + no;
   const T* blo = cpar + args.cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
   T* epso = args.eps_out + pr.epso_off;
+  // What a lane needs in every step does not change over the steps: it is read ONCE, here -- its trig
+  // argument (variable, frequency), its first KF features (two table indices, nx coefficients), the diagonal
+  // of the cost block.  The state lives in registers of every lane (all lanes of a group hold the sums after
+  // the group reduction); the LDS copy of x | u exists for the data-dependent reads only (a trig argument, a
+  // feature's factors).  Per step that leaves: noise + action, the trig argument, the feature's two factors
+  // and the two cross-row reduction stages as LDS round trips (the loop used to have sixty).
+  const bool cdiag = args.cost_diag != 0;
+  constexpr int KF = 2;
+  T xreg[NR], qd[NR], gl[NR], ln[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int ix = i < no ? i : 0;
+    xreg[i] = v[i < nx ? i : 0];
+    qd[i] = Qm[ix * no + ix]; gl[i] = goal[ix]; ln[i] = lin[ix];
+  }
+  const T lc = lint[no];
+  const bool t0 = g < m.n_trig;
+  const int tv0 = t0 ? m.tvar[g] : 0;
+  const T tp0 = t0 ? m.tpar[g] : T(0);
+  int fxr[KF], fyr[KF];
+  bool fk[KF];
+  T xir[KF][NR];
+#pragma unroll
+  for (int q = 0; q < KF; ++q) {
+    const int k = g + q * G;
+    fk[q] = k < m.n_feat;
+    const int kk = fk[q] ? k : 0;
+    fxr[q] = m.fx[kk]; fyr[q] = m.fy[kk];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) xir[q][i] = (fk[q] && i < nx) ? m.xi[(i < nx ? i : 0) * m.n_feat + kk] : T(0);
+  }
   T c = T(0), ca = T(0);
   for (int t = 0; t < H; ++t) {
     for (int j = 0; j < nu; ++j) {
@@ -438,31 +475,45 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
       const T ec = A - a;
       if (valid && g == 0) epso[((size_t)t * N + n) * nu + j] = ec;
       ca += A * ec;
-      if (g == 0) v[nx + j] = A * bsc[j];
+      const T uj = A * bsc[j];
+      if (g == 0) v[nx + j] = uj;
+      if (cdiag) c += uj * (Rm[j * nu + j] * uj);
     }
     // (the group's lanes run in one wave: LDS accesses of a wave complete in order, no barrier needed)
     // stage cost; diagonal blocks: the off-diagonal terms the dense loops add are exact zeros, skipped
-    const bool cdiag = args.cost_diag != 0;
-    for (int i = 0; i < no; ++i) {
-      T s = T(0);
-      if (cdiag) s = Qm[i * no + i] * (v[i] - goal[i]);
-      else
+    if (cdiag) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < no) {
+          const T d = xreg[i] - gl[i];
+          c += d * (qd[i] * d + ln[i]);
+        }
+    } else {
+      for (int i = 0; i < no; ++i) {
+        T s = T(0);
         for (int j = 0; j < no; ++j) s += Qm[i * no + j] * (v[j] - goal[j]);
-      c += (v[i] - goal[i]) * (s + lin[i]);
-    }
-    c += lint[no];
-    for (int i = 0; i < nu; ++i) {
-      T s = T(0);
-      if (cdiag) s = Rm[i * nu + i] * v[nx + i];
-      else
+        c += (v[i] - goal[i]) * (s + lin[i]);
+      }
+      for (int i = 0; i < nu; ++i) {
+        T s = T(0);
         for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[nx + j];
-      c += v[nx + i] * s;
+        c += v[nx + i] * s;
+      }
     }
-    // ---- table entries of this lane
-    for (int j = g; j < m.n_trig; j += G) {
-      const T arg = m.tpar[j] * v[m.tvar[j]];
+    c += lc;
+    // ---- table entries of this lane (the first one from hoisted operands)
+    if (t0) {
+      const T arg = tp0 * v[tv0];
       T sv, cv;
       if constexpr (sizeof(T) == 8) sincos(arg, &sv, &cv);    // (one argument reduction for the pair)
+      else sincosf(arg, &sv, &cv);
+      tr[2 * g] = sv;
+      tr[2 * g + 1] = cv;
+    }
+    for (int j = g + G; j < m.n_trig; j += G) {
+      const T arg = m.tpar[j] * v[m.tvar[j]];
+      T sv, cv;
+      if constexpr (sizeof(T) == 8) sincos(arg, &sv, &cv);
       else sincosf(arg, &sv, &cv);
       tr[2 * j] = sv;
       tr[2 * j + 1] = cv;
@@ -474,20 +525,37 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
     T acc[NR];
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[i] = T(0);
-    for (int k = g; k < m.n_feat; k += G) {
+#pragma unroll
+    for (int q = 0; q < KF; ++q) {
+      // (lanes without a q-th feature read entry 0 and multiply by zero coefficients: no branch around the reads)
+      const int ix = fxr[q];
+      const T fa = v[ix >= 0 ? ix : 0], fb = tr[ix >= 0 ? 0 : -ix - 1], fc = tr[fyr[q]];
+      const T f = (ix >= 0 ? fa : fb) * fc;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) acc[i] += xir[q][i] * f;
+    }
+    for (int k = g + KF * G; k < m.n_feat; k += G) {
       const int ix = m.fx[k], iy = m.fy[k];
       const T f = (ix >= 0 ? v[ix] : tr[-ix - 1]) * tr[iy];
 #pragma unroll
       for (int i = 0; i < NR; ++i)
         if (i < nx) acc[i] += m.xi[i * m.n_feat + k] * f;
     }
+    // (no branch per sum: side by side their shuffle stages overlap; sums past nx are sums of zeros)
+    if (nx <= NR / 2) {
+#pragma unroll
+      for (int i = 0; i < NR / 2; ++i) acc[i] = sindy_group_sum<G>(acc[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NR; ++i) acc[i] = sindy_group_sum<G>(acc[i]);
+    }
+    // ---- next state: in every lane's registers; lane i of the group refreshes the LDS copy
 #pragma unroll
     for (int i = 0; i < NR; ++i)
-      if (i < nx) acc[i] = sindy_group_sum<G>(acc[i]);
-    // ---- next state (every lane holds the sums; lane i of the group stores element i)
-#pragma unroll
-    for (int i = 0; i < NR; ++i)
-      if (i < nx && g == i % G) v[i] = m.continuous ? v[i] + m.dt * acc[i] : acc[i];
+      if (i < nx) {
+        xreg[i] = m.continuous ? xreg[i] + m.dt * acc[i] : acc[i];
+        if (g == i % G) v[i] = xreg[i];
+      }
   }
   T term = T(0);
   for (int i = 0; i < no; ++i) {
