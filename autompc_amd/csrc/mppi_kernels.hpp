@@ -510,6 +510,18 @@ __global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args
   T* scratch = wts + (cached ? N : 0);              // kWaves reduction slots + kWG partials
   T* part = scratch + kWaves;
   const T* c = args.costs + pr.cost_off;
+  // this thread's first U noise values are requested BEFORE the cost reductions: their global-memory
+  // round trip overlaps the costs' instead of following the two block reductions
+  const int active = (kWG / nu) * nu;               // threads with a fixed j = tid % nu
+  const T* e = args.eps_out + pr.epso_off + (size_t)t * N * nu;
+  constexpr int U = 8;                               // independent loads in flight per thread
+  const int total = N * nu;
+  T pre[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int idx = tid + k * active;
+    pre[k] = (tid < active && idx < total) ? e[idx] : T(0);
+  }
 
   T vmin = c[0];
   for (int n = tid; n < N; n += kWG) vmin = c[n] < vmin ? c[n] : vmin;
@@ -522,15 +534,20 @@ __global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args
   }
   ssum = block_sum(ssum, scratch);   // (barriers inside also publish wts)
 
-  const int active = (kWG / nu) * nu;               // threads with a fixed j = tid % nu
-  const T* e = args.eps_out + pr.epso_off + (size_t)t * N * nu;
   T acc = T(0);
   if (tid < active) {
-    const int total = N * nu;
     int n = tid / nu;
     const int dn = active / nu;
-    constexpr int U = 8;                               // independent loads in flight per thread
     int i = tid;
+    // (the prefetched values first, in index order -- the same order of additions as the loops below)
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      if (i < total) {
+        const T wgt = cached ? wts[n] : exp(pr.neg_inv_lambda * (c[n] - vmin));
+        acc += wgt * pre[k];
+        i += active; n += dn;
+      }
+    }
     for (; i + (U - 1) * active < total; i += U * active, n += U * dn) {
       T ev[U];
 #pragma unroll
