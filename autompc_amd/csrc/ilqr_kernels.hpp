@@ -52,6 +52,8 @@ template <typename T> struct IlqrArgs {
   int* ls_pass;                  // the problems the first left undecided: ls_pass[p] = 1)
   int* ls_need;                  // [B] four-row passes the slot's LAST line search needed (1..): what the host
                                  // picks the line-search kernel of the next launches from (ilqr_lsw.hpp)
+  const int* slot_h;             // [B] per-slot horizon <= H (ampc_ilqr_*_var: problems of different horizons share
+                                 // a plan; every array keeps the stride of H), nullptr: H for every problem
   int* slot_mode;                // queue mode (ampc_ilqr_solve_queue): per slot 0 = roll out the guess of the
                                  // problem just loaded, 1 = iterate; nullptr: `mode` for every problem
   int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   constexpr int NTHR = kRicThreads;
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, p = blockIdx.x;
-  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
+  const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   if (args.active[p] == 0) return;
   const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   for (int i = tid; i < cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * cost_stride + i];
   __syncthreads();
-  const T* st = args.states + (size_t)p * (H + 1) * nx;
-  const T* ct = args.ctrls + (size_t)p * H * nu;
-  T* Kg = args.Ks + (size_t)p * H * nu * nx;
-  T* kg = args.ks + (size_t)p * H * nu;
+  const T* st = args.states + (size_t)p * (HS + 1) * nx;
+  const T* ct = args.ctrls + (size_t)p * HS * nu;
+  T* Kg = args.Ks + (size_t)p * HS * nu * nx;
+  T* kg = args.ks + (size_t)p * HS * nu;
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
   const T dt = args.dt;
   AMPC_IMARK_ALWAYS(30);
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArg
   T jreg[JR];
   T xreg = T(0), ureg = T(0);
   auto fetch_step = [&](int t) {
-    const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
-    const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
+    const T* jxp = args.jx + ((size_t)p * HS + t) * nx * nx;
+    const T* jup = args.ju + ((size_t)p * HS + t) * nx * nu;
 #pragma unroll
     for (int k = 0; k < JR; ++k) {
       const int idx = tid + k * NTHR;
@@ -557,7 +560,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int nx = mlp.nx, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
+  const int nx = mlp.nx, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
+  const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   if (args.active[p] == 0) return;
   const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const RicLds R = make_ric_lds(nx, nu, no);
@@ -566,10 +570,10 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   T* xbar = Wr + R.xbar; T* ubar = Wr + R.ubar; T* goal = Wr + R.goal; T* scal = Wr + R.scal;
   const int ldV = R.ldV, ldJ = R.ldJ, ldQ = R.ldQ, ldB = R.ldB;
   const T* cpar = args.costs_par + (size_t)args.cost_idx[p] * cost_stride;   // Q R F goal
-  const T* st = args.states + (size_t)p * (H + 1) * nx;
-  const T* ct = args.ctrls + (size_t)p * H * nu;
-  T* Kg = args.Ks + (size_t)p * H * nu * nx;
-  T* kg = args.ks + (size_t)p * H * nu;
+  const T* st = args.states + (size_t)p * (HS + 1) * nx;
+  const T* ct = args.ctrls + (size_t)p * HS * nu;
+  T* Kg = args.Ks + (size_t)p * HS * nu * nx;
+  T* kg = args.ks + (size_t)p * HS * nu;
   const T dt = args.dt;
   for (int i = tid; i < R.total; i += NTHR) Wr[i] = T(0);
   __syncthreads();
@@ -602,8 +606,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   T jreg[JR];
   T xreg = T(0), ureg = T(0);
   auto fetch_step = [&](int t) {
-    const T* jxp = args.jx + ((size_t)p * H + t) * nx * nx;
-    const T* jup = args.ju + ((size_t)p * H + t) * nx * nu;
+    const T* jxp = args.jx + ((size_t)p * HS + t) * nx * nx;
+    const T* jup = args.ju + ((size_t)p * HS + t) * nx * nu;
 #pragma unroll
     for (int k = 0; k < JR; ++k) {
       const int idx = sid + k * SIDE;
@@ -847,7 +851,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x, p = blockIdx.x;
-  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
+  const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
+  const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   const int xs_ = L.xu_stride;
   const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
@@ -882,10 +887,10 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
   __syncthreads();
 
-  T* st = args.states + (size_t)p * (H + 1) * nx;
-  T* ct = args.ctrls + (size_t)p * H * nu;
-  T* Kg = args.Ks + (size_t)p * H * nu * nx;
-  T* kg = args.ks + (size_t)p * H * nu;
+  T* st = args.states + (size_t)p * (HS + 1) * nx;
+  T* ct = args.ctrls + (size_t)p * HS * nu;
+  T* Kg = args.Ks + (size_t)p * HS * nu * nx;
+  T* kg = args.ks + (size_t)p * HS * nu;
   T lin = T(0), quad = T(0), ksn2 = T(0);   // meaningful in thread 0 only
 
   // (backward Riccati sweep: ilqr_riccati_kernel above, launched just before this kernel)
@@ -908,8 +913,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
     xu[row * xs_ + col] = st[col];
   }
   __syncthreads();
-  T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
-  T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
+  T* lss = args.ls_states + (size_t)p * args.ls_n * (HS + 1) * nx;
+  T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * HS * nu;
   // K_t, k_t, ubar_t, xbar_t reach LDS one step ahead, through registers (as in the sweep): the
   // global loads for step t+1 are issued at the top of step t and committed at its end; the
   // barriers inside the loop are LDS-only, so neither these loads nor the line-search stores
@@ -966,12 +971,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
         const T fb = (f0 + f1) + (f2 + f3);
         u = alpha * kv[a] + ubar[a] + fb;
         if (args.bounded) { u = u < blo[a] ? blo[a] : u; u = u > bhi[a] ? bhi[a] : u; }
-        if (m < rows) lsc[((size_t)m * H + t) * nu + a] = u;
+        if (m < rows) lsc[((size_t)m * HS + t) * nu + a] = u;
       }
       xu[m * xs_ + nx + a] = u;
     }
     if (mode == 1 && m < rows)
-      for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + t) * nx + a] = xu[m * xs_ + a];
+      for (int a = r; a < nx; a += TPS) lss[((size_t)m * (HS + 1) + t) * nx + a] = xu[m * xs_ + a];
     AMPC_IMARK(41);
     lds_barrier();
     AMPC_IMARK(42);
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   }
   AMPC_IMARK_ALWAYS(32);
   if (mode == 1 && m < rows)
-    for (int a = r; a < nx; a += TPS) lss[((size_t)m * (H + 1) + H) * nx + a] = xu[m * xs_ + a];
+    for (int a = r; a < nx; a += TPS) lss[((size_t)m * (HS + 1) + H) * nx + a] = xu[m * xs_ + a];
   obj_part += quad_rows<T>(Fm, xu + m * xs_, goal, no, r, TPS, cdiag);
   if (caff) obj_part += affine_rows<T>(clint, xu + m * xs_, goal, no, r, TPS, clint[no + 1]);
 #pragma unroll
@@ -1021,7 +1026,6 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       args.obj[p] = lsobj[0];
       args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
       args.refresh[p] = 1; args.ls_rows[p] = 0;
-      if (args.slot_mode) args.slot_mode[p] = 1;
     }
     return;
   }
@@ -1062,12 +1066,12 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // ||new_ctrls - ctrls||, then swap in the selected candidate
   T du2 = T(0);
   for (int i = tid; i < H * nu; i += NTHR) {
-    const T d = lsc[(size_t)sel * H * nu + i] - ct[i];
+    const T d = lsc[(size_t)sel * HS * nu + i] - ct[i];
     du2 += d * d;
   }
   du2 = block_sum_any(du2, lsobj, W);
-  for (int i = tid; i < H * nu; i += NTHR) ct[i] = lsc[(size_t)sel * H * nu + i];
-  for (int i = tid; i < (H + 1) * nx; i += NTHR) st[i] = lss[(size_t)sel * (H + 1) * nx + i];
+  for (int i = tid; i < H * nu; i += NTHR) ct[i] = lsc[(size_t)sel * HS * nu + i];
+  for (int i = tid; i < (H + 1) * nx; i += NTHR) st[i] = lss[(size_t)sel * (HS + 1) * nx + i];
   if (tid == 0) {
     const bool conv = sqrt(du2) < args.u_threshold;
     args.obj[p] = scal[3];
@@ -1097,10 +1101,25 @@ template <typename T> struct IlqrQueue {
   int* out_flags;            // [P][4] converged, iters, status, candidate rows
 };
 
+// A slot's mode is IMMUTABLE within a line-search launch: the passes of a search may run as separate
+// workgroups of that launch (grid.y, ilqr_ls4.hpp), every one of which reads slot_mode[p] at entry -- were
+// the workgroup that rolls out a fresh guess to flip the mode to "iterate" itself, a pass workgroup
+// dispatched after it had finished would take the slot for an iterating one and search along the
+// PREVIOUS problem's gains.  So the rollout only raises active[p]; the flip happens here, in the first
+// kernel of the next iteration (one workgroup per slot, ahead of the sweep).  Returns true for such a slot
+// (it is running: nothing to harvest or refill).
+template <typename T> __device__ __forceinline__ bool ilqr_slot_started(const IlqrArgs<T>& args, int p, int tid) {
+  if (args.slot_mode[p] != 0 || args.active[p] == 0) return false;
+  __syncthreads();                                     // (every thread has read the mode before it changes)
+  if (tid == 0) args.slot_mode[p] = 1;
+  return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T> args, const IlqrQueue<T> q) {
   __shared__ int next_s;
   const int p = blockIdx.x, tid = threadIdx.x;
+  if (ilqr_slot_started(args, p, tid)) return;
   if (args.active[p] != 0 || args.slot_mode[p] == 0) return;      // running, or loaded and not yet started
   const int H = q.H, nx = q.nx, nu = q.nu;
   T* st = args.states + (size_t)p * (H + 1) * nx;
@@ -1160,6 +1179,7 @@ template <typename T>
 __global__ __launch_bounds__(64) void ilqr_chain_pre_kernel(const IlqrArgs<T> args, const IlqrChains<T> q) {
   const int p = blockIdx.x, tid = threadIdx.x;
   if (tid == 0) q.need[p] = 0;
+  if (ilqr_slot_started(args, p, tid)) return;
   if (args.active[p] != 0 || args.slot_mode[p] == 0) return;        // solving, or loaded and not yet started
   const int c = q.slot_chain[p];
   if (c < 0) { if (tid == 0) q.need[p] = 3; return; }

@@ -98,7 +98,13 @@ __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int 
   const int NT = hpad / 64, W = kLs4W, rows = 4 * rb;
   Ls4Lds L{};
   int o = 0;
-  L.xs = k1p + 1; L.as = hpad + 1;
+  // Activation row stride.  The A operand of a k-step is act[row l%4][4 ks + l/16]: four rows x two k
+  // offsets per 32-lane group of a ds_read_b64 (64 banks of 4 B).  The four-row kernel's reads pair up
+  // into ds_read2_b64 (16-lane groups, one k offset: any odd stride is conflict-free); the twelve-row
+  // kernel's rows 4 r + l%4 are too far apart for that, it issues ds_read_b64 -- with stride hpad + 1
+  // rows (a, k+1) and (a+1, k) share a bank (2-way: 37 % of its LDS cycles were conflict cycles,
+  // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE), with hpad + 2 the eight addresses take eight bank pairs.
+  L.xs = k1p + 1; L.as = rb > 1 ? hpad + 2 : hpad + 1;
   L.xu = o; o += rows * L.xs;
   L.act0 = o; o += rows * L.as;
   L.act1 = o; o += rows * L.as;
@@ -483,7 +489,6 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
         args.obj[p] = lsobj[0];
         args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
         args.refresh[p] = 1; args.ls_rows[p] = 0; args.ls_count[p] = 0;
-        if (args.slot_mode) args.slot_mode[p] = 1;
       }
       return;
     }

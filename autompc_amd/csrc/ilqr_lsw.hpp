@@ -554,7 +554,6 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
         args.obj[p] = lsobj[0];
         args.active[p] = 1; args.converged[p] = 0; args.iters[p] = 0; args.status[p] = 0;
         args.refresh[p] = 1; args.ls_rows[p] = 0; args.ls_count[p] = 0;
-        if (args.slot_mode) args.slot_mode[p] = 1;
       }
       return;
     }

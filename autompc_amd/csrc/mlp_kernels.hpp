@@ -18,10 +18,28 @@ namespace ampc {
 // same with c_stride / nu for controls).  A plain [n][nx] batch is grp = n, strides 0.  iLQR uses
 // grp = H with the [B][H+1][nx] / [B][H][nu] trajectory layout.  mask (optional) is per group:
 // groups with mask[g] == 0 are skipped by the Jacobian kernel (their Jacobians stay untouched).
+// glen (optional) is per group too: only the first glen[g] rows of group g exist (iLQR slots whose
+// horizon is shorter than the plan's, ampc_ilqr_solve_queue_var); the others are skipped like masked ones.
 struct RowMap {
   int grp;
   long long s_stride, c_stride;
   const int* mask;
+  const int* glen;
+  __device__ __forceinline__ bool plain() const { return mask == nullptr && glen == nullptr; }
+  __device__ __forceinline__ bool live(int r) const {
+    const int g = r / grp;
+    return (mask == nullptr || mask[g] != 0) && (glen == nullptr || r - g * grp < glen[g]);
+  }
+  // some row of [first, last] is live
+  __device__ __forceinline__ bool any_live(int first, int last) const {
+    for (int g = first / grp; g <= last / grp; ++g) {
+      if (mask != nullptr && mask[g] == 0) continue;
+      const int lo = first > g * grp ? first : g * grp;
+      const int hi = glen != nullptr ? g * grp + glen[g] - 1 : last;
+      if (lo <= (hi < last ? hi : last)) return true;
+    }
+    return false;
+  }
 };
 
 template <typename T, int NT, int MT, int W, bool DERIV, typename SH = DynShape, bool WIDE = false>
@@ -40,11 +58,8 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   const int first = blockIdx.x * M;
   T* xu = lds + L.xu;
-  if (rm.mask != nullptr && first < n) {   // (iLQR refresh) every group of this tile is masked out
-    const int last = (first + M - 1 < n ? first + M - 1 : n - 1) / rm.grp;
-    bool any = false;
-    for (int g = first / rm.grp; g <= last; ++g) any |= rm.mask[g] != 0;
-    if (!any) return;
+  if (!rm.plain() && first < n) {          // (iLQR refresh) every row of this tile is masked out
+    if (!rm.any_live(first, first + M - 1 < n ? first + M - 1 : n - 1)) return;
   }
   Net net;
   net.init(mlp);
@@ -54,13 +69,15 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
     const int row = i / nx, col = i - row * nx;
     const int gr = first + row;
     xu[row * L.xu_stride + col] =
-        (gr < n) ? states[(size_t)(gr / rm.grp) * rm.s_stride + (size_t)(gr % rm.grp) * nx + col] : T(0);
+        (gr < n && (rm.glen == nullptr || rm.live(gr)))    // (rows past a slot's horizon: never written)
+            ? states[(size_t)(gr / rm.grp) * rm.s_stride + (size_t)(gr % rm.grp) * nx + col] : T(0);
   }
   for (int i = tid; i < M * nu; i += NTHR) {
     const int row = i / nu, col = i - row * nu;
     const int gr = first + row;
     xu[row * L.xu_stride + nx + col] =
-        (gr < n) ? ctrls[(size_t)(gr / rm.grp) * rm.c_stride + (size_t)(gr % rm.grp) * nu + col] : T(0);
+        (gr < n && (rm.glen == nullptr || rm.live(gr)))
+            ? ctrls[(size_t)(gr / rm.grp) * rm.c_stride + (size_t)(gr % rm.grp) * nu + col] : T(0);
   }
   __syncthreads();
   // dz layout: [layer][n_pad][hpad]; this tile's rows start at `first`
@@ -138,11 +155,8 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   }
   const int s0 = sblk * M;                         // the tile's first sample
   const size_t lstride = (size_t)n_pad * hpad;
-  if (rm.mask != nullptr) {            // every group this tile touches is masked out: nothing to refresh
-    const int last = (s0 + M - 1 < n ? s0 + M - 1 : n - 1) / rm.grp;
-    bool any = false;
-    for (int g = s0 / rm.grp; g <= last; ++g) any |= rm.mask[g] != 0;
-    if (!any) return;
+  if (!rm.plain()) {                   // every row this tile touches is masked out: nothing to refresh
+    if (s0 >= n || !rm.any_live(s0, s0 + M - 1 < n ? s0 + M - 1 : n - 1)) return;
   }
 
   // G_L[s][k] = W_out'[i][k] * d_L[s][k]
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     const int row = e / mlp.kin, c = e - row * mlp.kin;
     const int s = s0 + row, i = i_out;
     if (s >= n) continue;
-    if (rm.mask != nullptr && rm.mask[s / rm.grp] == 0) continue;
+    if (!rm.plain() && !rm.live(s)) continue;
     T v = T(0);
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) v += G[ww * M * kinp + row * kinp + c];

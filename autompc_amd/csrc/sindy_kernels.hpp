@@ -226,7 +226,7 @@ __global__ void sindy_jacobian_kernel(const SindyDev<T> m, const T* __restrict__
                                       T* __restrict__ ju, int n, const RowMap rm) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  if (rm.mask != nullptr && rm.mask[r / rm.grp] == 0) return;
+  if (!rm.plain() && !rm.live(r)) return;
   const int nx = m.nx, nu = m.nu;
   states += (size_t)(r / rm.grp) * rm.s_stride + (size_t)(r % rm.grp) * nx - (size_t)r * nx;
   ctrls += (size_t)(r / rm.grp) * rm.c_stride + (size_t)(r % rm.grp) * nu - (size_t)r * nu;

@@ -144,3 +144,46 @@ def test_device_resident_ilqr_episodes_equal_the_host_loop():
     sing = dict(horizon=8, Q=np.ones(nx), R=np.zeros(nu), F=np.ones(nx))
     s2 = ev2.evaluate([good, sing, good, good])
     assert np.isinf(s2[1]) and np.all(np.isfinite(np.delete(s2, 1))) and s2[0] == s2[2] == s2[3]
+
+
+def test_concurrent_queues_with_side_by_side_passes_equal_one_problem_solves():
+    """Many small plans at once, each on its own handle / stream / host thread (what the candidate
+    evaluator's horizon groups do), every one with so few slots that the passes of a line search run as
+    separate workgroups of one launch (grid.y, ilqr_ls4.hpp): workgroup dispatch is oversubscribed and
+    a pass workgroup may start after the workgroup that rolled out a slot's fresh guess has finished.
+    A slot's mode must not change inside that launch (ilqr_slot_started, ilqr_kernels.hpp): every
+    problem gets exactly the one-problem solve's result, every time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from autompc_amd import _lib
+    nx, nu, hidden, act, H, B, P, max_iter, n_plans = 17, 6, [256, 256], "relu", 12, 3, 14, 20, 12
+    items = []
+    for g in range(n_plans):
+        p, h, _ = _setup(nx, nu, hidden, act, 3, seed=100 + g, bounds=(-0.25, 0.25))
+        rng = np.random.default_rng(g)
+        x0 = rng.uniform(-0.2, 0.2, size=(P, nx))
+        ci = rng.integers(0, 3, size=P).astype(np.int32)
+        plan = _lib.IlqrPlan(h, B, H, 0.05, cost_index=np.zeros(B, dtype=np.int32), clip_to_bounds=True)
+        items.append((h, plan, x0, ci))
+    refs = []
+    for h, plan, x0, ci in items:
+        rows = []
+        for j in range(P):
+            one = _lib.IlqrPlan(h, 1, H, 0.05, cost_index=ci[j:j + 1], clip_to_bounds=True)
+            rows.append(one.solve(x0[j], np.zeros((H, nu)), max_iter=max_iter))
+            one.close()
+        refs.append(rows)
+
+    def run(item):
+        _, plan, x0, ci = item
+        return plan.solve_queue(x0, None, ci, max_iter=max_iter)
+    for rep in range(6):
+        with ThreadPoolExecutor(max_workers=n_plans) as pool:
+            outs = list(pool.map(run, items))
+        for g, got in enumerate(outs):
+            for j in range(P):
+                for k in KEYS:
+                    np.testing.assert_array_equal(got[k][j], refs[g][j][k][0],
+                                                  err_msg="round %d, plan %d, problem %d, %s" % (rep, g, j, k))
+    for h, plan, _, _ in items:
+        plan.close()
+        h.close()
