@@ -91,6 +91,10 @@ SIGNATURES = {
                                       POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve_queue": (c_int, [c_void_p, c_int, _dp, _dp, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
                                       _dp]),
+    "ampc_ilqr_solve_queue_var": (c_int, [c_void_p, c_int, _dp, _dp, _ip, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip,
+                                          _ip, _dp]),
+    "ampc_ilqr_closed_loop_var": (c_int, [c_void_p, c_void_p, c_int, _dp, _ip, _ip, c_int, c_int, _dp, _dp, _ip,
+                                          _ip, POINTER(ctypes.c_longlong)]),
 }
 
 
@@ -640,29 +644,42 @@ class IlqrPlan:
                                        iptr(out["status"]), dptr(out["objective"])))
         return out
 
-    def closed_loop(self, init_obs, n_steps, cost_index=None, max_iter=50, surrogate=None):
+    def _horizons(self, horizon, n):
+        if horizon is None:
+            return None
+        hz = np.ascontiguousarray(np.broadcast_to(np.asarray(horizon, dtype=np.int32), (n,)))
+        if hz.min() < 1 or hz.max() > self.H:
+            raise ValueError("horizons must lie in [1, %d] (the plan's horizon)" % self.H)
+        return hz
+
+    def closed_loop(self, init_obs, n_steps, cost_index=None, max_iter=50, surrogate=None, horizon=None):
         """simulate() with IterativeLQR controllers for C episodes, device resident (ampc_ilqr_closed_loop):
         init_obs [C, nx]; returns dict(obs [C, n_steps+1, nx], ctrls [C, n_steps+1, nu], failed [C],
-        steps [C], iterations [C])."""
+        steps [C], iterations [C]).  horizon [C] (optional): each episode's iLQR horizon, at most the
+        plan's (ampc_ilqr_closed_loop_var)."""
         nx, nu = self.handle.nx, self.handle.nu
         init_obs = as_f64(init_obs).reshape(-1, nx)
         C = init_obs.shape[0]
         ci = None if cost_index is None else np.ascontiguousarray(np.broadcast_to(
             np.asarray(cost_index, dtype=np.int32), (C,)))
+        hz = self._horizons(horizon, C)
         out = {"obs": np.empty((C, n_steps + 1, nx)), "ctrls": np.empty((C, n_steps + 1, nu)),
                "failed": np.zeros(C, dtype=np.int32), "steps": np.zeros(C, dtype=np.int32),
                "iterations": np.zeros(C, dtype=np.int64)}
-        check(self.lib.ampc_ilqr_closed_loop(
-            self._p, surrogate._h if surrogate is not None else None, C, dptr(init_obs), iptr(ci), int(n_steps),
-            int(max_iter), dptr(out["obs"]), dptr(out["ctrls"]), iptr(out["failed"]), iptr(out["steps"]),
-            out["iterations"].ctypes.data_as(POINTER(ctypes.c_longlong))))
+        check(self.lib.ampc_ilqr_closed_loop_var(
+            self._p, surrogate._h if surrogate is not None else None, C, dptr(init_obs), iptr(ci), iptr(hz),
+            int(n_steps), int(max_iter), dptr(out["obs"]), dptr(out["ctrls"]), iptr(out["failed"]),
+            iptr(out["steps"]), out["iterations"].ctypes.data_as(POINTER(ctypes.c_longlong))))
         return out
 
-    def solve_queue(self, x0, uguess=None, cost_index=None, max_iter=50, gains=True, trajectories=True):
+    def solve_queue(self, x0, uguess=None, cost_index=None, max_iter=50, gains=True, trajectories=True,
+                    horizon=None):
         """P problems streamed through the plan's B slots (ampc_ilqr_solve_queue): a slot whose problem
         is finished takes the next one at the following iteration boundary, on the device.  x0 [P, nx];
         uguess [P, H, nu] or None (zeros); cost_index [P] or None (block 0).  Per-problem results are
-        bit-identical to one-problem solves.  gains / trajectories = False skip those downloads."""
+        bit-identical to one-problem solves.  gains / trajectories = False skip those downloads.
+        horizon [P] (optional): each problem's own horizon, at most the plan's (ampc_ilqr_solve_queue_var):
+        arrays keep the plan's H as their stride, rows past a problem's horizon come back zero."""
         nx, nu, H = self.handle.nx, self.handle.nu, self.H
         x0 = as_f64(x0).reshape(-1, nx)
         P = x0.shape[0]
@@ -675,8 +692,9 @@ class IlqrPlan:
             out["states"], out["ctrls"] = np.empty((P, H + 1, nx)), np.empty((P, H, nu))
         if gains:
             out["Ks"], out["ks"] = np.empty((P, H, nu, nx)), np.empty((P, H, nu))
-        check(self.lib.ampc_ilqr_solve_queue(self._p, P, dptr(x0), dptr(ug), iptr(ci), int(max_iter),
-                                             dptr(out.get("states")), dptr(out.get("ctrls")), dptr(out.get("Ks")),
-                                             dptr(out.get("ks")), iptr(out["converged"]), iptr(out["iters"]),
-                                             iptr(out["status"]), dptr(out["objective"])))
+        hz = self._horizons(horizon, P)
+        check(self.lib.ampc_ilqr_solve_queue_var(self._p, P, dptr(x0), dptr(ug), iptr(ci), iptr(hz), int(max_iter),
+                                                 dptr(out.get("states")), dptr(out.get("ctrls")), dptr(out.get("Ks")),
+                                                 dptr(out.get("ks")), iptr(out["converged"]), iptr(out["iters"]),
+                                                 iptr(out["status"]), dptr(out["objective"])))
         return out

@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 105; }   // 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
+extern "C" int ampc_version(void) { return 106; }   // 1.06: round 5 (ampc_ilqr_*_var); 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1545,7 +1545,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
                     &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric,
                     &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
-                    &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl};
+                    &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl, &p->slot_h};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->poll_host) (void)hipHostFree(p->poll_host);
@@ -1661,7 +1661,7 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, const double* uguess,
-                                 const int* cost_index, int max_iter, double* states, double* ctrls,
+                                 const int* cost_index, const int* horizon, int max_iter, double* states, double* ctrls,
                                  double* Ks, double* ks, int* converged, int* iters, int* status,
                                  double* objective) {
   ampc_handle* h = p->h;
@@ -1670,7 +1670,7 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
   HIP_OK(p->q_x0.reserve((size_t)P * nx * e));
   HIP_OK(p->q_u.reserve((size_t)P * H * nu * e));
-  HIP_OK(p->q_cost.reserve((size_t)P * sizeof(int)));
+  HIP_OK(p->q_cost.reserve((size_t)2 * P * sizeof(int)));               // cost block [P], horizon [P]
   HIP_OK(p->q_states.reserve((size_t)P * (H + 1) * nx * e));
   HIP_OK(p->q_ctrls.reserve((size_t)P * H * nu * e));
   HIP_OK(p->q_Ks.reserve((size_t)P * H * nu * nx * e));
@@ -1682,6 +1682,13 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   if (cost_index) std::memcpy(cost.data(), cost_index, (size_t)P * sizeof(int));
   HIP_OK(hipMemcpyAsync(p->q_ctl.p, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(p->q_cost.p, cost.data(), (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  std::vector<int> slot_h0;
+  if (horizon) {
+    slot_h0.assign(B, H);
+    HIP_OK(p->slot_h.reserve((size_t)B * sizeof(int)));
+    HIP_OK(hipMemcpyAsync(p->slot_h.p, slot_h0.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync((int*)p->q_cost.p + P, horizon, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_OK(upload_converted<T>(p->q_x0.p, x0, (size_t)P * nx, h->stream));
   if (uguess) HIP_OK(upload_converted<T>(p->q_u.p, uguess, (size_t)P * H * nu, h->stream));
   else HIP_OK(hipMemsetAsync(p->q_u.p, 0, (size_t)P * H * nu * e, h->stream));
@@ -1696,13 +1703,21 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
   struct Guard {
     ampc_ilqr_plan* p;
-    ~Guard() { p->queue_on = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+    // (every exit path: no copy into the pinned poll buffer may still be in flight when it is freed, and
+    //  the slots' cost blocks are the plan's own again, as ampc_ilqr_solve expects them)
+    ~Guard() {
+      (void)hipStreamSynchronize(p->h->stream);
+      (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
+      p->queue_on = false; p->var_h = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
+    }
   } guard{p};
   p->queue_on = true;
+  p->var_h = horizon != nullptr;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
   IlqrQueue<T> q;
   q.P = P; q.B = B; q.H = H; q.nx = nx; q.nu = nu;
+  q.horizon = horizon ? (const int*)p->q_cost.p + P : nullptr; q.slot_h = (int*)p->slot_h.p;
   q.ctl = (int*)p->q_ctl.p; q.slot_prob = q.ctl + 2;
   q.x0 = (const T*)p->q_x0.p; q.uguess = (const T*)p->q_u.p; q.cost = (const int*)p->q_cost.p;
   q.cost_idx = (int*)p->d_cost_idx.p;
@@ -1781,9 +1796,33 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   if (Ks) HIP_OK(download_converted<T>(Ks, p->q_Ks.p, (size_t)P * H * nu * nx, h->stream));
   if (ks) HIP_OK(download_converted<T>(ks, p->q_ks.p, (size_t)P * H * nu, h->stream));
   if (objective) HIP_OK(download_converted<T>(objective, p->q_obj.p, (size_t)P, h->stream));
-  // leave the plan as ampc_ilqr_solve expects it: the slots' cost blocks as given at plan creation
-  HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
+  return 0;      // (Guard: the slots' cost blocks as given at plan creation)
+}
+
+static int check_horizons(const ampc_ilqr_plan* p, int n, const int* horizon, const char* who) {
+  if (horizon)
+    for (int j = 0; j < n; ++j)
+      REQUIRE(horizon[j] >= 1 && horizon[j] <= p->H, std::string(who) + ": horizons must lie in [1, the plan's horizon]");
   return 0;
+}
+
+extern "C" int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
+                                         const int* cost_index, const int* horizon, int max_iter, double* states,
+                                         double* ctrls, double* Ks, double* ks, int* converged, int* iters,
+                                         int* status, double* objective) {
+  REQUIRE(p && x0, "ampc_ilqr_solve_queue_var: NULL argument");
+  REQUIRE(n_problems >= 1, "ampc_ilqr_solve_queue_var: n_problems < 1");
+  REQUIRE(max_iter >= 1, "ampc_ilqr_solve_queue_var: max_iter < 1");
+  if (cost_index)
+    for (int j = 0; j < n_problems; ++j)
+      REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_solve_queue_var: bad cost_index");
+  if (int rc = check_horizons(p, n_problems, horizon, "ampc_ilqr_solve_queue_var")) return rc;
+  HIP_OK(hipSetDevice(p->h->device));
+  return p->h->precision == AMPC_F64
+             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, horizon, max_iter, states, ctrls, Ks,
+                                             ks, converged, iters, status, objective)
+             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, horizon, max_iter, states, ctrls, Ks,
+                                            ks, converged, iters, status, objective);
 }
 
 extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
@@ -1798,9 +1837,9 @@ extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const do
       REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_solve_queue: bad cost_index");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
-             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, max_iter, states, ctrls, Ks, ks,
+             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, nullptr, max_iter, states, ctrls, Ks, ks,
                                              converged, iters, status, objective)
-             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, max_iter, states, ctrls, Ks, ks,
+             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, nullptr, max_iter, states, ctrls, Ks, ks,
                                             converged, iters, status, objective);
 }
 
@@ -1809,22 +1848,27 @@ extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const do
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, const double* init_obs,
-                                 const int* cost_index, int n_steps, int max_iter, double* traj_obs,
+                                 const int* cost_index, const int* horizon, int n_steps, int max_iter, double* traj_obs,
                                  double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, H = p->H, T1 = n_steps + 1;
   const size_t e = sizeof(T);
   // ints: ctl[2] | slot_mode[B] (where make_ilqr_args expects it: q_ctl + 2 + B) ...
   HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
-  HIP_OK(p->c_ints.reserve((size_t)(2 * B + 3 * C) * sizeof(int)));      // need[B] slot_chain[B] chain_t[C] chain_fail[C] cost[C]
+  HIP_OK(p->c_ints.reserve((size_t)(2 * B + 4 * C) * sizeof(int)));      // need[B] slot_chain[B] chain_t[C] chain_fail[C] cost[C] horizon[C]
   HIP_OK(p->c_iters.reserve((size_t)C * sizeof(long long)));
   HIP_OK(p->c_stage.reserve((size_t)B * (2 * nx + nu) * e));
   HIP_OK(p->c_obs.reserve((size_t)C * T1 * nx * e));
   HIP_OK(p->c_ctl.reserve((size_t)C * T1 * nu * e));
   HIP_OK(p->q_x0.reserve((size_t)C * nx * e));
-  std::vector<int> ctl(2 + 2 * B, 0), ci(2 * B + 3 * C, 0);
+  std::vector<int> ctl(2 + 2 * B, 0), ci(2 * B + 4 * C, 0), slot_h0(B, H);
   for (int b = 0; b < B; ++b) { ctl[2 + b] = -1; ctl[2 + B + b] = 1; ci[B + b] = -1; }
   if (cost_index) std::memcpy(ci.data() + 2 * B + 2 * C, cost_index, (size_t)C * sizeof(int));
+  if (horizon) {
+    std::memcpy(ci.data() + 2 * B + 3 * C, horizon, (size_t)C * sizeof(int));
+    HIP_OK(p->slot_h.reserve((size_t)B * sizeof(int)));
+    HIP_OK(hipMemcpyAsync(p->slot_h.p, slot_h0.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
   HIP_OK(hipMemcpyAsync(p->q_ctl.p, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(p->c_ints.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemsetAsync(p->c_iters.p, 0, (size_t)C * sizeof(long long), h->stream));
@@ -1842,9 +1886,14 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
   struct Guard {
     ampc_ilqr_plan* p;
-    ~Guard() { p->queue_on = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
+    ~Guard() {
+      (void)hipStreamSynchronize(p->h->stream);
+      (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
+      p->queue_on = false; p->var_h = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
+    }
   } guard{p};
   p->queue_on = true;
+  p->var_h = horizon != nullptr;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
   p->ls_rb_now = 1;
@@ -1854,6 +1903,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   int* ints = (int*)p->c_ints.p;
   q.need = ints; q.slot_chain = ints + B; q.chain_t = ints + 2 * B; q.chain_fail = ints + 2 * B + C;
   q.cost = ints + 2 * B + 2 * C;
+  q.horizon = horizon ? ints + 2 * B + 3 * C : nullptr; q.slot_h = (int*)p->slot_h.p;
   q.chain_iters = (long long*)p->c_iters.p;
   q.x0 = (const T*)p->q_x0.p; q.cost_idx = (int*)p->d_cost_idx.p;
   q.stage_x = (T*)p->c_stage.p; q.stage_u = q.stage_x + (size_t)B * nx; q.stage_next = q.stage_u + (size_t)B * nu;
@@ -1904,14 +1954,22 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   if (iterations) HIP_OK(hipMemcpy(iterations, p->c_iters.p, (size_t)C * sizeof(long long), hipMemcpyDeviceToHost));
   if (traj_obs) HIP_OK(download_converted<T>(traj_obs, p->c_obs.p, (size_t)C * T1 * nx, h->stream));
   if (traj_ctrls) HIP_OK(download_converted<T>(traj_ctrls, p->c_ctl.p, (size_t)C * T1 * nu, h->stream));
-  HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice));
   return 0;
 }
 
 extern "C" int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
                                      const int* cost_index, int n_steps, int max_iter, double* traj_obs,
                                      double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
+  return ampc_ilqr_closed_loop_var(p, surrogate, n_chains, init_obs, cost_index, nullptr, n_steps, max_iter, traj_obs,
+                                   traj_ctrls, failed, steps_done, iterations);
+}
+
+extern "C" int ampc_ilqr_closed_loop_var(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
+                                         const int* cost_index, const int* horizon, int n_steps, int max_iter,
+                                         double* traj_obs, double* traj_ctrls, int* failed, int* steps_done,
+                                         long long* iterations) {
   REQUIRE(p && init_obs, "ampc_ilqr_closed_loop: NULL argument");
+  if (int rc = check_horizons(p, n_chains, horizon, "ampc_ilqr_closed_loop_var")) return rc;
   REQUIRE(n_chains >= 1 && n_steps >= 1 && max_iter >= 1, "ampc_ilqr_closed_loop: n_chains, n_steps, max_iter must be >= 1");
   ampc_handle* sur = surrogate ? surrogate : p->h;
   REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
@@ -1923,9 +1981,9 @@ extern "C" int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, 
       REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_closed_loop: bad cost_index");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
-             ? ilqr_closed_loop_impl<double>(p, sur, n_chains, init_obs, cost_index, n_steps, max_iter, traj_obs,
+             ? ilqr_closed_loop_impl<double>(p, sur, n_chains, init_obs, cost_index, horizon, n_steps, max_iter, traj_obs,
                                              traj_ctrls, failed, steps_done, iterations)
-             : ilqr_closed_loop_impl<float>(p, sur, n_chains, init_obs, cost_index, n_steps, max_iter, traj_obs,
+             : ilqr_closed_loop_impl<float>(p, sur, n_chains, init_obs, cost_index, horizon, n_steps, max_iter, traj_obs,
                                             traj_ctrls, failed, steps_done, iterations);
 }
 

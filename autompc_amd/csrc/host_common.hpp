@@ -428,6 +428,10 @@ struct ampc_ilqr_plan {
   bool queue_on = false;        // kernels read the per-slot mode and the per-problem iteration cap
   int queue_max_iter = 0;
   DevBuf q_ctl;                 // ints: [0] next, [1] harvested, then slot_prob[B], slot_mode[B]
+  // problems / episodes of different horizons in one plan (ampc_ilqr_solve_queue_var, _closed_loop_var): every
+  // array keeps the plan's horizon H as its stride, a slot's loops run to slot_h[slot] <= H
+  bool var_h = false;
+  DevBuf slot_h;                // [B] ints
   DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
   DevBuf c_ints, c_iters, c_stage, c_obs, c_ctl;   // ampc_ilqr_closed_loop: chain bookkeeping, staged rows, trajectories
   long long last_queue_launches = 0;   // iterations launched by the last queue solve
@@ -461,6 +465,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   if (p->queue_on) {
     a.slot_mode = (int*)p->q_ctl.p + 2 + p->B;
     a.max_iter = p->queue_max_iter;
+    if (p->var_h) a.slot_h = (const int*)p->slot_h.p;
   }
   return a;
 }

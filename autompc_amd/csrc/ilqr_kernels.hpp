@@ -1090,7 +1090,9 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
 // its first iteration), the Jacobian launch refreshes it, and from the next iteration on the slot
 // iterates with everybody else.  No host round trip; a problem's arithmetic is the one-problem solve's.
 template <typename T> struct IlqrQueue {
-  int P, B, H, nx, nu;
+  int P, B, H, nx, nu;       // H: the plan's horizon = the stride of every [..][H][..] array below
+  const int* horizon;        // [P] per-problem horizon <= H (rows past it: zero in the outputs), nullptr: H
+  int* slot_h;               // [B] the plan's per-slot horizon (read by every kernel), with `horizon`
   int* ctl;                  // [0] next problem to hand out, [1] problems harvested
   int* slot_prob;            // [B] problem in the slot, -1: none
   const T* x0;               // [P][nx]
@@ -1125,11 +1127,13 @@ __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T
   T* st = args.states + (size_t)p * (H + 1) * nx;
   T* ct = args.ctrls + (size_t)p * H * nu;
   const int j = q.slot_prob[p];
-  if (j >= 0) {                                        // harvest
-    for (int i = tid; i < (H + 1) * nx; i += 256) q.out_states[(size_t)j * (H + 1) * nx + i] = st[i];
-    for (int i = tid; i < H * nu; i += 256) q.out_ctrls[(size_t)j * H * nu + i] = ct[i];
-    for (int i = tid; i < H * nu * nx; i += 256) q.out_Ks[(size_t)j * H * nu * nx + i] = args.Ks[(size_t)p * H * nu * nx + i];
-    for (int i = tid; i < H * nu; i += 256) q.out_ks[(size_t)j * H * nu + i] = args.ks[(size_t)p * H * nu + i];
+  if (j >= 0) {                                        // harvest (rows past the problem's own horizon: zeros)
+    const int hj = q.horizon ? q.horizon[j] : H;
+    for (int i = tid; i < (H + 1) * nx; i += 256) q.out_states[(size_t)j * (H + 1) * nx + i] = i < (hj + 1) * nx ? st[i] : T(0);
+    for (int i = tid; i < H * nu; i += 256) q.out_ctrls[(size_t)j * H * nu + i] = i < hj * nu ? ct[i] : T(0);
+    for (int i = tid; i < H * nu * nx; i += 256)
+      q.out_Ks[(size_t)j * H * nu * nx + i] = i < hj * nu * nx ? args.Ks[(size_t)p * H * nu * nx + i] : T(0);
+    for (int i = tid; i < H * nu; i += 256) q.out_ks[(size_t)j * H * nu + i] = i < hj * nu ? args.ks[(size_t)p * H * nu + i] : T(0);
     if (tid == 0) {
       q.out_obj[j] = args.obj[p];
       q.out_flags[4 * j] = args.converged[p]; q.out_flags[4 * j + 1] = args.iters[p];
@@ -1143,6 +1147,7 @@ __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T
     q.slot_prob[p] = n;
     if (n >= 0) {
       q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0;
+      if (q.horizon) q.slot_h[p] = q.horizon[n];
     }
     if (j >= 0) { __threadfence(); atomicAdd(&q.ctl[1], 1); }
   }
@@ -1160,7 +1165,9 @@ __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T
 // its chain -- solve, surrogate step, next solve -- until the episode ends, then takes the next chain.
 // Per iteration of the plan:   pre (this kernel)  ->  surrogate step over the B staged rows  ->  post.
 template <typename T> struct IlqrChains {
-  int C, B, H, nx, nu, n_steps, max_iter;
+  int C, B, H, nx, nu, n_steps, max_iter;     // H: the plan's horizon (array stride)
+  const int* horizon;        // [C] per-chain iLQR horizon <= H, nullptr: H
+  int* slot_h;               // [B] the plan's per-slot horizon, with `horizon`
   int* ctl;                  // [0] next chain to hand out, [1] chains finished
   int* slot_chain;           // [B] chain in the slot, -1: none
   int* need;                 // [B] 0 nothing, 1 step the surrogate and continue, 2 chain failed, 3 wants a chain
@@ -1229,7 +1236,10 @@ __global__ __launch_bounds__(256) void ilqr_chain_post_kernel(const IlqrArgs<T> 
     if (n >= q.C) n = -1;
     next_s = n;
     q.slot_chain[p] = n;
-    if (n >= 0) { q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0; q.chain_t[n] = 0; }
+    if (n >= 0) {
+      q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0; q.chain_t[n] = 0;
+      if (q.horizon) q.slot_h[p] = q.horizon[n];
+    }
   }
   __syncthreads();
   const int n = next_s;

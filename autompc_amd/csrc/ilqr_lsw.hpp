@@ -81,7 +81,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim, H = args.H;
+  const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
+  const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   const int Lh = RES ? 2 : mlp.n_hidden, nxp = mlp.nxp, tiles = nxp / 16, ks0 = mlp.k1p / 4;
   const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
   const Ls4Lds L = make_ls4_lds(nu, mlp.k1p, nxp, HP, Lh, RES, cost_stride, RB);
@@ -178,13 +179,13 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
   }
   const int arow = lane & 3, ak = lane >> 4, drow = lane >> 4, dcol = lane & 15;
 
-  const T* st = args.states + (size_t)p * (H + 1) * nx;
-  T* stw = args.states + (size_t)p * (H + 1) * nx;
-  T* ctw = args.ctrls + (size_t)p * H * nu;
-  const T* Kg = args.Ks + (size_t)p * H * nu * nx;
-  const T* kg = args.ks + (size_t)p * H * nu;
-  T* lss = args.ls_states + (size_t)p * args.ls_n * (H + 1) * nx;
-  T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * H * nu;
+  const T* st = args.states + (size_t)p * (HS + 1) * nx;
+  T* stw = args.states + (size_t)p * (HS + 1) * nx;
+  T* ctw = args.ctrls + (size_t)p * HS * nu;
+  const T* Kg = args.Ks + (size_t)p * HS * nu * nx;
+  const T* kg = args.ks + (size_t)p * HS * nu;
+  T* lss = args.ls_states + (size_t)p * args.ls_n * (HS + 1) * nx;
+  T* lsc = args.ls_ctrls + (size_t)p * args.ls_n * HS * nu;
   const int rows = mode == 0 ? 1 : args.ls_n;
   const bool cdiag = args.cost_diag != 0, caff = args.cost_affine != 0;
   // Wave w owns rows w, 4 + w, ... of the tile between time steps: it adds the network output to their
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
           if (r < RB && xj < nx) {
             const int row = 4 * r + w, jl = ROWS * pass + row;
             if (mode == 0) { if (t > 0 && row == 0) st_buf(stw, (unsigned)xj * 8u, (unsigned)(t * nx) * 8u, xn[q]); }
-            else if (jl < rows) st_buf(lss, (unsigned)(jl * (H + 1) * nx + xj) * 8u, (unsigned)(t * nx) * 8u, xn[q]);
+            else if (jl < rows) st_buf(lss, (unsigned)(jl * (HS + 1) * nx + xj) * 8u, (unsigned)(t * nx) * 8u, xn[q]);
           }
         }
       };
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
         if (mode == 1 && ca < nu && cpart == 0) {
 #pragma unroll
           for (int r = 0; r < RB; ++r)
-            if (livew[r]) st_buf(lsc, (unsigned)ca * 8u, (unsigned)((jw[r] * H + t) * nu) * 8u, u[r]);
+            if (livew[r]) st_buf(lsc, (unsigned)ca * 8u, (unsigned)((jw[r] * HS + t) * nu) * 8u, u[r]);
         }
         if (t + 1 < H) fetch_law(t + 1);
       }
@@ -525,8 +526,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           if (!livew[r]) continue;
-          const T* xsrc = mode == 0 ? stw : lss + (size_t)jw[r] * (H + 1) * nx;
-          const T* usrc = mode == 0 ? ctw : lsc + (size_t)jw[r] * H * nu;
+          const T* xsrc = mode == 0 ? stw : lss + (size_t)jw[r] * (HS + 1) * nx;
+          const T* usrc = mode == 0 ? ctw : lsc + (size_t)jw[r] * HS * nu;
           const T* xt = xsrc + (size_t)t * nx;
           if (t < H) obj_part[r] += args.dt * (quad_rows<T>(Qm, xt, goal, no, 0, 1, cdiag) +
                                                quad_rows<T>(Rm, usrc + (size_t)t * nu, nullptr, nu, 0, 1, cdiag));
@@ -602,12 +603,12 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
   // ||new_ctrls - ctrls||, then swap in the selected candidate
   T du2 = T(0);
   for (int i = tid; i < H * nu; i += NTHR) {
-    const T d = lsc[(size_t)sel * H * nu + i] - ctw[i];
+    const T d = lsc[(size_t)sel * HS * nu + i] - ctw[i];
     du2 += d * d;
   }
   du2 = block_sum_any(du2, lsobj + kIlqrMaxLs, W);
-  for (int i = tid; i < H * nu; i += NTHR) ctw[i] = lsc[(size_t)sel * H * nu + i];
-  for (int i = tid; i < (H + 1) * nx; i += NTHR) stw[i] = lss[(size_t)sel * (H + 1) * nx + i];
+  for (int i = tid; i < H * nu; i += NTHR) ctw[i] = lsc[(size_t)sel * HS * nu + i];
+  for (int i = tid; i < (H + 1) * nx; i += NTHR) stw[i] = lss[(size_t)sel * (HS + 1) * nx + i];
   if (tid == 0) {
     const bool conv = sqrt(du2) < args.u_threshold;
     args.obj[p] = scal[3];

@@ -81,7 +81,8 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
   const int n_pad = round_up(rows, 64);
-  const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B};
+  const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B,
+                  (p->queue_on && p->var_h) ? (const int*)p->slot_h.p : nullptr};
 #ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,

@@ -430,21 +430,26 @@ class IlqrCandidateEvaluator:
 
     ``IterativeLQR.run`` re-solves from a zero guess at every control step (ilqr.py:267-295 with the
     default ``reuse_feedback``).  Episodes of known length (the task only carries a step count) run
-    entirely on the device (``ampc_ilqr_closed_loop``): the candidates of a horizon group stream
-    through the plan's slots, each slot carrying one candidate's episode -- solve, surrogate step,
-    next solve -- without a host round trip and without waiting for the other slots' solves.  With a
-    user termination condition (asked on the host after every step) a control step of the batch is
-    one batched device solve (``ampc_ilqr_solve``) followed by one batched surrogate step.  Either
-    way everything is deterministic: a candidate's score does not depend on the batch it is in or
-    on the rank that evaluates it."""
+    entirely on the device (``ampc_ilqr_closed_loop_var``): ALL candidates, whatever their horizon,
+    stream through the slots of one plan built for the longest horizon (a slot's sweep, line search
+    and Jacobian refresh run over its own candidate's horizon), each slot carrying one candidate's
+    episode -- solve, surrogate step, next solve -- without a host round trip and without waiting
+    for the other slots' solves.  With a user termination condition (asked on the host after every
+    step) a control step of the batch is one queue of device solves (``ampc_ilqr_solve_queue_var``)
+    followed by one batched surrogate step.  Either way everything is deterministic and every solve
+    is bit-identical to a one-problem solve of its own horizon: a candidate's score does not depend
+    on the batch it is in or on the rank that evaluates it."""
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0, device_resident=True,
-                 max_slots=256, max_threads=32):
-        """device_resident: episodes of known length run entirely on the device (ampc_ilqr_closed_loop;
-        a user termination condition is asked on the host, one batched solve per control step);
-        max_slots: problems solved side by side per horizon group (one workgroup each); max_threads:
-        horizon groups evaluated concurrently (one plan, stream and host thread each)."""
+                 max_slots=256, max_threads=32, one_plan=True):
+        """device_resident: episodes of known length run entirely on the device (ampc_ilqr_closed_loop_var;
+        a user termination condition is asked on the host, one queue of solves per control step);
+        max_slots: problems solved side by side (one workgroup each);
+        one_plan = False: the round-4 scheme, kept for comparison (tools/ilqr_eval_rate.py) -- one plan per
+        horizon, the horizon groups evaluated concurrently on max_threads host threads (one plan and stream
+        each); same scores bit for bit."""
         self.device_resident, self.max_slots, self.max_threads = bool(device_resident), int(max_slots), max(1, int(max_threads))
+        self.one_plan = bool(one_plan)
         if not hasattr(model, "stage_into"):
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         if precision != "f64":
@@ -486,10 +491,12 @@ class IlqrCandidateEvaluator:
             max_steps, term_cond = episode_of(self.task)
             n_ctl = default_episode_controls(self.task) if term_cond is None else max_steps
         init_obs = self.task.get_init_obs() if init_obs is None else np.asarray(init_obs)
-        # one plan per horizon: the problems of a plan share the horizon, not the cost
+        # one plan for every horizon (a slot runs over its own candidate's horizon, ampc_ilqr_*_var);
+        # one_plan = False: one plan per horizon -- the problems of a plan share the horizon, not the cost
         groups = {}
+        hz_all = np.array([int(c["horizon"]) for c in candidates], dtype=np.int32)
         for i, c in enumerate(candidates):
-            groups.setdefault(int(c["horizon"]), []).append(i)
+            groups.setdefault(int(hz_all.max()) if self.one_plan else int(c["horizon"]), []).append(i)
         sur = _lib.Handle(self.device, self.precision)
         opened.append(sur)
         self.surrogate.stage_into(sur)
@@ -503,7 +510,7 @@ class IlqrCandidateEvaluator:
             h.set_cost_blocks(**blocks)
             if self.bounded:
                 h.set_ctrl_bounds(self.umin, self.umax)
-            slots = min(len(idx), self.max_slots) if device_loop else len(idx)
+            slots = min(len(idx), self.max_slots) if (device_loop or self.one_plan) else len(idx)
             plan = _lib.IlqrPlan(h, slots, H, self.system.dt, cost_index=np.arange(slots),
                                  clip_to_bounds=self.bounded, terminal_goal=term_goal)
             opened.append(plan)
@@ -528,7 +535,8 @@ class IlqrCandidateEvaluator:
             def run_group(item):
                 plan, idx = item
                 return idx, plan.closed_loop(np.tile(x0, (len(idx), 1)), n_ctl, cost_index=np.arange(len(idx)),
-                                             max_iter=max_iter, surrogate=sur)
+                                             max_iter=max_iter, surrogate=sur,
+                                             horizon=hz_all[idx] if self.one_plan else None)
             items = list(plans.values())
             if len(items) > 1:
                 from concurrent.futures import ThreadPoolExecutor
@@ -553,7 +561,11 @@ class IlqrCandidateEvaluator:
                     continue
                 # (finished candidates keep their slot: the solve is per problem, their result is unused)
                 x = np.where(live[:, None], obs[idx, t], obs[idx, 0])
-                out = plan.solve(x, np.zeros((len(idx), H, nu)), max_iter=max_iter)
+                if self.one_plan:
+                    out = plan.solve_queue(x, None, np.arange(len(idx)), max_iter=max_iter, gains=False,
+                                           horizon=hz_all[idx])
+                else:
+                    out = plan.solve(x, np.zeros((len(idx), H, nu)), max_iter=max_iter)
                 u = out["ctrls"][:, 0]              # u = ubar_0 + K_0 (x - xbar_0) with x = xbar_0
                 bad = live & (out["status"] == 1)
                 failed[idx[bad]] = True

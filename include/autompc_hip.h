@@ -37,7 +37,8 @@ enum { AMPC_ACT_RELU = 0, AMPC_ACT_TANH = 1, AMPC_ACT_SIGMOID = 2, AMPC_ACT_SELU
 enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 
 const char* ampc_last_error(void);
-int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs */
+int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs;
+                           * 106: + ampc_ilqr_solve_queue_var, ampc_ilqr_closed_loop_var */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -372,6 +373,18 @@ int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, c
                           double* Ks, double* ks, int* converged, int* iters, int* status,
                           double* objective);
 
+/* ampc_ilqr_solve_queue with a horizon per problem: horizon[n], each in [1, the plan's horizon H] (NULL: H for
+ * every problem = ampc_ilqr_solve_queue).  The tuner's iLQR candidates differ in their horizon
+ * (IterativeLQRFactory: 5..25, control/ilqr.py:31-41); with this they share ONE plan of H = the longest -- a
+ * slot's sweep, line search and Jacobian refresh run over its own problem's horizon, the launches are shared.
+ * All arrays keep H as their stride: uguess [n][H][nu] (rows past a problem's horizon are ignored), outputs
+ * states [n][H+1][nx], ctrls [n][H][nu], Ks [n][H][nu][nx], ks [n][H][nu] (rows past it are zero).  A
+ * problem's results are bit-identical to ampc_ilqr_solve on a one-problem plan of its own horizon. */
+int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
+                              const int* cost_index, const int* horizon, int max_iter, double* states,
+                              double* ctrls, double* Ks, double* ks, int* converged, int* iters, int* status,
+                              double* objective);
+
 /* simulate() with IterativeLQR controllers, device resident (utils/simulation.py:44-63 as eval_cfg drives it,
  * pipeline_tuner.py:222-231; IterativeLQR.run, ilqr.py:267-295: every control step is a full solve from a zero
  * guess, u = ubar_0, then obs <- surrogate.pred(obs, u)).  n_chains episodes of n_steps control steps stream
@@ -386,6 +399,12 @@ int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, c
 int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
                           const int* cost_index, int n_steps, int max_iter, double* traj_obs,
                           double* traj_ctrls, int* failed, int* steps_done, long long* iterations);
+/* ... with an iLQR horizon per episode: horizon[n] in [1, the plan's horizon] (NULL: the plan's), as
+ * ampc_ilqr_solve_queue_var; everything else as ampc_ilqr_closed_loop. */
+int ampc_ilqr_closed_loop_var(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
+                              const int* cost_index, const int* horizon, int n_steps, int max_iter,
+                              double* traj_obs, double* traj_ctrls, int* failed, int* steps_done,
+                              long long* iterations);
 
 #ifdef __cplusplus
 }

@@ -187,3 +187,76 @@ def test_concurrent_queues_with_side_by_side_passes_equal_one_problem_solves():
     for h, plan, _, _ in items:
         plan.close()
         h.close()
+
+
+@pytest.mark.parametrize("case", [
+    # nx, nu, hidden, act, Hmax, B, P, bounds, max_iter
+    (17, 6, [256, 256], "relu", 25, 6, 30, (-0.25, 0.25), 50),     # the tuner's range 5..25 on the c4 shape (MFMA sweep, four-row search)
+    (17, 6, [256, 256], "tanh", 25, 200, 260, None, 15),            # many slots: the twelve-row search takes over
+    (5, 2, [64, 48], "tanh", 18, 4, 11, None, 50),                  # run-time shapes
+    (40, 3, [64], "tanh", 12, 3, 7, None, 30),                      # wide states: general sweep + sixteen-row search
+])
+def test_one_plan_for_every_horizon_equals_one_horizon_plans(case):
+    """ampc_ilqr_solve_queue_var: problems of different horizons (IterativeLQRFactory's 5..25,
+    control/ilqr.py:31-41) stream through ONE plan built for the longest; each gets bit for bit what a
+    one-problem plan of its own horizon gives, and rows past its horizon come back zero."""
+    from autompc_amd import _lib
+    nx, nu, hidden, act, Hmax, B, P, bounds, max_iter = case
+    C = 4
+    p, h, _ = _setup(nx, nu, hidden, act, C, seed=nx + Hmax, bounds=bounds)
+    rng = np.random.default_rng(P)
+    x0 = rng.uniform(-0.2, 0.2, size=(P, nx))
+    hz = rng.integers(max(2, Hmax // 5), Hmax + 1, size=P).astype(np.int32)
+    hz[0], hz[-1] = Hmax, max(2, Hmax // 5)
+    ug = np.zeros((P, Hmax, nu))
+    ug[::3] = rng.uniform(-0.05, 0.05, size=ug[::3].shape)
+    ci = rng.integers(0, C, size=P).astype(np.int32)
+    plan = _lib.IlqrPlan(h, B, Hmax, 0.05, cost_index=np.zeros(B, dtype=np.int32), clip_to_bounds=bounds is not None)
+    got = plan.solve_queue(x0, ug, ci, max_iter=max_iter, horizon=hz)
+    check = range(P) if P <= 40 else rng.choice(P, size=40, replace=False)
+    for j in check:
+        H = int(hz[j])
+        one = _lib.IlqrPlan(h, 1, H, 0.05, cost_index=ci[j:j + 1], clip_to_bounds=bounds is not None)
+        ref = one.solve(x0[j], ug[j, :H], max_iter=max_iter)
+        one.close()
+        for k in ("converged", "iters", "status", "objective"):
+            np.testing.assert_array_equal(got[k][j], ref[k][0], err_msg="problem %d (H %d), %s" % (j, H, k))
+        np.testing.assert_array_equal(got["states"][j, :H + 1], ref["states"][0], err_msg="problem %d states" % j)
+        for k in ("ctrls", "Ks", "ks"):
+            np.testing.assert_array_equal(got[k][j, :H], ref[k][0], err_msg="problem %d %s" % (j, k))
+            assert not got[k][j, H:].any()
+        assert not got["states"][j, H + 1:].any()
+    # the same plan without horizons is an ordinary queue again
+    plain = plan.solve_queue(x0[:B], None, ci[:B], max_iter=3)
+    one = _lib.IlqrPlan(h, 1, Hmax, 0.05, cost_index=ci[:1], clip_to_bounds=bounds is not None)
+    ref = one.solve(x0[0], np.zeros((Hmax, nu)), max_iter=3)
+    np.testing.assert_array_equal(plain["states"][0], ref["states"][0])
+    with pytest.raises(ValueError):
+        plan.solve_queue(x0, None, ci, horizon=np.full(P, Hmax + 1))
+
+
+def test_evaluator_one_plan_equals_horizon_groups():
+    """IlqrCandidateEvaluator: all horizons through one plan (device-resident episodes and the host loop)
+    against the round-4 scheme of one plan per horizon -- the same scores and trajectories bit for bit."""
+    from autompc_amd import MLP, QuadCost, Task
+    from autompc_amd.tuning import IlqrCandidateEvaluator, random_ilqr_candidates
+    nx, nu, T = 4, 2, 7
+    system = make_system(nx, nu)
+    pp = omlp.random_params(nx, nu, [64, 48], "tanh", seed=21)
+    m = MLP(system, n_hidden_layers=2, hidden_size_1=64, hidden_size_2=48, nonlintype="tanh")
+    m.weights, m.biases = [w.copy() for w in pp["weights"]], [b.copy() for b in pp["biases"]]
+    m.xu_means, m.xu_std, m.dy_means, m.dy_std = pp["xu_means"], pp["xu_std"], pp["dy_means"], pp["dy_std"]
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(nx), 0.1 * np.eye(nu), 2.0 * np.eye(nx)))
+    task.set_ctrl_bounds(-0.6 * np.ones(nu), 0.6 * np.ones(nu))
+    task.set_init_obs(np.array([0.3, -0.2, 0.25, 0.1]))
+    task.set_num_steps(T)
+    cands = random_ilqr_candidates(system, 14, seed=9)
+    for c in cands:
+        c["Q"], c["R"], c["F"] = c["Q"] ** 0.3, c["R"] ** 0.3, c["F"] ** 0.3
+    for kw in ({"max_slots": 5}, {}, {"device_resident": False}, {"device_resident": False, "max_slots": 4}):
+        mode = {"device_resident": kw.get("device_resident", True)}
+        ref = IlqrCandidateEvaluator(system, task, m, one_plan=False, **mode).evaluate(cands, return_trajectories=True)
+        got = IlqrCandidateEvaluator(system, task, m, **kw).evaluate(cands, return_trajectories=True)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b, err_msg=str(kw))
