@@ -49,6 +49,7 @@ SIGNATURES = {
     "ampc_sindy_pred_batch": (c_int, [c_void_p, _dp, _dp, _dp, c_int]),
     "ampc_sindy_pred_diff_batch": (c_int, [c_void_p, _dp, _dp, _dp, _dp, _dp, c_int]),
     "ampc_set_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp]),
+    "ampc_set_indicator_costs": (c_int, [c_void_p, c_int, _ip, _dp]),
     "ampc_set_affine_quad_costs": (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "ampc_set_ctrl_bounds": (c_int, [c_void_p, _dp, _dp]),
     "ampc_mppi_plan_create": (c_int, [c_void_p, c_int, _ip, _ip, _dp, _dp, _ip, c_int,
@@ -91,10 +92,12 @@ SIGNATURES = {
                                       POINTER(ctypes.c_longlong)]),
     "ampc_ilqr_solve_queue": (c_int, [c_void_p, c_int, _dp, _dp, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip, _ip,
                                       _dp]),
-    "ampc_ilqr_solve_queue_var": (c_int, [c_void_p, c_int, _dp, _dp, _ip, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip,
+    "ampc_ilqr_solve_queue_var": (c_int, [c_void_p, c_int, _dp, _dp, _ip, _ip, _ip, c_int, _dp, _dp, _dp, _dp, _ip, _ip,
                                           _ip, _dp]),
-    "ampc_ilqr_closed_loop_var": (c_int, [c_void_p, c_void_p, c_int, _dp, _ip, _ip, c_int, c_int, _dp, _dp, _ip,
+    "ampc_ilqr_closed_loop_var": (c_int, [c_void_p, c_void_p, c_int, _dp, _ip, _ip, _ip, c_int, c_int, _dp, _dp, _ip,
                                           _ip, POINTER(ctypes.c_longlong)]),
+    "ampc_ilqr_plan_set_models": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "ampc_mppi_plan_set_models": (c_int, [c_void_p, c_int, POINTER(c_void_p), _ip]),
 }
 
 
@@ -323,6 +326,19 @@ class Handle:
         self.obs_dim = no
         self.n_costs = C
 
+    def set_indicator_costs(self, terms=None):
+        """Threshold / box terms of an MPPI controller's cost (ampc_set_indicator_costs): `terms` =
+        (kinds int32[n], params f64[...]) as autompc_amd.costs.cost_terms lays them out, kinds 1 / 2 only;
+        None or empty removes them.  Call after set_quad_costs / set_cost_blocks."""
+        if terms is None or len(terms[0]) == 0:
+            check(self.lib.ampc_set_indicator_costs(self._h, 0, None, None))
+            self.n_ind = 0
+            return
+        kinds = np.ascontiguousarray(terms[0], dtype=np.int32)
+        params = as_f64(terms[1])
+        check(self.lib.ampc_set_indicator_costs(self._h, int(kinds.shape[0]), iptr(kinds), dptr(params)))
+        self.n_ind = int(kinds.shape[0])
+
     def set_ctrl_bounds(self, lo, hi):
         lo, hi = as_f64(lo), as_f64(hi)
         check(self.lib.ampc_set_ctrl_bounds(self._h, dptr(lo), dptr(hi)))
@@ -462,6 +478,15 @@ class MppiPlan:
         if ids.shape != (self.B,):
             raise ValueError("one noise id per problem expected")
         check(self.lib.ampc_mppi_plan_set_noise_ids(self._p, ids.ctypes.data_as(POINTER(c_uint32))))
+
+    def set_models(self, handles, model_index):
+        """Controller models per problem (ampc_mppi_plan_set_models): `handles` hold MLPs of the plan's shape,
+        model_index [B] names each problem's.  None / empty handles: back to the plan handle's own model."""
+        hs = list(handles or [])
+        arr = (c_void_p * max(len(hs), 1))(*[h._h for h in hs])
+        mi = None if not hs else np.ascontiguousarray(np.broadcast_to(np.asarray(model_index, dtype=np.int32), (self.B,)))
+        check(self.lib.ampc_mppi_plan_set_models(self._p, len(hs), arr, iptr(mi)))
+        self._models = hs
 
     def solve(self):
         check(self.lib.ampc_mppi_solve(self._p))
@@ -652,7 +677,21 @@ class IlqrPlan:
             raise ValueError("horizons must lie in [1, %d] (the plan's horizon)" % self.H)
         return hz
 
-    def closed_loop(self, init_obs, n_steps, cost_index=None, max_iter=50, surrogate=None, horizon=None):
+    def set_models(self, handles):
+        """Controller models per problem (ampc_ilqr_plan_set_models): `handles` hold MLPs of the plan's shape;
+        solve_queue / closed_loop then take model_index.  None / empty removes the table."""
+        hs = list(handles or [])
+        arr = (c_void_p * max(len(hs), 1))(*[h._h for h in hs])
+        check(self.lib.ampc_ilqr_plan_set_models(self._p, len(hs), arr))
+        self._models = hs                   # (kept alive on this side as well)
+
+    def _model_index(self, model_index, n):
+        if model_index is None:
+            return None
+        return np.ascontiguousarray(np.broadcast_to(np.asarray(model_index, dtype=np.int32), (n,)))
+
+    def closed_loop(self, init_obs, n_steps, cost_index=None, max_iter=50, surrogate=None, horizon=None,
+                    model_index=None):
         """simulate() with IterativeLQR controllers for C episodes, device resident (ampc_ilqr_closed_loop):
         init_obs [C, nx]; returns dict(obs [C, n_steps+1, nx], ctrls [C, n_steps+1, nu], failed [C],
         steps [C], iterations [C]).  horizon [C] (optional): each episode's iLQR horizon, at most the
@@ -663,17 +702,18 @@ class IlqrPlan:
         ci = None if cost_index is None else np.ascontiguousarray(np.broadcast_to(
             np.asarray(cost_index, dtype=np.int32), (C,)))
         hz = self._horizons(horizon, C)
+        mi = self._model_index(model_index, C)
         out = {"obs": np.empty((C, n_steps + 1, nx)), "ctrls": np.empty((C, n_steps + 1, nu)),
                "failed": np.zeros(C, dtype=np.int32), "steps": np.zeros(C, dtype=np.int32),
                "iterations": np.zeros(C, dtype=np.int64)}
         check(self.lib.ampc_ilqr_closed_loop_var(
-            self._p, surrogate._h if surrogate is not None else None, C, dptr(init_obs), iptr(ci), iptr(hz),
+            self._p, surrogate._h if surrogate is not None else None, C, dptr(init_obs), iptr(ci), iptr(hz), iptr(mi),
             int(n_steps), int(max_iter), dptr(out["obs"]), dptr(out["ctrls"]), iptr(out["failed"]),
             iptr(out["steps"]), out["iterations"].ctypes.data_as(POINTER(ctypes.c_longlong))))
         return out
 
     def solve_queue(self, x0, uguess=None, cost_index=None, max_iter=50, gains=True, trajectories=True,
-                    horizon=None):
+                    horizon=None, model_index=None):
         """P problems streamed through the plan's B slots (ampc_ilqr_solve_queue): a slot whose problem
         is finished takes the next one at the following iteration boundary, on the device.  x0 [P, nx];
         uguess [P, H, nu] or None (zeros); cost_index [P] or None (block 0).  Per-problem results are
@@ -693,7 +733,8 @@ class IlqrPlan:
         if gains:
             out["Ks"], out["ks"] = np.empty((P, H, nu, nx)), np.empty((P, H, nu))
         hz = self._horizons(horizon, P)
-        check(self.lib.ampc_ilqr_solve_queue_var(self._p, P, dptr(x0), dptr(ug), iptr(ci), iptr(hz), int(max_iter),
+        mi = self._model_index(model_index, P)
+        check(self.lib.ampc_ilqr_solve_queue_var(self._p, P, dptr(x0), dptr(ug), iptr(ci), iptr(hz), iptr(mi), int(max_iter),
                                                  dptr(out.get("states")), dptr(out.get("ctrls")), dptr(out.get("Ks")),
                                                  dptr(out.get("ks")), iptr(out["converged"]), iptr(out["iters"]),
                                                  iptr(out["status"]), dptr(out["objective"])))

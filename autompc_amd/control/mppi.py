@@ -20,18 +20,24 @@ What runs where
 import numpy as np
 
 from .. import _lib, _npstate
-from ..costs.blocks import quad_sum_block, is_quad_sum
+from ..costs.blocks import is_mppi_cost, mppi_cost_parts, quad_sum_block
 from .controller import Controller, ControllerFactory
 
 
-def _stage_cost(handle, cost, obs_dim, ctrl_dim):
+def _stage_cost(handle, cost, obs_dim, ctrl_dim, indicators=False):
     """Hand `cost` -- a QuadCost or any (nested) sum of QuadCosts, this package's or the
     reference's own objects, shared goal or not -- to the device as one affine-quadratic block
     (costs/blocks.py; mppi.py:73-82 and ilqr.py:124-129 evaluate it term by term).  Returns the
-    block (its ``terminal_goal`` flag matters to iLQR only)."""
-    blk = quad_sum_block(cost, obs_dim, ctrl_dim)
+    block (its ``terminal_goal`` flag matters to iLQR only).
+    indicators (MPPI only): the sum may also hold threshold / box terms (thresh_cost.py:8-83), which the
+    rollout kernels add to the stage cost (ampc_set_indicator_costs); iLQR needs Hessians they do not have."""
+    if indicators:
+        blk, terms = mppi_cost_parts(cost, obs_dim, ctrl_dim)
+    else:
+        blk, terms = quad_sum_block(cost, obs_dim, ctrl_dim), None
     handle.set_cost_blocks(blk["Q"], blk["R"], blk["F"], blk["goal"], blk["lin"], blk["lin_term"],
                            blk["consts"])
+    handle.set_indicator_costs(terms)
     return blk
 
 
@@ -137,7 +143,7 @@ class MPPI(Controller):
         if self._handle is None:
             h = _lib.Handle(self.device, self.precision)
             self.model.stage_into(h)
-            _stage_cost(h, self.task.get_cost(), self.system.obs_dim, self.dim_ctrl)
+            _stage_cost(h, self.task.get_cost(), self.system.obs_dim, self.dim_ctrl, indicators=True)
             h.set_ctrl_bounds(self.umin, self.umax)
             self._handle = h
         if self._plan is None:
@@ -257,7 +263,7 @@ class MPPI(Controller):
 
     @staticmethod
     def is_compatible(system, task, model):
-        return is_quad_sum(task.get_cost()) and hasattr(model, "stage_into")
+        return is_mppi_cost(task.get_cost()) and hasattr(model, "stage_into")
 
 
 class MPPIFactory(ControllerFactory):

@@ -41,7 +41,11 @@ def is_quad_sum(cost):
         leaves = _leaves(cost)
     except Exception:
         return False
-    return bool(leaves) and all(bool(getattr(c, "is_quad", False)) for c in leaves)
+    if not leaves or not all(bool(getattr(c, "is_quad", False)) for c in leaves):
+        return False
+    # (terms that disagree on strict_reference have no single device block: quad_sum_block refuses them,
+    #  so the controllers' is_compatible must not promise the pairing)
+    return len({bool(getattr(c, "strict_reference", True)) for c in leaves}) == 1
 
 
 def quad_sum_block(cost, obs_dim, ctrl_dim):
@@ -81,6 +85,54 @@ def quad_sum_block(cost, obs_dim, ctrl_dim):
         raise TypeError("terms of one controller cost must agree on strict_reference")
     return {"Q": Q, "R": R, "F": F, "goal": g0, "lin": lin, "lin_term": lint,
             "consts": np.array([c0, c1]), "terminal_goal": not strict[0]}
+
+
+def _is_indicator(c):
+    from .terms import _is_box, _is_threshold
+    return _is_threshold(c) or _is_box(c)
+
+
+def is_mppi_cost(cost):
+    """True when `cost` is something the device MPPI evaluates in-kernel: a (nested) sum whose terms are
+    quadratic costs and / or threshold / box indicators (thresh_cost.py:8-83; at most 8 of those) -- the
+    reference's MPPI charges any Cost term by term (mppi.py:73-82)."""
+    try:
+        leaves = _leaves(cost)
+    except Exception:
+        return False
+    quads = [c for c in leaves if getattr(c, "is_quad", False)]
+    inds = [c for c in leaves if not getattr(c, "is_quad", False)]
+    if not leaves or not all(_is_indicator(c) for c in inds) or len(inds) > 8:
+        return False
+    return len({bool(getattr(c, "strict_reference", True)) for c in quads}) <= 1
+
+
+class _Terms:
+    """The quadratic leaves of a cost as a sum (quad_sum_block walks `.costs`)."""
+    def __init__(self, costs):
+        self.costs = costs
+
+
+def mppi_cost_parts(cost, obs_dim, ctrl_dim):
+    """(block, terms): the affine-quadratic block of the quadratic terms of `cost` (all zeros when it
+    has none) and the flattened threshold / box terms (kinds, params -- costs/terms.py's layout) or None.
+    TypeError for a term of neither kind."""
+    from .terms import cost_terms
+    leaves = _leaves(cost)
+    quads = [c for c in leaves if getattr(c, "is_quad", False)]
+    inds = [c for c in leaves if not getattr(c, "is_quad", False)]
+    for c in inds:
+        if not _is_indicator(c):
+            raise TypeError("the HIP MPPI evaluates quadratic, threshold and box cost terms in-kernel; got a %s term"
+                            % type(c).__name__)
+    no, nu = int(obs_dim), int(ctrl_dim)
+    if quads:
+        blk = quad_sum_block(_Terms(quads), no, nu)
+    else:
+        blk = {"Q": np.zeros((no, no)), "R": np.zeros((nu, nu)), "F": np.zeros((no, no)), "goal": np.zeros(no),
+               "lin": np.zeros(no), "lin_term": np.zeros(no), "consts": np.zeros(2), "terminal_goal": False}
+    terms = cost_terms(_Terms(inds), no, nu) if inds else None
+    return blk, terms
 
 
 def stack_blocks(blocks):

@@ -116,7 +116,7 @@ static void handle_release(ampc_handle* h) {
 static void handle_free(ampc_handle* h) {
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->model_buf, &h->lin_buf, &h->sindy_int, &h->sindy_flt, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->s_states,
+  DevBuf* bufs[] = {&h->model_buf, &h->lin_buf, &h->sindy_int, &h->sindy_flt, &h->cost_buf, &h->bounds_buf, &h->ubounds_buf, &h->ind_buf, &h->s_states,
                     &h->s_ctrls,   &h->s_out,      &h->s_dz,     &h->s_jx,       &h->s_ju};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -394,7 +394,7 @@ static int set_linear_wide(ampc_handle* h, int nx, int nu, const double* A, cons
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
   else HIP_OK(upload_converted<float>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
-  if (nx != h->nx || nu != h->nu) { h->n_costs = 0; h->obs_dim = 0; h->has_bounds = false; }   // other dimensions
+  if (nx != h->nx || nu != h->nu) { h->n_costs = 0; h->obs_dim = 0; h->has_bounds = false; h->n_ind = 0; }   // other dimensions
   h->nx = nx; h->nu = nu; h->l_nxp = nxp; h->l_kp = kp;
   h->n_hidden = 0; h->act = 4; h->hpad = 0;
   std::memset(&h->md, 0, sizeof(h->md));
@@ -456,6 +456,7 @@ extern "C" int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_d
   else HIP_OK(upload_converted<float>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   h->n_costs = n_costs;
+  if (h->obs_dim != obs_dim) h->n_ind = 0;      // (the indicator table is laid out for the old observation)
   h->obs_dim = obs_dim;
   h->cost_stride = stride;
   h->cost_affine = affine ? 1 : 0;
@@ -477,6 +478,45 @@ extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, con
                                    const double* R, const double* F, const double* goal) {
   REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
   return ampc_set_affine_quad_costs(h, n_costs, obs_dim, Q, R, F, goal, nullptr, nullptr, nullptr);
+}
+
+// Indicator terms of the MPPI stage cost (mlp_tile.hpp: indicator_rows): threshold / box terms of the
+// controller's cost, added to every cost block's stage cost of x_0 .. x_{H-1}
+extern "C" int ampc_set_indicator_costs(ampc_handle* h, int n_terms, const int* kinds, const double* params) {
+  REQUIRE(h, "ampc_set_indicator_costs: NULL handle");
+  REQUIRE(n_terms >= 0 && n_terms <= kMaxInd, "ampc_set_indicator_costs: at most 8 indicator terms");
+  if (n_terms == 0) { h->n_ind = 0; return 0; }
+  REQUIRE(kinds && params, "ampc_set_indicator_costs: NULL argument");
+  REQUIRE(h->n_costs > 0 && h->obs_dim > 0,
+          "ampc_set_indicator_costs: set the quadratic part first (ampc_set_quad_costs; zeros for a cost without one)");
+  HIP_OK(hipSetDevice(h->device));
+  const int no = h->obs_dim, st = ind_stride(no);
+  std::vector<double> tab((size_t)n_terms * st, 0.0);
+  const double* par = params;
+  for (int k = 0; k < n_terms; ++k) {
+    double* t = tab.data() + (size_t)k * st;
+    if (kinds[k] == SCORE_THRESHOLD) {            // goal[no] lo hi threshold  (as ampc_score_trajectories)
+      const int lo = std::max(0, (int)par[no]), hi = std::min(no, (int)par[no + 1]);
+      t[0] = 1.0;
+      for (int i = 0; i < no; ++i) {
+        t[2 + i] = par[i];
+        t[2 + no + i] = (i >= lo && i < hi) ? par[no + 2] : INFINITY;
+      }
+      par += no + 3;
+    } else if (kinds[k] == SCORE_BOX) {           // lower[no] upper[no]
+      t[0] = 2.0;
+      for (int i = 0; i < no; ++i) { t[2 + i] = par[i]; t[2 + no + i] = par[no + i]; }
+      par += 2 * no;
+    } else {
+      return fail("ampc_set_indicator_costs: kinds must be 1 (threshold) or 2 (box)");
+    }
+  }
+  HIP_OK(h->ind_buf.reserve(tab.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->ind_buf.p, tab.data(), tab.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->ind_buf.p, tab.data(), tab.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->n_ind = n_terms;
+  return 0;
 }
 
 extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
@@ -650,7 +690,10 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   // implies (ping-pong activations + separate partials -- tile_lds_for picked it iff it fits)
   p->static_shape = -1;
   p->jit = nullptr;
-  if (p->quad && env_int("AMPC_STATIC", 1) != 0) {          // (the four-row kernel has one LDS map)
+  // (indicator cost terms and per-problem models live in the run-time-shape kernels only: mppi_kernels.hpp)
+  const bool ext = h->n_ind > 0 || !p->models.empty();
+  if (ext) {
+  } else if (p->quad && env_int("AMPC_STATIC", 1) != 0) {          // (the four-row kernel has one LDS map)
     int sid = static_shape_of<T>(h, m);
     if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;
     p->static_shape = sid;
@@ -682,6 +725,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     q.eps_off = p->eps_off[b]; q.epso_off = p->epso_off[b]; q.cost_off = p->cost_off[b];
     q.a_off = p->a_off[b];
     q.noise_id = p->noise_id[b];
+    q.model = p->model_idx.empty() ? 0 : p->model_idx[b];
     const int nt = (q.N + M - 1) / M;
     for (int t = 0; t < nt; ++t) tile_prob.push_back(b);
     tile += nt;
@@ -777,10 +821,81 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
   for (DevBuf* b : bufs) b->release();
+  p->mlp_tab.release();
+  for (ampc_handle* mh : p->models) handle_release(mh);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
   delete p;
   handle_release(h);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// several controller models of one shape in a plan (tuning candidates that carry their own model)
+// ---------------------------------------------------------------------------------------------
+template <typename T> static int mppi_set_noise_ids_impl(ampc_mppi_plan* p);
+static int check_same_shape(const ampc_handle* h, const ampc_handle* m, const char* who) {
+  const std::string w(who);
+  REQUIRE(m != nullptr, w + ": NULL model handle");
+  REQUIRE(m->has_mlp && h->has_mlp, w + ": per-problem models are MLP models");
+  REQUIRE(m->device == h->device && m->precision == h->precision, w + ": models must share the plan's device and precision");
+  bool same = m->nx == h->nx && m->nu == h->nu && m->n_hidden == h->n_hidden && m->act == h->act &&
+              m->hpad == h->hpad && m->nw == h->nw && m->nt == h->nt;
+  for (int l = 0; l < kMaxHidden; ++l) same = same && m->hidden[l] == h->hidden[l];
+  REQUIRE(same, w + ": every model must have the shape (dimensions, hidden layers, activation) of the plan's model");
+  return 0;
+}
+
+// device table of the models' buffer offsets (mlp_tile.hpp: shift_model); takes a reference on every handle
+template <typename T>
+static int build_model_table(ampc_handle* h, int n, ampc_handle* const* ms, DevBuf* tab, std::vector<ampc_handle*>* keep) {
+  std::vector<long long> host(n);
+  const MlpDev<T>& m0 = model_of<T>(h);
+  for (int i = 0; i < n; ++i) {
+    const MlpDev<T>& mi = model_of<T>(ms[i]);
+    host[i] = (long long)((const char*)mi.wbase - (const char*)m0.wbase);
+    // same shape => same packing: every array sits at the same offset of its model's buffer
+    bool same = true;
+    for (int l = 0; l <= h->n_hidden; ++l)
+      same = same && (mi.w[l] - mi.wbase) == (m0.w[l] - m0.wbase) && (mi.b[l] - mi.wbase) == (m0.b[l] - m0.wbase) &&
+             (mi.w4[l] - mi.wbase) == (m0.w4[l] - m0.wbase);
+    REQUIRE(same && ((const T*)ms[i]->wout_plain - mi.wbase) == ((const T*)h->wout_plain - m0.wbase),
+            "internal: models of one shape are packed differently");
+  }
+  HIP_OK(tab->reserve(host.size() * sizeof(long long)));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(tab->p, host.data(), host.size() * sizeof(long long), hipMemcpyHostToDevice));
+  for (ampc_handle* old : *keep) handle_release(old);
+  keep->assign(ms, ms + n);
+  for (ampc_handle* mh : *keep) mh->refs++;
+  return 0;
+}
+
+extern "C" int ampc_mppi_plan_set_models(ampc_mppi_plan* p, int n_models, ampc_handle* const* models,
+                                         const int* model_index) {
+  REQUIRE(p, "ampc_mppi_plan_set_models: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  if (n_models == 0) {                               // back to the handle's own model
+    HIP_OK(hipStreamSynchronize(p->h->stream));
+    for (ampc_handle* mh : p->models) handle_release(mh);
+    p->models.clear();
+    p->model_idx.clear();
+    return 0;
+  }
+  REQUIRE(n_models >= 1 && models && model_index, "ampc_mppi_plan_set_models: NULL argument");
+  for (int i = 0; i < n_models; ++i)
+    if (int rc = check_same_shape(p->h, models[i], "ampc_mppi_plan_set_models")) return rc;
+  for (int b = 0; b < p->B; ++b)
+    REQUIRE(model_index[b] >= 0 && model_index[b] < n_models, "ampc_mppi_plan_set_models: bad model_index");
+  if (int rc = p->h->precision == AMPC_F64 ? build_model_table<double>(p->h, n_models, models, &p->mlp_tab, &p->models)
+                                           : build_model_table<float>(p->h, n_models, models, &p->mlp_tab, &p->models))
+    return rc;
+  p->model_idx.assign(model_index, model_index + p->B);
+  // the problems' descriptors carry the entry
+  if (int rc = p->h->precision == AMPC_F64 ? mppi_set_noise_ids_impl<double>(p) : mppi_set_noise_ids_impl<float>(p)) return rc;
+  // a plan built on shape-specialised kernels moves to the run-time-shape ones (which carry the model
+  // offsets): same tiles, same LDS map, same results
+  if (p->static_shape >= 0 || p->jit) { p->static_shape = -1; p->jit = nullptr; }
   return 0;
 }
 
@@ -1216,7 +1331,14 @@ extern "C" int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int
   if (horizon_cap > p->max_h) p->max_h = horizon_cap;
   p->lds_eps = -1;
   p->lds_red = 0;
-  return p->h->precision == AMPC_F64 ? plan_build<double>(p) : plan_build<float>(p);
+  // noise drawn by the device generator before the rebuild: the rebuild may change HOW the plan holds it
+  // (formed inside the four-row rollout, or in the noise buffer, which a rebuild resets) -- draw it again
+  // for the new geometry, the same (seed, stream): the values the caller asked for
+  const bool redraw = p->eps_from_generator;
+  const uint64_t seed = p->eps_seed, stream = p->eps_stream;
+  p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
+  if (int rc = p->h->precision == AMPC_F64 ? plan_build<double>(p) : plan_build<float>(p)) return rc;
+  return redraw ? ampc_mppi_generate_eps(p, seed, stream) : 0;
 }
 
 extern "C" int ampc_mppi_plan_set_step_offset(ampc_mppi_plan* p, uint64_t first_step) {
@@ -1230,9 +1352,19 @@ template <typename T> static int mppi_set_noise_ids_impl(ampc_mppi_plan* p) {
   std::vector<MppiProblem<T>> pr(p->B);
   HIP_OK(hipStreamSynchronize(p->h->stream));
   HIP_OK(hipMemcpy(pr.data(), p->probs.p, pr.size() * sizeof(MppiProblem<T>), hipMemcpyDeviceToHost));
-  for (int b = 0; b < p->B; ++b) pr[b].noise_id = p->noise_id[b];
+  for (int b = 0; b < p->B; ++b) {
+    pr[b].noise_id = p->noise_id[b];
+    pr[b].model = p->model_idx.empty() ? 0 : p->model_idx[b];
+  }
   HIP_OK(hipMemcpy(p->probs.p, pr.data(), pr.size() * sizeof(MppiProblem<T>), hipMemcpyHostToDevice));
   p->ahead_valid = false;          // (noise formed ahead carried the old ids)
+  // noise already drawn by the device generator is keyed by the ids: draw it again, so that the plan's
+  // noise is Philox(seed, stream, NEW id) whether it is formed inside the rollout or held in the buffer
+  if (p->eps_from_generator) {
+    const uint64_t seed = p->eps_seed, stream = p->eps_stream;
+    p->eps_from_generator = false; p->ahead_on = false;
+    return mppi_generate_impl<T>(p, seed, stream);
+  }
   return 0;
 }
 
@@ -1478,6 +1610,8 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   REQUIRE(h->nx + h->nu + 1 <= 64,
           "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
+  REQUIRE(h->n_ind == 0, "ampc_ilqr_plan_create: the handle's cost has indicator terms (threshold / box): they have no "
+                         "gradient or Hessian, iLQR takes sums of quadratic costs only");
   REQUIRE(B >= 1 && horizon >= 1, "ampc_ilqr_plan_create: B >= 1 and horizon >= 1 required");
   REQUIRE(!clip_to_bounds || h->has_bounds, "ampc_ilqr_plan_create: bounds requested but not set");
   HIP_OK(hipSetDevice(h->device));
@@ -1547,6 +1681,8 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
                     &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
                     &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl, &p->slot_h};
   for (DevBuf* b : bufs) b->release();
+  p->mlp_tab.release(); p->slot_model.release();
+  for (ampc_handle* mh : p->models) handle_release(mh);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->poll_host) (void)hipHostFree(p->poll_host);
   for (hipEvent_t e : p->poll_ev) if (e) (void)hipEventDestroy(e);
@@ -1661,16 +1797,16 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, const double* uguess,
-                                 const int* cost_index, const int* horizon, int max_iter, double* states, double* ctrls,
-                                 double* Ks, double* ks, int* converged, int* iters, int* status,
-                                 double* objective) {
+                                 const int* cost_index, const int* horizon, const int* model_index, int max_iter,
+                                 double* states, double* ctrls, double* Ks, double* ks, int* converged, int* iters,
+                                 int* status, double* objective) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
   const size_t e = sizeof(T);
   HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
   HIP_OK(p->q_x0.reserve((size_t)P * nx * e));
   HIP_OK(p->q_u.reserve((size_t)P * H * nu * e));
-  HIP_OK(p->q_cost.reserve((size_t)2 * P * sizeof(int)));               // cost block [P], horizon [P]
+  HIP_OK(p->q_cost.reserve((size_t)3 * P * sizeof(int)));               // cost block [P], horizon [P], model [P]
   HIP_OK(p->q_states.reserve((size_t)P * (H + 1) * nx * e));
   HIP_OK(p->q_ctrls.reserve((size_t)P * H * nu * e));
   HIP_OK(p->q_Ks.reserve((size_t)P * H * nu * nx * e));
@@ -1688,6 +1824,11 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
     HIP_OK(p->slot_h.reserve((size_t)B * sizeof(int)));
     HIP_OK(hipMemcpyAsync(p->slot_h.p, slot_h0.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipMemcpyAsync((int*)p->q_cost.p + P, horizon, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  if (model_index) {
+    HIP_OK(p->slot_model.reserve((size_t)B * sizeof(int)));
+    HIP_OK(hipMemsetAsync(p->slot_model.p, 0, (size_t)B * sizeof(int), h->stream));
+    HIP_OK(hipMemcpyAsync((int*)p->q_cost.p + 2 * P, model_index, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream));
   }
   HIP_OK(upload_converted<T>(p->q_x0.p, x0, (size_t)P * nx, h->stream));
   if (uguess) HIP_OK(upload_converted<T>(p->q_u.p, uguess, (size_t)P * H * nu, h->stream));
@@ -1708,16 +1849,19 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
     ~Guard() {
       (void)hipStreamSynchronize(p->h->stream);
       (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
-      p->queue_on = false; p->var_h = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
+      p->queue_on = false; p->var_h = false; p->var_model = false; p->ev_cur = nullptr;
+      (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
     }
   } guard{p};
   p->queue_on = true;
   p->var_h = horizon != nullptr;
+  p->var_model = model_index != nullptr;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
   IlqrQueue<T> q;
   q.P = P; q.B = B; q.H = H; q.nx = nx; q.nu = nu;
   q.horizon = horizon ? (const int*)p->q_cost.p + P : nullptr; q.slot_h = (int*)p->slot_h.p;
+  q.model = model_index ? (const int*)p->q_cost.p + 2 * P : nullptr; q.slot_model = (int*)p->slot_model.p;
   q.ctl = (int*)p->q_ctl.p; q.slot_prob = q.ctl + 2;
   q.x0 = (const T*)p->q_x0.p; q.uguess = (const T*)p->q_u.p; q.cost = (const int*)p->q_cost.p;
   q.cost_idx = (int*)p->d_cost_idx.p;
@@ -1806,10 +1950,36 @@ static int check_horizons(const ampc_ilqr_plan* p, int n, const int* horizon, co
   return 0;
 }
 
+static int check_models(const ampc_ilqr_plan* p, int n, const int* model_index, const char* who) {
+  if (model_index) {
+    REQUIRE(!p->models.empty(), std::string(who) + ": model_index given but the plan has no model table (ampc_ilqr_plan_set_models)");
+    for (int j = 0; j < n; ++j)
+      REQUIRE(model_index[j] >= 0 && model_index[j] < (int)p->models.size(), std::string(who) + ": bad model_index");
+  }
+  return 0;
+}
+
+extern "C" int ampc_ilqr_plan_set_models(ampc_ilqr_plan* p, int n_models, ampc_handle* const* models) {
+  REQUIRE(p, "ampc_ilqr_plan_set_models: NULL plan");
+  HIP_OK(hipSetDevice(p->h->device));
+  if (n_models == 0) {
+    HIP_OK(hipStreamSynchronize(p->h->stream));
+    for (ampc_handle* mh : p->models) handle_release(mh);
+    p->models.clear();
+    return 0;
+  }
+  REQUIRE(n_models >= 1 && models, "ampc_ilqr_plan_set_models: NULL argument");
+  for (int i = 0; i < n_models; ++i)
+    if (int rc = check_same_shape(p->h, models[i], "ampc_ilqr_plan_set_models")) return rc;
+  p->static_shape = -1; p->jit = nullptr;       // (per-slot models: the run-time-shape kernels, ilqr_ls4.hpp)
+  return p->h->precision == AMPC_F64 ? build_model_table<double>(p->h, n_models, models, &p->mlp_tab, &p->models)
+                                     : build_model_table<float>(p->h, n_models, models, &p->mlp_tab, &p->models);
+}
+
 extern "C" int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
-                                         const int* cost_index, const int* horizon, int max_iter, double* states,
-                                         double* ctrls, double* Ks, double* ks, int* converged, int* iters,
-                                         int* status, double* objective) {
+                                         const int* cost_index, const int* horizon, const int* model_index,
+                                         int max_iter, double* states, double* ctrls, double* Ks, double* ks,
+                                         int* converged, int* iters, int* status, double* objective) {
   REQUIRE(p && x0, "ampc_ilqr_solve_queue_var: NULL argument");
   REQUIRE(n_problems >= 1, "ampc_ilqr_solve_queue_var: n_problems < 1");
   REQUIRE(max_iter >= 1, "ampc_ilqr_solve_queue_var: max_iter < 1");
@@ -1817,12 +1987,13 @@ extern "C" int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, cons
     for (int j = 0; j < n_problems; ++j)
       REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_solve_queue_var: bad cost_index");
   if (int rc = check_horizons(p, n_problems, horizon, "ampc_ilqr_solve_queue_var")) return rc;
+  if (int rc = check_models(p, n_problems, model_index, "ampc_ilqr_solve_queue_var")) return rc;
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
-             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, horizon, max_iter, states, ctrls, Ks,
-                                             ks, converged, iters, status, objective)
-             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, horizon, max_iter, states, ctrls, Ks,
-                                            ks, converged, iters, status, objective);
+             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, horizon, model_index, max_iter, states,
+                                             ctrls, Ks, ks, converged, iters, status, objective)
+             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, horizon, model_index, max_iter, states,
+                                            ctrls, Ks, ks, converged, iters, status, objective);
 }
 
 extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
@@ -1837,10 +2008,10 @@ extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const do
       REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_solve_queue: bad cost_index");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
-             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, nullptr, max_iter, states, ctrls, Ks, ks,
-                                             converged, iters, status, objective)
-             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, nullptr, max_iter, states, ctrls, Ks, ks,
-                                            converged, iters, status, objective);
+             ? ilqr_solve_queue_impl<double>(p, n_problems, x0, uguess, cost_index, nullptr, nullptr, max_iter, states, ctrls,
+                                             Ks, ks, converged, iters, status, objective)
+             : ilqr_solve_queue_impl<float>(p, n_problems, x0, uguess, cost_index, nullptr, nullptr, max_iter, states, ctrls,
+                                            Ks, ks, converged, iters, status, objective);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1848,26 +2019,32 @@ extern "C" int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const do
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, const double* init_obs,
-                                 const int* cost_index, const int* horizon, int n_steps, int max_iter, double* traj_obs,
+                                 const int* cost_index, const int* horizon, const int* model_index, int n_steps,
+                                 int max_iter, double* traj_obs,
                                  double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, H = p->H, T1 = n_steps + 1;
   const size_t e = sizeof(T);
   // ints: ctl[2] | slot_mode[B] (where make_ilqr_args expects it: q_ctl + 2 + B) ...
   HIP_OK(p->q_ctl.reserve((size_t)(2 + 2 * B) * sizeof(int)));
-  HIP_OK(p->c_ints.reserve((size_t)(2 * B + 4 * C) * sizeof(int)));      // need[B] slot_chain[B] chain_t[C] chain_fail[C] cost[C] horizon[C]
+  HIP_OK(p->c_ints.reserve((size_t)(2 * B + 5 * C) * sizeof(int)));      // need[B] slot_chain[B] chain_t[C] chain_fail[C] cost[C] horizon[C] model[C]
   HIP_OK(p->c_iters.reserve((size_t)C * sizeof(long long)));
   HIP_OK(p->c_stage.reserve((size_t)B * (2 * nx + nu) * e));
   HIP_OK(p->c_obs.reserve((size_t)C * T1 * nx * e));
   HIP_OK(p->c_ctl.reserve((size_t)C * T1 * nu * e));
   HIP_OK(p->q_x0.reserve((size_t)C * nx * e));
-  std::vector<int> ctl(2 + 2 * B, 0), ci(2 * B + 4 * C, 0), slot_h0(B, H);
+  std::vector<int> ctl(2 + 2 * B, 0), ci(2 * B + 5 * C, 0), slot_h0(B, H);
   for (int b = 0; b < B; ++b) { ctl[2 + b] = -1; ctl[2 + B + b] = 1; ci[B + b] = -1; }
   if (cost_index) std::memcpy(ci.data() + 2 * B + 2 * C, cost_index, (size_t)C * sizeof(int));
   if (horizon) {
     std::memcpy(ci.data() + 2 * B + 3 * C, horizon, (size_t)C * sizeof(int));
     HIP_OK(p->slot_h.reserve((size_t)B * sizeof(int)));
     HIP_OK(hipMemcpyAsync(p->slot_h.p, slot_h0.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  if (model_index) {
+    std::memcpy(ci.data() + 2 * B + 4 * C, model_index, (size_t)C * sizeof(int));
+    HIP_OK(p->slot_model.reserve((size_t)B * sizeof(int)));
+    HIP_OK(hipMemsetAsync(p->slot_model.p, 0, (size_t)B * sizeof(int), h->stream));
   }
   HIP_OK(hipMemcpyAsync(p->q_ctl.p, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIP_OK(hipMemcpyAsync(p->c_ints.p, ci.data(), ci.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -1889,11 +2066,13 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
     ~Guard() {
       (void)hipStreamSynchronize(p->h->stream);
       (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
-      p->queue_on = false; p->var_h = false; p->ev_cur = nullptr; (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
+      p->queue_on = false; p->var_h = false; p->var_model = false; p->ev_cur = nullptr;
+      (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
     }
   } guard{p};
   p->queue_on = true;
   p->var_h = horizon != nullptr;
+  p->var_model = model_index != nullptr;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
   p->ls_rb_now = 1;
@@ -1904,6 +2083,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   q.need = ints; q.slot_chain = ints + B; q.chain_t = ints + 2 * B; q.chain_fail = ints + 2 * B + C;
   q.cost = ints + 2 * B + 2 * C;
   q.horizon = horizon ? ints + 2 * B + 3 * C : nullptr; q.slot_h = (int*)p->slot_h.p;
+  q.model = model_index ? ints + 2 * B + 4 * C : nullptr; q.slot_model = (int*)p->slot_model.p;
   q.chain_iters = (long long*)p->c_iters.p;
   q.x0 = (const T*)p->q_x0.p; q.cost_idx = (int*)p->d_cost_idx.p;
   q.stage_x = (T*)p->c_stage.p; q.stage_u = q.stage_x + (size_t)B * nx; q.stage_next = q.stage_u + (size_t)B * nu;
@@ -1960,16 +2140,17 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
 extern "C" int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
                                      const int* cost_index, int n_steps, int max_iter, double* traj_obs,
                                      double* traj_ctrls, int* failed, int* steps_done, long long* iterations) {
-  return ampc_ilqr_closed_loop_var(p, surrogate, n_chains, init_obs, cost_index, nullptr, n_steps, max_iter, traj_obs,
-                                   traj_ctrls, failed, steps_done, iterations);
+  return ampc_ilqr_closed_loop_var(p, surrogate, n_chains, init_obs, cost_index, nullptr, nullptr, n_steps, max_iter,
+                                   traj_obs, traj_ctrls, failed, steps_done, iterations);
 }
 
 extern "C" int ampc_ilqr_closed_loop_var(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
-                                         const int* cost_index, const int* horizon, int n_steps, int max_iter,
-                                         double* traj_obs, double* traj_ctrls, int* failed, int* steps_done,
-                                         long long* iterations) {
+                                         const int* cost_index, const int* horizon, const int* model_index,
+                                         int n_steps, int max_iter, double* traj_obs, double* traj_ctrls, int* failed,
+                                         int* steps_done, long long* iterations) {
   REQUIRE(p && init_obs, "ampc_ilqr_closed_loop: NULL argument");
   if (int rc = check_horizons(p, n_chains, horizon, "ampc_ilqr_closed_loop_var")) return rc;
+  if (int rc = check_models(p, n_chains, model_index, "ampc_ilqr_closed_loop_var")) return rc;
   REQUIRE(n_chains >= 1 && n_steps >= 1 && max_iter >= 1, "ampc_ilqr_closed_loop: n_chains, n_steps, max_iter must be >= 1");
   ampc_handle* sur = surrogate ? surrogate : p->h;
   REQUIRE(sur->has_model() && sur->nx == p->h->nx && sur->nu == p->h->nu,
@@ -1981,10 +2162,10 @@ extern "C" int ampc_ilqr_closed_loop_var(ampc_ilqr_plan* p, ampc_handle* surroga
       REQUIRE(cost_index[j] >= 0 && cost_index[j] < p->h->n_costs, "ampc_ilqr_closed_loop: bad cost_index");
   HIP_OK(hipSetDevice(p->h->device));
   return p->h->precision == AMPC_F64
-             ? ilqr_closed_loop_impl<double>(p, sur, n_chains, init_obs, cost_index, horizon, n_steps, max_iter, traj_obs,
-                                             traj_ctrls, failed, steps_done, iterations)
-             : ilqr_closed_loop_impl<float>(p, sur, n_chains, init_obs, cost_index, horizon, n_steps, max_iter, traj_obs,
-                                            traj_ctrls, failed, steps_done, iterations);
+             ? ilqr_closed_loop_impl<double>(p, sur, n_chains, init_obs, cost_index, horizon, model_index, n_steps, max_iter,
+                                             traj_obs, traj_ctrls, failed, steps_done, iterations)
+             : ilqr_closed_loop_impl<float>(p, sur, n_chains, init_obs, cost_index, horizon, model_index, n_steps, max_iter,
+                                            traj_obs, traj_ctrls, failed, steps_done, iterations);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -143,6 +143,9 @@ struct ampc_handle {
   // cost blocks / bounds ----------------------------------------------------------------------
   int n_costs = 0, obs_dim = 0, cost_stride = 0, cost_diag = 0, cost_affine = 0;
   DevBuf cost_buf;
+  // indicator terms of the MPPI stage cost (ampc_set_indicator_costs): [n_ind][ind_stride(obs_dim)], compute precision
+  int n_ind = 0;
+  DevBuf ind_buf;
   bool has_bounds = false;
   std::vector<double> lo, hi;
   DevBuf bounds_buf;  // lo/scale, hi/scale, scale   (MPPI units)
@@ -292,6 +295,11 @@ struct ampc_mppi_plan {
   DevBuf eps_next;
   bool ahead_on = false, ahead_valid = false, eps_from_generator = false;
   uint64_t ahead_seed = 0, ahead_stream = 0;
+  // several controller models of the handle's shape (ampc_mppi_plan_set_models): device table of their
+  // descriptors, MppiProblem::model names a problem's entry; the handles are kept alive by the plan
+  std::vector<ampc_handle*> models;
+  std::vector<int> model_idx;     // [B]
+  DevBuf mlp_tab;                 // [n_models] byte offsets of the models' buffers from the plan model's
   int lift_n = 0;             // ampc_mppi_plan_set_state_lift: basis functions of the controller model's lift
   DevBuf lift_prog;           // [lift_n][2] (kind, parameter) in compute precision
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
@@ -366,6 +374,9 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.tile_part = (T*)p->tile_part.p;
   a.tile_done = (int*)p->tile_done.p;
   a.fused_combine = p->fused_combine ? 1 : 0;
+  a.model_delta = p->models.empty() ? nullptr : (const long long*)p->mlp_tab.p;
+  a.ind_tab = (const T*)h->ind_buf.p;
+  a.n_ind = h->n_ind;
   a.costs_par = (const T*)h->cost_buf.p;
   a.bounds = (const T*)h->bounds_buf.p;
   a.probs = (const MppiProblem<T>*)p->probs.p;
@@ -432,6 +443,11 @@ struct ampc_ilqr_plan {
   // array keeps the plan's horizon H as its stride, a slot's loops run to slot_h[slot] <= H
   bool var_h = false;
   DevBuf slot_h;                // [B] ints
+  // several controller models of the handle's shape (ampc_ilqr_plan_set_models): device table of their
+  // descriptors; a queue problem / episode names its entry (ampc_ilqr_*_var), the slot carries it
+  std::vector<ampc_handle*> models;
+  DevBuf mlp_tab, slot_model;   // [n_models] byte offsets of the models' buffers, [B] ints
+  bool var_model = false;       // the running queue / closed loop uses per-slot models
   DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
   DevBuf c_ints, c_iters, c_stage, c_obs, c_ctl;   // ampc_ilqr_closed_loop: chain bookkeeping, staged rows, trajectories
   long long last_queue_launches = 0;   // iterations launched by the last queue solve
@@ -466,6 +482,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
     a.slot_mode = (int*)p->q_ctl.p + 2 + p->B;
     a.max_iter = p->queue_max_iter;
     if (p->var_h) a.slot_h = (const int*)p->slot_h.p;
+    if (p->var_model) { a.model_delta = (const long long*)p->mlp_tab.p; a.slot_model = (const int*)p->slot_model.p; }
   }
   return a;
 }

@@ -52,6 +52,8 @@ template <typename T> struct IlqrArgs {
   int* ls_pass;                  // the problems the first left undecided: ls_pass[p] = 1)
   int* ls_need;                  // [B] four-row passes the slot's LAST line search needed (1..): what the host
                                  // picks the line-search kernel of the next launches from (ilqr_lsw.hpp)
+  const long long* model_delta;  // controller models of the plan's shape (ampc_ilqr_plan_set_models; byte offsets of
+  const int* slot_model;         // their buffers, mlp_tile.hpp) and the entry each slot's problem uses, or nullptr
   const int* slot_h;             // [B] per-slot horizon <= H (ampc_ilqr_*_var: problems of different horizons share
                                  // a plan; every array keeps the stride of H), nullptr: H for every problem
   int* slot_mode;                // queue mode (ampc_ilqr_solve_queue): per slot 0 = roll out the guess of the
@@ -848,9 +850,11 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // resident fragments does not pay (measured with a static shape: 0.74 ms resident vs 0.58 ms)
   using Net = TileNet<T, NT, 1, W, false, 2, SH, WIDE>;
   constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
-  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
-  const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x, p = blockIdx.x;
+  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  if constexpr (!SH::kStatic)       // (per-slot models: run-time-shape kernels only, as in mppi_rollout_kernel)
+    mlp = shift_model(mlp, model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0));
+  const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   const int xs_ = L.xu_stride;
@@ -1093,6 +1097,8 @@ template <typename T> struct IlqrQueue {
   int P, B, H, nx, nu;       // H: the plan's horizon = the stride of every [..][H][..] array below
   const int* horizon;        // [P] per-problem horizon <= H (rows past it: zero in the outputs), nullptr: H
   int* slot_h;               // [B] the plan's per-slot horizon (read by every kernel), with `horizon`
+  const int* model;          // [P] per-problem controller model (entry of IlqrArgs::model_delta), nullptr: the plan's
+  int* slot_model;           // [B] the plan's per-slot model, with `model`
   int* ctl;                  // [0] next problem to hand out, [1] problems harvested
   int* slot_prob;            // [B] problem in the slot, -1: none
   const T* x0;               // [P][nx]
@@ -1148,6 +1154,7 @@ __global__ __launch_bounds__(256) void ilqr_queue_refill_kernel(const IlqrArgs<T
     if (n >= 0) {
       q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0;
       if (q.horizon) q.slot_h[p] = q.horizon[n];
+      if (q.model) q.slot_model[p] = q.model[n];
     }
     if (j >= 0) { __threadfence(); atomicAdd(&q.ctl[1], 1); }
   }
@@ -1168,6 +1175,8 @@ template <typename T> struct IlqrChains {
   int C, B, H, nx, nu, n_steps, max_iter;     // H: the plan's horizon (array stride)
   const int* horizon;        // [C] per-chain iLQR horizon <= H, nullptr: H
   int* slot_h;               // [B] the plan's per-slot horizon, with `horizon`
+  const int* model;          // [C] per-chain controller model, nullptr: the plan's
+  int* slot_model;           // [B]
   int* ctl;                  // [0] next chain to hand out, [1] chains finished
   int* slot_chain;           // [B] chain in the slot, -1: none
   int* need;                 // [B] 0 nothing, 1 step the surrogate and continue, 2 chain failed, 3 wants a chain
@@ -1239,6 +1248,7 @@ __global__ __launch_bounds__(256) void ilqr_chain_post_kernel(const IlqrArgs<T> 
     if (n >= 0) {
       q.cost_idx[p] = q.cost[n]; args.slot_mode[p] = 0; args.refresh[p] = 0; q.chain_t[n] = 0;
       if (q.horizon) q.slot_h[p] = q.horizon[n];
+      if (q.model) q.slot_model[p] = q.model[n];
     }
   }
   __syncthreads();

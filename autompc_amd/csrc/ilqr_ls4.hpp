@@ -145,8 +145,10 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   static_assert(NGH % NB == 0 && D < NGH, "ring phase must repeat per layer");
   constexpr bool STREAM = !RES || SPR > 0;
   constexpr bool W0LDS = ls4_w0_lds(NT);
-  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
+  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  if constexpr (!SH::kStatic)       // (per-slot models: run-time-shape kernels only, as in mppi_rollout_kernel)
+    mlp = shift_model(mlp, model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0));
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon

@@ -79,10 +79,17 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
 #endif
   ampc_handle* h = p->h;
   const MlpDev<T>& m = model_of<T>(h);
-  const int nx = h->nx, nu = h->nu, rows = p->B * p->H;
+  const int nx = h->nx, nu = h->nu;
+  // slots that carry different controller models (ampc_ilqr_plan_set_models): groups padded to whole
+  // 16-row tiles, so that a tile's rows share one model
+  const bool per_slot = p->queue_on && p->var_model;
+  const int gpad = per_slot ? round_up(p->H, 16) : 0;
+  const int rows = p->B * (per_slot ? gpad : p->H);
   const int n_pad = round_up(rows, 64);
   const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B,
-                  (p->queue_on && p->var_h) ? (const int*)p->slot_h.p : nullptr};
+                  (p->queue_on && p->var_h) ? (const int*)p->slot_h.p : nullptr,
+                  gpad, per_slot ? (const int*)p->slot_model.p : nullptr, per_slot ? (const long long*)p->mlp_tab.p : nullptr};
+  if (per_slot) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
 #ifndef AMPC_JIT_PLUGIN
   if (h->has_sindy) {
     hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
@@ -125,7 +132,7 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
     // c4 than 32- or 64-row tiles (AMPC_JMT overrides for experiments).
     const int kinp = 16 * ((m.kin + 15) / 16);
     int jmt = env_int("AMPC_JMT", 0);
-    if (jmt == 0) jmt = 1;
+    if (jmt == 0 || per_slot) jmt = 1;          // (per-slot models: groups are padded to 16-row tiles)
     while (jmt > 1 && (size_t)16 * jmt * imax(m.hpad + 2, h->nw * kinp) * sizeof(T) > kLdsLimit) jmt /= 2;
     const int JM = 16 * jmt, jtiles = ((rows + JM - 1) / JM) * nx;   // (sample block, output) tiles
     const size_t jl = (size_t)JM * imax(m.hpad + 2, h->nw * kinp) * sizeof(T);

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64 * kLinW) void linear_rollout_kernel(const MppiAr
     T* nxt = xb[(t + 1) & 1];
     // ---- stage cost of (x_t, u_t): TPS partials per sample, reduced once after the loop
     c_part += quad_rows<T>(Qm, cur + ms * xs, goal, no, r, TPS, diag);
+    if (args.n_ind) c_part += indicator_rows<T>(args.ind_tab, args.n_ind, cur + ms * xs, 1, no, r, TPS);
     if (!diag) c_part += quad_rows<T>(Rm, cur + ms * xs + nx, nullptr, nu, r, TPS, false);
     if (affine) c_part += affine_rows<T>(lin, cur + ms * xs, goal, no, r, TPS, T(0));
     // ---- dynamics: x_{t+1} = M [x_t ; u_t] into the other buffer; the next step's actions beside it

@@ -20,25 +20,43 @@ namespace ampc {
 // groups with mask[g] == 0 are skipped by the Jacobian kernel (their Jacobians stay untouched).
 // glen (optional) is per group too: only the first glen[g] rows of group g exist (iLQR slots whose
 // horizon is shorter than the plan's, ampc_ilqr_solve_queue_var); the others are skipped like masked ones.
+// grp_pad (optional, a multiple of the tile height): the kernels' row index runs over groups PADDED to
+// grp_pad rows -- row v is step v % grp_pad of group v / grp_pad and exists for steps < grp -- so that no
+// tile straddles two groups; with it grp_model[g] names the group's entry of the table model_delta
+// (iLQR slots that carry different controller models, ampc_ilqr_plan_set_models; mlp_tile.hpp).  Outputs (jx, ju, out)
+// are indexed by the UNPADDED row g * grp + step either way; the stored derivatives by the kernels' row.
 struct RowMap {
   int grp;
   long long s_stride, c_stride;
   const int* mask;
   const int* glen;
-  __device__ __forceinline__ bool plain() const { return mask == nullptr && glen == nullptr; }
-  __device__ __forceinline__ bool live(int r) const {
-    const int g = r / grp;
-    return (mask == nullptr || mask[g] != 0) && (glen == nullptr || r - g * grp < glen[g]);
+  int grp_pad;
+  const int* grp_model;
+  const long long* model_delta;
+  __device__ __forceinline__ bool plain() const { return mask == nullptr && glen == nullptr && grp_pad == 0; }
+  __device__ __forceinline__ int gp() const { return grp_pad > 0 ? grp_pad : grp; }
+  __device__ __forceinline__ int group(int v) const { return v / gp(); }
+  __device__ __forceinline__ int step(int v) const { return v % gp(); }
+  __device__ __forceinline__ long long out_row(int v) const { return (long long)group(v) * grp + step(v); }
+  __device__ __forceinline__ bool live(int v) const {
+    const int g = group(v), t = v - g * gp();
+    return t < grp && (mask == nullptr || mask[g] != 0) && (glen == nullptr || t < glen[g]);
   }
   // some row of [first, last] is live
   __device__ __forceinline__ bool any_live(int first, int last) const {
-    for (int g = first / grp; g <= last / grp; ++g) {
+    const int G = gp();
+    for (int g = first / G; g <= last / G; ++g) {
       if (mask != nullptr && mask[g] == 0) continue;
-      const int lo = first > g * grp ? first : g * grp;
-      const int hi = glen != nullptr ? g * grp + glen[g] - 1 : last;
+      const int len = glen != nullptr ? (glen[g] < grp ? glen[g] : grp) : grp;
+      const int lo = first > g * G ? first : g * G;
+      const int hi = g * G + len - 1;
       if (lo <= (hi < last ? hi : last)) return true;
     }
     return false;
+  }
+  // byte offset of the model the tile starting at row `first` runs on
+  __device__ __forceinline__ long long delta(int first) const {
+    return model_delta_of(model_delta, model_delta != nullptr ? grp_model[group(first)] : 0);
   }
 };
 
@@ -53,10 +71,11 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   T* lds = reinterpret_cast<T*>(smem_raw);
   using Net = TileNet<T, NT, MT, W, DERIV, 0, SH, WIDE>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
-  const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
+  const int first = blockIdx.x * M;
+  MlpDev<T> mlp = SH::template fold<T>(mlp_in);
+  if constexpr (!SH::kStatic) mlp = shift_model(mlp, rm.delta(first));   // (per-group models: run-time shapes only)
   const TileLds L = SH::template fold_lds<T, M, W>(L_in);
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
-  const int first = blockIdx.x * M;
   T* xu = lds + L.xu;
   if (!rm.plain() && first < n) {          // (iLQR refresh) every row of this tile is masked out
     if (!rm.any_live(first, first + M - 1 < n ? first + M - 1 : n - 1)) return;
@@ -69,23 +88,23 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
     const int row = i / nx, col = i - row * nx;
     const int gr = first + row;
     xu[row * L.xu_stride + col] =
-        (gr < n && (rm.glen == nullptr || rm.live(gr)))    // (rows past a slot's horizon: never written)
-            ? states[(size_t)(gr / rm.grp) * rm.s_stride + (size_t)(gr % rm.grp) * nx + col] : T(0);
+        (gr < n && ((rm.glen == nullptr && rm.grp_pad == 0) || rm.live(gr)))    // (rows past a slot's horizon: never written)
+            ? states[(size_t)rm.group(gr) * rm.s_stride + (size_t)rm.step(gr) * nx + col] : T(0);
   }
   for (int i = tid; i < M * nu; i += NTHR) {
     const int row = i / nu, col = i - row * nu;
     const int gr = first + row;
     xu[row * L.xu_stride + nx + col] =
-        (gr < n && (rm.glen == nullptr || rm.live(gr)))
-            ? ctrls[(size_t)(gr / rm.grp) * rm.c_stride + (size_t)(gr % rm.grp) * nu + col] : T(0);
+        (gr < n && ((rm.glen == nullptr && rm.grp_pad == 0) || rm.live(gr)))
+            ? ctrls[(size_t)rm.group(gr) * rm.c_stride + (size_t)rm.step(gr) * nu + col] : T(0);
   }
   __syncthreads();
   // dz layout: [layer][n_pad][hpad]; this tile's rows start at `first`
   net.run(mlp, L, lds, DERIV ? dz + (size_t)first * mlp.hpad : nullptr, (size_t)n_pad * mlp.hpad);
   for (int i = tid; i < M * nx; i += NTHR) {
     const int row = i / nx, col = i - row * nx;
-    if (out != nullptr && first + row < n)
-      out[(size_t)(first + row) * nx + col] = xu[row * L.xu_stride + col] + Net::output(mlp, L, lds, row, col);
+    if (out != nullptr && first + row < n && (rm.grp_pad == 0 || rm.step(first + row) < rm.grp))
+      out[(size_t)rm.out_row(first + row) * nx + col] = xu[row * L.xu_stride + col] + Net::output(mlp, L, lds, row, col);
   }
 }
 
@@ -117,7 +136,7 @@ __device__ __forceinline__ void ksplit_mma(const T* __restrict__ arow, int as,
 // overlap one tile's global loads with the others' MFMAs; measured +4 % on c4 over the default 88)
 template <typename T, int NT, int MT, int W, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacobian_kernel(const MlpDev<T> mlp_in,
-                                                              const T* __restrict__ wout_plain,
+                                                              const T* __restrict__ wout_plain_in,
                                                               const T* __restrict__ dz, int n,
                                                               int n_pad, T* __restrict__ jx,
                                                               T* __restrict__ ju, const RowMap rm) {
@@ -127,14 +146,13 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   using Net = TileNet<T, NT, MT, W, false>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int NIMAX = WIDE ? 5 : 3;  // kin <= 48 (80 when WIDE)
-  const MlpDev<T> mlp = SH::template fold<T>(mlp_in);
   constexpr int KSH = Net::KSH, KSW = Net::KSW, GH = Net::GH;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int nx = mlp.nx, nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
+  const int nx = SH::template fold<T>(mlp_in).nx;       // (every model of a plan has the plan's shape)
   constexpr int HP = Net::HP;                      // == hpad for this instantiation
-  const int gs = hpad + (sizeof(T) == 8 ? 1 : 2);  // same padding rule as TileLds::act_stride
+  const int gs = HP + (sizeof(T) == 8 ? 1 : 2);    // same padding rule as TileLds::act_stride
   // blockIdx -> (sample block, output index), XCD-aware: workgroups are dealt round-robin to the 8
   // XCDs (blockIdx % 8), each with its own L2.  The nx tiles of one sample block read the same
   // stored activation derivatives, so they are given block indices of one residue mod 8 -- one
@@ -154,6 +172,12 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     }
   }
   const int s0 = sblk * M;                         // the tile's first sample
+  MlpDev<T> mlp = SH::template fold<T>(mlp_in);
+  if constexpr (!SH::kStatic) mlp = shift_model(mlp, rm.delta(s0 < n ? s0 : 0));
+  const int nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
+  // (the folded output weights lie in the model's buffer as well: the same byte offset applies)
+  const T* wout_plain = SH::kStatic ? wout_plain_in
+      : reinterpret_cast<const T*>(reinterpret_cast<const char*>(wout_plain_in) + rm.delta(s0 < n ? s0 : 0));
   const size_t lstride = (size_t)n_pad * hpad;
   if (!rm.plain()) {                   // every row this tile touches is masked out: nothing to refresh
     if (s0 >= n || !rm.any_live(s0, s0 + M - 1 < n ? s0 + M - 1 : n - 1)) return;
@@ -228,8 +252,9 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     T v = T(0);
 #pragma unroll
     for (int ww = 0; ww < W; ++ww) v += G[ww * M * kinp + row * kinp + c];
-    if (c < nx) jx[((size_t)s * nx + i) * nx + c] = v + (c == i ? T(1) : T(0));
-    else ju[((size_t)s * nx + i) * nu + (c - nx)] = v;
+    const size_t so = (size_t)rm.out_row(s);
+    if (c < nx) jx[(so * nx + i) * nx + c] = v + (c == i ? T(1) : T(0));
+    else ju[(so * nx + i) * nu + (c - nx)] = v;
   }
 }
 

@@ -216,6 +216,27 @@ template <typename T> struct MlpDev {
   const T* w4[kMaxHidden + 1];
 };
 
+// Several controller models of ONE shape in a plan (tuning candidates that carry their own model,
+// pipeline.py:138-145).  Models of one shape are packed identically (build_model: every array at the same
+// offset of the model's buffer), so model k is the plan handle's descriptor with every pointer moved by
+// ONE byte offset, delta[k] = buffer of model k - buffer of the plan's model: the plan holds the table of
+// deltas, a problem / slot names its entry.  One wave-uniform 64-bit value per workgroup; the descriptor
+// itself stays the kernel argument (scalar registers, fields fetched where they are used).
+__device__ __forceinline__ long long model_delta_of(const long long* __restrict__ tab, int idx) {
+  if (tab == nullptr) return 0;
+  const long long d = tab[idx];
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)d >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+template <typename T> __device__ __forceinline__ MlpDev<T> shift_model(MlpDev<T> m, long long d) {
+  auto sh = [d](const T* p) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + d); };
+  m.wbase = sh(m.wbase); m.wt = sh(m.wt);
+#pragma unroll
+  for (int l = 0; l <= kMaxHidden; ++l) { m.w[l] = sh(m.w[l]); m.b[l] = sh(m.b[l]); m.wj[l] = sh(m.wj[l]); m.w4[l] = sh(m.w4[l]); }
+  return m;
+}
+
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
 struct TileLds {
   int act;      // [M][hpad+pad]
@@ -1012,6 +1033,55 @@ __device__ __forceinline__ T affine_rows(const T* __restrict__ lin, const T* __r
                                          const T* __restrict__ g, int n, int r, int tps, T c) {
   T acc = r == 0 ? c : T(0);
   for (int i = r; i < n; i += tps) acc += lin[i] * (v[i] - g[i]);
+  return acc;
+}
+
+// ---- indicator terms of an MPPI stage cost ---------------------------------------------------------
+// The reference's MPPI charges whatever Cost the task holds (mppi.py:73-82), e.g. QuadCost + ThresholdCost
+// or a bare BoxThresholdCost (thresh_cost.py:27-32, 73-77): 1 per time step whose observation violates the
+// term, no control or terminal part (thresh_cost.py:34-38, 79-83).  Device table, kIndStride(no) values
+// per term:   kind | 0 | a[no] | b[no]
+//   kind 1  threshold: a = goal, b_i = threshold inside the term's observation range, +inf outside;
+//                      violated where  x_i - a_i > b_i  or  a_i - x_i > b_i   (|x - g|_inf > threshold)
+//   kind 2  box:       a = lower, b = upper limits;  violated where  x_i < a_i  or  x_i > b_i
+// A NaN observation violates nothing, as in the reference (its comparisons are false).
+constexpr int kMaxInd = 8;
+__host__ __device__ constexpr int ind_stride(int no) { return 2 * no + 2; }
+template <typename T> __device__ __forceinline__ bool ind_entry(int kind, T x, T a, T b) {
+  if (kind == 1) { const T d = x - a; return d > b || -d > b; }
+  return x < a || x > b;
+}
+// The rows of a sample split over `tps` consecutive lanes of a wave (tps a power of two <= 64; lane r of the
+// group checks entries r, r + tps, ...; v[i * vs] = entry i): number of violated terms, on the group's lane
+// r == 0 (zero elsewhere -- the callers' per-sample partial sums are added up over the group).  Every lane of
+// the wave must call it (ballot).
+template <typename T>
+__device__ __forceinline__ T indicator_rows(const T* __restrict__ tab, int n_ind, const T* __restrict__ v, int vs,
+                                            int no, int r, int tps) {
+  T acc = T(0);
+  const int lane = threadIdx.x & 63;
+  for (int k = 0; k < n_ind; ++k) {
+    const T* tk = tab + (size_t)k * ind_stride(no);
+    const int kind = (int)tk[0];
+    bool viol = false;
+    for (int i = r; i < no; i += tps) viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
+    const unsigned long long bal = __ballot(viol);
+    const unsigned long long grp = tps >= 64 ? bal : (bal >> (lane & ~(tps - 1))) & ((1ull << tps) - 1ull);
+    if (r == 0 && grp != 0ull) acc += T(1);
+  }
+  return acc;
+}
+// ... with the whole observation in every lane: the count itself
+template <typename T>
+__device__ __forceinline__ T indicator_all(const T* __restrict__ tab, int n_ind, const T* __restrict__ v, int vs, int no) {
+  T acc = T(0);
+  for (int k = 0; k < n_ind; ++k) {
+    const T* tk = tab + (size_t)k * ind_stride(no);
+    const int kind = (int)tk[0];
+    bool viol = false;
+    for (int i = 0; i < no; ++i) viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
+    if (viol) acc += T(1);
+  }
   return acc;
 }
 

@@ -36,6 +36,7 @@ template <typename T> struct MppiProblem {
   unsigned noise_id;   // keys the problem's device noise stream (default: index in the plan; the
                        // candidate evaluator sets the candidate's GLOBAL index, so a candidate's
                        // noise does not depend on how the batch is sharded over GPUs)
+  int model;           // entry of MppiArgs::model_delta (ampc_mppi_plan_set_models), 0 without a table
 };
 
 template <typename T> struct MppiArgs {
@@ -71,6 +72,11 @@ template <typename T> struct MppiArgs {
   int* tile_done;               // [B] tickets: the four-row rollout's last workgroup of a problem finishes the
                                 // softmin update itself (fused_combine; no combine launch)
   int fused_combine;
+  // (behind everything the shape-specialised kernels read: their argument layout is the tuned one)
+  int n_ind;                    // indicator terms of the stage cost (threshold / box; mlp_tile.hpp), shared by every
+  const T* ind_tab;             // cost block: [n_ind][ind_stride(obs_dim)]; 0: none
+  const long long* model_delta; // per-problem controller models of the plan's shape: byte offsets of their buffers
+                                // from the plan model's (MppiProblem::model names the entry; mlp_tile.hpp), or nullptr
 };
 
 template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
@@ -171,7 +177,12 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int TPS = NTHR / M;                 // threads per sample (32..4), all in one wave
   constexpr int EPT = (16 + TPS - 1) / TPS;     // noise elements per thread (nu <= 16)
-  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  // Extended stage costs (indicator terms) and per-problem models (MppiArgs::n_ind, model_delta) are compiled
+  // into the run-time-shape instantiation only: the shape-specialised kernels are the tuned hot path (a few
+  // instructions more in their time loop cost 2-5 % through scheduling and register allocation alone), and a
+  // plan that needs either runs the run-time-shape kernels (plan_build).
+  constexpr bool EXT = !SH::kStatic;
+  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
@@ -185,6 +196,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
 
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
+  if constexpr (EXT) mlp = shift_model(mlp, model_delta_of(args.model_delta, pr.model));
   const int first = (blockIdx.x - pr.tile0) * M;
   const int H = pr.H, N = pr.N;
 
@@ -302,6 +314,8 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     AMPC_PROBE_STEP(net.probe, t == 5);
     AMPC_MARK(0);
     // ---- stage cost of (x_t, u_t): partial per thread, reduced once after the loop ------------
+    if constexpr (EXT)
+      if (args.n_ind) c_part += indicator_rows<T>(args.ind_tab, args.n_ind, xu + m * xs_, 1, no, r, TPS);   // (x_t)
     if (!diag && !Probe::no_cost) {
       c_part += quad_rows<T>(Qm, xu + m * xs_, goal, no, r, TPS, false);
       c_part += quad_rows<T>(Rm, xu + m * xs_ + nx, nullptr, nu, r, TPS, false);
@@ -624,8 +638,19 @@ __global__ void state_lift_kernel(const T* __restrict__ sim, T* __restrict__ x0,
   const T par = prog[2 * f + 1];
   T v = o;
   if (kind == 1) {
-    v = T(1);
-    for (int k = 0; k < (int)par; ++k) v *= o;
+    // o ** p as the host computes it (Koopman's basis, koopman.py:105-122: numpy power = x * x for p = 2,
+    // the C library's pow() above): the product is carried as a double-double and rounded ONCE, which is
+    // pow()'s result except where the exact value lies within ~1e-16 relative of a rounding boundary --
+    // a chain of rounded multiplications would be off by an ulp or two for p >= 3
+    const int pw = (int)par;
+    double hi = pw >= 1 ? (double)o : 1.0, lo = 0.0;
+    for (int k = 1; k < pw; ++k) {
+      const double ph = hi * (double)o;
+      const double pe = fma(hi, (double)o, -ph) + lo * (double)o;
+      hi = ph + pe;
+      lo = pe - (hi - ph);
+    }
+    v = (T)hi;
   } else if (kind == 2) {
     v = sin(par * o);
   } else if (kind == 3) {

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   // layer and the next first layer, so the barrier there goes (it stays for an odd number of hidden
   // layers, where the first layer would overwrite the activations a slower wave is still reading).
   constexpr bool BAR_A = !FULL || (NH & 1);
-  const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  constexpr bool EXT = !SH::kStatic;           // (indicator terms, per-problem models: run-time shapes only, as
+  MlpDev<T> mlp = SH::template fold<T>(args.mlp);   //  in mppi_rollout_kernel)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
 
   const int p = args.tile_prob[blockIdx.x];
   const MppiProblem<T> pr = args.probs[p];
+  if constexpr (EXT) mlp = shift_model(mlp, model_delta_of(args.model_delta, pr.model));
   const int first = (blockIdx.x - pr.tile0) * ROWS;
   const int H = pr.H, N = pr.N;
 
@@ -229,6 +231,8 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
     AMPC_MARK(0);
     if (BAR_A) lds_barrier();                    // state and controls of step t are in xu
     AMPC_MARK(1);
+    if constexpr (EXT)
+      if (args.n_ind) c_part += indicator_rows<T>(args.ind_tab, args.n_ind, xu + m * xs, 1, no, r, 64);   // (x_t)
     if (!diag) {
       c_part += quad_rows<T>(Qm, xu + m * xs, goal, no, r, 64, false);
       if (affine) c_part += affine_rows<T>(lin, xu + m * xs, goal, no, r, 64, T(0));

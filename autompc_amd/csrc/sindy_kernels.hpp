@@ -331,6 +331,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_kernel(const MppiArgs<T
       c += (v[i * BS] - goal[i]) * (s + lin[i]);
     }
     c += lint[no];
+    if (args.n_ind) c += indicator_all<T>(args.ind_tab, args.n_ind, v, BS, no);
     for (int i = 0; i < nu; ++i) {
       T s = T(0);
       for (int j = 0; j < nu; ++j) s += Rm[i * nu + j] * v[(nx + j) * BS];
@@ -501,6 +502,17 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
       }
     }
     c += lc;
+    if (args.n_ind) {                      // indicator terms (threshold / box, mlp_tile.hpp), from the register copy
+      for (int k = 0; k < args.n_ind; ++k) {
+        const T* tk = args.ind_tab + (size_t)k * ind_stride(no);
+        const int kind = (int)tk[0];
+        bool viol = false;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          if (i < no) viol = viol || ind_entry<T>(kind, xreg[i], tk[2 + i], tk[2 + no + i]);
+        if (viol) c += T(1);
+      }
+    }
     // ---- table entries of this lane (the first one from hoisted operands)
     if (t0) {
       const T arg = tp0 * v[tv0];

@@ -30,6 +30,69 @@ def shard_bounds(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def candidate_work(c):
+    """Relative device work of one candidate's episode: rollouts per control step for MPPI candidates
+    (num_path x horizon), the horizon for iLQR candidates -- what evaluate_sharded balances."""
+    return float(c.get("num_path", 1)) * float(c.get("horizon", 1)) if isinstance(c, dict) else 1.0
+
+
+def balanced_shards(weights, world):
+    """Deal items to `world` ranks so that the heaviest rank carries little more than the mean work:
+    heaviest item first onto the least-loaded rank (ties: fewer items, then the lower rank).  Returns one
+    ascending index array per rank; deterministic, so every rank computes the same assignment."""
+    w = np.asarray(weights, dtype=np.float64)
+    order = sorted(range(len(w)), key=lambda i: (-w[i], i))
+    load, count, out = [0.0] * world, [0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], count[k], k))
+        out[r].append(i)
+        load[r] += w[i]
+        count[r] += 1
+    return [np.array(sorted(ix), dtype=np.int64) for ix in out]
+
+
+def model_shape_key(model):
+    """What two controller models must share to run in one plan (ampc_*_plan_set_models): the class, the
+    state dimension and -- MLPs -- hidden sizes and activation."""
+    return (type(model).__name__, int(model.state_dim), tuple(int(v) for v in getattr(model, "hidden_sizes", ())),
+            str(getattr(model, "nonlintype", "")))
+
+
+def candidate_models(candidates, default):
+    """(models, index): the distinct controller models the candidates carry under "model" (the evaluator's
+    own for candidates without one), in order of first appearance, and each candidate's entry."""
+    models, index, seen = [], [], {}
+    for c in candidates:
+        m = c.get("model") if isinstance(c, dict) else None
+        m = default if m is None else m
+        if id(m) not in seen:
+            seen[id(m)] = len(models)
+            models.append(m)
+        index.append(seen[id(m)])
+    return models, np.asarray(index, dtype=np.int32)
+
+
+def _by_model_shape(candidates, default):
+    """Candidate indices grouped by the shape of the model they carry (first appearance order), or None
+    when all share one shape."""
+    groups = {}
+    for i, c in enumerate(candidates):
+        m = c.get("model") if isinstance(c, dict) else None
+        groups.setdefault(model_shape_key(default if m is None else m), []).append(i)
+    return None if len(groups) <= 1 else list(groups.values())
+
+
+def global_ids(index_offset, n):
+    """Global indices of a shard's n candidates: index_offset is the first one's (a contiguous shard) or
+    the array of all of them (a balanced shard, evaluate_sharded(..., weights=...))."""
+    if np.ndim(index_offset) == 0:
+        return int(index_offset) + np.arange(n, dtype=np.int64)
+    ids = np.asarray(index_offset, dtype=np.int64).reshape(-1)
+    if ids.shape[0] != n:
+        raise ValueError("index_offset lists %d global indices for %d candidates" % (ids.shape[0], n))
+    return ids
+
+
 def _as_matrix(v, n):
     v = np.asarray(v, dtype=np.float64)
     return np.diag(v) if v.ndim == 1 else v.reshape(n, n)
@@ -222,13 +285,53 @@ class CandidateEvaluator:
             raise ValueError("candidate horizon %d exceeds the evaluator's horizon_cap %d; construct "
                              "CandidateEvaluator(horizon_cap=...) for the range being searched"
                              % (max(too_long), self.horizon_cap))
+        ids = global_ids(index_offset, B)
+        shape_groups = _by_model_shape(candidates, self.model)
+        if shape_groups is not None:
+            # Candidates that carry controller models of DIFFERENT shapes (pipeline.py:138-145: a model per
+            # configuration): one plan per shape, evaluated in turn; same-shape models share a plan
+            # (ampc_mppi_plan_set_models).  A candidate's randomness is keyed by its global index either way.
+            if eps_all is not None or act_init is not None:
+                raise ValueError("recorded noise / warm starts are laid out for ONE plan: evaluate the candidates of "
+                                 "each model shape separately")
+            return self._evaluate_shape_groups(shape_groups, candidates, ids, dict(
+                n_steps=n_steps, seed=seed, init_obs=init_obs, return_trajectories=return_trajectories))
         opened = []                       # device objects, closed on every exit path
         try:
             return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
-                                  return_trajectories, int(index_offset), opened, timing)
+                                  return_trajectories, ids, opened, timing)
         finally:
             for obj in reversed(opened):
                 obj.close()
+
+    def _evaluate_shape_groups(self, groups, candidates, ids, kw):
+        import copy
+        B = len(candidates)
+        scores, trajs, lengths = np.empty(B), [None] * B, np.zeros(B, dtype=np.int64)
+        for idx in groups:
+            sub = copy.copy(self)
+            sub.model = candidates[idx[0]].get("model") or self.model
+            if sub.surrogate is self.model and self.surrogate is self.model:
+                sub.surrogate = self.model               # (the simulation model stays the evaluator's)
+            out = sub.evaluate([candidates[i] for i in idx], index_offset=ids[idx], **kw)
+            if kw["return_trajectories"]:
+                sc, ob, ct = out
+                for k, i in enumerate(idx):
+                    trajs[i] = (ob[k], ct[k])
+            else:
+                sc = out
+            scores[idx] = sc
+            if sub.last_lengths is not None:
+                lengths[idx] = sub.last_lengths
+        self.last_lengths = lengths if lengths.any() else None
+        if not kw["return_trajectories"]:
+            return scores
+        L = max(t[0].shape[0] for t in trajs)
+        obs = np.full((B, L) + trajs[0][0].shape[1:], np.nan)
+        ctl = np.full((B, L) + trajs[0][1].shape[1:], np.nan)
+        for i, (o, c) in enumerate(trajs):
+            obs[i, :o.shape[0]], ctl[i, :c.shape[0]] = o, c
+        return scores, obs, ctl
 
     # -- pieces ---------------------------------------------------------------------------------
     def _stage(self, candidates, opened):
@@ -237,6 +340,18 @@ class CandidateEvaluator:
         h = _lib.Handle(self.device, self.precision)
         opened.append(h)
         self.model.stage_into(h)
+        # controller models the candidates carry (same shape as the evaluator's: evaluate() groups by shape):
+        # one handle each, holding only the weights; the plan gets their table (ampc_mppi_plan_set_models)
+        models, self._model_index = candidate_models(candidates, self.model)
+        self._model_handles = []
+        if len(models) > 1 or models[0] is not self.model:
+            for m in models:
+                if not hasattr(m, "stage_into"):
+                    raise TypeError("a candidate's model must be device-stageable (autompc_amd.sysid.MLP)")
+                hm = _lib.Handle(self.device, self.precision)
+                opened.append(hm)
+                m.stage_into(hm)
+                self._model_handles.append(hm)
         blocks, _ = candidate_cost_blocks(candidates, self.goal, no, nu)
         h.set_cost_blocks(**blocks)
         h.set_ctrl_bounds(self.umin, self.umax)
@@ -258,6 +373,8 @@ class CandidateEvaluator:
         if self._lift is not None:
             plan.set_state_lift(*self._lift)
         plan.set_noise_ids(np.asarray(noise_ids)[which])
+        if self._model_handles:
+            plan.set_models(self._model_handles, self._model_index[np.asarray(which)])
         plan.upload(act_seq=act_seq)
         return plan
 
@@ -277,11 +394,11 @@ class CandidateEvaluator:
             # MPPI.__init__ / reset() draw the warm start ~ N(0, sigma) (mppi.py:97-99); here from
             # a stream seeded by (seed, global candidate index)
             act_init = np.concatenate([
-                np.random.default_rng([int(seed), index_offset + i]).normal(
+                np.random.default_rng([int(seed), int(index_offset[i])]).normal(
                     scale=np.sqrt(c["sigma"]), size=Hs[i] * nu)
                 for i, c in enumerate(candidates)])
         act_init = np.asarray(act_init, dtype=np.float64).ravel()
-        noise_ids = index_offset + np.arange(B)
+        noise_ids = index_offset               # (global candidate indices: global_ids)
         try:
             terms = cost_terms(self.task.get_cost(), no, nu)
         except TypeError:
@@ -474,6 +591,11 @@ class IlqrCandidateEvaluator:
         B = len(candidates)
         if B == 0:
             return (np.zeros(0), None, None) if return_trajectories else np.zeros(0)
+        shape_groups = _by_model_shape(candidates, self.model)
+        if shape_groups is not None:       # controller models of different shapes: one plan per shape, in turn
+            return CandidateEvaluator._evaluate_shape_groups(
+                self, shape_groups, candidates, global_ids(index_offset, B),
+                dict(n_steps=n_steps, init_obs=init_obs, return_trajectories=return_trajectories, max_iter=max_iter))
         opened = []
         try:
             return self._evaluate(candidates, n_steps, init_obs, return_trajectories, int(max_iter), opened)
@@ -502,6 +624,18 @@ class IlqrCandidateEvaluator:
         self.surrogate.stage_into(sur)
         plans = {}
         device_loop = term_cond is None and n_ctl >= 1 and self.device_resident
+        # controller models the candidates carry (one shape: evaluate() groups by shape): a handle each,
+        # the plan gets their table (ampc_ilqr_plan_set_models), a queue problem / episode names its entry
+        models, model_index = candidate_models(candidates, self.model)
+        model_handles = []
+        if len(models) > 1 or models[0] is not self.model:
+            if not self.one_plan:
+                raise ValueError("candidates that carry their own model need the one-plan evaluator (one_plan=True)")
+            for m in models:
+                hm = _lib.Handle(self.device, self.precision)
+                opened.append(hm)
+                m.stage_into(hm)
+                model_handles.append(hm)
         for H, idx in groups.items():
             h = _lib.Handle(self.device, self.precision)
             opened.append(h)
@@ -514,7 +648,10 @@ class IlqrCandidateEvaluator:
             plan = _lib.IlqrPlan(h, slots, H, self.system.dt, cost_index=np.arange(slots),
                                  clip_to_bounds=self.bounded, terminal_goal=term_goal)
             opened.append(plan)
+            if model_handles:
+                plan.set_models(model_handles)
             plans[H] = (plan, np.array(idx))
+        mi_all = model_index if model_handles else None
         obs = np.full((B, n_ctl + 1, nx), np.nan)
         ctl = np.full((B, n_ctl + 1, nu), np.nan)
         obs[:, 0] = init_obs
@@ -536,7 +673,8 @@ class IlqrCandidateEvaluator:
                 plan, idx = item
                 return idx, plan.closed_loop(np.tile(x0, (len(idx), 1)), n_ctl, cost_index=np.arange(len(idx)),
                                              max_iter=max_iter, surrogate=sur,
-                                             horizon=hz_all[idx] if self.one_plan else None)
+                                             horizon=hz_all[idx] if self.one_plan else None,
+                                             model_index=None if mi_all is None else mi_all[idx])
             items = list(plans.values())
             if len(items) > 1:
                 from concurrent.futures import ThreadPoolExecutor
@@ -563,7 +701,7 @@ class IlqrCandidateEvaluator:
                 x = np.where(live[:, None], obs[idx, t], obs[idx, 0])
                 if self.one_plan:
                     out = plan.solve_queue(x, None, np.arange(len(idx)), max_iter=max_iter, gains=False,
-                                           horizon=hz_all[idx])
+                                           horizon=hz_all[idx], model_index=None if mi_all is None else mi_all[idx])
                 else:
                     out = plan.solve(x, np.zeros((len(idx), H, nu)), max_iter=max_iter)
                 u = out["ctrls"][:, 0]              # u = ubar_0 + K_0 (x - xbar_0) with x = xbar_0
@@ -615,12 +753,19 @@ def random_ilqr_candidates(system, n, seed=0):
                  R=10 ** rng.uniform(-3, 4, size=nu), F=10 ** rng.uniform(-3, 4, size=no)) for _ in range(n)]
 
 
-def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None, stats=None):
+def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None, stats=None, weights=None):
     """Score ``candidates`` with ``local_eval(sub_list, lo) -> scores`` on this rank's contiguous
     shard ``candidates[lo:hi]`` and all-gather the scores so every rank returns the full vector
     (candidate order).  ``lo`` is the global index of the shard's first candidate: an evaluator that
     keys its randomness by it (CandidateEvaluator.evaluate(..., index_offset=lo)) returns the same
     score for a candidate whatever the world size.
+
+    weights: None -- contiguous shards (equal counts; fine for candidates in random order).  "auto" or
+    one weight per candidate -- shards balanced by work (``candidate_work``: num_path x horizon;
+    ``balanced_shards``), for batches that arrive sorted (a horizon sweep, an optimiser's ranked
+    proposals): ``local_eval(sub_list, ids)`` then receives the ARRAY of the shard's global indices
+    (``index_offset=ids`` is accepted by the evaluators), and the scores still come back in candidate
+    order, the same for any world size.
     Uses the default torch.distributed process group when one is initialised; with none (or world
     size 1) it is a plain local evaluation.
 
@@ -637,25 +782,40 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None,
     if rank is None:
         rank = dist.get_rank() if world > 1 else 0
     n = len(candidates)
-    lo, hi = shard_bounds(n, rank, world)
+    if weights is None:
+        spans = [shard_bounds(n, r, world) for r in range(world)]
+        shards = [np.arange(a, b, dtype=np.int64) for a, b in spans]
+        mine, key = candidates[spans[rank][0]:spans[rank][1]], spans[rank][0]
+    else:
+        w = [candidate_work(c) for c in candidates] if isinstance(weights, str) else weights
+        if len(w) != n:
+            raise ValueError("evaluate_sharded: %d weights for %d candidates" % (len(w), n))
+        shards = balanced_shards(w, world)
+        mine, key = [candidates[i] for i in shards[rank]], shards[rank]
+        if len(key) and np.array_equal(key, np.arange(key[0], key[0] + len(key))):
+            key = int(key[0])                            # (a shard that happens to be contiguous: its first index)
+        if stats is not None:
+            loads = [float(np.sum(np.asarray(w, dtype=np.float64)[ix])) for ix in shards]
+            stats.update(shard_work=loads, heaviest_over_mean=max(loads) / max(np.mean(loads), 1e-300))
+    n_mine = len(shards[rank])
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         # (a one-rank process group still takes the collective below: the same code runs at any N)
         if stats is not None:
             stats.update(backend=None, ranks_in_gather=1, gather_ms=0.0, device=None)
-        return np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)
+        return np.asarray(local_eval(mine, key), dtype=np.float64)
     error = None
     try:
-        local = np.asarray(local_eval(candidates[lo:hi], lo), dtype=np.float64)
-        if local.shape != (hi - lo,):
-            raise ValueError("local_eval returned %r scores for %d candidates" % (local.shape, hi - lo))
+        local = np.asarray(local_eval(mine, key), dtype=np.float64)
+        if local.shape != (n_mine,):
+            raise ValueError("local_eval returned %r scores for %d candidates" % (local.shape, n_mine))
     except Exception as e:           # noqa: BLE001 -- reported after the collective
-        error, local = e, np.zeros(hi - lo)
-    per = (n + world - 1) // world                     # equal-sized slots for the all-gather
+        error, local = e, np.zeros(n_mine)
+    per = max(len(ix) for ix in shards)                # equal-sized slots for the all-gather
     dev = device if device is not None else (
         torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
         else torch.device("cpu"))
     slot = torch.full((per + 1,), float("nan"), dtype=torch.float64, device=dev)
-    slot[:hi - lo] = torch.from_numpy(local).to(dev)
+    slot[:n_mine] = torch.from_numpy(local).to(dev)
     slot[per] = 0.0 if error is None else 1.0          # failure marker of this rank
     gathered = torch.empty(world * (per + 1), dtype=torch.float64, device=dev)
     import time
@@ -676,8 +836,7 @@ def evaluate_sharded(local_eval, candidates, rank=None, world=None, device=None,
         raise RuntimeError("candidate evaluation failed on rank(s) %s" % failed)
     out = np.empty(n)
     for r in range(world):
-        a, b = shard_bounds(n, r, world)
-        out[a:b] = g[r, :b - a]
+        out[shards[r]] = g[r, :len(shards[r])]
     return out
 
 

@@ -22,7 +22,8 @@ from collections import namedtuple
 
 import numpy as np
 
-from .batch_eval import IlqrCandidateEvaluator, evaluate_sharded, random_candidates, random_ilqr_candidates
+from .batch_eval import (IlqrCandidateEvaluator, evaluate_sharded, global_ids, random_candidates,
+                         random_ilqr_candidates)
 
 # same fields, same order as the reference's namedtuple (pipeline_tuner.py:19-21)
 PipelineTuneResult = namedtuple("PipelineTuneResult", [
@@ -35,7 +36,7 @@ class BatchPipelineTuner:
     required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
 
     def __init__(self, system, evaluator, batch_size=64, sampler=None, truedyn_noise="device",
-                 eval_kwargs=None, keep_trajs=False):
+                 eval_kwargs=None, keep_trajs=False, balance=True, models=None):
         """truedyn_noise: the noise mode of the controllers scored against the true dynamics
         (MPPI(noise=...): "device" Philox, or "numpy" / "numpy_device" = the reference's global
         legacy stream).  eval_kwargs: extra keyword arguments for every ``evaluator.evaluate`` call
@@ -47,6 +48,16 @@ class BatchPipelineTuner:
         # lists, what the reference keeps in info["surr_traj"] (pipeline_tuner.py:234) and returns
         # as PipelineTuneResult.surr_trajs; they travel between ranks with all_gather_object
         self.keep_trajs = bool(keep_trajs)
+        # balance: the shards of a batch are balanced by work (num_path x horizon; evaluate_sharded's
+        # weights="auto") instead of being contiguous; scores are the same either way
+        self.balance = bool(balance)
+        # models: the model axis of the search -- the reference's pipeline configuration space joins
+        # `_model:`, `_ctrlr:` and `_cost:` sub-spaces (pipeline.py:90-105) and eval_cfg builds (trains) the
+        # model of every configuration (pipeline.py:138-145).  Here the candidate models are given
+        # (trained beforehand, on the host or with torch on the GPU: sysid stays PyTorch); the default
+        # sampler draws each candidate's "model" among them, the evaluators run candidates with
+        # different models in one batch (ampc_*_plan_set_models).  Custom samplers may set c["model"] too.
+        self.models = list(models) if models else None
         self.batch_size = int(batch_size)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -61,7 +72,11 @@ class BatchPipelineTuner:
 
     def _random_search(self, n, rng):
         draw = random_ilqr_candidates if isinstance(self.evaluator, IlqrCandidateEvaluator) else random_candidates
-        return draw(self.system, n, seed=int(rng.integers(1 << 31)))
+        cands = draw(self.system, n, seed=int(rng.integers(1 << 31)))
+        if self.models:
+            for c, k in zip(cands, rng.integers(len(self.models), size=n)):
+                c["model"], c["model_index"] = self.models[int(k)], int(k)
+        return cands
 
     # -- ask / tell ---------------------------------------------------------------------------
     def ask(self, n, rng):
@@ -120,10 +135,10 @@ class BatchPipelineTuner:
                                goal=ev.goal))
         task.set_ctrl_bounds(ev.umin, ev.umax)
         if "num_path" not in cand:            # an iLQR candidate (horizon + cost weights)
-            ctl = IterativeLQR(self.system, task, ev.model, int(cand["horizon"]), precision=ev.precision,
-                               device=ev.device)
+            ctl = IterativeLQR(self.system, task, cand.get("model") or ev.model, int(cand["horizon"]),
+                               precision=ev.precision, device=ev.device)
         else:
-            ctl = MPPI(self.system, task, ev.model, horizon=int(cand["horizon"]),
+            ctl = MPPI(self.system, task, cand.get("model") or ev.model, horizon=int(cand["horizon"]),
                        num_path=int(cand["num_path"]), sigma=float(cand["sigma"]),
                        lmda=float(cand["lmda"]), noise=self.truedyn_noise, seed=seed,
                        precision=ev.precision, device=ev.device)
@@ -157,17 +172,21 @@ class BatchPipelineTuner:
             kept = {}
 
             def local(shard, lo, d=done):
+                # (lo: the shard's first index in the batch, or -- balanced shards -- all of its indices)
                 if not self.keep_trajs:
                     return self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo, **self.eval_kwargs)
                 sc, obs, ctl = self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo,
                                                        return_trajectories=True, **self.eval_kwargs)
                 lens = getattr(self.evaluator, "last_lengths", None)
                 no = self.system.obs_dim
+                ids = global_ids(lo, len(shard))
                 for i in range(len(shard)):
                     L = int(lens[i]) if lens is not None else obs.shape[1]
-                    kept[lo + i] = (obs[i, :L, :no].tolist(), ctl[i, :L].tolist())
+                    kept[int(ids[i])] = (obs[i, :L, :no].tolist(), ctl[i, :L].tolist())
                 return sc
-            scores = evaluate_sharded(local, batch)
+            # shards balanced by work (num_path x horizon): a batch an optimiser hands over sorted would
+            # otherwise load the ranks unevenly
+            scores = evaluate_sharded(local, batch, weights="auto" if self.balance else None)
             if self.keep_trajs:
                 self.surr_trajs.extend(self._gather_trajs(kept, n))
             td = None

@@ -122,6 +122,13 @@ def _baseline_record(legs, sample, torch_legs=None):
     if torch_legs:
         every.update({"torch_" + k: v for k, v in torch_legs.items()})
     best = max(every.values(), key=lambda leg: leg["value"])
+    if "all_cores" not in legs:       # trimmed record of a sub-record: the one-thread leg only
+        one = legs["one_thread"]
+        return {"value": one["value"], "unit": "solves/s", "cores": 1, "kind": "port", "cpu": cpu_model_name(),
+                "host_cores": os.cpu_count(),
+                "sample": "%s; one-thread leg only, %d solves (trimmed: the full two-leg record is "
+                          "`bench.py --workload ...`'s); value = 1 / median solve time" % (sample, one["solves"]),
+                "one_thread": one}
     rec = {"value": best["value"], "unit": "solves/s", "cores": best["threads"], "kind": "port",
            "cpu": cpu_model_name(), "host_cores": os.cpu_count(),
            "sample": "%s; all-core leg %d solves, one-thread leg %d solves; value = 1 / median solve "
@@ -192,7 +199,7 @@ def cpu_baseline_mppi(workload, spec, budget_s):
                             torch_legs)
 
 
-def cpu_baseline_ilqr(system, spec, x0s, budget_s, bounded=False):
+def cpu_baseline_ilqr(system, spec, x0s, budget_s, bounded=False, only=None):
     from oracle.costs import QuadCostOracle
     from oracle.ilqr import ILQROracle
     from oracle.mlp import MLPOracle, make_params
@@ -207,12 +214,12 @@ def cpu_baseline_ilqr(system, spec, x0s, budget_s, bounded=False):
     def run_once():
         orc.solve(x0s[k["i"] % len(x0s)], np.zeros((50, nu)))
         k["i"] += 1
-    return _baseline_record(_timed_legs(run_once, budget_s),
+    return _baseline_record(_timed_legs(run_once, budget_s, only=only),
                             "HalfCheetah iLQR H=50 solves from the bench's initial states%s (oracle: numpy f64)"
                             % (", controls clipped to +-0.25" if bounded else ""))
 
 
-def cpu_baseline_c5(system, spec, cands, budget_s, n_ctl=16):
+def cpu_baseline_c5(system, spec, cands, budget_s, n_ctl=16, only=None):
     """One control step of one candidate's closed loop = one MPPI solve + one surrogate step: the
     unit the c5 value counts.  Same structure as the c3 baseline: the oracle in strict_reference
     mode (per-step pred_batch + the reference's per-particle Python cost loop, mppi.py:73-78),
@@ -244,7 +251,7 @@ def cpu_baseline_c5(system, spec, cands, budget_s, n_ctl=16):
     def run_once():
         advance(loops[state["i"] % len(loops)])
         state["i"] += 1
-    return _baseline_record(_timed_legs(run_once, budget_s, target=4 * len(loops)),
+    return _baseline_record(_timed_legs(run_once, budget_s, target=4 * len(loops), only=only),
                             "steady-state closed-loop control steps (MPPI solve + surrogate step) of the bench's "
                             "first %d candidates in turn (oracle: numpy f64 pred_batch per step + the reference's "
                             "per-particle Python cost loop)" % len(loops))
@@ -529,7 +536,7 @@ def secondary_workload(args, R, emit=True):
         task.set_num_steps(200)
         from autompc_amd.tuning.batch_eval import default_episode_controls
         n_ctl = default_episode_controls(task)     # eval_cfg's episode: 200 rows = 199 control steps
-        # BASELINE config 5: one candidate list for the whole job, contiguous shards of B per GPU,
+        # BASELINE config 5: one candidate list for the whole job, shards of ~B per GPU balanced by work,
         # randomness keyed by the global candidate index (scores independent of the world size),
         # scores exchanged with one all-gather (RCCL over xGMI under the nccl backend)
         cands = random_candidates(system, B * world, seed=0)
@@ -540,7 +547,7 @@ def secondary_workload(args, R, emit=True):
         def step(i):
             scores = evaluate_sharded(
                 lambda shard, lo: ev.evaluate(shard, seed=max(i, 0), index_offset=lo, timing=last),
-                cands)
+                cands, weights="auto")      # shards balanced by num_path x horizon (the gather is max-over-ranks bound)
             if not np.all(np.isfinite(scores)) or scores.shape[0] != B * world:
                 raise RuntimeError("candidate scores incomplete")
         label = ("c5: %d tuning candidates (MPPI horizon/sigma/lmda/num_path + QuadCost weights from "
@@ -552,8 +559,10 @@ def secondary_workload(args, R, emit=True):
         elapsed, n_pre = timed_loop(R, step, steps, warm, 0.0)
         kt = last.get("timing")
         if rank == 0:
-            lo, hi = 0, B                                   # rank 0's shard
-            per_ctrl_step = sum(c["num_path"] * c["horizon"] for c in cands[lo:hi])
+            from autompc_amd.tuning import balanced_shards, candidate_work
+            mine = balanced_shards([candidate_work(c) for c in cands], world)[0]      # rank 0's shard
+            extra["candidates_on_rank0"] = int(len(mine))
+            per_ctrl_step = sum(cands[int(k)]["num_path"] * cands[int(k)]["horizon"] for k in mine)
             flops = per_ctrl_step * (2 * mlp_macs + 2 * (nx * nx + nx) + 2 * nu * nu + 2 * nu)
             all_steps = sum(c["num_path"] * c["horizon"] for c in cands) * \
                 (2 * mlp_macs + 2 * (nx * nx + nx) + 2 * nu * nu + 2 * nu)
@@ -575,11 +584,14 @@ def secondary_workload(args, R, emit=True):
                "dtype": args.precision, "data": "synthetic", "preheat_steps": n_pre,
                "config": {"workload": label, "parallelism": "independent problems per GPU (dp%d)" % world},
                "roofline": roof, **extra}
-        if not args.no_cpu_baseline and world == 1:
+        trimmed = getattr(args, "trimmed_cpu_seconds", 0.0)     # (sub-record of the default line)
+        if (not args.no_cpu_baseline or trimmed > 0) and world == 1:
+            only = ("one_thread",) if trimmed > 0 else None
+            budget = trimmed if trimmed > 0 else args.cpu_seconds
             if args.workload == "c4":
-                out["cpu_baseline"] = cpu_baseline_ilqr(system, spec, x0, args.cpu_seconds, bounded=True)
+                out["cpu_baseline"] = cpu_baseline_ilqr(system, spec, x0, budget, bounded=True, only=only)
             else:
-                out["cpu_baseline"] = cpu_baseline_c5(system, spec, cands, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline_c5(system, spec, cands, budget, n_ctl=4 if trimmed > 0 else 16, only=only)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         if emit:
             print(json.dumps(out))
@@ -587,16 +599,43 @@ def secondary_workload(args, R, emit=True):
     return None
 
 
+def ilqr_eval_record(args, R, n_cand=64, n_rows=50):
+    """The tuner's OTHER controller on the same surrogate: iLQR candidates from the reference's ranges
+    (IterativeLQRFactory horizon 5..25, control/ilqr.py:31-41; QuadCostFactory gains) x one eval_cfg episode
+    each (pipeline_tuner.py:222-231), device resident, all horizons through one plan
+    (ampc_ilqr_closed_loop_var).  One solve = one full compute_ilqr_default from a zero guess."""
+    from autompc_amd.synthetic import make_workload
+    from autompc_amd.tuning import IlqrCandidateEvaluator, random_ilqr_candidates
+    system, task, model, spec = make_workload("c3", precision="f64", device=R.local_rank)
+    task.set_num_steps(n_rows)
+    cands = random_ilqr_candidates(system, n_cand, seed=0)
+    for c in cands:                    # gains 0.18 .. 10 (the ranges' fourth root): O(1) stage costs on this surrogate
+        c["Q"], c["R"], c["F"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25
+    ev = IlqrCandidateEvaluator(system, task, model, device=R.local_rank)
+    ev.evaluate(cands[:8])
+    R.sync_all()
+    t0 = time.perf_counter()
+    scores = ev.evaluate(cands)
+    elapsed = time.perf_counter() - t0
+    n_ctl = n_rows - 1
+    return {"workload": "%d iLQR candidates (horizons %d..%d, QuadCost gains) x one eval_cfg episode of %d rows = %d "
+                        "control steps on the HalfCheetah surrogate; one plan for every horizon, episodes device resident"
+                        % (n_cand, min(c["horizon"] for c in cands), max(c["horizon"] for c in cands), n_rows, n_ctl),
+            "value": n_cand * n_ctl / elapsed, "unit": "solves/s", "elapsed_s": elapsed,
+            "mean_iterations_per_solve": float(ev.last_iterations.sum() / (n_cand * n_ctl)),
+            "scores_finite": int(np.isfinite(scores).sum())}
+
+
 def c5_sharded_record(args, R, per_gpu=64, probes=4):
     """north_star's multi-GPU path inside the default (c3) bench line of an N > 1 run: BASELINE
-    config 5's candidate sharding -- per_gpu * world candidates, contiguous shards, randomness keyed
+    config 5's candidate sharding -- per_gpu * world candidates, shards balanced by num_path x horizon, randomness keyed
     by the global candidate index, ONE all_gather_into_tensor of the scores (RCCL over xGMI under
     backend nccl) -- run once after an untimed pass.  Rank 0 then re-evaluates `probes` candidates
     spread over all shards on its own GPU: the gathered scores must be what a single rank
     computes.  Every rank takes part; rank 0 returns the record."""
     from autompc_amd.synthetic import make_workload
     from autompc_amd.tuning import CandidateEvaluator, evaluate_sharded, random_candidates
-    from autompc_amd.tuning.batch_eval import default_episode_controls, shard_bounds
+    from autompc_amd.tuning.batch_eval import balanced_shards, candidate_work, default_episode_controls
     system, task, model, spec = make_workload("c3", precision=args.precision, device=R.local_rank)
     task.set_num_steps(200)
     world = R.world
@@ -605,31 +644,31 @@ def c5_sharded_record(args, R, per_gpu=64, probes=4):
 
     def local(shard, lo):
         return ev.evaluate(shard, seed=0, index_offset=lo)
-    evaluate_sharded(local, cands)                       # untimed pass (plans, clocks)
+    evaluate_sharded(local, cands, weights="auto")       # untimed pass (plans, clocks)
     stats = {}
     R.sync_all()
     t0 = time.perf_counter()
-    scores = evaluate_sharded(local, cands, stats=stats)
+    scores = evaluate_sharded(local, cands, stats=stats, weights="auto")
     R.sync_all()
     elapsed = R.max_over_ranks(time.perf_counter() - t0)
     if R.rank != 0:
         return None
     n = len(cands)
+    owner = [set(ix.tolist()) for ix in balanced_shards([candidate_work(c) for c in cands], world)]
     idx = sorted({min(n - 1, (2 * k + 1) * n // (2 * probes)) for k in range(probes)})
     dev = 0.0
     for gi in idx:
         alone = ev.evaluate([cands[gi]], seed=0, index_offset=gi)[0]
         dev = max(dev, abs(alone - scores[gi]))
     n_ctl = default_episode_controls(task)
-    return {"workload": "BASELINE config 5: %d candidates = %d per GPU, contiguous shards, one eval_cfg "
+    return {"workload": "BASELINE config 5: %d candidates = ~%d per GPU (shards balanced by work), one eval_cfg "
                         "episode each (200 rows = %d control steps)" % (n, per_gpu, n_ctl),
             "candidates": n, "candidates_per_gpu": per_gpu, "control_steps_per_episode": n_ctl,
             "value": n * n_ctl / elapsed, "unit": "solves/s", "elapsed_s": elapsed,
             "backend": stats.get("backend"), "ranks_in_gather": stats.get("ranks_in_gather"),
             "gather_ms": stats.get("gather_ms"), "gather_device": stats.get("device"),
-            "probe_candidates": idx, "probe_shards": [next(r for r in range(world)
-                                                           if shard_bounds(n, r, world)[0] <= gi < shard_bounds(n, r, world)[1])
-                                                      for gi in idx],
+            "probe_candidates": idx, "probe_shards": [next(r for r in range(world) if gi in owner[r]) for gi in idx],
+            "sharding": "balanced by num_path x horizon", "heaviest_rank_over_mean_work": stats.get("heaviest_over_mean"),
             "max_abs_score_deviation_vs_single_rank": dev, "scores_finite": bool(np.all(np.isfinite(scores)))}
 
 
@@ -849,11 +888,13 @@ def main():
             sub = argparse.Namespace(**vars(args))
             sub.no_cpu_baseline, sub.no_extras, sub.batch = True, False, 0
             recs = {"c2": mppi_record("c2", 400, 40)}
-            for wl, st in (("c4", 3), ("c5", 2)):
+            sub.trimmed_cpu_seconds = 0.0 if args.no_cpu_baseline else 4.0
+            for wl, st in (("c4", 5), ("c5", 2)):
                 sub.workload, sub.steps, sub.warmup, sub.preheat = wl, st, 1, 0.0
                 r = secondary_workload(sub, R, emit=False)
                 recs[wl] = {k: v for k, v in r.items()
                             if k not in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "preheat_steps")}
+            recs["ilqr_eval"] = ilqr_eval_record(args, R)
             recs["dropin"] = dropin_record()
             out["sub_records"] = recs
         if not args.no_cpu_baseline and world == 1:

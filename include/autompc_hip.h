@@ -38,7 +38,8 @@ enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 
 const char* ampc_last_error(void);
 int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs;
-                           * 106: + ampc_ilqr_solve_queue_var, ampc_ilqr_closed_loop_var */
+                           * 106: + ampc_ilqr_solve_queue_var, ampc_ilqr_closed_loop_var, ampc_set_indicator_costs,
+                           *      ampc_mppi_plan_set_models, ampc_ilqr_plan_set_models */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -147,6 +148,16 @@ int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* 
 int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
                                const double* R, const double* F, const double* goal,
                                const double* lin, const double* lin_term, const double* consts);
+/* Indicator terms of an MPPI controller's cost.  The reference's MPPI charges whatever Cost the task holds,
+ * term by term (mppi.py:73-82 over sum_cost.py:49-54): e.g. QuadCost + ThresholdCost, or a bare
+ * BoxThresholdCost -- 1 per time step whose observation violates the term, no control or terminal part
+ * (thresh_cost.py:27-38, 73-83).  The n_terms (<= 8) terms are added to the stage cost x_0 .. x_{H-1} of
+ * EVERY cost block of the handle; kinds / params as ampc_score_trajectories (1 threshold: goal[no]
+ * obs_range_lo obs_range_hi threshold; 2 box: lower[no] upper[no]).  Call after ampc_set_quad_costs /
+ * ampc_set_affine_quad_costs (the quadratic part; all zeros for a cost without one), which fix obs_dim;
+ * n_terms = 0 removes the terms.  MPPI plans and the MPPI closed loop evaluate them (every model family);
+ * ampc_ilqr_plan_create refuses a handle that has them (no gradient / Hessian). */
+int ampc_set_indicator_costs(ampc_handle* h, int n_terms, const int* kinds, const double* params);
 /* Task.get_ctrl_bounds (task.py:257-267): lo[nu], hi[nu] (MPPI requires finite bounds,
  * mppi.py:100-102; iLQR clips only if bounded, ilqr.py:62-64). */
 int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi);
@@ -213,7 +224,9 @@ int ampc_set_mt_jump_table(const uint32_t* polys, int n_polys, int jump_blocks);
 /* ids[B]: the noise id of every problem (default: its index in the plan).  The candidate
  * evaluator passes each candidate's GLOBAL index, so that the noise -- and therefore the
  * surrogate score pipeline_tuner.py:213-258 returns for it -- does not depend on how a batch of
- * candidates is sharded over GPUs or on the candidate's position in its shard. */
+ * candidates is sharded over GPUs or on the candidate's position in its shard.
+ * Noise already drawn with ampc_mppi_generate_eps is drawn again with the new ids (same seed and stream);
+ * ampc_mppi_plan_set_geometry likewise re-draws it for the rebuilt plan. */
 int ampc_mppi_plan_set_noise_ids(ampc_mppi_plan* p, const uint32_t* ids);
 /* One MPPI solve per problem, enqueued on the handle's stream (MPPI.do_rollouts + update,
  * mppi.py:110-152): shift warm start, rollout all samples, softmin weights, update act_seq. */
@@ -379,11 +392,25 @@ int ampc_ilqr_solve_queue(ampc_ilqr_plan* p, int n_problems, const double* x0, c
  * slot's sweep, line search and Jacobian refresh run over its own problem's horizon, the launches are shared.
  * All arrays keep H as their stride: uguess [n][H][nu] (rows past a problem's horizon are ignored), outputs
  * states [n][H+1][nx], ctrls [n][H][nu], Ks [n][H][nu][nx], ks [n][H][nu] (rows past it are zero).  A
- * problem's results are bit-identical to ampc_ilqr_solve on a one-problem plan of its own horizon. */
+ * problem's results are bit-identical to ampc_ilqr_solve on a one-problem plan of its own horizon.
+ * model_index[n] (NULL: the plan's own model for every problem): the problem's controller model, an entry of
+ * the table installed with ampc_ilqr_plan_set_models -- results are those of a plan built on that model. */
 int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, const double* x0, const double* uguess,
-                              const int* cost_index, const int* horizon, int max_iter, double* states,
-                              double* ctrls, double* Ks, double* ks, int* converged, int* iters, int* status,
-                              double* objective);
+                              const int* cost_index, const int* horizon, const int* model_index, int max_iter,
+                              double* states, double* ctrls, double* Ks, double* ks, int* converged, int* iters,
+                              int* status, double* objective);
+/* Controller models per problem.  The tuner's eval_cfg builds the controller with pipeline(cfg, task, trajs),
+ * which instantiates and trains a model PER CONFIGURATION when the pipeline has a model factory
+ * (pipeline.py:138-145; tuning/pipeline_tuner.py:213-215): candidates of one batch may carry different models.
+ * models[n_models]: handles holding MLPs of the plan's shape (same dimensions, hidden layers, activation,
+ * precision, device) with their own weights and normalisers; the plan keeps a device table of their
+ * descriptors (and the handles alive).  Staging new weights into one of them afterwards needs another call.
+ * n_models = 0 removes the table.  Cost blocks, bounds and the surrogate remain the plan handle's. */
+int ampc_ilqr_plan_set_models(ampc_ilqr_plan* p, int n_models, ampc_handle* const* models);
+/* ... for an MPPI plan: model_index[B] names the table entry of each of the plan's problems; every rollout of
+ * problem b then runs on models[model_index[b]] (MLP plans: the sixteen-row and the four-row rollout). */
+int ampc_mppi_plan_set_models(ampc_mppi_plan* p, int n_models, ampc_handle* const* models,
+                              const int* model_index);
 
 /* simulate() with IterativeLQR controllers, device resident (utils/simulation.py:44-63 as eval_cfg drives it,
  * pipeline_tuner.py:222-231; IterativeLQR.run, ilqr.py:267-295: every control step is a full solve from a zero
@@ -399,11 +426,12 @@ int ampc_ilqr_solve_queue_var(ampc_ilqr_plan* p, int n_problems, const double* x
 int ampc_ilqr_closed_loop(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
                           const int* cost_index, int n_steps, int max_iter, double* traj_obs,
                           double* traj_ctrls, int* failed, int* steps_done, long long* iterations);
-/* ... with an iLQR horizon per episode: horizon[n] in [1, the plan's horizon] (NULL: the plan's), as
- * ampc_ilqr_solve_queue_var; everything else as ampc_ilqr_closed_loop. */
+/* ... with an iLQR horizon per episode: horizon[n] in [1, the plan's horizon] (NULL: the plan's), and a
+ * controller model per episode: model_index[n] (NULL: the plan's own), as ampc_ilqr_solve_queue_var;
+ * everything else as ampc_ilqr_closed_loop (the surrogate is shared). */
 int ampc_ilqr_closed_loop_var(ampc_ilqr_plan* p, ampc_handle* surrogate, int n_chains, const double* init_obs,
-                              const int* cost_index, const int* horizon, int n_steps, int max_iter,
-                              double* traj_obs, double* traj_ctrls, int* failed, int* steps_done,
+                              const int* cost_index, const int* horizon, const int* model_index, int n_steps,
+                              int max_iter, double* traj_obs, double* traj_ctrls, int* failed, int* steps_done,
                               long long* iterations);
 
 #ifdef __cplusplus

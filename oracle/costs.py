@@ -114,6 +114,58 @@ class SumCostOracle:
         return sum(t.traj_cost(obs, ctrls) for t in self.terms)
 
 
+class _IndicatorOracle:
+    """A cost term that is 1 for every row whose observation violates a condition and has no control or
+    terminal part (thresh_cost.py:34-38, 79-83)."""
+
+    def violated(self, obs):
+        raise NotImplementedError
+
+    def eval_obs_cost(self, obs):
+        return 1.0 if self.violated(np.asarray(obs, dtype=np.float64)) else 0.0
+
+    def eval_ctrl_cost(self, ctrl):
+        return 0.0
+
+    def eval_term_obs_cost(self, obs):
+        return 0.0
+
+    def obs_cost_batch(self, obs):
+        return np.array([self.eval_obs_cost(o) for o in np.asarray(obs, dtype=np.float64)])
+
+    def ctrl_cost_batch(self, ctrls):
+        return np.zeros(np.asarray(ctrls).shape[0])
+
+    def term_cost_batch(self, obs):
+        return np.zeros(np.asarray(obs).shape[0])
+
+    def traj_cost(self, obs, ctrls):
+        return float(self.obs_cost_batch(obs).sum())
+
+
+class ThresholdCostOracle(_IndicatorOracle):
+    """ThresholdCost.eval_obs_cost (thresh_cost.py:27-32): 1 when the infinity norm of (obs - goal) over
+    obs_range[0] <= i < obs_range[1] exceeds the threshold."""
+
+    def __init__(self, goal, obs_range, threshold):
+        self.goal, self.thr = np.asarray(goal, dtype=np.float64), float(threshold)
+        self.lo, self.hi = int(obs_range[0]), int(obs_range[1])
+
+    def violated(self, obs):
+        gap = np.abs(obs[self.lo:self.hi] - self.goal[self.lo:self.hi])
+        return bool(gap.size) and bool(np.max(gap) > self.thr)
+
+
+class BoxCostOracle(_IndicatorOracle):
+    """BoxThresholdCost.eval_obs_cost (thresh_cost.py:73-77): 1 when some obs_i leaves [lower_i, upper_i]."""
+
+    def __init__(self, limits):
+        self.limits = np.asarray(limits, dtype=np.float64)
+
+    def violated(self, obs):
+        return bool((obs < self.limits[:, 0]).any() or (obs > self.limits[:, 1]).any())
+
+
 def score_terms(kinds, params, obs, ctrls, obs_dim=None):
     """Cost.__call__ (cost.py:27-41) of ONE trajectory obs [T,ns], ctrls [T,nu] under a flattened
     sum of terms (layout of include/autompc_hip.h: ampc_score_trajectories): row by row, term by

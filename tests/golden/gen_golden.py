@@ -1033,7 +1033,141 @@ def gen_evalcfg_koopman():
          wsum=weight_checksum(p), **out)
 
 
-GENERATORS = {"linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# ---------------------------------------------- MPPI on costs with threshold / box terms
+def gen_mppi_indicator():
+    """The reference's MPPI charges whatever Cost the task holds, term by term (mppi.py:73-82): a
+    QuadCost + ThresholdCost sum, a bare BoxThresholdCost, and quad + threshold + box.  Thresholds /
+    limits sit inside the cloud of rolled-out states, so some samples pay and some do not."""
+    from autompc.costs import ThresholdCost, BoxThresholdCost
+    cases = [
+        # tag, nx, hidden, act, mlpseed, N, H, sigma, lmda, bounds, npseed
+        ("quadthresh", 2, [64, 64], "tanh", 61, 256, 12, 1.0, 0.8, (-2.0, 2.0), 11),
+        ("box", 2, [64, 64], "tanh", 62, 256, 12, 1.0, 1.0, (-2.0, 2.0), 12),
+        ("all_hc", 17, [256, 256], "relu", 63, 128, 10, 1.0, 1.0, (-1.0, 1.0), 13),
+    ]
+    for tag, nx, hidden, act, mseed, N, H, sigma, lmda, bnd, npseed in cases:
+        system = make_system(nx, 1)
+        model, p = ref_mlp(system, hidden, act, mseed, plain_norm=True)
+        rng = np.random.default_rng(mseed)
+        obs0 = np.random.default_rng(npseed + 99).uniform(-0.1, 0.1, size=nx)
+        goal = rng.normal(scale=0.05, size=nx)
+        quad = QuadCost(system, np.diag(rng.uniform(0.5, 2.0, size=nx)), 0.05 * np.eye(1),
+                        np.diag(rng.uniform(0.5, 2.0, size=nx)), goal=goal)
+        # probe the spread of the rollouts once to place the thresholds (a separate controller: the
+        # global stream is re-seeded below)
+        np.random.seed(1000 + npseed)
+        t0 = Task(system)
+        t0.set_cost(quad)
+        t0.set_ctrl_bound("u0", bnd[0], bnd[1])
+        spread = {}
+        orig = model.pred_batch
+
+        def spy(states, ctrls, spread=spread, orig=orig):
+            out = orig(states, ctrls)
+            spread.setdefault("dev", []).append(np.abs(out - goal).max(axis=1))
+            return out
+        model.pred_batch = spy               # (MPPI binds model.pred_batch at construction, mppi.py:71)
+        probe = quiet(MPPI, system, t0, model, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+        probe.run(np.concatenate([obs0, np.zeros(1)]), obs0)
+        del model.pred_batch                 # back to the class's method
+        dev = np.concatenate(spread["dev"])
+        thr = float(np.quantile(dev, 0.6))
+        lo, hi = (0, nx) if nx == 2 else (2, 11)
+        thresh = ThresholdCost(system, goal, [lo, hi], thr)
+        limits = np.stack([goal - np.quantile(dev, 0.8), goal + np.quantile(dev, 0.7)], axis=1)
+        limits[nx - 1, 0] = -np.inf
+        if nx > 2:
+            limits[3] = [-np.inf, np.inf]
+        box = BoxThresholdCost(system, limits, goal=goal)
+        cost = {"quadthresh": quad + thresh, "box": box, "all_hc": quad + thresh + box}[tag]
+        task = Task(system)
+        task.set_cost(cost)
+        task.set_ctrl_bound("u0", bnd[0], bnd[1])
+        np.random.seed(npseed)
+        ctl = quiet(MPPI, system, task, model, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
+        out = {"act0": ctl.act_sequence.copy()}
+        obs = obs0.copy()
+        constate = np.concatenate([obs, np.zeros(1)])
+        n_runs = 3
+        for r in range(n_runs):
+            cap = {}
+            orig_update = ctl.update
+
+            def spy_u(costs, eps, cap=cap, orig=orig_update):
+                cap["costs"] = costs.copy()
+                return orig(costs, eps)
+            ctl.update = spy_u
+            u, constate = ctl.run(constate, obs)
+            ctl.update = orig_update
+            out["x0_%d" % r] = obs.copy()
+            out["costs_%d" % r] = cap["costs"]
+            out["act_%d" % r] = ctl.act_sequence.copy()
+            out["u_%d" % r] = u.copy()
+            obs = model.pred(obs, u)
+        # the indicator part really discriminates between samples
+        ind = cap["costs"] - np.floor(cap["costs"])
+        assert len(np.unique(np.round(cap["costs"] - ind))) > 2, tag
+        Q, R, F = quad.get_cost_matrices()
+        save("indmppi_" + tag, nx=nx, hidden=np.array(hidden), activation=act, mlp_seed=mseed, plain_norm=True,
+             wsum=weight_checksum(p), N=N, H=H, sigma=sigma, lmda=lmda, bounds=np.array(bnd), np_seed=npseed,
+             n_runs=n_runs, has_quad=tag != "box", has_thresh=tag != "box", has_box=tag != "quadthresh",
+             Q=Q, R=R, F=F, goal=goal, thr_range=np.array([lo, hi]), thr=thr, limits=limits, **out)
+
+
+# ------------------------------------------- eval_cfg with a controller model per configuration
+def gen_evalcfg_twomodels():
+    """eval_cfg builds the controller with pipeline(cfg, task, trajs), which instantiates (trains) a model
+    PER CONFIGURATION when the pipeline has a model factory (pipeline.py:138-145, pipeline_tuner.py:213-215),
+    and simulates it against the ONE surrogate.  Two configurations whose controller models differ in their
+    weights (same architecture): model A is also the surrogate, model B is not.  MPPI (own numpy seed each)
+    and iLQR (different horizons)."""
+    nx, hidden, act = 3, [48, 48], "tanh"
+    system = make_system(nx, 1, dt=0.05)
+    model_a, pa = ref_mlp(system, hidden, act, 51, plain_norm=True)
+    model_b, pb = ref_mlp(system, hidden, act, 52, plain_norm=True)
+    cost = make_cost(system, "dense", 600)
+    Q, R, F = cost.get_cost_matrices()
+    init = np.array([0.25, -0.15, 0.1])
+
+    def eval_cfg(make_controller, task):
+        controller = make_controller()
+        controller.reset()
+        tr = quiet(simulate, controller, task.get_init_obs(), task.term_cond, sim_model=model_a,
+                   max_steps=task.get_num_steps(), silent=True)
+        return tr.obs, tr.ctrls, task.get_cost()(tr)
+
+    out = {}
+    T = 12
+    task = Task(system)
+    task.set_cost(cost)
+    task.set_ctrl_bound("u0", -1.0, 1.0)
+    task.set_init_obs(init)
+    task.set_num_steps(T)
+    hyper = dict(horizon=9, num_path=96, sigma=0.7, lmda=0.6)
+    for tag, model, seed in (("a", model_a, 16), ("b", model_b, 17)):
+        np.random.seed(seed)
+        o, c, sc = eval_cfg(lambda: quiet(MPPI, system, task, model, **hyper), task)
+        assert len(o) == T
+        out.update({"mppi_%s_obs" % tag: o, "mppi_%s_ctrls" % tag: c, "mppi_%s_cost" % tag: sc,
+                    "mppi_%s_np_seed" % tag: seed})
+    T2 = 9
+    task2 = Task(system)
+    task2.set_cost(cost)
+    task2.set_init_obs(init)
+    task2.set_num_steps(T2)
+    for tag, model, H in (("a", model_a, 12), ("b", model_b, 9)):
+        o, c, sc = eval_cfg(lambda: IterativeLQR(system, task2, model, H), task2)
+        assert len(o) == T2
+        out.update({"ilqr_%s_obs" % tag: o, "ilqr_%s_ctrls" % tag: c, "ilqr_%s_cost" % tag: sc, "ilqr_%s_H" % tag: H})
+    assert np.max(np.abs(out["mppi_a_obs"] - out["mppi_b_obs"])) > 1e-3
+    assert np.max(np.abs(out["ilqr_a_obs"] - out["ilqr_b_obs"])) > 1e-3
+    save("loop_evalcfg_twomodels", nx=nx, hidden=np.array(hidden), activation=act, mlp_seed_a=51, mlp_seed_b=52,
+         wsum_a=weight_checksum(pa), wsum_b=weight_checksum(pb), Q=Q, R=R, F=F, goal=cost.get_goal(), init=init,
+         num_steps_mppi=T, num_steps_ilqr=T2, dt=0.05, N=96, H=9, sigma=0.7, lmda=0.6, bounds=np.array([-1.0, 1.0]),
+         **out)
+
+
+GENERATORS = {"evalcfg_twomodels": gen_evalcfg_twomodels, "mppi_indicator": gen_mppi_indicator, "linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost, "linear_wide2": gen_linear_wide2, "evalcfg_koopman": gen_evalcfg_koopman}
 
 if __name__ == "__main__":

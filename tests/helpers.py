@@ -4,7 +4,7 @@ import numpy as np
 
 from autompc_amd import System
 from oracle import mlp as omlp
-from oracle.costs import QuadCostOracle, SumCostOracle
+from oracle.costs import BoxCostOracle, QuadCostOracle, SumCostOracle, ThresholdCostOracle
 
 
 def make_system(nx, nu, dt=0.05):
@@ -53,6 +53,35 @@ def hip_cost_from_golden(system, g):
             cost = cost + t
         return cost
     return QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"])
+
+
+def indicator_cost_from_golden(g):
+    """Controller cost of an indmppi_* fixture (gen_golden.gen_mppi_indicator) for the oracle: the sum,
+    in the reference's order, of the quadratic / threshold / box terms the fixture holds."""
+    terms = []
+    if bool(g["has_quad"]):
+        terms.append(QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"]))
+    if bool(g["has_thresh"]):
+        terms.append(ThresholdCostOracle(g["goal"], g["thr_range"], float(g["thr"])))
+    if bool(g["has_box"]):
+        terms.append(BoxCostOracle(g["limits"]))
+    return SumCostOracle(terms)
+
+
+def hip_indicator_cost_from_golden(system, g):
+    """The same cost as product objects."""
+    from autompc_amd import BoxThresholdCost, QuadCost, ThresholdCost
+    terms = []
+    if bool(g["has_quad"]):
+        terms.append(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    if bool(g["has_thresh"]):
+        terms.append(ThresholdCost(system, g["goal"], [int(v) for v in g["thr_range"]], float(g["thr"])))
+    if bool(g["has_box"]):
+        terms.append(BoxThresholdCost(system, g["limits"], goal=g["goal"]))
+    cost = terms[0]
+    for t in terms[1:]:
+        cost = cost + t
+    return cost
 
 
 def rel_err(a, b):

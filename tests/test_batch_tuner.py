@@ -36,11 +36,11 @@ class _FormulaEvaluator:
         return np.array(out), obs, ctl
 
 
-def _run(n_iters, batch, keep_trajs=False):
+def _run(n_iters, batch, keep_trajs=False, balance=True):
     from autompc_amd.tuning import BatchPipelineTuner
     system = make_system(3, 2)
     ev = _FormulaEvaluator()
-    tuner = BatchPipelineTuner(system, ev, batch_size=batch, keep_trajs=keep_trajs)
+    tuner = BatchPipelineTuner(system, ev, batch_size=batch, keep_trajs=keep_trajs, balance=balance)
     best, res = tuner.run(n_iters, np.random.default_rng(4), seed=10)
     return ev, best, res
 
@@ -95,8 +95,11 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ev, best, res = _run(21, 8, keep_trajs=True)
-    q.put((rank, res.costs, [c[0] for c in ev.calls], [c[2] for c in ev.calls], res.surr_trajs))
+    ev, best, res = _run(21, 8, keep_trajs=True, balance=False)         # contiguous shards
+    evb, _, resb = _run(21, 8, keep_trajs=True)                          # balanced by work (the default)
+    assert resb.costs == res.costs and resb.surr_trajs == res.surr_trajs
+    q.put((rank, res.costs, [c[0] for c in ev.calls], [c[2] for c in ev.calls], res.surr_trajs,
+           [np.atleast_1d(c[2]).tolist() if np.ndim(c[2]) else list(range(c[2], c[2] + c[0])) for c in evb.calls]))
     dist.destroy_process_group()
 
 
@@ -110,8 +113,8 @@ def test_two_ranks_agree_and_split_the_work():
         p.start()
     got = {}
     for _ in range(2):
-        rank, costs, sizes, offsets, trajs = q.get(timeout=120)
-        got[rank] = (costs, sizes, offsets, trajs)
+        rank, costs, sizes, offsets, trajs, bal = q.get(timeout=120)
+        got[rank] = (costs, sizes, offsets, trajs, bal)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -126,6 +129,9 @@ def test_two_ranks_agree_and_split_the_work():
     np.testing.assert_array_equal(got[1][0], single.costs)
     assert got[0][1] == [4, 4, 3] and got[1][1] == [4, 4, 2]    # shards of batches 8, 8, 5
     assert got[0][2] == [0, 8, 16] and got[1][2] == [4, 12, 19]  # global index of each shard's first candidate
+    # balanced shards: per batch the two ranks' global indices cover the batch exactly once
+    for b, (lo, n) in enumerate([(0, 8), (8, 8), (16, 5)]):
+        assert sorted(got[0][4][b] + got[1][4][b]) == list(range(lo, lo + n))
 
 
 def test_truedyn_scores_are_recorded_but_do_not_steer(monkeypatch):

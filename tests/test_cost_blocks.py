@@ -61,6 +61,8 @@ def test_nonstrict_terms_put_the_goal_into_the_terminal_gradient():
     mixed = SumCost(system, [cost.costs[0], QuadCost(system, np.eye(5), np.eye(3), goal=np.ones(5))])
     with pytest.raises(TypeError):
         quad_sum_block(mixed, 5, 3)
+    # ... and the controllers' is_compatible (is_quad_sum) does not promise what quad_sum_block refuses
+    assert is_quad_sum(cost) and not is_quad_sum(mixed)
 
 
 class _RefLikeQuad:
@@ -122,3 +124,36 @@ def test_terms_without_a_quadratic_form_are_refused():
     assert is_quad_sum(q) and not is_quad_sum(q + t)
     with pytest.raises(TypeError):
         quad_sum_block(q + t, 3, 1)
+
+
+def test_mppi_cost_parts_split_quadratic_and_indicator_terms():
+    """MPPI takes sums of quadratic, threshold and box terms (mppi.py:73-82 charges any Cost term by term);
+    iLQR's is_quad_sum stays quadratic-only."""
+    from autompc_amd import BoxThresholdCost
+    from autompc_amd.costs.blocks import is_mppi_cost, mppi_cost_parts
+    g = golden("cost_sum")
+    system = make_system(5, 3)
+    quad = _sum_from(g, "dense", system)
+    goal = np.arange(5) * 0.1
+    thr = ThresholdCost(system, goal, [1, 4], 0.3)
+    limits = np.array([[-1.0, 1.0], [-np.inf, 0.5], [-0.2, np.inf], [-np.inf, np.inf], [-2.0, 2.0]])
+    box = BoxThresholdCost(system, limits)
+    cost = SumCost(system, [quad, thr, box])
+    assert is_mppi_cost(cost) and is_mppi_cost(box) and is_mppi_cost(quad) and not is_quad_sum(cost)
+    blk, terms = mppi_cost_parts(cost, 5, 3)
+    ref = quad_sum_block(quad, 5, 3)
+    for k in ("Q", "R", "F", "goal", "lin", "lin_term", "consts"):
+        np.testing.assert_array_equal(blk[k], ref[k])
+    kinds, params = terms
+    assert kinds.tolist() == [1, 2]
+    np.testing.assert_array_equal(params, np.concatenate([goal, [1, 4, 0.3], limits[:, 0], limits[:, 1]]))
+    blk0, terms0 = mppi_cost_parts(box, 5, 3)
+    assert not any(np.any(blk0[k]) for k in ("Q", "R", "F", "lin", "lin_term", "consts")) and terms0[0].tolist() == [2]
+    assert mppi_cost_parts(quad, 5, 3)[1] is None
+
+    class Other:
+        is_quad = False
+    assert not is_mppi_cost(SumCost(system, [quad, Other()]))
+    with pytest.raises(TypeError):
+        mppi_cost_parts(SumCost(system, [quad, Other()]), 5, 3)
+    assert not is_mppi_cost(SumCost(system, [quad] + [thr] * 9))          # at most 8 indicator terms

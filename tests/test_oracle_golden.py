@@ -95,6 +95,34 @@ def test_mppi_matches_reference(name):
         obs = model.pred(obs, u)
 
 
+@pytest.mark.parametrize("name", _names("indmppi_"))
+def test_mppi_with_threshold_and_box_terms_matches_reference(name):
+    """MPPI on QuadCost + ThresholdCost, a bare BoxThresholdCost and quad + threshold + box
+    (mppi.py:73-82 charges the task's Cost term by term; thresh_cost.py:27-38, 73-83)."""
+    from helpers import indicator_cost_from_golden
+    g = golden(name)
+    nx = int(g["nx"])
+    system = make_system(nx, 1)
+    p = golden_params(nx, 1, g["hidden"], g["activation"], g["mlp_seed"], True)
+    check_weights(p, g)
+    model = MLPOracle(system, p)
+    for strict in (False, True):
+        np.random.seed(int(g["np_seed"]))
+        ctl = MPPIOracle(model, indicator_cost_from_golden(g), np.array([[g["bounds"][0], g["bounds"][1]]]),
+                         horizon=int(g["H"]), num_path=int(g["N"]), sigma=float(g["sigma"]), lmda=float(g["lmda"]),
+                         strict_reference=strict)
+        np.testing.assert_array_equal(ctl.act_sequence, g["act0"])
+        obs = np.random.default_rng(int(g["np_seed"]) + 99).uniform(-0.1, 0.1, size=nx)
+        constate = np.concatenate([obs, np.zeros(1)])
+        for r in range(int(g["n_runs"])):
+            np.testing.assert_allclose(obs, g["x0_%d" % r], rtol=1e-10, atol=1e-12)
+            u, constate = ctl.run(constate, obs)
+            assert rel_err(ctl.last_costs, g["costs_%d" % r]) < 1e-10
+            assert rel_err(ctl.act_sequence, g["act_%d" % r]) < 1e-9
+            assert rel_err(u, g["u_%d" % r]) < 1e-9
+            obs = model.pred(obs, u)
+
+
 def test_mppi_strict_loop_equals_vectorised():
     g = golden("mppi_clip_asym")
     _, a = _mppi_from_golden(g, strict=True)

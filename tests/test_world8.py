@@ -99,8 +99,12 @@ def _tuner_worker(rank, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     ev = _Formula()
-    tuner = BatchPipelineTuner(make_system(3, 2), ev, batch_size=512)
+    tuner = BatchPipelineTuner(make_system(3, 2), ev, batch_size=512, balance=False)
     best, res = tuner.run(600, np.random.default_rng(4), seed=3)
+    # the default: shards balanced by work -- the same costs, every candidate evaluated exactly once
+    ev2 = _Formula()
+    best2, res2 = BatchPipelineTuner(make_system(3, 2), ev2, batch_size=512).run(600, np.random.default_rng(4), seed=3)
+    np.testing.assert_array_equal(np.asarray(res2.costs), np.asarray(res.costs))
     q.put((rank, np.asarray(res.costs), ev.calls, res.cfgs.index(best)))
     dist.destroy_process_group()
 
@@ -117,3 +121,47 @@ def test_batch_tuner_over_eight_ranks():
         assert best == best0 == int(np.argmin(costs0))
         assert calls == [(64, 64 * r), (11, 512 + 11 * r)]
     assert len(costs0) == 600
+
+
+def _balanced_worker(rank, port, q):
+    import torch.distributed as dist
+    from autompc_amd.tuning import candidate_work, evaluate_sharded, random_candidates
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    # a batch that arrives SORTED by work (a horizon sweep, an optimiser's ranked proposals)
+    cands = sorted(random_candidates(make_system(3, 2), 512, seed=0), key=lambda c: c["num_path"] * c["horizon"])
+    seen, stats = [], {}
+
+    def local(shard, ids):
+        seen.append(np.asarray(ids).copy())
+        assert all(shard[k] is cands[int(i)] for k, i in enumerate(np.atleast_1d(ids)))
+        return np.array([_score(c) for c in shard])
+    scores = evaluate_sharded(local, cands, stats=stats, weights="auto")
+    work = float(sum(candidate_work(cands[int(i)]) for i in seen[0]))
+    q.put((rank, scores, seen[0], work, stats["heaviest_over_mean"]))
+    dist.destroy_process_group()
+
+
+def test_balanced_shards_of_a_sorted_batch():
+    """evaluate_sharded(weights="auto") on a work-sorted batch of 512 over 8 ranks: every candidate is
+    evaluated exactly once, scores come back in candidate order, and the heaviest rank carries at most
+    1.15 x the mean work (contiguous shards of the same batch: the last rank carries ~2.5 x)."""
+    from autompc_amd.tuning import balanced_shards, candidate_work, random_candidates, shard_bounds
+    port = _free_port()
+    got = _spawn(_balanced_worker, lambda r: (r, port))
+    cands = sorted(random_candidates(make_system(3, 2), 512, seed=0), key=lambda c: c["num_path"] * c["horizon"])
+    ref = np.array([_score(c) for c in cands])
+    all_ids = np.concatenate([np.atleast_1d(got[r][1]) for r in range(WORLD)])
+    assert sorted(all_ids.tolist()) == list(range(512))
+    works = np.array([got[r][2] for r in range(WORLD)])
+    for r in range(WORLD):
+        np.testing.assert_array_equal(got[r][0], ref)
+        assert abs(got[r][3] - works.max() / works.mean()) < 1e-12
+    assert works.max() <= 1.15 * works.mean()
+    w = np.array([candidate_work(c) for c in cands])
+    contiguous = np.array([w[slice(*shard_bounds(512, r, WORLD))].sum() for r in range(WORLD)])
+    assert contiguous.max() > 1.5 * contiguous.mean()              # what balancing is for
+    # the assignment is a pure function of the weights (every rank computes the same one)
+    for r, ix in enumerate(balanced_shards(w, WORLD)):
+        np.testing.assert_array_equal(ix, np.atleast_1d(got[r][1]))
