@@ -378,7 +378,8 @@ constexpr int kLinMaxNx = 256;
 static int set_linear_wide(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
   HIP_OK(hipSetDevice(h->device));
   const int k = nx + nu, nxp = round_up(nx, 16), kp = round_up(k, 4), ntile = nxp / 16, ksn = kp / 4;
-  std::vector<double> buf((size_t)ntile * ksn * 64 + (size_t)nx * k, 0.0);
+  const int ldj = round_up(k, 16), plain_sz = round_up(nx * k, 4);
+  std::vector<double> buf((size_t)ntile * ksn * 64 + (size_t)plain_sz + (size_t)nxp * ldj, 0.0);
   auto Mat = [&](int row, int col) -> double {
     if (row >= nx || col >= k) return 0.0;
     return col < nx ? A[(size_t)row * nx + col] : B[(size_t)row * nu + (col - nx)];
@@ -390,6 +391,9 @@ static int set_linear_wide(ampc_handle* h, int nx, int nu, const double* A, cons
   double* plain = buf.data() + (size_t)ntile * ksn * 64;
   for (int r = 0; r < nx; ++r)
     for (int c = 0; c < k; ++c) plain[(size_t)r * k + c] = Mat(r, c);
+  double* jp = plain + plain_sz;                         // [nxp][ldj], zero padded: the wide iLQR sweep's J
+  for (int r = 0; r < nx; ++r)
+    for (int c = 0; c < k; ++c) jp[(size_t)r * ldj + c] = Mat(r, c);
   HIP_OK(h->lin_buf.reserve(buf.size() * h->esz()));
   if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
   else HIP_OK(upload_converted<float>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
@@ -1547,13 +1551,19 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   ampc_handle* h = p->h;
   const MlpDev<T>& m = model_of<T>(h);
   const int nx = h->nx, nu = h->nu, B = p->B, H = p->H;
-  const IlqrWork wk = make_ilqr_work(nx, nu, h->cost_stride);
+  const IlqrWork wk = make_ilqr_work(nx, nu, h->cost_stride, h->has_lin);
   if (h->has_sindy) {
     std::memset(&p->L, 0, sizeof(p->L));
     p->L.xu = 0;
     p->L.xu_stride = nx + nu + 1;
     p->lds_xn = round_up(16 * p->L.xu_stride, 4);
     p->L.extra = round_up(p->lds_xn + 16 * nx + 16 * h->s_ntab, 4);   // xnext + table scratch
+  } else if (h->has_lin) {         // line search: [x | u] rows for lin_tile, next states, compact work map
+    std::memset(&p->L, 0, sizeof(p->L));
+    p->L.xu = 0;
+    p->L.xu_stride = lin_xs(h->l_kp, (int)sizeof(T));
+    p->lds_xn = round_up(16 * p->L.xu_stride, 4);
+    p->L.extra = round_up(p->lds_xn + 16 * nx, 4);
   } else {
     p->L = tile_lds_for<T>(h, m, 16, (size_t)wk.total + 8);
   }
@@ -1566,7 +1576,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   { const int rb = env_int("AMPC_LS4_RB", 0); p->ls_rb = (rb == 1 || rb == 3) ? rb : 0; }
   p->static_shape = -1;
   p->jit = nullptr;
-  if (!h->has_sindy && env_int("AMPC_STATIC", 1) != 0) {
+  if (!h->has_sindy && !h->has_lin && env_int("AMPC_STATIC", 1) != 0) {
     int sid = static_shape_of<T>(h, m);
     if (sid < 0 && (p->jit = jit::get<T>(h)) != nullptr) sid = 0;      // run-time compiled shape
     if (sid >= 0) {
@@ -1578,13 +1588,20 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   REQUIRE(p->lds_bytes <= kLdsLimit, "ilqr plan: model does not fit the 160 KB LDS");
   REQUIRE((size_t)wk.total * sizeof(T) <= kLdsLimit,
           "ilqr plan: the Riccati workspace for this state dimension does not fit the 160 KB LDS");
+  if (h->has_lin)
+    REQUIRE((size_t)make_wide_lds(nx, nu, h->obs_dim).total * sizeof(T) <= kLdsLimit,
+            "ilqr plan: the sweep's workspace for this state / observation dimension does not fit the 160 KB LDS");
   const size_t e = sizeof(T);
   HIP_OK(p->d_cost_idx.reserve(B * sizeof(int)));
   HIP_OK(hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), B * sizeof(int), hipMemcpyHostToDevice));
   HIP_OK(p->states.reserve((size_t)B * (H + 1) * nx * e));
   HIP_OK(p->ctrls.reserve((size_t)B * H * nu * e));
-  HIP_OK(p->jx.reserve((size_t)B * H * nx * nx * e));
-  HIP_OK(p->ju.reserve((size_t)B * H * nx * nu * e));
+  if (!h->has_lin) {              // (a linear model's Jacobians are the constant [A | B]: LinDev::jp)
+    HIP_OK(p->jx.reserve((size_t)B * H * nx * nx * e));
+    HIP_OK(p->ju.reserve((size_t)B * H * nx * nu * e));
+  } else {
+    HIP_OK(p->vj.reserve((size_t)B * h->l_nxp * round_up(nx + nu, 16) * e));
+  }
   HIP_OK(p->Ks.reserve((size_t)B * H * nu * nx * e));
   HIP_OK(p->ks.reserve((size_t)B * H * nu * e));
   HIP_OK(hipMemset(p->Ks.p, 0, (size_t)B * H * nu * nx * e));
@@ -1596,7 +1613,7 @@ template <typename T> static int ilqr_plan_build(ampc_ilqr_plan* p) {
   HIP_OK(hipMemset(p->flags.p, 0, (size_t)9 * B * sizeof(int)));
   const int rows = B * H;
   const int n_pad = round_up(rows, 64);
-  if (!h->has_sindy) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
+  if (!h->has_sindy && !h->has_lin) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * e));
   HIP_OK(p->ric.reserve((size_t)kRicStride * p->B * e));
   return 0;
 }
@@ -1605,10 +1622,15 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
                                      const int* cost_index, int clip_to_bounds,
                                      ampc_ilqr_plan** out) {
   REQUIRE(h && out, "ampc_ilqr_plan_create: NULL argument");
-  REQUIRE(!h->has_lin, "ampc_ilqr_plan_create: iLQR plans take model states up to 64 (the Riccati workspace lives "
-                       "in LDS); wide linear models (65..256 states) run MPPI and the closed loop");
-  REQUIRE(h->nx + h->nu + 1 <= 64,
-          "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
+  if (h->has_lin) {      // wide linear models: ilqr_wide.hpp (V [nx][nx] in LDS, per-thread Quu solves)
+    REQUIRE(h->nx <= kLinMaxIlqrNx, "ampc_ilqr_plan_create: iLQR on wide linear models takes up to 128 model states (the "
+                                    "value function's Hessian lives in LDS); larger ones run MPPI and the closed loop");
+    REQUIRE(h->nu == 1 || h->nu == 2 || h->nu == 3 || h->nu == 4 || h->nu == 6 || h->nu == 8,
+            "ampc_ilqr_plan_create: iLQR on wide linear models is built for 1, 2, 3, 4, 6 or 8 controls");
+  } else {
+    REQUIRE(h->nx + h->nu + 1 <= 64,
+            "ampc_ilqr_plan_create: state dim + ctrl dim must be <= 63 (one wave holds the augmented Quu system)");
+  }
   REQUIRE(h->has_model() && h->n_costs > 0, "ampc_ilqr_plan_create: model and cost must be set first");
   REQUIRE(h->n_ind == 0, "ampc_ilqr_plan_create: the handle's cost has indicator terms (threshold / box): they have no "
                          "gradient or Hessian, iLQR takes sums of quadratic costs only");
@@ -1679,7 +1701,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
   DevBuf* bufs[] = {&p->d_cost_idx, &p->states, &p->ctrls, &p->jx, &p->ju, &p->Ks, &p->ks,
                     &p->ls_states, &p->ls_ctrls, &p->obj, &p->flags, &p->dz, &p->ric,
                     &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
-                    &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl, &p->slot_h};
+                    &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl, &p->slot_h, &p->vj};
   for (DevBuf* b : bufs) b->release();
   p->mlp_tab.release(); p->slot_model.release();
   for (ampc_handle* mh : p->models) handle_release(mh);

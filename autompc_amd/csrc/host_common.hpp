@@ -24,6 +24,7 @@
 #include "ilqr_kernels.hpp"
 #include "ilqr_ls4.hpp"
 #include "ilqr_lsw.hpp"
+#include "ilqr_wide.hpp"
 #include "mppi_kernels.hpp"
 #include "mppi_rollout4.hpp"
 #include "rng_kernels.hpp"
@@ -171,6 +172,8 @@ template <typename T> static LinDev<T> lin_of(const ampc_handle* h) {
   m.nx = h->nx; m.nu = h->nu; m.nxp = h->l_nxp; m.kp = h->l_kp; m.ntile = h->l_nxp / 16; m.ksn = h->l_kp / 4;
   m.wf = (const T*)h->lin_buf.p;
   m.plain = m.wf + (size_t)m.ntile * m.ksn * 64;
+  m.ldj = round_up(h->nx + h->nu, 16);
+  m.jp = m.plain + (size_t)round_up(h->nx * (h->nx + h->nu), 4);
   return m;
 }
 
@@ -449,6 +452,7 @@ struct ampc_ilqr_plan {
   DevBuf mlp_tab, slot_model;   // [n_models] byte offsets of the models' buffers, [B] ints
   bool var_model = false;       // the running queue / closed loop uses per-slot models
   DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
+  DevBuf vj;                    // wide linear models: the sweep's VJ scratch [B][nxp][ldj] (ilqr_wide.hpp)
   DevBuf c_ints, c_iters, c_stage, c_obs, c_ctl;   // ampc_ilqr_closed_loop: chain bookkeeping, staged rows, trajectories
   long long last_queue_launches = 0;   // iterations launched by the last queue solve
 };
@@ -459,6 +463,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   std::memset(&a, 0, sizeof(a));
   a.mlp = model_of<T>(h);
   if (h->has_sindy) a.sindy = sindy_of<T>(h);
+  if (h->has_lin) { a.lin = lin_of<T>(h); a.vj = (T*)p->vj.p; }
   a.lds_xn = p->lds_xn;
   a.lds = p->L;
   a.lds_work = p->lds_work;

@@ -27,6 +27,7 @@
 #pragma once
 #include "mlp_tile.hpp"
 #include "sindy_kernels.hpp"
+#include "linear_kernels.hpp"
 
 namespace ampc {
 
@@ -84,28 +85,33 @@ template <typename T> struct IlqrArgs {
                                  //    then the candidates' objectives when their passes run in parallel
   int* ls_count;                 // [B] passes of the running line search that have finished (parallel passes)
   int par_passes;                // line-search passes of one problem on separate workgroups (grid.y)
+  // wide linear models (65..128 states; ilqr_wide.hpp, ilqr_iter_kernel<.., DYN = 2>): the model and the
+  // sweep's per-problem VJ scratch [B][nxp][ldj] -- behind everything the MLP kernels read
+  LinDev<T> lin;
+  T* vj;
 };
 
 // Scratch map inside the work region (offsets in elements of T), nx/nu/n known at run time.
 struct IlqrWork {
   int V, v, J, VJ, Qt, qt, K, k, Wk, wq, lu, rhs, xbar, ubar, cpar, lo, hi, scal, lsobj, piv, total;
 };
-__host__ __device__ inline IlqrWork make_ilqr_work(int nx, int nu, int cost_stride) {
+// (compact: the map of a kernel that only runs the line search -- no Riccati matrices; wide linear models)
+__host__ __device__ inline IlqrWork make_ilqr_work(int nx, int nu, int cost_stride, bool compact = false) {
   const int n = nx + nu;
   IlqrWork w;
   int o = 0;
-  w.V = o; o += nx * nx;
-  w.v = o; o += nx;
-  w.J = o; o += nx * n;
-  w.VJ = o; o += nx * n;
-  w.Qt = o; o += n * n;
-  w.qt = o; o += n;
+  w.V = o; o += compact ? 0 : nx * nx;
+  w.v = o; o += compact ? 0 : nx;
+  w.J = o; o += compact ? 0 : nx * n;
+  w.VJ = o; o += compact ? 0 : nx * n;
+  w.Qt = o; o += compact ? 0 : n * n;
+  w.qt = o; o += compact ? 0 : n;
   w.K = o; o += nu * nx;
   w.k = o; o += nu;
-  w.Wk = o; o += nu * nx;
+  w.Wk = o; o += compact ? 0 : nu * nx;
   w.wq = o; o += nu;
   w.lu = o; o += nu * nu;
-  w.rhs = o; o += nu * (nx + 1);
+  w.rhs = o; o += compact ? 0 : nu * (nx + 1);
   w.xbar = o; o += nx;
   w.ubar = o; o += nu;
   w.cpar = o; o += cost_stride;
@@ -840,7 +846,8 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
 }
 
 // DYN = 0: MLP dynamics through the MFMA tile;  DYN = 1: SINDy feature-library dynamics, one
-// thread per line-search candidate (the model is tiny; see sindy_kernels.hpp).
+// thread per line-search candidate (the model is tiny; see sindy_kernels.hpp);  DYN = 2: wide linear
+// models (65..128 states), the K-tiled step of linear_kernels.hpp on the 16 candidate rows.
 template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
   const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
@@ -859,7 +866,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   const int xs_ = L.xu_stride;
   const int cost_stride = SH::kStatic ? cost_block_stride(SH::no, SH::nu) : args.cost_stride;
-  const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride);
+  const IlqrWork wk = make_ilqr_work(nx, nu, cost_stride, DYN == 2);
   T* Wr = lds + (SH::kStatic ? L.extra : args.lds_work);
   T* V = Wr + wk.V; T* v = Wr + wk.v; T* Jm = Wr + wk.J; T* VJ = Wr + wk.VJ;
   T* Qt = Wr + wk.Qt; T* qt = Wr + wk.qt; T* Km = Wr + wk.K; T* kv = Wr + wk.k;
@@ -924,7 +931,7 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   // barriers inside the loop are LDS-only, so neither these loads nor the line-search stores
   // (lss / lsc) stall a step.
   // nu <= 16; nx <= 32 with the MLP tile, <= 64 on the feature-library path (predicated on nu * nx)
-  constexpr int KR = (16 * ((DYN == 1 || WIDE) ? 64 : 32) + NTHR - 1) / NTHR;
+  constexpr int KR = (16 * (DYN == 2 ? kLinMaxIlqrNx : (DYN == 1 || WIDE) ? 64 : 32) + NTHR - 1) / NTHR;
   T kreg[KR];
   T kvr = T(0), ubr = T(0), xbr = T(0);
   auto fetch_ls = [&](int t) {
@@ -994,6 +1001,23 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
       AMPC_IMARK(44);
       for (int a = r; a < nx; a += TPS) {
         const T xn = xu[m * xs_ + a] + Net::output(mlp, L, lds, m, a);
+        xu[m * xs_ + a] = xn;
+        if (mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
+      }
+    } else if constexpr (DYN == 2) {
+      // x_{t+1} = M [x_t ; u_t] for the 16 rows: wave w takes output column tiles w, w + W, ...
+      T* xnext = lds + args.lds_xn;
+      const int lane = tid & 63, wv = tid >> 6;
+      for (int nt = wv; nt < args.lin.ntile; nt += W) {
+        const typename Acc<T>::type acc = lin_tile<T>(args.lin, xu, xs_, nt, lane);
+        const int col = 16 * nt + (lane & 15);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          if (col < nx) xnext[acc_row<T>(lane >> 4, rr) * nx + col] = acc[rr];
+      }
+      __syncthreads();
+      for (int a = r; a < nx; a += TPS) {
+        const T xn = xnext[m * nx + a];
         xu[m * xs_ + a] = xn;
         if (mode == 0 && m == 0) st[(size_t)(t + 1) * nx + a] = xn;
       }

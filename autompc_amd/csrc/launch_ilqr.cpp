@@ -15,6 +15,29 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
   hipEvent_t* e = mode == 1 ? p->ev_cur : nullptr;
   if (e) HIP_OK(hipEventRecord(e[0], h->stream));
+#ifndef AMPC_JIT_PLUGIN
+  if (h->has_lin) {     // wide linear models: ilqr_wide.hpp + the sixteen-row line search on the K-tiled linear step
+    if (mode == 1) {
+      const size_t wb = (size_t)make_wide_lds(h->nx, h->nu, h->obs_dim).total * sizeof(T);
+#define AMPC_WIDE_NU(NUV)                                                                          \
+      case NUV: { auto rk = ilqr_riccati_wide_kernel<T, NUV>; HIP_OK(allow_lds(rk, wb));              \
+        hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), wb, h->stream, a); } break;
+      switch (h->nu) {
+        AMPC_WIDE_NU(1) AMPC_WIDE_NU(2) AMPC_WIDE_NU(3) AMPC_WIDE_NU(4) AMPC_WIDE_NU(6) AMPC_WIDE_NU(8)
+        default: return fail("internal: control dimension of a wide linear iLQR plan");
+      }
+#undef AMPC_WIDE_NU
+      HIP_OK(hipGetLastError());
+    }
+    if (e) HIP_OK(hipEventRecord(e[1], h->stream));
+    auto k = ilqr_iter_kernel<T, 1, 8, 2>;
+    HIP_OK(allow_lds(k, p->lds_bytes));
+    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * 8), p->lds_bytes, h->stream, a);
+    HIP_OK(hipGetLastError());
+    if (e) HIP_OK(hipEventRecord(e[2], h->stream));
+    return 0;
+  }
+#endif
   if (mode == 1) {      // backward sweep first: gains + expected reduction for the line search
     const IlqrWork wk = make_ilqr_work(h->nx, h->nu, h->cost_stride);
     const size_t rb = (size_t)wk.total * sizeof(T);

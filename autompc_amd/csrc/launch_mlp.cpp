@@ -91,6 +91,10 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
                   gpad, per_slot ? (const int*)p->slot_model.p : nullptr, per_slot ? (const long long*)p->mlp_tab.p : nullptr};
   if (per_slot) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
 #ifndef AMPC_JIT_PLUGIN
+  if (h->has_lin) {               // a linear model's Jacobians are constant ([A | B], LinDev::jp): nothing to refresh
+    if (p->ev_cur) { HIP_OK(hipEventRecord(p->ev_cur[3], h->stream)); HIP_OK(hipEventRecord(p->ev_cur[4], h->stream)); }
+    return 0;
+  }
   if (h->has_sindy) {
     hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((rows + 63) / 64), dim3(64), 0, h->stream,
                        sindy_of<T>(h), (const T*)p->states.p, (const T*)p->ctrls.p, (T*)p->jx.p,

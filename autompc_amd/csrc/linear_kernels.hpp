@@ -29,9 +29,12 @@ template <typename T> struct LinDev {
   int nx, nu, nxp, kp, ntile, ksn;     // nxp = 16 * ntile >= nx;  kp = 4 * ksn >= nx + nu
   const T* wf;                         // [ntile][ksn][64] fragments of M = [A | B]
   const T* plain;                      // [nx][nx + nu] row-major
+  const T* jp;                         // [nxp][ldj] the same, zero padded to MFMA tiles (ldj = nx + nu rounded up to 16):
+  int ldj;                             // the constant Jacobian of the wide iLQR sweep (ilqr_wide.hpp)
 };
 
 constexpr int kLinW = 8;                                     // waves per workgroup
+constexpr int kLinMaxIlqrNx = 128;                           // iLQR on wide linear models: V [nx][nx] lives in LDS (ilqr_wide.hpp)
 __host__ __device__ constexpr int lin_xs(int kp, int esz) {  // LDS row stride of [x | u]: odd in 8-byte units
   return esz == 8 ? (kp | 1) : ((kp + 2) | 2);
 }

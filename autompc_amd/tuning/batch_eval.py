@@ -571,11 +571,19 @@ class IlqrCandidateEvaluator:
             raise TypeError("needs a device-stageable model (autompc_amd.sysid.MLP)")
         if precision != "f64":
             raise ValueError("iLQR solves in f64 (control/ilqr.py: f32 is outside the parity mode)")
-        if model.state_dim != system.obs_dim:
-            raise TypeError("IlqrCandidateEvaluator carries the observation as the model state (MLP, SINDy); "
-                            "score %s candidates with simulate() and the drop-in controller" % type(model).__name__)
         self.system, self.task, self.model = system, task, model
         self.surrogate = surrogate if surrogate is not None else model
+        # The loop hands the surrogate's predicted STATE to the next solve: simulate()'s loop exactly when
+        # the model state is the observation (MLP, SINDy), or when controller and surrogate are ONE model
+        # whose update_state reproduces its own prediction (ARX: the stacked history, arx.py:94-99,113-127;
+        # up to 128 states, csrc/ilqr_wide.hpp).  Koopman re-lifts every observation (koopman.py:166-168):
+        # score such candidates with simulate() and the drop-in controller.
+        if model.state_dim != system.obs_dim and not (getattr(model, "device_closed_loop", False)
+                                                     and self.surrogate is model):
+            raise TypeError("IlqrCandidateEvaluator carries the model state from one solve to the next: the "
+                            "observation itself (MLP, SINDy) or the state of a model that is its own surrogate "
+                            "(ARX); score %s candidates with simulate() and the drop-in controller"
+                            % type(model).__name__)
         self.precision, self.device = precision, device
         self.bounded = bool(task.are_ctrl_bounded())
         b = task.get_ctrl_bounds()
@@ -654,6 +662,10 @@ class IlqrCandidateEvaluator:
         mi_all = model_index if model_handles else None
         obs = np.full((B, n_ctl + 1, nx), np.nan)
         ctl = np.full((B, n_ctl + 1, nu), np.nan)
+        init_obs = np.asarray(init_obs, dtype=np.float64)
+        if nx != no and init_obs.shape != (nx,):
+            # the state of the one-row trajectory simulate() starts from (simulation.py:44-47)
+            init_obs = self.model.traj_to_state(Trajectory(self.system, 1, init_obs[None, :no].copy(), np.zeros((1, nu))))
         obs[:, 0] = init_obs
         lengths = np.full(B, n_ctl + 1)
         failed = np.zeros(B, dtype=bool)          # singular Quu: the reference's LinAlgError -> inf

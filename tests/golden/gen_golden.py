@@ -1167,7 +1167,42 @@ def gen_evalcfg_twomodels():
          **out)
 
 
-GENERATORS = {"evalcfg_twomodels": gen_evalcfg_twomodels, "mppi_indicator": gen_mppi_indicator, "linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# --------------------------------------------------- iLQR on a model with more than 64 states
+def gen_ilqr_arx4():
+    """The reference's ARX default history is 4 (arx.py:27,37-45,165-166): on the 18-observation /
+    6-control HalfCheetah that is 4*18 + 3*6 + 1 = 91 model states.  compute_ilqr_default (ilqr.py:100-265)
+    unbounded and with clipped controls, and IterativeLQR.run on the lifted state."""
+    from autompc.sysid.arx import ARX
+    system = make_system(18, 6)
+    trajs = linear_train_trajs(system, n_traj=10, T=70, seed=404)
+    model = quiet(ARX, system, history=4)
+    quiet(model.train, trajs)
+    ns = model.state_dim
+    assert ns == 91
+    cost = make_cost(system, "dense", 1404)
+    Q, R, F = cost.get_cost_matrices()
+    H = 14
+    init = np.random.default_rng(14).uniform(-0.4, 0.4, size=18)
+    x0 = model.traj_to_state(trajs[2][:9])                    # a state with a real history in it
+    out = {}
+    for tag, bnd in (("free", None), ("clip", (-0.15, 0.2))):
+        task = Task(system)
+        task.set_cost(cost)
+        if bnd is not None:
+            task.set_ctrl_bounds(np.full(6, bnd[0]), np.full(6, bnd[1]))
+        ctl = IterativeLQR(system, task, model, H)
+        conv, st, ct, Ks, ks = quiet(ctl.compute_ilqr_default, x0, np.zeros((H, 6)), silent=True)
+        u, newstate = quiet(ctl.run, np.concatenate([x0, np.zeros(6)]), trajs[2][8].obs)
+        out.update({tag + "_converged": conv, tag + "_states": st, tag + "_ctrls": ct, tag + "_Ks": Ks,
+                    tag + "_ks": ks, tag + "_u": u, tag + "_newstate": newstate})
+    assert np.max(np.abs(out["clip_ctrls"] - out["free_ctrls"])) > 1e-3
+    save("wideilqr_arx4_hc", coeffs=np.concatenate([model.A[:18], model.B[:18]], axis=1), state_dim=ns, history=4,
+         A_sum=model.A.sum(), A_abs_sum=np.abs(model.A).sum(), B_abs_sum=np.abs(model.B).sum(),
+         Q=Q, R=R, F=F, goal=cost.get_goal(), H=H, dt=system.dt, x0=x0, run_obs=trajs[2][8].obs.copy(),
+         clip_bounds=np.array([-0.15, 0.2]), **out)
+
+
+GENERATORS = {"ilqr_arx4": gen_ilqr_arx4, "evalcfg_twomodels": gen_evalcfg_twomodels, "mppi_indicator": gen_mppi_indicator, "linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost, "linear_wide2": gen_linear_wide2, "evalcfg_koopman": gen_evalcfg_koopman}
 
 if __name__ == "__main__":

@@ -238,12 +238,17 @@ def test_wide_linear_mppi_vs_oracle(case):
 
 
 @pytest.mark.gpu
-def test_wide_linear_models_refuse_ilqr_with_a_clear_message():
+def test_ilqr_limits_on_wide_linear_models_are_stated():
+    """iLQR on wide linear models: up to 128 states (ilqr_wide.hpp); beyond that a clear refusal."""
     from autompc_amd import _lib
     h = _lib.Handle(0, "f64")
-    h.set_linear(np.eye(70), np.ones((70, 2)))
+    h.set_linear(0.5 * np.eye(140), np.ones((140, 2)))
     h.set_quad_costs(np.eye(5), np.eye(2), np.eye(5), np.zeros(5))
-    with pytest.raises(_lib.AmpcError, match="up to 64"):
+    with pytest.raises(_lib.AmpcError, match="up to 128"):
+        _lib.IlqrPlan(h, 1, 5, 0.05)
+    h.set_linear(0.5 * np.eye(70), np.ones((70, 5)))
+    h.set_quad_costs(np.eye(5), np.eye(5), np.eye(5), np.zeros(5))
+    with pytest.raises(_lib.AmpcError, match="1, 2, 3, 4, 6 or 8 controls"):
         _lib.IlqrPlan(h, 1, 5, 0.05)
     h.close()
 
@@ -303,3 +308,172 @@ def test_candidate_evaluator_carries_a_lifted_controller_state(tag):
     c2 = dict(cand, horizon=6, num_path=100, sigma=0.9)
     both = ev.evaluate([cand, c2, cand], seed=5)
     assert both[1] == ev.evaluate([c2], seed=5, index_offset=1)[0]
+
+
+# ---- iLQR beyond 64 model states (ARX history 4 on 18 observations / 6 controls: 91 states) ------------
+def _arx4(g):
+    from autompc_amd import ARX
+    system = make_system(18, 6, dt=float(g["dt"]))
+    m = ARX(system, history=4)
+    m.set_parameters({"coeffs": g["coeffs"]})
+    assert m.state_dim == int(g["state_dim"]) == 91
+    assert abs(m.A.sum() - g["A_sum"]) < 1e-9 * g["A_abs_sum"] and abs(np.abs(m.B).sum() - g["B_abs_sum"]) < 1e-12 * g["B_abs_sum"]
+    return system, m
+
+
+@pytest.mark.parametrize("tag", ["free", "clip"])
+def test_oracle_ilqr_on_the_91_state_arx_matches_reference(tag):
+    """The reference's compute_ilqr_default (ilqr.py:100-265) on its ARX model with the default history 4
+    (arx.py:27,37-45): pins the oracle beyond 64 states."""
+    from oracle.ilqr import ILQROracle
+    g = golden("wideilqr_arx4_hc")
+    system, m = _arx4(g)
+    orc_model = ARXOracle(system, 4, m.A, m.B)
+    ub = (np.full(6, g["clip_bounds"][0]), np.full(6, g["clip_bounds"][1])) if tag == "clip" else None
+    orc = ILQROracle(orc_model, QuadCostOracle(g["Q"], g["R"], g["F"], g["goal"]), float(g["dt"]), int(g["H"]), ubounds=ub)
+    conv, st, ct, Ks, ks = orc.solve(g["x0"], np.zeros((int(g["H"]), 6)))
+    assert conv == bool(g[tag + "_converged"])
+    assert rel_err(st, g[tag + "_states"]) < 1e-6 and rel_err(ct, g[tag + "_ctrls"]) < 1e-6
+    assert rel_err(Ks, g[tag + "_Ks"]) < 1e-5 and np.max(np.abs(ks - g[tag + "_ks"])) < 1e-9 * max(1.0, np.max(np.abs(ct)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["free", "clip"])
+def test_device_ilqr_on_the_91_state_arx_matches_reference(tag):
+    """The drop-in IterativeLQR on the reference's default-history ARX model (91 states: ilqr_wide.hpp):
+    compute_ilqr_default and run() against the reference's own results."""
+    from autompc_amd import IterativeLQR, QuadCost, Task
+    g = golden("wideilqr_arx4_hc")
+    system, m = _arx4(g)
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    if tag == "clip":
+        task.set_ctrl_bounds(np.full(6, g["clip_bounds"][0]), np.full(6, g["clip_bounds"][1]))
+    ctl = IterativeLQR(system, task, m, int(g["H"]))
+    conv, st, ct, Ks, ks = ctl.compute_ilqr_default(g["x0"], np.zeros((int(g["H"]), 6)))
+    assert conv == bool(g[tag + "_converged"])
+    assert rel_err(st, g[tag + "_states"]) < 1e-6 and rel_err(ct, g[tag + "_ctrls"]) < 1e-6
+    # (at convergence the feed-forward terms are rounding noise, ~1e-15: an absolute bound on the controls' scale)
+    assert rel_err(Ks, g[tag + "_Ks"]) < 1e-5 and np.max(np.abs(ks - g[tag + "_ks"])) < 1e-9 * max(1.0, np.max(np.abs(ct)))
+    u, newstate = ctl.run(np.concatenate([g["x0"], np.zeros(6)]), g["run_obs"])
+    assert rel_err(u, g[tag + "_u"]) < 1e-6 and rel_err(newstate, g[tag + "_newstate"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # ns, nu, no, H, bounded, dense cost
+    (66, 6, 18, 12, False, False),          # ARX history 3 on HalfCheetah: just past the MLP tile's 64
+    (115, 6, 18, 10, True, True),           # history 5
+    (128, 8, 20, 8, False, True),           # the largest shape
+    (97, 1, 4, 15, True, False),
+])
+def test_wide_linear_ilqr_vs_oracle_and_queue(case):
+    """Random stable linear models: the device solve against the oracle, and problems of different
+    horizons / cost blocks streamed through one plan (ampc_ilqr_solve_queue_var) equal to one-problem solves."""
+    from autompc_amd import _lib
+    from oracle.ilqr import ILQROracle
+    ns, nu, no, H, bounded, dense = case
+    rng = np.random.default_rng(ns + nu)
+    A = 0.92 * np.linalg.qr(rng.normal(size=(ns, ns)))[0] + 0.02 * rng.normal(size=(ns, ns)) / np.sqrt(ns)
+    Bm = rng.normal(scale=0.3, size=(ns, nu))
+    system = make_system(no, nu)
+
+    class Lin:
+        state_dim = ns
+
+        def __init__(self):
+            self.system = system
+
+        def pred(self, s, u):
+            return A @ s + Bm @ u
+
+        def pred_batch(self, s, u):
+            return s @ A.T + u @ Bm.T
+
+        def pred_diff(self, s, u):
+            return A @ s + Bm @ u, A.copy(), Bm.copy()
+
+        def pred_diff_batch(self, s, u):
+            n = s.shape[0]
+            return s @ A.T + u @ Bm.T, np.tile(A, (n, 1, 1)), np.tile(Bm, (n, 1, 1))
+    C = 3
+    costs = []
+    for c in range(C):
+        if dense:
+            W = rng.normal(size=(no, no))
+            Q, F = W @ W.T / no + 0.05 * rng.normal(size=(no, no)), np.diag(rng.uniform(0.5, 2, size=no))
+            R = np.diag(rng.uniform(0.05, 0.2, size=nu)) + 0.01
+        else:
+            Q, F, R = np.diag(rng.uniform(0.5, 2, size=no)), np.diag(rng.uniform(0.5, 2, size=no)), np.diag(rng.uniform(0.05, 0.2, size=nu))
+        costs.append((Q, R, F, rng.normal(scale=0.1, size=no)))
+    h = _lib.Handle(0, "f64")
+    h.set_linear(A, Bm)
+    h.set_quad_costs(np.stack([c[0] for c in costs]), np.stack([c[1] for c in costs]), np.stack([c[2] for c in costs]),
+                     np.stack([c[3] for c in costs]))
+    lo, hi = -0.3, 0.4
+    if bounded:
+        h.set_ctrl_bounds(np.full(nu, lo), np.full(nu, hi))
+    P = 7
+    x0 = rng.uniform(-0.5, 0.5, size=(P, ns))
+    ci = rng.integers(0, C, size=P).astype(np.int32)
+    hz = rng.integers(3, H + 1, size=P).astype(np.int32)
+    hz[0] = H
+    model = Lin()
+    for j in range(3):
+        Q, R, F, goal = costs[ci[j]]
+        orc = ILQROracle(model, QuadCostOracle(Q, R, F, goal), 0.05, int(hz[j]),
+                         ubounds=(np.full(nu, lo), np.full(nu, hi)) if bounded else None)
+        conv, st, ct, Ks, ks = orc.solve(x0[j], np.zeros((int(hz[j]), nu)))
+        one = _lib.IlqrPlan(h, 1, int(hz[j]), 0.05, cost_index=ci[j:j + 1], clip_to_bounds=bounded)
+        got = one.solve(x0[j], np.zeros((int(hz[j]), nu)), max_iter=50)
+        one.close()
+        assert bool(got["converged"][0]) == conv and int(got["iters"][0]) == orc.n_iter
+        assert rel_err(got["states"][0], st) < 1e-7 and rel_err(got["ctrls"][0], ct) < 1e-6
+        assert rel_err(got["Ks"][0], Ks) < 1e-6 and abs(got["objective"][0] - orc.final_obj) < 1e-8 * max(1.0, abs(orc.final_obj))
+    plan = _lib.IlqrPlan(h, 3, H, 0.05, cost_index=np.zeros(3, dtype=np.int32), clip_to_bounds=bounded)
+    q = plan.solve_queue(x0, None, ci, max_iter=50, horizon=hz)
+    for j in range(P):
+        Hj = int(hz[j])
+        one = _lib.IlqrPlan(h, 1, Hj, 0.05, cost_index=ci[j:j + 1], clip_to_bounds=bounded)
+        ref = one.solve(x0[j], np.zeros((Hj, nu)), max_iter=50)
+        one.close()
+        for k in ("converged", "iters", "status", "objective"):
+            np.testing.assert_array_equal(q[k][j], ref[k][0])
+        np.testing.assert_array_equal(q["states"][j, :Hj + 1], ref["states"][0])
+        np.testing.assert_array_equal(q["Ks"][j, :Hj], ref["Ks"][0])
+    plan.close()
+    h.close()
+
+
+@pytest.mark.gpu
+def test_ilqr_candidate_evaluator_on_the_91_state_arx():
+    """IlqrCandidateEvaluator with an ARX controller model that is its own surrogate (history 4: 91 states,
+    the stacked history carried on the device from one solve to the next): device-resident episodes against
+    host simulate() + the drop-in controller, and against the per-step host loop."""
+    from autompc_amd import IterativeLQR, QuadCost, Task, simulate
+    from autompc_amd.tuning import IlqrCandidateEvaluator
+    g = golden("wideilqr_arx4_hc")
+    system, m = _arx4(g)
+    task = Task(system)
+    task.set_cost(QuadCost(system, g["Q"], g["R"], g["F"], goal=g["goal"]))
+    task.set_ctrl_bounds(np.full(6, -0.3), np.full(6, 0.3))
+    task.set_init_obs(np.random.default_rng(2).uniform(-0.3, 0.3, size=18))
+    T = 6
+    task.set_num_steps(T)
+    rng = np.random.default_rng(5)
+    cands = [dict(horizon=int(h), Q=rng.uniform(0.5, 2.0, size=18), R=rng.uniform(0.05, 0.3, size=6),
+                  F=rng.uniform(0.5, 2.0, size=18)) for h in (6, 11, 8, 14)]
+    dev = IlqrCandidateEvaluator(system, task, m, max_slots=3)
+    sd, od, cd = dev.evaluate(cands, return_trajectories=True)
+    sh, oh, ch = IlqrCandidateEvaluator(system, task, m, device_resident=False).evaluate(cands, return_trajectories=True)
+    np.testing.assert_allclose(od, oh, rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(sd, sh, rtol=1e-11)
+    assert od.shape == (4, T, 91) and np.all(np.isfinite(sd))
+    c = cands[1]
+    t1 = Task(system)
+    t1.set_cost(QuadCost(system, np.diag(c["Q"]), np.diag(c["R"]), np.diag(c["F"]), goal=g["goal"]))
+    t1.set_ctrl_bounds(np.full(6, -0.3), np.full(6, 0.3))
+    ctl = IterativeLQR(system, t1, m, c["horizon"])
+    traj = simulate(ctl, task.get_init_obs(), task.term_cond, sim_model=m, max_steps=T)
+    assert np.max(np.abs(od[1][:, :18] - traj.obs)) < 1e-8 and np.max(np.abs(cd[1] - traj.ctrls)) < 1e-8
+    assert abs(sd[1] - task.get_cost()(traj)) < 1e-8 * abs(sd[1])
