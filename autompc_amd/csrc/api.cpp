@@ -613,6 +613,58 @@ extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, co
                                   : pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }
 
+// Workgroup -> tile order of a plan whose problems run on several models: workgroups are dealt round-robin
+// to the eight XCDs (blockIdx % 8), each with its own 4 MB L2, and the rollout streams its model's weights
+// from L2 at every time step -- eight 2 x 256 f64 models (610 KB each) in flight on every XCD do not fit.
+// The tiles (in the plan's longest-horizon-first order) are poured model by model into eight queues of
+// equal length, queue x feeding the workgroups of XCD x: an XCD then sees one or two models.
+static int build_tile_order(ampc_mppi_plan* p) {
+  p->use_tile_order = false;
+  int n_models = 0;
+  for (int m : p->model_idx) n_models = std::max(n_models, m + 1);
+  if (p->models.empty() || n_models < 2 || p->quad || p->h->has_sindy || p->h->has_lin) return 0;
+  // MEASURED (tools/models_rate.py, 64 candidates x 8 models of 2 x 256, 199 control steps): the plan's plain
+  // longest-horizon-first order 35 076 solves/s -- the one-model rate, 35 086: eight models' weights (4.9 MB)
+  // stream from L2 / MALL without loss -- against 26 558 with this order, which gives up part of the
+  // longest-first dispatch.  Kept behind the switch for batches with many more models; off by default.
+  if (env_int("AMPC_MODEL_XCD", 0) == 0) return 0;
+  // (a tile's run time is proportional to its horizon: the queues are filled to equal WORK, not equal length)
+  const int n = p->n_tiles, nx = 8;
+  double total = 0.0;
+  for (int t = 0; t < n; ++t) total += p->H[p->tile_prob_host[t]];
+  const double cap = total / nx;
+  std::vector<std::vector<int>> queue(nx);
+  int x = 0;
+  double filled = 0.0;
+  for (int m = 0; m < n_models; ++m)
+    for (int t = 0; t < n; ++t)
+      if (p->model_idx[p->tile_prob_host[t]] == m) {
+        const double wt = p->H[p->tile_prob_host[t]];
+        if (x < nx - 1 && filled + 0.5 * wt > cap * (x + 1)) ++x;
+        queue[x].push_back(t);
+        filled += wt;
+      }
+  // workgroup i runs on XCD i % 8: deal the queues round-robin; a queue that runs dry (they differ in
+  // length, not in work) hands its turns to the longest remaining one
+  std::vector<int> order;
+  order.reserve(n);
+  std::vector<size_t> pos(nx, 0);
+  while ((int)order.size() < n)
+    for (int q = 0; q < nx && (int)order.size() < n; ++q) {
+      int src = q;
+      if (pos[src] >= queue[src].size()) {
+        size_t best = 0;
+        for (int k = 0; k < nx; ++k)
+          if (queue[k].size() - pos[k] > best) { best = queue[k].size() - pos[k]; src = k; }
+      }
+      order.push_back(queue[src][pos[src]++]);
+    }
+  HIP_OK(p->tile_order.reserve(order.size() * sizeof(int)));
+  HIP_OK(hipMemcpy(p->tile_order.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice));
+  p->use_tile_order = true;
+  return 0;
+}
+
 template <typename T> static int plan_build(ampc_mppi_plan* p) {
   ampc_handle* h = p->h;
   const MlpDev<T>& m = model_of<T>(h);
@@ -694,8 +746,8 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
   // implies (ping-pong activations + separate partials -- tile_lds_for picked it iff it fits)
   p->static_shape = -1;
   p->jit = nullptr;
-  // (indicator cost terms and per-problem models live in the run-time-shape kernels only: mppi_kernels.hpp)
-  const bool ext = h->n_ind > 0 || !p->models.empty();
+  // (indicator cost terms live in the run-time-shape kernels only: mppi_kernels.hpp)
+  const bool ext = h->n_ind > 0;
   if (ext) {
   } else if (p->quad && env_int("AMPC_STATIC", 1) != 0) {          // (the four-row kernel has one LDS map)
     int sid = static_shape_of<T>(h, m);
@@ -735,6 +787,8 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     tile += nt;
   }
   p->n_tiles = tile;
+  p->tile_prob_host = tile_prob;
+  if (int rc = build_tile_order(p)) return rc;
   HIP_OK(p->probs.reserve(pr.size() * sizeof(MppiProblem<T>)));
   HIP_OK(hipMemcpy(p->probs.p, pr.data(), pr.size() * sizeof(MppiProblem<T>), hipMemcpyHostToDevice));
   HIP_OK(p->tile_prob.reserve(tile_prob.size() * sizeof(int)));
@@ -825,7 +879,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
   for (DevBuf* b : bufs) b->release();
-  p->mlp_tab.release();
+  p->mlp_tab.release(); p->tile_order.release();
   for (ampc_handle* mh : p->models) handle_release(mh);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   ampc_handle* h = p->h;
@@ -875,6 +929,23 @@ static int build_model_table(ampc_handle* h, int n, ampc_handle* const* ms, DevB
   return 0;
 }
 
+// Several models in a plan run on the shape-specialised kernels (mlp_tile.hpp: plan_model): a registered
+// shape, or the shape's run-time compiled plugin -- waited for here if it is still building.
+static const char* kNeedStatic =
+    ": several controller models in one plan run on the kernels specialised for the model's shape; they are "
+    "not available for this plan (AMPC_STATIC=0 / AMPC_JIT=0, no hipcc for the run-time build of an unregistered "
+    "shape, a tile geometry without a specialised instantiation, or a cost with indicator terms)";
+template <typename T> static int plan_build(ampc_mppi_plan* p);
+template <typename T> static int mppi_require_static(ampc_mppi_plan* p, const char* who) {
+  if (p->static_shape >= 0) return 0;
+  if (p->h->n_ind == 0 && jit::eligible(p->h) && jit::get<T>(p->h, true) != nullptr) {
+    HIP_OK(hipStreamSynchronize(p->h->stream));
+    if (int rc = plan_build<T>(p)) return rc;          // (the plugin is ready now: the rebuilt plan takes it)
+  }
+  REQUIRE(p->static_shape >= 0, std::string(who) + kNeedStatic);
+  return 0;
+}
+
 extern "C" int ampc_mppi_plan_set_models(ampc_mppi_plan* p, int n_models, ampc_handle* const* models,
                                          const int* model_index) {
   REQUIRE(p, "ampc_mppi_plan_set_models: NULL plan");
@@ -884,6 +955,7 @@ extern "C" int ampc_mppi_plan_set_models(ampc_mppi_plan* p, int n_models, ampc_h
     for (ampc_handle* mh : p->models) handle_release(mh);
     p->models.clear();
     p->model_idx.clear();
+    p->use_tile_order = false;
     return 0;
   }
   REQUIRE(n_models >= 1 && models && model_index, "ampc_mppi_plan_set_models: NULL argument");
@@ -891,16 +963,16 @@ extern "C" int ampc_mppi_plan_set_models(ampc_mppi_plan* p, int n_models, ampc_h
     if (int rc = check_same_shape(p->h, models[i], "ampc_mppi_plan_set_models")) return rc;
   for (int b = 0; b < p->B; ++b)
     REQUIRE(model_index[b] >= 0 && model_index[b] < n_models, "ampc_mppi_plan_set_models: bad model_index");
+  if (int rc = p->h->precision == AMPC_F64 ? mppi_require_static<double>(p, "ampc_mppi_plan_set_models")
+                                           : mppi_require_static<float>(p, "ampc_mppi_plan_set_models")) return rc;
   if (int rc = p->h->precision == AMPC_F64 ? build_model_table<double>(p->h, n_models, models, &p->mlp_tab, &p->models)
                                            : build_model_table<float>(p->h, n_models, models, &p->mlp_tab, &p->models))
     return rc;
   p->model_idx.assign(model_index, model_index + p->B);
+  HIP_OK(hipStreamSynchronize(p->h->stream));
+  if (int rc = build_tile_order(p)) return rc;
   // the problems' descriptors carry the entry
-  if (int rc = p->h->precision == AMPC_F64 ? mppi_set_noise_ids_impl<double>(p) : mppi_set_noise_ids_impl<float>(p)) return rc;
-  // a plan built on shape-specialised kernels moves to the run-time-shape ones (which carry the model
-  // offsets): same tiles, same LDS map, same results
-  if (p->static_shape >= 0 || p->jit) { p->static_shape = -1; p->jit = nullptr; }
-  return 0;
+  return p->h->precision == AMPC_F64 ? mppi_set_noise_ids_impl<double>(p) : mppi_set_noise_ids_impl<float>(p);
 }
 
 template <typename T>
@@ -1993,7 +2065,15 @@ extern "C" int ampc_ilqr_plan_set_models(ampc_ilqr_plan* p, int n_models, ampc_h
   REQUIRE(n_models >= 1 && models, "ampc_ilqr_plan_set_models: NULL argument");
   for (int i = 0; i < n_models; ++i)
     if (int rc = check_same_shape(p->h, models[i], "ampc_ilqr_plan_set_models")) return rc;
-  p->static_shape = -1; p->jit = nullptr;       // (per-slot models: the run-time-shape kernels, ilqr_ls4.hpp)
+  if (p->static_shape < 0) {
+    const bool ready = jit::eligible(p->h) && (p->h->precision == AMPC_F64 ? jit::get<double>(p->h, true) != nullptr
+                                                                           : jit::get<float>(p->h, true) != nullptr);
+    if (ready) {
+      HIP_OK(hipStreamSynchronize(p->h->stream));
+      if (int rc = p->h->precision == AMPC_F64 ? ilqr_plan_build<double>(p) : ilqr_plan_build<float>(p)) return rc;
+    }
+    REQUIRE(p->static_shape >= 0, std::string("ampc_ilqr_plan_set_models") + kNeedStatic);
+  }
   return p->h->precision == AMPC_F64 ? build_model_table<double>(p->h, n_models, models, &p->mlp_tab, &p->models)
                                      : build_model_table<float>(p->h, n_models, models, &p->mlp_tab, &p->models);
 }

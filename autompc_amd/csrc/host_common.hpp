@@ -303,6 +303,9 @@ struct ampc_mppi_plan {
   std::vector<ampc_handle*> models;
   std::vector<int> model_idx;     // [B]
   DevBuf mlp_tab;                 // [n_models] byte offsets of the models' buffers from the plan model's
+  DevBuf tile_order;              // [n_tiles] workgroup -> tile, XCD-aware by model (MppiArgs::tile_order)
+  bool use_tile_order = false;
+  std::vector<int> tile_prob_host;   // [n_tiles] tile -> problem, as uploaded
   int lift_n = 0;             // ampc_mppi_plan_set_state_lift: basis functions of the controller model's lift
   DevBuf lift_prog;           // [lift_n][2] (kind, parameter) in compute precision
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
@@ -378,6 +381,7 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.tile_done = (int*)p->tile_done.p;
   a.fused_combine = p->fused_combine ? 1 : 0;
   a.model_delta = p->models.empty() ? nullptr : (const long long*)p->mlp_tab.p;
+  a.tile_order = p->use_tile_order ? (const int*)p->tile_order.p : nullptr;
   a.ind_tab = (const T*)h->ind_buf.p;
   a.n_ind = h->n_ind;
   a.costs_par = (const T*)h->cost_buf.p;

@@ -858,9 +858,8 @@ __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> arg
   using Net = TileNet<T, NT, 1, W, false, 2, SH, WIDE>;
   constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
   const int tid = threadIdx.x, p = blockIdx.x;
-  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
-  if constexpr (!SH::kStatic)       // (per-slot models: run-time-shape kernels only, as in mppi_rollout_kernel)
-    mlp = shift_model(mlp, model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0));
+  const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] {               // (per-slot models: mlp_tile.hpp)
+    return model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0); });
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon

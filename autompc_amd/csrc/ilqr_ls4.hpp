@@ -146,9 +146,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   constexpr bool STREAM = !RES || SPR > 0;
   constexpr bool W0LDS = ls4_w0_lds(NT);
   const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
-  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
-  if constexpr (!SH::kStatic)       // (per-slot models: run-time-shape kernels only, as in mppi_rollout_kernel)
-    mlp = shift_model(mlp, model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0));
+  const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] {               // (per-slot models: mlp_tile.hpp)
+    return model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0); });
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
@@ -170,8 +169,8 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   if (mode == 1 && args.ric[(size_t)p * kRicStride + 3] != T(0)) return;   // singular Quu: retired by the sweep
 
   for (int l = 0; l < Lh; ++l)
-    for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.b[l][i];
-  for (int i = tid; i < nxp; i += NTHR) bias[Lh * HP + i] = mlp.b[Lh][i];
+    for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.B(l)[i];
+  for (int i = tid; i < nxp; i += NTHR) bias[Lh * HP + i] = mlp.B(Lh)[i];
   for (int i = tid; i < 4 * xs; i += NTHR) xu[i] = T(0);
   for (int i = tid; i < cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)args.cost_idx[p] * cost_stride + i];
@@ -185,11 +184,11 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   }
 
   // ---- resident fragments + the hidden-layer ring ------------------------------------------------
-  const rsrc_t wr = weight_rsrc(mlp.wbase);
+  const rsrc_t wr = weight_rsrc(mlp.WB());
   T w0[W0LDS ? 1 : KS0MAX][NT];
   T* w0l = lds + L.w0 + (size_t)w * ks0 * 64 * NT;               // this wave's fragments, k-step stride 64 * NT
   {
-    const unsigned s0 = (unsigned)(mlp.w4[0] - mlp.wbase) + (unsigned)w * (unsigned)ks0 * 64u * NT;
+    const unsigned s0 = (unsigned)(mlp.W4(0) - mlp.WB()) + (unsigned)w * (unsigned)ks0 * 64u * NT;
 #pragma unroll
     for (int ks = 0; ks < KS0MAX; ++ks) {
       if constexpr (W0LDS) {
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   }
   T wout[KSW][2];
   {
-    const T* wl = mlp.w4[Lh] + ((size_t)w * KSW * 64 + lane) * tiles;
+    const T* wl = mlp.W4(Lh) + ((size_t)w * KSW * 64 + lane) * tiles;
 #pragma unroll
     for (int ks = 0; ks < KSW; ++ks) {
       wout[ks][0] = wl[(size_t)ks * 64 * tiles];
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
     }
   }
   auto slice_h = [&](int l) {
-    return (unsigned)(mlp.w4[l] - mlp.wbase) + (unsigned)w * (unsigned)KSH * 64u * NT;
+    return (unsigned)(mlp.W4(l) - mlp.WB()) + (unsigned)w * (unsigned)KSH * 64u * NT;
   };
   // position (k-step index in this wave's packed stream) of streamed k-step kk of group g
   auto spos = [&](int g, int kk) { return RES ? g * PPR + kk : g * G + kk; };

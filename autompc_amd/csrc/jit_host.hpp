@@ -64,7 +64,7 @@ inline std::string package_dir() {          // directory of libautompc_hip.so
 inline const std::vector<std::string>& source_files() {
   static const std::vector<std::string> f = {
       "host_common.hpp", "shapes.hpp", "probe.hpp", "mlp_tile.hpp", "mlp_kernels.hpp", "linear_kernels.hpp", "mppi_kernels.hpp", "mppi_rollout4.hpp",
-      "ilqr_kernels.hpp", "ilqr_ls4.hpp", "ilqr_lsw.hpp", "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp",
+      "ilqr_kernels.hpp", "ilqr_ls4.hpp", "ilqr_lsw.hpp", "ilqr_wide.hpp", "rng_kernels.hpp", "sindy_kernels.hpp", "score_kernels.hpp",
       "launch_mppi.cpp", "launch_mlp.cpp", "launch_ilqr.cpp", "jit_plugin.cpp", "../../include/autompc_hip.h"};
   return f;
 }

@@ -9,9 +9,9 @@
 
 template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
 #ifndef AMPC_JIT_PLUGIN
-  // indicator cost terms (set on the handle, possibly after the plan was built) and per-problem models live
-  // in the run-time-shape kernels only (mppi_kernels.hpp): same tiles, same LDS map, same arithmetic
-  if ((p->static_shape >= 0 || p->jit) && (p->h->n_ind > 0 || !p->models.empty())) { p->static_shape = -1; p->jit = nullptr; }
+  // indicator cost terms (set on the handle, possibly after the plan was built) live in the run-time-shape
+  // kernels only (mppi_kernels.hpp): same tiles, same LDS map, same arithmetic
+  if ((p->static_shape >= 0 || p->jit) && p->h->n_ind > 0) { p->static_shape = -1; p->jit = nullptr; }
   if (p->jit) return jit_result(p->jit, p->jit->mppi_solve(p));     // same function, compiled for the shape
 #endif
   ampc_handle* h = p->h;

@@ -72,8 +72,7 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   using Net = TileNet<T, NT, MT, W, DERIV, 0, SH, WIDE>;
   constexpr int M = 16 * MT, NTHR = 64 * W;
   const int first = blockIdx.x * M;
-  MlpDev<T> mlp = SH::template fold<T>(mlp_in);
-  if constexpr (!SH::kStatic) mlp = shift_model(mlp, rm.delta(first));   // (per-group models: run-time shapes only)
+  const MlpDev<T> mlp = plan_model<SH, T>(mlp_in, [&] { return rm.delta(first); });   // (per-group models)
   const TileLds L = SH::template fold_lds<T, M, W>(L_in);
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   T* xu = lds + L.xu;
@@ -172,12 +171,10 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     }
   }
   const int s0 = sblk * M;                         // the tile's first sample
-  MlpDev<T> mlp = SH::template fold<T>(mlp_in);
-  if constexpr (!SH::kStatic) mlp = shift_model(mlp, rm.delta(s0 < n ? s0 : 0));
+  const MlpDev<T> mlp = plan_model<SH, T>(mlp_in, [&] { return rm.delta(s0 < n ? s0 : 0); });
   const int nu = mlp.nu, hpad = mlp.hpad, Lh = mlp.n_hidden;
   // (the folded output weights lie in the model's buffer as well: the same byte offset applies)
-  const T* wout_plain = SH::kStatic ? wout_plain_in
-      : reinterpret_cast<const T*>(reinterpret_cast<const char*>(wout_plain_in) + rm.delta(s0 < n ? s0 : 0));
+  const T* wout_plain = reinterpret_cast<const T*>(reinterpret_cast<const char*>(wout_plain_in) + mlp.delta);
   const size_t lstride = (size_t)n_pad * hpad;
   if (!rm.plain()) {                   // every row this tile touches is masked out: nothing to refresh
     if (s0 >= n || !rm.any_live(s0, s0 + M - 1 < n ? s0 + M - 1 : n - 1)) return;
@@ -200,8 +197,8 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = acc_t{0, 0, 0, 0};
-    const rsrc_t wr = weight_rsrc(mlp.wbase);
-    const unsigned wl = (unsigned)(mlp.wj[l] - mlp.wbase) + (unsigned)w * KSH * 64u * NT;   // uniform
+    const rsrc_t wr = weight_rsrc(mlp.WB());
+    const unsigned wl = (unsigned)(mlp.WJ(l) - mlp.WB()) + (unsigned)w * KSH * 64u * NT;   // uniform
     T first_group[GH][NT];
     load_group<T, NT, GH>(wr, wl, (unsigned)lane * NT, 0, first_group);
     layer_mma_static<T, NT, MT, KSH, GH>(G, gs, wr, wl, lane, first_group, acc);
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
 #pragma unroll
     for (int nn = 0; nn < NIMAX; ++nn) oacc[mt][nn] = acc_t{0, 0, 0, 0};
   ksplit_mma<T, MT, KSW, NIMAX>(G + i16 * gs + q + 4 * w * KSW, gs,
-                                mlp.wj[0] + ((size_t)w * KSW * 64 + lane) * ni, ni, oacc);
+                                mlp.WJ(0) + ((size_t)w * KSW * 64 + lane) * ni, ni, oacc);
   __syncthreads();
   T* part = G + w * M * kinp;
 #pragma unroll

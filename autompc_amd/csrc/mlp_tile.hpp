@@ -214,6 +214,32 @@ template <typename T> struct MlpDev {
   // fragment load is coalesced -- see build_model; K-split output layer): the four-row line-search
   // kernel (ilqr_ls4.hpp).
   const T* w4[kMaxHidden + 1];
+  // Byte offset of the model a kernel runs on from the one staged here (0 on the host side; set per
+  // problem / slot by the kernels of a plan that holds several models of one shape, see model_delta_of
+  // below).  The kernels take every pointer through the accessors, which add it: the pointer ARRAYS are
+  // never rewritten -- a descriptor whose arrays are modified and then indexed with a run-time layer
+  // number is kept in scratch memory, and every weight pointer read back from there is a per-lane value.
+  long long delta;
+  __device__ __forceinline__ const T* sh(const T* p) const {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + delta);
+  }
+  // (entry l of a pointer array by a chain of selects over CONSTANT indices: with no run-time index into
+  //  the descriptor left, it is split into scalar registers whether or not a kernel has modified it)
+  __device__ __forceinline__ const T* pick(const T* const (&a)[kMaxHidden + 1], int l) const {
+    static_assert(kMaxHidden == 4, "one select per entry, written out (a loop would be a run-time index until unrolled)");
+    const T* p = a[0];
+    p = l == 1 ? a[1] : p;
+    p = l == 2 ? a[2] : p;
+    p = l == 3 ? a[3] : p;
+    p = l == 4 ? a[4] : p;
+    return sh(p);
+  }
+  __device__ __forceinline__ const T* WB() const { return sh(wbase); }
+  __device__ __forceinline__ const T* W(int l) const { return pick(w, l); }
+  __device__ __forceinline__ const T* B(int l) const { return pick(b, l); }
+  __device__ __forceinline__ const T* WJ(int l) const { return pick(wj, l); }
+  __device__ __forceinline__ const T* W4(int l) const { return pick(w4, l); }
+  __device__ __forceinline__ const T* WT() const { return sh(wt); }
 };
 
 // Several controller models of ONE shape in a plan (tuning candidates that carry their own model,
@@ -230,11 +256,19 @@ __device__ __forceinline__ long long model_delta_of(const long long* __restrict_
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 template <typename T> __device__ __forceinline__ MlpDev<T> shift_model(MlpDev<T> m, long long d) {
-  auto sh = [d](const T* p) { return reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + d); };
-  m.wbase = sh(m.wbase); m.wt = sh(m.wt);
-#pragma unroll
-  for (int l = 0; l <= kMaxHidden; ++l) { m.w[l] = sh(m.w[l]); m.b[l] = sh(m.b[l]); m.wj[l] = sh(m.wj[l]); m.w4[l] = sh(m.w4[l]); }
+  m.delta = d;
   return m;
+}
+// The descriptor a kernel works with: folded for the shape and -- SHAPE-SPECIALISED instantiations only --
+// moved to the problem's / slot's model.  The run-time-shape instantiations read the kernel argument in
+// place (their layer loops have run-time trip counts: a modified copy of the descriptor ends up in scratch
+// memory there, every pointer a per-lane value, the kernel 40 % longer), so a plan that holds several
+// models needs the shape-specialised kernels -- a registered shape or its run-time compiled plugin; the
+// host waits for the plugin (api.cpp: require_static_for_models).
+template <typename SH, typename T, typename F>
+__device__ __forceinline__ MlpDev<T> plan_model(const MlpDev<T>& in, F delta) {
+  if constexpr (SH::kStatic) return shift_model(SH::template fold<T>(in), delta());
+  else return SH::template fold<T>(in);
 }
 
 // LDS carve-up shared by all kernels that run the tile (offsets in elements of T).
@@ -368,8 +402,8 @@ __device__ __forceinline__ void tile_load_constants(const MlpDev<T>& m, const Ti
                                                     int M) {       // (callers pass folded m, L)
   const int tid = threadIdx.x;
   for (int l = 0; l < m.n_hidden; ++l)
-    for (int i = tid; i < m.hpad; i += 64 * W) lds[L.bias + l * m.hpad + i] = m.b[l][i];
-  for (int i = tid; i < m.nxp; i += 64 * W) lds[L.bias + m.n_hidden * m.hpad + i] = m.b[m.n_hidden][i];
+    for (int i = tid; i < m.hpad; i += 64 * W) lds[L.bias + l * m.hpad + i] = m.B(l)[i];
+  for (int i = tid; i < m.nxp; i += 64 * W) lds[L.bias + m.n_hidden * m.hpad + i] = m.B(m.n_hidden)[i];
   for (int i = tid; i < M * L.xu_stride; i += 64 * W) lds[L.xu + i] = T(0);
 }
 
@@ -583,10 +617,10 @@ struct TileNet {
   // wave-uniform element offsets (from MlpDev::wbase) of this wave's fragment streams; the lane's
   // own offset is lane*NT elements
   __device__ __forceinline__ static unsigned slice0(const MlpDev<T>& m, int w) {
-    return (unsigned)(m.w[0] - m.wbase) + (unsigned)w * (unsigned)(m.k1p / 4) * 64u * NT;
+    return (unsigned)(m.W(0) - m.WB()) + (unsigned)w * (unsigned)(m.k1p / 4) * 64u * NT;
   }
   __device__ __forceinline__ static unsigned slice_h(const MlpDev<T>& m, int l, int w) {
-    return (unsigned)(m.w[l] - m.wbase) + (unsigned)w * (unsigned)KSH * 64u * NT;
+    return (unsigned)(m.W(l) - m.WB()) + (unsigned)w * (unsigned)KSH * 64u * NT;
   }
   rsrc_t wr;                      // buffer resource of the packed model (set by init())
   template <int KS> __device__ __forceinline__ const T (&first0() const)[KS][NT] {
@@ -608,21 +642,21 @@ struct TileNet {
                                                   T (&dst)[KSW][NOMAX]) {
     if constexpr (WIDE) {              // packed [w][ks][lane][tile], tiles = nxp / 16 (1..4)
       const int tiles = m.nxp / 16;
-      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * tiles;
+      const T* wl = m.W(m.n_hidden) + ((size_t)w * KSW * 64 + lane) * tiles;
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
         for (int n = 0; n < NOMAX; ++n) dst[ks][n] = n < tiles ? wl[(size_t)ks * 64 * tiles + n] : T(0);
     } else if (m.nxp == 16) {
-      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
+      const T* wl = m.W(m.n_hidden) + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) { dst[ks][0] = wl[ks * 64]; dst[ks][1] = T(0); }
     } else {
-      const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
+      const T* wl = m.W(m.n_hidden) + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) { const vec_t<T, 2> v = *reinterpret_cast<const vec_t<T, 2>*>(wl + ks * 128); dst[ks][0] = v[0]; dst[ks][1] = v[1]; }
       if (m.tail4) {          // second slot: the 4x4x4 tail fragment instead of tile 1
-        const T* wt = m.wt + ((size_t)w * KSW * 64 + lane);
+        const T* wt = m.WT() + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
         for (int ks = 0; ks < KSW; ++ks) dst[ks][1] = wt[ks * 64];
       }
@@ -652,8 +686,8 @@ struct TileNet {
     for (int l = 0; l < kResBias; ++l)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
-        bias_r[l][nt] = (RESIDENT_BIAS && l < m.n_hidden) ? m.b[l][16 * (NT * w + nt) + (lane & 15)] : T(0);
-    wr = weight_rsrc(m.wbase);
+        bias_r[l][nt] = (RESIDENT_BIAS && l < m.n_hidden) ? m.B(l)[16 * (NT * w + nt) + (lane & 15)] : T(0);
+    wr = weight_rsrc(m.WB());
     if constexpr (RESIDENT_OUT) load_out(m, w, lane, wout);
     load0_all(m);
     // first group of hidden layer 1 for the FIRST call (later calls request it at the end of the
@@ -755,11 +789,11 @@ struct TileNet {
         // ([GH][NT], the same 8*NT values) -- one register range for whatever comes next
         T* flat = &pfn[0][0];
         if (m.nxp == 16) {
-          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane);
+          const T* wl = m.W(m.n_hidden) + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
           for (int ks = 0; ks < KSW; ++ks) { flat[2 * ks] = wl[ks * 64]; flat[2 * ks + 1] = T(0); }
         } else {
-          const T* wl = m.w[m.n_hidden] + ((size_t)w * KSW * 64 + lane) * 2;
+          const T* wl = m.W(m.n_hidden) + ((size_t)w * KSW * 64 + lane) * 2;
 #pragma unroll
           for (int ks = 0; ks < KSW; ++ks) {
             T two[2];
@@ -769,7 +803,7 @@ struct TileNet {
             flat[2 * ks + 1] = two[1];
           }
           if (m.tail4) {
-            const T* wt = m.wt + ((size_t)w * KSW * 64 + lane);
+            const T* wt = m.WT() + ((size_t)w * KSW * 64 + lane);
 #pragma unroll
             for (int ks = 0; ks < KSW; ++ks) flat[2 * ks + 1] = wt[ks * 64];
           }

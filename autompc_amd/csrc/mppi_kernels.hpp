@@ -77,6 +77,10 @@ template <typename T> struct MppiArgs {
   const T* ind_tab;             // cost block: [n_ind][ind_stride(obs_dim)]; 0: none
   const long long* model_delta; // per-problem controller models of the plan's shape: byte offsets of their buffers
                                 // from the plan model's (MppiProblem::model names the entry; mlp_tile.hpp), or nullptr
+  const int* tile_order;        // workgroup -> tile (nullptr: the identity).  With several models in a plan the
+                                // tiles of one model are dealt to ONE XCD (workgroups go round-robin over the eight
+                                // XCDs, each with its own 4 MB L2): an XCD then streams one or two models' weights
+                                // from its L2 instead of all of them
 };
 
 template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
@@ -177,12 +181,18 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   constexpr int M = 16 * MT, NTHR = 64 * W;
   constexpr int TPS = NTHR / M;                 // threads per sample (32..4), all in one wave
   constexpr int EPT = (16 + TPS - 1) / TPS;     // noise elements per thread (nu <= 16)
-  // Extended stage costs (indicator terms) and per-problem models (MppiArgs::n_ind, model_delta) are compiled
-  // into the run-time-shape instantiation only: the shape-specialised kernels are the tuned hot path (a few
-  // instructions more in their time loop cost 2-5 % through scheduling and register allocation alone), and a
-  // plan that needs either runs the run-time-shape kernels (plan_build).
+  // Indicator terms of the stage cost (MppiArgs::n_ind) are compiled into the run-time-shape instantiation
+  // only: the shape-specialised kernels are the tuned hot path (a branch and a ballot more in their time loop
+  // cost 2.5 % through scheduling alone), and a plan whose cost has such terms runs the run-time-shape kernels
+  // (plan_build).  Per-problem models cost one scalar add per pointer: every instantiation takes them.
+  // (the descriptor is initialised ONCE, as a constant: a struct that is assigned again and indexed with a
+  //  run-time layer number is kept in scratch memory, and every weight pointer becomes a per-lane value)
   constexpr bool EXT = !SH::kStatic;
-  MlpDev<T> mlp = SH::template fold<T>(args.mlp);
+  // (wave-uniform by construction; said explicitly for the loaded index)
+  const int tile = args.tile_order ? __builtin_amdgcn_readfirstlane(args.tile_order[blockIdx.x]) : (int)blockIdx.x;
+  const int p = args.tile_prob[tile];
+  const MppiProblem<T> pr = args.probs[p];
+  const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] { return model_delta_of(args.model_delta, pr.model); });
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
   const int tid = threadIdx.x;
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
@@ -194,10 +204,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   const int lds_cost = SH::kStatic ? L.extra : args.lds_cost;
   const int lds_aseq = SH::kStatic ? round_up(L.extra + cost_stride + 3 * SH::nu, 4) : args.lds_aseq;
 
-  const int p = args.tile_prob[blockIdx.x];
-  const MppiProblem<T> pr = args.probs[p];
-  if constexpr (EXT) mlp = shift_model(mlp, model_delta_of(args.model_delta, pr.model));
-  const int first = (blockIdx.x - pr.tile0) * M;
+  const int first = (tile - pr.tile0) * M;
   const int H = pr.H, N = pr.N;
 
   // The two waves that share a SIMD (w and w + 4: a workgroup's waves are dealt to the SIMDs
@@ -380,7 +387,7 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
     sred[tid] = (first + tid < N && !dead_tile) ? exp(pr.neg_inv_lambda * (cred[tid] - mw)) : T(0);
   __syncthreads();
   const T* el = lds + args.lds_eps;
-  T* tp = args.tile_part + (size_t)blockIdx.x * args.hnu_stride;
+  T* tp = args.tile_part + (size_t)tile * args.hnu_stride;
   for (int e = tid; e < H * nu; e += NTHR) {
     const int t = e / nu, j = e - t * nu;
     T s = T(0);
@@ -390,8 +397,8 @@ __global__ __launch_bounds__(64 * W) void mppi_rollout_kernel(const MppiArgs<T> 
   if (tid == 0) {
     T ss = T(0);
     for (int i = 0; i < M; ++i) ss += sred[i];
-    args.tile_stat[2 * blockIdx.x] = mw;
-    args.tile_stat[2 * blockIdx.x + 1] = ss;
+    args.tile_stat[2 * tile] = mw;
+    args.tile_stat[2 * tile + 1] = ss;
   }
 }
 

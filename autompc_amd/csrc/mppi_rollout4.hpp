@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   // layer and the next first layer, so the barrier there goes (it stays for an odd number of hidden
   // layers, where the first layer would overwrite the activations a slower wave is still reading).
   constexpr bool BAR_A = !FULL || (NH & 1);
-  constexpr bool EXT = !SH::kStatic;           // (indicator terms, per-problem models: run-time shapes only, as
-  MlpDev<T> mlp = SH::template fold<T>(args.mlp);   //  in mppi_rollout_kernel)
+  constexpr bool EXT = !SH::kStatic;           // (indicator cost terms: run-time shapes only, as in mppi_rollout_kernel)
+  const int p = args.tile_prob[blockIdx.x];
+  const MppiProblem<T> pr = args.probs[p];
+  const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] { return model_delta_of(args.model_delta, pr.model); });
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = mlp.nx, nu = mlp.nu, no = SH::kStatic ? SH::no : args.obs_dim;
@@ -85,9 +87,6 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   const T* lin = goal + no; const T* lint = lin + no;      // affine part (stage / terminal), c0 c1 behind
   const T* blo = cpar + cost_stride; const T* bhi = blo + nu; const T* bsc = bhi + nu;
 
-  const int p = args.tile_prob[blockIdx.x];
-  const MppiProblem<T> pr = args.probs[p];
-  if constexpr (EXT) mlp = shift_model(mlp, model_delta_of(args.model_delta, pr.model));
   const int first = (blockIdx.x - pr.tile0) * ROWS;
   const int H = pr.H, N = pr.N;
 
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   };
   T w0[KS0MAX][NT];
   {
-    const T* b0 = mlp.w4[0] + (size_t)w * ks0 * 64 * NT;
+    const T* b0 = mlp.W4(0) + (size_t)w * ks0 * 64 * NT;
 #pragma unroll
     for (int ks = 0; ks < KS0MAX; ++ks) {
       if (ks < ks0) frag(b0, ks, w0[ks]);
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   T wh[NH > 1 ? NH - 1 : 1][KSH][NT];
 #pragma unroll
   for (int l = 1; l < NH; ++l) {
-    const T* bl = mlp.w4[l] + (size_t)w * KSH * 64 * NT;
+    const T* bl = mlp.W4(l) + (size_t)w * KSH * 64 * NT;
 #pragma unroll
     for (int ks = 0; ks < KSH; ++ks) frag(bl, ks, wh[l - 1][ks]);
   }
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
   constexpr int KSO = FULL ? KSH : KSW;
   T wout[KSO][2];
   {
-    const T* wl = mlp.w4[NH] + ((size_t)(FULL ? 0 : w * KSW) * 64 + lane) * tiles;
+    const T* wl = mlp.W4(NH) + ((size_t)(FULL ? 0 : w * KSW) * 64 + lane) * tiles;
 #pragma unroll
     for (int ks = 0; ks < KSO; ++ks) {
       wout[ks][0] = wl[(size_t)ks * 64 * tiles];
@@ -152,8 +151,8 @@ __global__ __launch_bounds__(256) void mppi_rollout4_kernel(const MppiArgs<doubl
 
   // ---- prologue: constants, shifted sequence, initial state ---------------------------------
   for (int l = 0; l < NH; ++l)
-    for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.b[l][i];
-  for (int i = tid; i < nxp; i += NTHR) bias[NH * HP + i] = mlp.b[NH][i];
+    for (int i = tid; i < HP; i += NTHR) bias[l * HP + i] = mlp.B(l)[i];
+  for (int i = tid; i < nxp; i += NTHR) bias[NH * HP + i] = mlp.B(NH)[i];
   for (int i = tid; i < cost_stride; i += NTHR)
     cpar[i] = args.costs_par[(size_t)pr.cost_idx * cost_stride + i];
   for (int i = tid; i < 3 * nu; i += NTHR) cpar[cost_stride + i] = args.bounds[i];

@@ -72,6 +72,20 @@ def candidate_models(candidates, default):
     return models, np.asarray(index, dtype=np.int32)
 
 
+def model_handle(m, device, precision, opened):
+    """A handle holding model `m` for a plan's model table: the model's own cached handle (staged once,
+    refreshed by the model when its parameters change; the plan keeps it alive) when it lives on this
+    device in this precision, else a fresh one (closed with the evaluation)."""
+    if not hasattr(m, "stage_into"):
+        raise TypeError("a candidate's model must be device-stageable (autompc_amd.sysid.MLP)")
+    if hasattr(m, "_dev") and getattr(m, "device", None) == device and getattr(m, "precision", None) == precision:
+        return m._dev()
+    hm = _lib.Handle(device, precision)
+    opened.append(hm)
+    m.stage_into(hm)
+    return hm
+
+
 def _by_model_shape(candidates, default):
     """Candidate indices grouped by the shape of the model they carry (first appearance order), or None
     when all share one shape."""
@@ -345,13 +359,7 @@ class CandidateEvaluator:
         models, self._model_index = candidate_models(candidates, self.model)
         self._model_handles = []
         if len(models) > 1 or models[0] is not self.model:
-            for m in models:
-                if not hasattr(m, "stage_into"):
-                    raise TypeError("a candidate's model must be device-stageable (autompc_amd.sysid.MLP)")
-                hm = _lib.Handle(self.device, self.precision)
-                opened.append(hm)
-                m.stage_into(hm)
-                self._model_handles.append(hm)
+            self._model_handles = [model_handle(m, self.device, self.precision, opened) for m in models]
         blocks, _ = candidate_cost_blocks(candidates, self.goal, no, nu)
         h.set_cost_blocks(**blocks)
         h.set_ctrl_bounds(self.umin, self.umax)
@@ -639,11 +647,7 @@ class IlqrCandidateEvaluator:
         if len(models) > 1 or models[0] is not self.model:
             if not self.one_plan:
                 raise ValueError("candidates that carry their own model need the one-plan evaluator (one_plan=True)")
-            for m in models:
-                hm = _lib.Handle(self.device, self.precision)
-                opened.append(hm)
-                m.stage_into(hm)
-                model_handles.append(hm)
+            model_handles = [model_handle(m, self.device, self.precision, opened) for m in models]
         for H, idx in groups.items():
             h = _lib.Handle(self.device, self.precision)
             opened.append(h)

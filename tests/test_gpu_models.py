@@ -1,4 +1,6 @@
-"""Per-candidate controller models (ampc_mppi_plan_set_models / ampc_ilqr_plan_set_models): eval_cfg builds
+"""Per-candidate controller models (ampc_mppi_plan_set_models / ampc_ilqr_plan_set_models; they run on the
+shape-specialised kernels: registered shapes, or -- the two-model golden's 3-state network -- the shape's
+run-time compiled plugin, which set_models waits for): eval_cfg builds
 the controller with pipeline(cfg, task, trajs), which instantiates a model PER CONFIGURATION when the pipeline
 has a model factory (pipeline.py:138-145, tuning/pipeline_tuner.py:213-231).  The reference's two-model golden
 (tests/golden/loop_evalcfg_twomodels.npz) evaluated in ONE batch, and the property that a candidate's score
@@ -124,7 +126,7 @@ def test_a_score_does_not_depend_on_the_models_sharing_the_batch():
         assert own.evaluate([c2], seed=4, index_offset=k)[0] == full[k]
     assert len(set(np.round(full, 9).tolist())) == len(full)
     # a second architecture in the same batch: split by shape, same scores for the first ten
-    _, small = _hc_models(1, hidden=(64, 64))
+    _, small = _hc_models(1, hidden=(128, 128))
     extra = random_candidates(system, 3, seed=5)
     for c in extra:
         c["model"] = small[0]
@@ -148,10 +150,10 @@ def test_a_score_does_not_depend_on_the_models_sharing_the_batch():
 def test_batch_tuner_searches_over_models():
     from autompc_amd import QuadCost, Task
     from autompc_amd.tuning import BatchPipelineTuner, CandidateEvaluator
-    system, models = _hc_models(3, hidden=(64, 64), nx=4, nu=2)
+    system, models = _hc_models(3, hidden=(64, 64), nx=4, nu=1)        # (a registered shape: CartPole, csrc/shapes.hpp)
     task = Task(system)
-    task.set_cost(QuadCost(system, np.eye(4), 0.01 * np.eye(2), np.eye(4)))
-    task.set_ctrl_bounds(-np.ones(2), np.ones(2))
+    task.set_cost(QuadCost(system, np.eye(4), 0.01 * np.eye(1), np.eye(4)))
+    task.set_ctrl_bounds(-np.ones(1), np.ones(1))
     task.set_init_obs(np.array([0.1, -0.1, 0.05, 0.0]))
     task.set_num_steps(5)
     tuner = BatchPipelineTuner(system, CandidateEvaluator(system, task, models[0]), batch_size=12, models=models)
@@ -162,8 +164,8 @@ def test_batch_tuner_searches_over_models():
         from autompc_amd import _lib
         h0, h1 = _lib.Handle(0, "f64"), _lib.Handle(0, "f64")
         models[0].stage_into(h0)
-        _hc_models(1, hidden=(64, 48), nx=4, nu=2)[1][0].stage_into(h1)
-        h0.set_quad_costs(np.eye(4), np.eye(2), np.eye(4), np.zeros(4))
-        h0.set_ctrl_bounds(-np.ones(2), np.ones(2))
+        _hc_models(1, hidden=(64, 48), nx=4, nu=1)[1][0].stage_into(h1)
+        h0.set_quad_costs(np.eye(4), np.eye(1), np.eye(4), np.zeros(4))
+        h0.set_ctrl_bounds(-np.ones(1), np.ones(1))
         plan = _lib.MppiPlan(h0, [64], [5], [1.0], [1.0])
         plan.set_models([h1], [0])
