@@ -224,7 +224,16 @@ class Handle:
         model is being compiled, 2 ready, -1 failed."""
         buf = ctypes.create_string_buffer(512)
         st = self.lib.ampc_jit_status(self._h, buf, 512)
-        return st, buf.value.decode()
+        msg = buf.value.decode()
+        if st == -1 and not getattr(self, "_jit_warned", False):
+            # say it once: the controller keeps working, on the run-time-shape kernels (1.1-1.9x slower)
+            import warnings
+            self._jit_warned = True
+            warnings.warn("autompc_amd: the kernels specialised for this model's shape could not be compiled at run "
+                          "time (%s); plans on this model run the run-time-shape kernels, which are 1.1-1.9x slower. "
+                          "A box without hipcc can ship a cache built elsewhere ($AMPC_JIT_CACHE)." % (msg or "no log"),
+                          RuntimeWarning, stacklevel=3)
+        return st, msg
 
     def jit_wait(self):
         """Block until the kernels specialised for the staged model's shape are compiled; plans

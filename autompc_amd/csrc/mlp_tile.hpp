@@ -543,6 +543,48 @@ __device__ __forceinline__ void layer_mma_static(const T* __restrict__ A, int a_
           __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
         }
+      } else if constexpr (sizeof(T) == 4 && (Probe::f32_ahead > 0 || Probe::f32_fine > 0)) {
+        // f32 (round 5): one fragment read and one weight load behind EVERY k-step's MFMAs instead of two reads and
+        // two loads behind every pair -- a 32-cycle f32 MFMA covers half of what a 64-cycle f64 one does, and the
+        // pair pattern left the second k-step's requests waiting behind four MFMAs: c3 f32 rollout 0.1716 ->
+        // 0.1650 ms, 0.693 -> 0.72 of the f32 peak.  Reads further ahead (4, 6, 8 k-steps), a request behind every
+        // half of a k-step's MFMAs, or the weight load before the fragment read measured the same or worse
+        // (profiles/r05_f32_sched_variants.log).  f64 keeps the pair pattern: its hidden layer already runs at the
+        // issue rate.
+        constexpr int AH = Probe::f32_ahead > 0 ? Probe::f32_ahead : 2;
+        __builtin_amdgcn_sched_group_barrier(0x100, AH * MT, 0);
+        if constexpr (Probe::f32_fine == 1) {
+#pragma unroll
+          for (int i = 0; i < SG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            if (i + AH < SG) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        } else if constexpr (Probe::f32_fine == 2) {      // a request behind every half of a k-step's MFMAs
+          constexpr int H1 = (MT * NT + 1) / 2, H2 = MT * NT - H1;
+#pragma unroll
+          for (int i = 0; i < SG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, H1, 0);
+            if (i + AH < SG) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+            if (H2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, H2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        } else if constexpr (Probe::f32_fine == 3) {      // weight load first, fragment read second
+#pragma unroll
+          for (int i = 0; i < SG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (i + AH < SG) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < SG / 2; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT * NT, 0);
+            if (2 * i + AH < SG) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+            if (2 * i + AH + 1 < SG) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          }
+        }
       } else {
         __builtin_amdgcn_sched_group_barrier(0x100, 2 * MT, 0);
 #pragma unroll

@@ -12,6 +12,7 @@
 //   vmem_first   all weight loads of a sub-group up front
 //   valu_pad(64) 64 dummy int32 / f64 VALU instructions per layer call (VALU cost calibration)
 //   no_res0      layer-0 fragments not register-resident
+//   f32_ahead / f32_fine   f32 hidden layer: A-fragment reads further ahead / request pattern (0 = f64's, 1 = product)
 //   sg8          whole-group weight streaming in f64
 //   side_late    the caller's side work after the hidden layers instead of inside them
 //   no_cost      dense stage cost skipped
@@ -74,6 +75,16 @@ struct Probe {
   AMPC_PROBE_FLAG(no_res0, true);
 #else
   AMPC_PROBE_FLAG(no_res0, false);
+#endif
+#ifdef AMPC_X_F32AHEAD     // f32 hidden layer: k-steps of A-fragment LDS reads issued ahead of the MFMAs (product: 2)
+  static constexpr int f32_ahead = AMPC_X_F32AHEAD;
+#else
+  static constexpr int f32_ahead = 0;
+#endif
+#ifdef AMPC_X_F32FINE      // f32 hidden layer: request pattern 0 (per pair of k-steps, the f64 pattern), 1 (product), 2, 3
+  static constexpr int f32_fine = AMPC_X_F32FINE;
+#else
+  static constexpr int f32_fine = 1;
 #endif
 #ifdef AMPC_X_SG8
   AMPC_PROBE_FLAG(sg8, true);

@@ -106,6 +106,13 @@ def test_mppi_multi_ctrl_tanh_per_particle_terminal():
                    per_particle=True)
 
 
+@pytest.mark.parametrize("nx,nu,hidden", [(40, 3, [256, 256]), (64, 8, [256, 128, 64]), (48, 6, [192, 192])])
+def test_mppi_wide_states_with_wide_networks_vs_oracle(nx, nu, hidden):
+    """More than 32 model states with hidden layers of up to 256 units (the reference's MLP configuration
+    space is 16-256 units on any system, mlp.py:113-122): the WIDE tile (three or four output column tiles)."""
+    _oracle_vs_hip(nx, nu, hidden, "tanh", 200, 8, 0.8, 0.9, (-1.0, 1.0), "f64", 1e-9, seed=nx)
+
+
 def test_mppi_halfcheetah_full_size_vs_oracle():
     # BASELINE config 3: 4096 samples x 30 horizon, 17-dim state, 6 controls, MLP 2x256
     _oracle_vs_hip(17, 6, [256, 256], "relu", 4096, 30, 1.0, 1.0, (-1.0, 1.0), "f64", 1e-9, runs=1)

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session for the record: parity tests, smoke, every bench line, rocprofv3 summaries.
-# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r04
+# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r05
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
@@ -16,7 +16,7 @@ b c2_f64 --workload c2 --cpu-seconds 10
 b c3_f64_batch8 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline
 b arx_f64 --workload arx --cpu-seconds 10
 b c1_sindy_f64 --workload c1 --cpu-seconds 10
-b c4_ilqr_f64 --workload c4 --steps 3 --warmup 1
+b c4_ilqr_f64 --workload c4 --steps 5 --warmup 1
 b c4_ilqr_f64_b512 --workload c4 --batch 512 --steps 2 --warmup 1 --no-cpu-baseline
 b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 # launcher plumbing: `bench.py --gpus 2` starts its own two ranks; both mapped onto this box's one
@@ -26,6 +26,10 @@ AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
 timeout 600 python tools/jit_rate.py > $OUT/jit_rate.log 2>&1
+timeout 600 python tools/ilqr_eval_rate.py 64 50 > $OUT/ilqr_eval_rate.log 2>&1
+timeout 600 python tools/ilqr_eval_rate.py 256 30 >> $OUT/ilqr_eval_rate.log 2>&1
+timeout 900 python tools/models_rate.py > $OUT/models_rate.log 2>&1
+timeout 600 python tools/wide_ilqr_rate.py > $OUT/wide_ilqr_rate.log 2>&1
 timeout 300 python tools/c4_queue_rate.py 1024 256 > $OUT/c4_queue_rate.log 2>&1
 timeout 300 python tools/c4_queue_rate.py 8192 256 512 >> $OUT/c4_queue_rate.log 2>&1
 timeout 300 python tools/c4_queue_groups.py 4096 512 1 2 >> $OUT/c4_queue_rate.log 2>&1
