@@ -869,9 +869,9 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   (void)hipStreamSynchronize(p->h->stream);
   DevBuf* bufs[] = {&p->lift_prog, &p->probs, &p->tile_prob, &p->x0, &p->act[0], &p->act[1], &p->eps, &p->eps_next,
                     &p->eps_out, &p->costs, &p->term_last, &p->u_out, &p->tile_stat, &p->tile_part, &p->tile_done,
-                    &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt, &p->lg_fin,
+                    &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
-                    &p->lg_win, &p->lg_logtab, &p->lg_gather};
+                    &p->lg_win, &p->lg_logtab};
   if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
@@ -1188,7 +1188,8 @@ struct LegacyDraw {
   long long n = 0, n_pairs = 0, n_att = 0;
 };
 
-constexpr size_t kLegacyGather = 3 * sizeof(long long) + kMtN * sizeof(uint32_t);
+constexpr size_t kLegacyStatusSlot = 3 + kMtN * sizeof(uint32_t) / sizeof(long long);   // (in long longs) 1: a look-back wait expired
+constexpr size_t kLegacyGather = (kLegacyStatusSlot + 1) * sizeof(long long);
 
 // blocks a draw of n_att attempts can touch, counted from the block holding the generator's key
 static int legacy_blocks_for(int start_pos, long long n_att) {
@@ -1249,10 +1250,17 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
     for (hipEvent_t& e : p->lg_evs) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&p->lg_drawn, hipEventDisableTiming));
   }
-  HIP_OK(p->lg_cnt.reserve(((size_t)n_wg + 1) * sizeof(int)));
-  HIP_OK(p->lg_fin.reserve(2 * sizeof(long long)));
-  HIP_OK(p->lg_gather.reserve(kLegacyGather));
-  if (!p->lg_pin) HIP_OK(hipHostMalloc(&p->lg_pin, kLegacyGather, hipHostMallocDefault));
+  // look-back words of the draw kernel: cleared when (re)allocated and when the 24-bit epoch wraps
+  if ((size_t)n_wg * sizeof(unsigned long long) > p->lg_cnt.bytes || (++p->lg_epoch & 0xffffffu) == 0) {
+    HIP_OK(p->lg_cnt.reserve((size_t)n_wg * sizeof(unsigned long long)));
+    HIP_OK(hipMemsetAsync(p->lg_cnt.p, 0, p->lg_cnt.bytes, h->stream));
+    p->lg_epoch = 1;
+  }
+  if (!p->lg_pin) {
+    HIP_OK(hipHostMalloc(&p->lg_pin, kLegacyGather, hipHostMallocDefault));
+    HIP_OK(hipHostGetDevicePointer(&p->lg_pin_dev, p->lg_pin, 0));
+  }
+  ((long long*)p->lg_pin)[kLegacyStatusSlot] = 0;      // (the previous draw's results have been read: legacy_finish)
   if (!p->lg_scale_set) {            // sqrt(sigma_b): once per plan
     HIP_OK(p->lg_scale.reserve((size_t)p->B * sizeof(double)));
     std::vector<double> sc(p->B);
@@ -1288,29 +1296,19 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
   p->lg_spec = false;
   const uint32_t* stream = (const uint32_t*)p->lg_stream[p->lg_cur].p + (size_t)p->lg_blk0 * kMtN;
   const uint32_t* u = stream + pos;                 // the generator's next output
-  int* cnt = (int*)p->lg_cnt.p;
-  hipLaunchKernelGGL(polar_count_kernel, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, cnt);
-  hipLaunchKernelGGL(polar_scan_kernel, dim3(1), dim3(256), 0, h->stream, cnt, n_wg, cnt + n_wg,
-                     (long long*)p->lg_fin.p);
-  if (shift)
-    hipLaunchKernelGGL(legacy_first_value_kernel<T>, dim3(1), dim3(64), 0, h->stream, cached,
-                       (const double*)p->lg_scale.p, (T*)p->eps.p);
   const int logv = host_log_mode();
   if (logv && p->lg_logtab.bytes == 0) {
     HIP_OK(p->lg_logtab.reserve(sizeof(g_log_table)));
     HIP_OK(hipMemcpyAsync(p->lg_logtab.p, g_log_table, sizeof(g_log_table), hipMemcpyHostToDevice, h->stream));
   }
-  auto scatter = logv == 1 ? polar_scatter_kernel<T, 1> : logv == 2 ? polar_scatter_kernel<T, 2>
-                                                                    : polar_scatter_kernel<T, 0>;
-  hipLaunchKernelGGL(scatter, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att,
-                     (const int*)cnt, n, shift, (const MppiProblem<T>*)p->probs.p,
-                     (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, (long long*)p->lg_fin.p,
+  // ONE launch: attempts, the scan of the accept flags, the normals, and what the host needs afterwards (last
+  // attempt, cached value, pair count, the stream block the generator ends in) straight into pinned memory
+  auto draw = logv == 1 ? polar_draw_kernel<T, 1> : logv == 2 ? polar_draw_kernel<T, 2> : polar_draw_kernel<T, 0>;
+  hipLaunchKernelGGL(draw, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, (unsigned long long*)p->lg_cnt.p,
+                     p->lg_epoch & 0xffffffu, n, shift, cached, (const MppiProblem<T>*)p->probs.p,
+                     (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, stream, pos, (long long*)p->lg_pin_dev,
                      (const double*)p->lg_logtab.p);
   HIP_OK(hipGetLastError());
-  // fin, the pair count and the stream block the generator ends in: one copy back
-  hipLaunchKernelGGL(legacy_gather_kernel, dim3(1), dim3(256), 0, h->stream, (const long long*)p->lg_fin.p,
-                     (const int*)(cnt + n_wg), stream, pos, (long long*)p->lg_gather.p);
-  HIP_OK(hipMemcpyAsync(p->lg_pin, p->lg_gather.p, kLegacyGather, hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
 
@@ -1351,6 +1349,7 @@ static int legacy_finish(ampc_mppi_plan* p, const LegacyDraw& d, const uint32_t*
   const long long* gl = (const long long*)p->lg_pin;
   const long long fin[2] = {gl[0], gl[1]};
   const int total = (int)gl[2];
+  REQUIRE(gl[kLegacyStatusSlot] == 0, "legacy normal: the draw kernel gave up waiting for a workgroup's pair count");
   REQUIRE(total >= d.n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
   // generator state after the last consumed word
   const long long idx = (long long)d.pos + 4 * (fin[0] + 1);

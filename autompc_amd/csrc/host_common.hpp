@@ -325,8 +325,10 @@ struct ampc_mppi_plan {
   // numpy legacy-stream generation (ampc_mppi_legacy_normal).  The raw MT19937 stream of the NEXT
   // call is generated speculatively on a side stream (it only depends on the generator state this
   // call leaves behind) and used if the next call indeed starts from that state.
-  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_fin, lg_scale, lg_xraw, lg_poly[4], lg_win, lg_logtab, lg_gather;
-  void* lg_pin = nullptr;         // pinned landing buffer of lg_gather (fin, total, the final stream block)
+  DevBuf lg_key[2], lg_stream[2], lg_cnt, lg_scale, lg_xraw, lg_poly[4], lg_win, lg_logtab;
+  void* lg_pin = nullptr;         // pinned results of a draw, written by the draw kernel (last attempt, cached value, total, final stream block, status)
+  void* lg_pin_dev = nullptr;     //   ... its device address
+  unsigned lg_epoch = 0;          // call counter that tags the draw kernel's look-back words in lg_cnt
   bool lg_scale_set = false;      // sqrt(sigma_b) uploaded (the sigmas of a plan never change)
   // The raw MT19937 stream is generated AHEAD of the draws, several calls' worth per buffer, on a
   // side stream (api.cpp: legacy_enqueue / legacy_speculate / legacy_finish):

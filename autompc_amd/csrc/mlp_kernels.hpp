@@ -201,7 +201,10 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
     const unsigned wl = (unsigned)(mlp.WJ(l) - mlp.WB()) + (unsigned)w * KSH * 64u * NT;   // uniform
     T first_group[GH][NT];
     load_group<T, NT, GH>(wr, wl, (unsigned)lane * NT, 0, first_group);
-    layer_mma_static<T, NT, MT, KSH, GH>(G, gs, wr, wl, lane, first_group, acc);
+    // (round 5: the rollout's issue pattern -- fragment reads one k-step pair ahead, weight loads spread between
+    // MFMA clusters -- also pays here despite three workgroups per CU: 0.369 -> 0.350 ms per c4 launch.  Fetching
+    // the activation derivatives before the MFMAs instead of after them measured slower: 8 more live VGPRs.)
+    layer_mma_static<T, NT, MT, KSH, GH, Probe::jac_pipe>(G, gs, wr, wl, lane, first_group, acc);
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)

@@ -86,6 +86,11 @@ struct Probe {
 #else
   static constexpr int f32_fine = 1;
 #endif
+#ifdef AMPC_X_NOJACPIPE     // Jacobian chain without the hidden layer's hand-placed issue pattern (round-4 code)
+  AMPC_PROBE_FLAG(jac_pipe, false);
+#else
+  AMPC_PROBE_FLAG(jac_pipe, true);
+#endif
 #ifdef AMPC_X_SG8
   AMPC_PROBE_FLAG(sg8, true);
 #else
