@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
-PROFILE_TAG = "r04"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r05"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
 
 
 def parse():

@@ -53,7 +53,9 @@ int ampc_precision(const ampc_handle* h);
 /* ---- model: MLP surrogate dynamics --------------------------------------------------------
  * Replaces the state held by autompc.sysid.MLP (mlp.py:137-165 net, :308-321 parameters).
  * weights[l] is torch.nn.Linear layout [out_l][in_l]; l = 0..n_hidden (last = output layer).
- * nx <= 32 for hidden widths up to 256; nx <= 64 when every hidden layer has at most 64 units.
+ * nx <= 64, hidden widths 16..256 (MPPI, prediction and Jacobians: tests/test_gpu_mppi.py
+ * test_mppi_wide_states_with_wide_networks_vs_oracle runs 40 / 48 / 64 states against 192..256-unit layers);
+ * iLQR plans on MLP models: nx + nu <= 63, the four- / twelve-row line search for nx <= 32 (else the sixteen-row kernel).
  * x' = x + dy_mean + dy_std * net(([x,u] - xu_mean) / xu_std)          (mlp.py:219-236)
  * activation: 0 relu, 1 tanh, 2 sigmoid, 3 selu (mlp.py:44-51); 4 identity (ampc_set_linear). */
 int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,

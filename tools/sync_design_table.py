@@ -1,13 +1,12 @@
-"""Rewrite the measurement table of DESIGN.md section 5 (and the README headline) from the
-committed bench JSONs in profiles/, so that the prose never drifts from the evidence.
-Usage: python tools/sync_design_table.py [tag]   (default tag r01)"""
+"""Rewrite the measurement table of DESIGN.md section 5 (between "## 5." and "## 6."; the history in Appendix H
+is never touched) from the committed bench JSONs in profiles/, so that the table cannot drift from the evidence.
+Usage: python tools/sync_design_table.py [tag]   (default r05)"""
 import json
 import os
-import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r01"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 
 
 def load(name):
@@ -20,39 +19,37 @@ def th(x):
     return "%d %03d" % (x // 1000, x % 1000) if x >= 10000 else str(x)
 
 
-d, b = load("c3_f64"), load("c3_f64_batch8")
-r, f, rb, fb = d["roofline"], d["f32_fast_mode"], b["roofline"], b["f32_fast_mode"]
-c1, c2, ax, c4, c5 = load("c1_sindy_f64"), load("c2_f64"), load("arx_f64"), load("c4_ilqr_f64"), load("c5_candidates_f64")
-rows = {
-    "| **c3**": "| **c3** HalfCheetah MPPI 4096×30 (headline) | f64 | **%s** | %.3f ms | %.1f | **%.1f %%** of 78.6 |"
-                % (th(d["value"]), r["kernel_ms"], r["achieved"], 100 * r["frac"]),
-    "| c3 | f32": "| c3 | f32 | %s | %.3f ms | %.1f | %.1f %% of 157.3 |"
-                  % (th(f["value"]), f["kernel_ms"], f["achieved_tflops"], 100 * f["frac_of_f32_mfma_peak"]),
-    "| c3, 8 independent": "| c3, 8 independent solves per launch (64-row tiles) | f64 | %s | %.2f ms | %.1f | %.1f %% |"
-                           % (th(b["value"]), rb["kernel_ms"], rb["achieved"], 100 * rb["frac"]),
-    "| c3, 8 per launch": "| c3, 8 per launch (64-row tiles) | f32 | %s | %.2f ms | %.1f | %.1f %% |"
-                          % (th(fb["value"]), fb["kernel_ms"], fb["achieved_tflops"], 100 * fb["frac_of_f32_mfma_peak"]),
-    "| c2 Pendulum": "| c2 Pendulum MPPI 1024×30 (four-row kernel §4.1b, 256 WGs; latency-bound) | f64 | %s | %.3f ms | %.1f | %.1f %% |"
-                     % (th(c2["value"]), c2["roofline"]["kernel_ms"], c2["roofline"]["achieved"], 100 * c2["roofline"]["frac"]),
-    "| arx: MPPI": "| arx: MPPI 1024×30 on a 20-state ARX model (§8 f3; latency-bound) | f64 | %s | %.3f ms | %.1f | — |"
-                   % (th(ax["value"]), ax["roofline"]["kernel_ms"], ax["roofline"]["achieved"]),
-    "| c1 CartPole": "| c1 CartPole SINDy MPPI 256×20 (a sample's features over 64 lanes, §4.5: 256 single-wave workgroups; latency-bound; one thread per sample: 3037) | f64 | %s | %.3f ms | — | — |"
-                     % (th(c1["value"]), c1["roofline"]["kernel_ms"]),
-    "| c4 HalfCheetah": "| c4 HalfCheetah iLQR H=50, 256 problems × 50 iterations | f64 | %s | — | %.1f (whole iteration) | %.0f %% |"
-                        % (th(c4["value"]), c4["algorithmic_tflops"], 100 * c4["algorithmic_tflops"] / 78.6),
-    "| c5 64 candidates": "| c5 64 candidates × 200-step closed loop, scored on device | f64 | %s (MPPI solves) | — | %.1f (whole closed loop) | %.1f %% |"
-                          % (th(c5["value"]), c5["algorithmic_tflops"], 100 * c5["algorithmic_tflops"] / 78.6),
-}
+d=load('c3_f64'); b=load('c3_f64_batch8'); f32=load('c3_f32'); c1=load('c1_sindy_f64'); c2=load('c2_f64'); ax=load('arx_f64'); c4=load('c4_ilqr_f64'); c5=load('c5_candidates_f64'); drv=load('c3_f64_driver')
+r=d['roofline']; sub=d.get('sub_records',{})
+rw=d.get('repeat_windows',{})
+out = []
+out.append("| workload | precision | solves/s | dominant kernel | algorithmic TFLOP/s | of dense MFMA peak |\n|---|---|---|---|---|---|")
+out.append("| **c3** HalfCheetah MPPI 4096×30 (headline) | f64 | **%s** | %.3f ms | %.1f | **%.1f %%** of 78.6 |"%(th(d['value']),r['kernel_ms'],r['achieved'],100*r['frac']))
+fr=f32['roofline']
+out.append("| c3 | f32 | %s | %.3f ms | %.1f | %.1f %% of 157.3 |"%(th(f32['value']),fr['kernel_ms'],fr['achieved'],100*fr['frac']))
+rb=b['roofline']
+out.append("| c3, 8 independent solves per launch (64-row tiles) | f64 | %s | %.2f ms | %.1f | %.1f %% |"%(th(b['value']),rb['kernel_ms'],rb['achieved'],100*rb['frac']))
+out.append("| c2 Pendulum MPPI 1024×30 (four-row kernel §4.1b; latency-bound) | f64 | %s | %.3f ms | %.1f | %.1f %% |"%(th(c2['value']),c2['roofline']['kernel_ms'],c2['roofline']['achieved'],100*c2['roofline']['frac']))
+out.append("| arx: MPPI 1024×30 on a 20-state ARX model (latency-bound) | f64 | %s | %.3f ms | %.1f | — |"%(th(ax['value']),ax['roofline']['kernel_ms'],ax['roofline']['achieved']))
+out.append("| c1 CartPole SINDy MPPI 256×20 (§4.5; latency-bound) | f64 | %s | %.3f ms | — | — |"%(th(c1['value']),c1['roofline']['kernel_ms']))
+k4=c4['roofline']
+out.append("| **c4** HalfCheetah iLQR H=50, converging set, %d problems through %d slots | f64 | **%s** (4096-problem stream %s; two queues %s; lock-step batches %s) | %s %.3f ms per launch | %.1f (whole solve) | %.0f %% |"
+ %(c4['problems_per_step'],c4['slots'],th(c4['value']),th(c4.get('stream_4096',{}).get('value',0)),th(c4.get('two_queues_4096',{}).get('value',0)),th(c4.get('lockstep_batches',{}).get('value',0)),k4['kernel'],k4['kernel_ms'],c4['algorithmic_tflops'],100*c4['algorithmic_tflops']/78.6))
+out.append("| c5 64 candidates × 200-row closed loop, scored on device | f64 | %s (MPPI solves) | rollout %.3f ms per control step | %.1f (whole closed loop) | %.1f %% |"%(th(c5['value']),c5['roofline']['kernel_ms'],c5['algorithmic_tflops'],100*c5['algorithmic_tflops']/78.6))
+ie=sub.get('ilqr_eval')
+if ie: out.append("| iLQR candidates: 64 × 49 control steps, horizons 5–25 in one plan (`sub_records.ilqr_eval`) | f64 | %s (full solves) | — | — | — |"%th(ie['value']))
+c4b = load('c4_ilqr_f64_b512')
+rows = [l for l in out if l.startswith("| ") and not l.startswith("| workload")]
+rows.insert(7, "| c4, 512 slots, 2048 problems | f64 | %d | — | %.1f | %.0f %% |"
+            % (round(c4b['value']), c4b['algorithmic_tflops'], 100 * c4b['algorithmic_tflops'] / 78.6))
 path = os.path.join(ROOT, "DESIGN.md")
 lines = open(path).read().split("\n")
-for i, line in enumerate(lines):
-    for key, row in rows.items():
-        if line.startswith(key):
-            lines[i] = row
+lo = next(i for i, l in enumerate(lines) if l.startswith("## 5."))
+hi = next(i for i, l in enumerate(lines) if l.startswith("## 6."))
+first = next(i for i in range(lo, hi) if lines[i].startswith("|---"))
+last = first
+while last + 1 < hi and lines[last + 1].startswith("|"):
+    last += 1
+lines[first + 1:last + 1] = rows
 open(path, "w").write("\n".join(lines))
-path = os.path.join(ROOT, "README.md")
-t = open(path).read()
-t = re.sub(r"\d{4} MPPI solves/s", "%d MPPI solves/s" % round(d["value"]), t)
-t = re.sub(r"\(\d+\.\d TFLOP/s algorithmic = \d+ %", "(%.1f TFLOP/s algorithmic = %d %%" % (r["achieved"], round(100 * r["frac"])), t)
-open(path, "w").write(t)
-print("\n".join(rows.values()))
+print("\n".join(rows))
