@@ -111,7 +111,7 @@ template <typename T> inline std::string key_of(const ampc_handle* h) {
 
 // shapes the StaticShape kernels exist for (what the registered ones are used with)
 inline bool eligible(const ampc_handle* h) {
-  return env_int("AMPC_JIT", 1) != 0 && h->has_mlp && !h->has_sindy && h->act != 4 /* linear staging */ &&
+  return env_int("AMPC_JIT", 1) != 0 && h->has_mlp && !h->has_sindy &&     // (linear models of <= 32 states are staged as a one-layer identity network: they qualify)
          h->nx >= 1 && h->nx <= 32 && h->obs_dim >= 1 && h->n_hidden >= 1 && h->n_hidden <= kMaxHidden &&
          (h->hpad == 64 || h->hpad == 128 || h->hpad == 192 || h->hpad == 256) && !source_hash().empty();
 }

@@ -700,6 +700,8 @@ def main():
         bounds = task.get_ctrl_bounds()
         h.set_ctrl_bounds(bounds[:, 0], bounds[:, 1])
         N, H = spec["num_path"], spec["horizon"]
+        if (workload or args.workload) == "arx":
+            h.jit_wait()         # (an unregistered shape: its run-time compiled kernels, as a long-lived controller gets them)
         plan = _lib.MppiPlan(h, [N] * nb, [H] * nb, [1.0] * nb, [1.0] * nb)
         return h, plan, task, spec
 

@@ -104,7 +104,7 @@ def test_jit_kernels_equal_the_runtime_shape_kernels(shape, precision, monkeypat
     h.close()
 
 
-def test_registered_shape_and_other_models_need_no_plugin():
+def test_registered_shape_needs_no_plugin():
     from autompc_amd import _lib
     h = _handle(17, 6, [256, 256], "relu", "f64")        # shapes.hpp entry 0
     assert h.jit_status()[0] == 0
@@ -113,11 +113,43 @@ def test_registered_shape_and_other_models_need_no_plugin():
     assert plan.kernel_kind() == 1
     plan.close()
     h.close()
-    h = _lib.Handle(0, "f64")                           # a linear model is staged through the MLP tile
-    h.set_linear(0.9 * np.eye(3), 0.1 * np.ones((3, 1)))
-    h.set_quad_costs(np.eye(3), np.eye(1), np.eye(3), np.zeros(3))
-    assert h.jit_status()[0] == 0
-    h.close()
+
+
+def test_small_linear_models_get_a_plugin_with_the_same_bits(monkeypatch):
+    """A linear model of up to 32 states is staged through the MLP tile (one identity layer): it gets
+    shape-specialised kernels like any MLP (round 5: the 20-state ARX bench line 13.9 k -> 24.4 k solves/s),
+    with the bits of the run-time-shape kernels."""
+    from autompc_amd import _lib
+    rng = np.random.default_rng(5)
+    nx, nu, N, H = 11, 2, 300, 12
+    A = 0.9 * np.eye(nx) + 0.02 * rng.normal(size=(nx, nx))
+    B = 0.1 * rng.normal(size=(nx, nu))
+    x0 = rng.uniform(-0.5, 0.5, size=(1, nx))
+    out = {}
+    for jit in ("0", "1"):
+        monkeypatch.setenv("AMPC_JIT", jit)
+        h = _lib.Handle(0, "f64")
+        h.set_linear(A, B)
+        h.set_quad_costs(np.eye(nx), 0.1 * np.eye(nu), 2.0 * np.eye(nx), np.zeros(nx))
+        h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+        if jit == "1":
+            assert h.jit_status()[0] in (1, 2)
+            h.jit_wait()
+            assert h.jit_status()[0] == 2, h.jit_status()
+        plan = _lib.MppiPlan(h, [N], [H], [0.7], [0.9])
+        plan.upload(x0, np.zeros(H * nu), None)
+        plan.generate_eps(3, 1)
+        plan.solve()
+        a, u, c, _ = plan.download(costs=True)
+        ip = _lib.IlqrPlan(h, 3, H, 0.05)
+        o = ip.solve(np.repeat(x0, 3, axis=0) * np.array([[1.0], [0.5], [-1.0]]), np.zeros((3, H, nu)), 8)
+        out[jit] = (a, u, c, o["ctrls"], plan.kernel_kind(), ip.kernel_kind())
+        ip.close()
+        plan.close()
+        h.close()
+    assert out["1"][4] == 2 and out["1"][5] == 2
+    for k in range(4):
+        assert np.array_equal(out["0"][k], out["1"][k])
 
 
 def test_controllers_switch_to_the_compiled_kernels_mid_run(monkeypatch, tmp_path):
