@@ -89,16 +89,17 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
                        sindy_stage_bytes<T>(h);
     if (fp_allowed && sm.stage && sm.n_tab > 0 && h->nx <= 8 && lbf <= kLdsLimit) {
       const dim3 grid((unsigned)(p->n_tiles * G));
-      if (G == 64) {
-        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 64>, lbf));
-        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 64>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
-      } else if (G == 32) {
-        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 32>, lbf));
-        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 32>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
-      } else {
-        HIP_OK(allow_lds(mppi_rollout_sindy_fp_kernel<T, 16>, lbf));
-        hipLaunchKernelGGL((mppi_rollout_sindy_fp_kernel<T, 16>), grid, dim3(64), lbf, h->stream, a, sm, hcap);
-      }
+      auto launch = [&](auto kernel) -> int {
+        HIP_OK(allow_lds(kernel, lbf));
+        hipLaunchKernelGGL(kernel, grid, dim3(64), lbf, h->stream, a, sm, hcap);
+        return 0;
+      };
+      const bool ind = h->n_ind > 0;
+      int rc;
+      if (G == 64) rc = ind ? launch(mppi_rollout_sindy_fp_kernel<T, 64, true>) : launch(mppi_rollout_sindy_fp_kernel<T, 64>);
+      else if (G == 32) rc = ind ? launch(mppi_rollout_sindy_fp_kernel<T, 32, true>) : launch(mppi_rollout_sindy_fp_kernel<T, 32>);
+      else rc = ind ? launch(mppi_rollout_sindy_fp_kernel<T, 16, true>) : launch(mppi_rollout_sindy_fp_kernel<T, 16>);
+      if (rc) return rc;
     } else {
       const size_t lb = ((size_t)(2 * h->nx + h->nu + h->s_ntab) * 64 + h->cost_stride + 3 * h->nu + 2) * sizeof(T) +
                         sindy_stage_bytes<T>(h);

@@ -393,7 +393,9 @@ template <int G, typename T> __device__ __forceinline__ T sindy_group_sum(T v) {
 // (G lanes per sample: 16, 32 or 64 -- the fewer samples a plan has, the more lanes each can use; hcap =
 //  max_h * nu rounded up: a sample's noise row and the shifted action sequence are read into LDS once,
 //  ahead of the time loop, instead of a global-memory round trip per step on the chain)
-template <typename T, int G>
+// IND: the handle's cost has indicator terms (a separate instantiation: the never-taken branch cost the c1 kernel
+//  10 % through scheduling alone, 0.037 -> 0.041 ms)
+template <typename T, int G, bool IND = false>
 __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArgs<T> args, const SindyDev<T> mg,
                                                                    const int hcap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
       }
     }
     c += lc;
-    if (args.n_ind) {                      // indicator terms (threshold / box, mlp_tile.hpp), from the register copy
+    if constexpr (IND) {                   // indicator terms (threshold / box, mlp_tile.hpp), from the register copy
       for (int k = 0; k < args.n_ind; ++k) {
         const T* tk = args.ind_tab + (size_t)k * ind_stride(no);
         const int kind = (int)tk[0];
