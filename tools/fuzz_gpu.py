@@ -90,8 +90,30 @@ def main():
                     hip_cost = hip_cost + QuadCost(system, *t_[:3], goal=t_[3])
                 orc_cost = SumCostOracle.from_arrays(*zip(*terms))
                 tag += " sumcost%d" % len(terms)
+            # a quarter of the cases: threshold / box terms on top (MPPI only -- they have no gradient; round 5,
+            # ampc_set_indicator_costs): integer steps in the cost that tell samples apart
+            mppi_hip, mppi_orc = hip_cost, orc_cost
+            if rng.random() < 0.25:
+                from autompc_amd import BoxThresholdCost, ThresholdCost
+                from oracle.costs import BoxCostOracle, ThresholdCostOracle
+                ind_h, ind_o = [], []
+                for _ in range(int(rng.integers(1, 4))):
+                    if rng.random() < 0.5:
+                        a = int(rng.integers(0, nx)); b = int(rng.integers(a + 1, nx + 1))
+                        g2, thr = goal + rng.normal(scale=0.02, size=nx), float(rng.uniform(0.02, 0.3))
+                        ind_h.append(ThresholdCost(system, g2, [a, b], thr)); ind_o.append(ThresholdCostOracle(g2, [a, b], thr))
+                    else:
+                        lim = np.stack([goal - rng.uniform(0.02, 0.4, size=nx), goal + rng.uniform(0.02, 0.4, size=nx)], axis=1)
+                        lim[rng.random(nx) < 0.3, 0] = -np.inf
+                        ind_h.append(BoxThresholdCost(system, lim)); ind_o.append(BoxCostOracle(lim))
+                for t_ in ind_h:
+                    mppi_hip = mppi_hip + t_
+                mppi_orc = SumCostOracle((orc_cost.terms if isinstance(orc_cost, SumCostOracle) else [orc_cost]) + ind_o)
+                tag += " ind%d" % len(ind_h)
+                worst.setdefault("mppi_indicator_cases", 0.0)
+                worst["mppi_indicator_cases"] += 1
             task = Task(system)
-            task.set_cost(hip_cost)
+            task.set_cost(mppi_hip)
             lo, hi = -float(rng.uniform(0.3, 1.5)), float(rng.uniform(0.3, 1.5))
             task.set_ctrl_bounds(np.full(nu, lo), np.full(nu, hi))
             N, H = int(rng.choice([17, 64, 100, 300])), int(rng.integers(2, 20))   # (H = 1 raises in the reference: a[-2])
@@ -99,7 +121,7 @@ def main():
             seed = int(rng.integers(1 << 30))
             omodel = MLPOracle(system, p)
             np.random.seed(seed)
-            orc = MPPIOracle(omodel, orc_cost, np.tile([lo, hi], (nu, 1)),
+            orc = MPPIOracle(omodel, mppi_orc, np.tile([lo, hi], (nu, 1)),
                              horizon=H, num_path=N, sigma=sigma, lmda=lmda)
             np.random.seed(seed)
             ctl = MPPI(system, task, m, horizon=H, num_path=N, sigma=sigma, lmda=lmda)
@@ -161,6 +183,24 @@ def main():
                     worst["ilqr_queue"] = max(worst.get("ilqr_queue", 0.0), 0.0 if same else 1e9)
                     if not same:
                         bad.append((tag + " H=%d" % Hh, "ilqr queue differs from the one-problem solve", 0.0, 0.0))
+                    # per-problem horizons through ONE plan (round 5, ampc_ilqr_solve_queue_var): each problem bit for
+                    # bit what a one-problem plan of its own horizon gives
+                    hz = rng.integers(2, Hh + 1, size=5).astype(np.int32)
+                    qp = _lib.IlqrPlan(il._handle, 2, Hh, system.dt, clip_to_bounds=False, terminal_goal=il._terminal_goal)
+                    rv = qp.solve_queue(xs, max_iter=n_it, horizon=hz)
+                    qp.close()
+                    same = True
+                    for j in (0, 3):
+                        Hj = int(hz[j])
+                        one = _lib.IlqrPlan(il._handle, 1, Hj, system.dt, clip_to_bounds=False, terminal_goal=il._terminal_goal)
+                        rj = one.solve(xs[j], np.zeros((Hj, nu)), n_it)
+                        one.close()
+                        same = same and np.array_equal(rv["states"][j, :Hj + 1], rj["states"][0]) and \
+                            all(np.array_equal(rv[k][j, :Hj], rj[k][0]) for k in ("ctrls", "Ks", "ks")) and \
+                            np.array_equal(rv["iters"][j], rj["iters"][0]) and not rv["ctrls"][j, Hj:].any()
+                    worst["ilqr_var_horizon"] = max(worst.get("ilqr_var_horizon", 0.0), 0.0 if same else 1e9)
+                    if not same:
+                        bad.append((tag + " H=%d hz=%s" % (Hh, hz.tolist()), "per-problem horizons differ from one-horizon plans", 0.0, 0.0))
         except Exception as ex:          # noqa: BLE001 -- report and continue
             bad.append((tag, "exception", repr(ex)[:200], 0.0))
     # ---- linear models, closed loop and device scoring ------------------------------------------
@@ -255,6 +295,53 @@ def main():
                     bad.append(("closed loop case %d cand %d" % (case, b), "score", e, 0.0))
         except Exception as ex:      # noqa: BLE001
             bad.append(("closed loop case %d" % case, "exception", repr(ex)[:200], 0.0))
+    # ---- several controller models of one (random, run-time compiled) shape in one candidate batch (round 5) ----
+    # a candidate's score is bit for bit what it gets alone with only its own model (MPPI and iLQR evaluators)
+    from autompc_amd.tuning import IlqrCandidateEvaluator, random_candidates, random_ilqr_candidates
+    os.environ["AMPC_JIT"] = "1"
+    worst["model_tables"] = 0.0
+    for case in range(max(2, n_cases // 100)):
+        nx, nu = int(rng.integers(2, 20)), int(rng.integers(1, 5))
+        nl = int(rng.integers(1, 4))
+        hidden = [int(rng.choice([32, 64, 100, 128, 192, 256])) for _ in range(nl)]
+        act = str(rng.choice(["relu", "tanh"]))
+        system = System(["x%d" % i for i in range(nx)], ["u%d" % i for i in range(nu)], dt=0.05)
+        tag = "model table case %d nx=%d nu=%d hidden=%s %s" % (case, nx, nu, hidden, act)
+        try:
+            models = []
+            for k in range(3):
+                p = omlp.random_params(nx, nu, hidden, act, seed=int(rng.integers(1 << 30)))
+                m = MLP(system, n_hidden_layers=nl, nonlintype=act, **{"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)})
+                m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+                m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+                models.append(m)
+            task = Task(system)
+            task.set_cost(QuadCost(system, np.eye(nx), 0.01 * np.eye(nu), np.eye(nx)))
+            task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+            task.set_init_obs(rng.uniform(-0.1, 0.1, size=nx))
+            task.set_num_steps(int(rng.integers(4, 9)))
+            cands = random_candidates(system, 7, seed=case)
+            for k, c in enumerate(cands):
+                c["model"] = models[k % 3]
+                c["num_path"] = int(rng.choice([32, 64, 100]))
+            full = CandidateEvaluator(system, task, models[0]).evaluate(cands, seed=4)
+            ok = np.all(np.isfinite(full))
+            for k in (1, 5):
+                own = CandidateEvaluator(system, task, cands[k]["model"], surrogate=models[0])
+                ok = ok and own.evaluate([{kk: v for kk, v in cands[k].items() if kk != "model"}], seed=4, index_offset=k)[0] == full[k]
+            ic = random_ilqr_candidates(system, 5, seed=case)
+            for k, c in enumerate(ic):
+                c["Q"], c["R"], c["F"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25
+                c["model"] = models[(k + 1) % 3]
+            ifull = IlqrCandidateEvaluator(system, task, models[0], max_slots=2).evaluate(ic)
+            own = IlqrCandidateEvaluator(system, task, ic[3]["model"], surrogate=models[0])
+            ok = ok and own.evaluate([{kk: v for kk, v in ic[3].items() if kk != "model"}])[0] == ifull[3]
+            if not ok:
+                worst["model_tables"] = 1e9
+                bad.append((tag, "a score depends on the models sharing the batch", 0.0, 0.0))
+        except Exception as ex:      # noqa: BLE001
+            bad.append((tag, "exception", repr(ex)[:200], 0.0))
+    os.environ["AMPC_JIT"] = "0"
     # ---- SINDy libraries (incl. polynomial cross terms), both time modes, strict and true Jacobians ----
     from autompc_amd import SINDy
     from oracle.sindy import SINDyOracle
