@@ -14,7 +14,8 @@
 //   ampc_jit_status   reaps a finished build: a controller that polls it switches over by itself
 //   ampc_jit_wait     block until the build of the handle's shape has finished (tools / tests)
 //
-// <cache> = $AMPC_JIT_CACHE or <package>/jit_cache (in-tree: it travels with the package).  The key
+// <cache> = $AMPC_JIT_CACHE or <package>/jit_cache (in-tree: it travels with the package; ~/.cache/autompc_amd when
+// the package directory is read-only).  The key
 // holds precision + shape, the file name also a hash of every source the plugin is compiled from
 // and of `hipcc --version`, so a plugin is never used with other headers or another compiler /
 // ROCm release than the ones at hand.  Processes that want the same plugin at the same time (the
@@ -89,9 +90,24 @@ inline const std::string& source_hash() {
   return h;
 }
 
+// $AMPC_JIT_CACHE, else <package>/jit_cache (in-tree: it travels with the package), else -- a package installed
+// read-only -- $XDG_CACHE_HOME/autompc_amd or ~/.cache/autompc_amd
 inline std::string cache_dir() {
   const char* e = std::getenv("AMPC_JIT_CACHE");
-  return e && *e ? std::string(e) : package_dir() + "/jit_cache";
+  if (e && *e) return std::string(e);
+  static const std::string dir = [] {
+    const std::string in_tree = package_dir() + "/jit_cache";
+    ::mkdir(in_tree.c_str(), 0755);
+    if (::access(in_tree.c_str(), W_OK | X_OK) == 0) return in_tree;
+    const char* x = std::getenv("XDG_CACHE_HOME");
+    const char* home = std::getenv("HOME");
+    std::string base = x && *x ? std::string(x) : (home && *home ? std::string(home) + "/.cache" : std::string("/tmp"));
+    ::mkdir(base.c_str(), 0755);
+    base += "/autompc_amd";
+    ::mkdir(base.c_str(), 0755);
+    return base;
+  }();
+  return dir;
 }
 
 inline bool exists(const std::string& p) { struct stat st; return ::stat(p.c_str(), &st) == 0; }

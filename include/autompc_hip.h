@@ -70,10 +70,10 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
  * (csrc/shapes.hpp).  For any other MLP shape the library compiles them itself: once a handle has
  * both a model and a cost (the observation dimension is part of the shape), an out-of-process hipcc
  * build of a "shape plugin" starts in the background -- cached on disk in $AMPC_JIT_CACHE (default
- * <package>/jit_cache), keyed by precision, shape and a hash of the kernel sources -- and plans
+ * <package>/jit_cache; ~/.cache/autompc_amd when the package directory is read-only), keyed by precision, shape and a hash of the kernel sources -- and plans
  * created after it has finished use it; until then the run-time-shape kernels run.  Results are
  * bit-identical either way.  AMPC_JIT=0 in the environment disables it.
- *   ampc_jit_status  0 nothing to do (registered shape, SINDy / linear model, JIT disabled), 1 building,
+ *   ampc_jit_status  0 nothing to do (registered shape, SINDy / wide linear model, JIT disabled), 1 building,
  *                    2 ready, -1 failed; msg (optional) receives the plugin path or the build log's path
  *   ampc_jit_wait    block until the handle's shape is ready (returns 0) or failed (< 0)            */
 int ampc_jit_status(ampc_handle* h, char* msg, int msg_len);
