@@ -20,5 +20,5 @@ for r in rows:
     print("%-110s calls=%-7s avg_ns=%-9.0f pct=%s" % (r["Name"][:110], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
 PY
 tail -12 $OUT/dropin_trace.log >> $OUT/dropin_kernels.txt
-rm -rf $OUT/dropin_trace
+rm -rf $OUT/dropin_trace $OUT/dropin_trace.log
 head -30 $OUT/dropin_kernels.txt

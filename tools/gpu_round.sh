@@ -25,6 +25,7 @@ AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
+timeout 500 bash tools/dropin_kernels.sh $TAG > /dev/null 2>&1
 timeout 600 python tools/jit_rate.py > $OUT/jit_rate.log 2>&1
 timeout 600 python tools/ilqr_eval_rate.py 64 50 > $OUT/ilqr_eval_rate.log 2>&1
 timeout 600 python tools/ilqr_eval_rate.py 256 30 >> $OUT/ilqr_eval_rate.log 2>&1
