@@ -1304,10 +1304,10 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
   // ONE launch: attempts, the scan of the accept flags, the normals, and what the host needs afterwards (last
   // attempt, cached value, pair count, the stream block the generator ends in) straight into pinned memory
   auto draw = logv == 1 ? polar_draw_kernel<T, 1> : logv == 2 ? polar_draw_kernel<T, 2> : polar_draw_kernel<T, 0>;
-  hipLaunchKernelGGL(draw, dim3(n_wg), dim3(256), 0, h->stream, u, (int)n_att, (unsigned long long*)p->lg_cnt.p,
-                     p->lg_epoch & 0xffffffu, n, shift, cached, (const MppiProblem<T>*)p->probs.p,
-                     (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, stream, pos, (long long*)p->lg_pin_dev,
-                     (const double*)p->lg_logtab.p);
+  hipLaunchKernelGGL(draw, dim3(std::min(n_wg, kPolarMaxWgs)), dim3(256), 0, h->stream, u, (int)n_att,
+                     (unsigned long long*)p->lg_cnt.p, p->lg_epoch & 0xffffffu, n, shift, cached,
+                     (const MppiProblem<T>*)p->probs.p, (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, stream, pos,
+                     (long long*)p->lg_pin_dev, (const double*)p->lg_logtab.p, n_wg);
   HIP_OK(hipGetLastError());
   return 0;
 }

@@ -328,3 +328,41 @@ def test_run_ahead_over_many_calls_with_random_interruptions(N, H, nu, ahead, mo
         np.random.set_state(st_dev)
     plan.close()
     h.close()
+
+
+def test_concurrent_draws_of_several_plans_continue_their_own_streams():
+    """Four plans on four host threads, each with its own generator state, six c3-sized draws each (459 slices
+    through at most 256 workgroups: the draw kernel's look-back across launches that run side by side)."""
+    import threading
+    N, H, nu, sigma = 4096, 30, 6, 0.0049
+    made = [_plan(N, H, sigma, nx=2, nu=nu) for _ in range(4)]
+    errors = []
+
+    def work(k):
+        try:
+            h, plan = made[k]
+            rs = np.random.RandomState(100 + k)
+            state = rs.get_state()
+            for call in range(6):
+                ref = rs.normal(scale=np.sqrt(sigma), size=(N, H, nu))
+                state = plan.legacy_normal(state)
+                st_ref = rs.get_state()
+                np.testing.assert_array_equal(state[1], st_ref[1], err_msg="plan %d call %d" % (k, call))
+                assert tuple(state[2:]) == tuple(st_ref[2:])
+                plan.upload(x0=np.zeros((1, 2)), act_seq=np.zeros(plan.sum_hnu))
+                plan.solve()
+                e = plan.download(act_seq=False, u=False, eps_out=True)[3]
+                if _exact():
+                    np.testing.assert_array_equal(e.reshape(H, N, nu).transpose(1, 0, 2), ref)
+        except Exception as ex:      # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(ex)[:300]))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for h, plan in made:
+        plan.close()
+        h.close()
+    assert not errors, errors
