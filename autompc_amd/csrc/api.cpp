@@ -1774,7 +1774,7 @@ extern "C" int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p) {
                     &p->q_ctl, &p->q_x0, &p->q_u, &p->q_cost, &p->q_states, &p->q_ctrls, &p->q_Ks, &p->q_ks,
                     &p->q_obj, &p->q_flags, &p->c_ints, &p->c_iters, &p->c_stage, &p->c_obs, &p->c_ctl, &p->slot_h, &p->vj};
   for (DevBuf* b : bufs) b->release();
-  p->mlp_tab.release(); p->slot_model.release();
+  p->mlp_tab.release(); p->slot_model.release(); p->slot_of.release();
   for (ampc_handle* mh : p->models) handle_release(mh);
   for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
   if (p->poll_host) (void)hipHostFree(p->poll_host);
@@ -1886,6 +1886,22 @@ extern "C" int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double
 }
 
 // ---------------------------------------------------------------------------------------------
+// More slots than CUs (a finite batch admitted at once, or a wide evaluator plan): the kernels of an iteration
+// take their slot through ilqr_slot_of -- the slots with work first -- rebuilt by one small launch per iteration.
+// MLP models only (the feature-library and wide-linear kernels keep workgroup b = slot b).
+static bool ilqr_wants_compaction(const ampc_ilqr_plan* p) {
+  const int force = env_int("AMPC_ILQR_COMPACT", -1);
+  if (force == 0 || !p->h->has_mlp || p->h->has_sindy || p->h->has_lin) return false;
+  return force == 1 || p->B > p->h->n_cus;
+}
+template <typename T> static int ilqr_compact(ampc_ilqr_plan* p) {
+  if (!p->compact_on) return 0;
+  IlqrArgs<T> a = make_ilqr_args<T>(p, 1);
+  hipLaunchKernelGGL(ilqr_compact_kernel<T>, dim3(1), dim3(256), 0, p->h->stream, a, p->B, (int*)p->slot_of.p);
+  HIP_OK(hipGetLastError());
+  return 0;
+}
+
 // Continuous batching: P problems through the plan's B slots (ilqr_queue_refill_kernel)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -1942,7 +1958,7 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
     ~Guard() {
       (void)hipStreamSynchronize(p->h->stream);
       (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
-      p->queue_on = false; p->var_h = false; p->var_model = false; p->ev_cur = nullptr;
+      p->queue_on = false; p->var_h = false; p->var_model = false; p->compact_on = false; p->ev_cur = nullptr;
       (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
     }
   } guard{p};
@@ -1951,6 +1967,8 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   p->var_model = model_index != nullptr;
   p->queue_max_iter = max_iter;
   p->active_hint = B;
+  p->compact_on = ilqr_wants_compaction(p);
+  if (p->compact_on) HIP_OK(p->slot_of.reserve((size_t)(B + 1) * sizeof(int)));
   IlqrQueue<T> q;
   q.P = P; q.B = B; q.H = H; q.nx = nx; q.nu = nu;
   q.horizon = horizon ? (const int*)p->q_cost.p + P : nullptr; q.slot_h = (int*)p->slot_h.p;
@@ -1971,11 +1989,13 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
   int batch = 0, pending = -1;
   bool done = false;
   const size_t ev_first = p->ev_used / 5;
-  while (!done && it < bound) {
-    for (int k = 0; k < kPoll; ++k) {
+  int poll_now = kPoll;                      // (2 once every problem has been handed out and the grids follow the
+  while (!done && it < bound) {             //  count of slots with work, compact_on: the count is then 4 iterations old)
+    for (int k = 0; k < poll_now; ++k) {
       IlqrArgs<T> a = make_ilqr_args<T>(p, 1);
       hipLaunchKernelGGL(ilqr_queue_refill_kernel<T>, dim3(B), dim3(256), 0, h->stream, a, q);
       HIP_OK(hipGetLastError());
+      if (int rc = ilqr_compact<T>(p)) return rc;
       if (p->timing) {
         if (p->ev_used + 5 > p->ev.size())
           for (int i = 0; i < 5; ++i) {
@@ -1991,7 +2011,7 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
       p->ev_cur = nullptr;
       if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
     }
-    it += kPoll;
+    it += poll_now;
     const int slot = batch & 1;
     int* ph = p->poll_host + (size_t)slot * npoll;
     HIP_OK(hipMemcpyAsync(ph, (const int*)p->flags.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -2006,6 +2026,7 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
       p->ls_rb_now = ls_rb_from_poll(pp, pp + B, B);
       // while the queue still holds problems every slot is (about to be) busy
       p->active_hint = pp[2 * B] < P ? B : std::max(live, 1);
+      if (p->compact_on && pp[2 * B] >= P) poll_now = 2;
       if (pp[2 * B + 1] >= P) done = true;
     }
     pending = batch++;
@@ -2167,7 +2188,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
     ~Guard() {
       (void)hipStreamSynchronize(p->h->stream);
       (void)hipMemcpy(p->d_cost_idx.p, p->cost_idx.data(), (size_t)p->B * sizeof(int), hipMemcpyHostToDevice);
-      p->queue_on = false; p->var_h = false; p->var_model = false; p->ev_cur = nullptr;
+      p->queue_on = false; p->var_h = false; p->var_model = false; p->compact_on = false; p->ev_cur = nullptr;
       (void)hipHostFree(p->poll_host); p->poll_host = nullptr;
     }
   } guard{p};
@@ -2177,6 +2198,8 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   p->queue_max_iter = max_iter;
   p->active_hint = B;
   p->ls_rb_now = 1;
+  p->compact_on = ilqr_wants_compaction(p);
+  if (p->compact_on) HIP_OK(p->slot_of.reserve((size_t)(B + 1) * sizeof(int)));
   IlqrChains<T> q;
   q.C = C; q.B = B; q.H = H; q.nx = nx; q.nu = nu; q.n_steps = n_steps; q.max_iter = max_iter;
   q.ctl = (int*)p->q_ctl.p;
@@ -2203,6 +2226,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
       if (int rc = surrogate_step<T>(h, sur, q.stage_x, q.stage_u, q.stage_next, B)) return rc;
       hipLaunchKernelGGL(ilqr_chain_post_kernel<T>, dim3(B), dim3(256), 0, h->stream, a, q);
       HIP_OK(hipGetLastError());
+      if (int rc = ilqr_compact<T>(p)) return rc;
       int rc = ilqr_launch_iter<T>(p, 1);
       if (rc == 0) rc = ilqr_refresh_jacobians<T>(p);
       if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }

@@ -456,6 +456,8 @@ struct ampc_ilqr_plan {
   // descriptors; a queue problem / episode names its entry (ampc_ilqr_*_var), the slot carries it
   std::vector<ampc_handle*> models;
   DevBuf mlp_tab, slot_model;   // [n_models] byte offsets of the models' buffers, [B] ints
+  DevBuf slot_of;               // [B] workgroup -> slot, the slots with work first (queues with more slots than CUs)
+  bool compact_on = false;      //   ... in use by the running queue
   bool var_model = false;       // the running queue / closed loop uses per-slot models
   DevBuf q_x0, q_u, q_cost, q_states, q_ctrls, q_Ks, q_ks, q_obj, q_flags;
   DevBuf vj;                    // wide linear models: the sweep's VJ scratch [B][nxp][ldj] (ilqr_wide.hpp)
@@ -491,6 +493,7 @@ template <typename T> static IlqrArgs<T> make_ilqr_args(ampc_ilqr_plan* p, int m
   a.ric = (T*)p->ric.p;
   if (p->queue_on) {
     a.slot_mode = (int*)p->q_ctl.p + 2 + p->B;
+    a.slot_of = p->compact_on ? (const int*)p->slot_of.p : nullptr;
     a.max_iter = p->queue_max_iter;
     if (p->var_h) a.slot_h = (const int*)p->slot_h.p;
     if (p->var_model) { a.model_delta = (const long long*)p->mlp_tab.p; a.slot_model = (const int*)p->slot_model.p; }
@@ -547,6 +550,11 @@ template <typename T> int pred_impl(ampc_handle* h, const double* states, const 
                                     double* jx, double* ju, int n);
 template <typename T> int surrogate_step(ampc_handle* h, ampc_handle* sur, const void* x, const void* u,
                                          void* x_next, int B);
+// Workgroups (slots) a per-slot launch of the running iteration needs: with the slots that have work listed first
+// (compact_on) and an upper bound of their number known from the polls, the grid ends there.
+inline int ilqr_grid_slots(const ampc_ilqr_plan* p) {
+  return (p->compact_on && p->active_hint > 0 && p->active_hint < p->B) ? p->active_hint : p->B;
+}
 template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p);
 template <typename T> int mppi_solve_impl(ampc_mppi_plan* p);
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode);

@@ -59,6 +59,8 @@ template <typename T> struct IlqrArgs {
                                  // a plan; every array keeps the stride of H), nullptr: H for every problem
   int* slot_mode;                // queue mode (ampc_ilqr_solve_queue): per slot 0 = roll out the guess of the
                                  // problem just loaded, 1 = iterate; nullptr: `mode` for every problem
+  const int* slot_of;            // queue with more slots than CUs: workgroup -> slot, the slots with work FIRST
+                                 // (ilqr_compact_kernel, rebuilt every iteration); nullptr: workgroup b = slot b
   int term_goal;                 // 0: terminal gradient (F+F')x_N as the reference computes it
                                  //    (cost.py:195, goal ignored); 1: (F+F')(x_N - goal)
   T dt, u_threshold, ls_cost_threshold;
@@ -212,13 +214,23 @@ __device__ __attribute__((noinline)) int quu_solve(const T* __restrict__ Qt, con
 // it needs none of the MLP tile's registers or LDS, so it is compiled once per precision, keeps
 // the Quu solve in registers without spilling, and leaves K_t, k_t (global) and the expected-
 // reduction sums `ric[p] = {lin, quad, |k|, singular}` for the line-search kernel.
+// The slot a per-slot workgroup works on.  With more slots than CUs (a finite batch admitted at once: no drain)
+// the slots that still have work are scattered over the grid: their workgroups -- each the size of a CU in the
+// line search -- would land on the XCDs unevenly (workgroup b goes to XCD b % 8) and queue behind each other
+// while other CUs idle, and every launch would cost what the full grid costs.  args.slot_of lists the slots with
+// work first, in slot order, then the idle ones (whose workgroups exit at once, as before).
+template <typename T> __device__ __forceinline__ int ilqr_slot(const IlqrArgs<T>& args) {
+  const int b = blockIdx.x;
+  return args.slot_of ? __builtin_amdgcn_readfirstlane(args.slot_of[b]) : b;
+}
+
 template <typename T, bool WIDE = false, typename SH = DynShape>   // WIDE: model states above 32 (longer register staging)
 __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Wr = reinterpret_cast<T*>(smem_raw);
   constexpr int NTHR = kRicThreads;
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
-  const int tid = threadIdx.x, p = blockIdx.x;
+  const int tid = threadIdx.x, p = ilqr_slot(args);
   const int nx = mlp.nx, nu = mlp.nu, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
   const int HS = args.H, H = args.slot_h ? args.slot_h[p] : HS;      // array stride, this slot's horizon
   if (args.active[p] == 0) return;
@@ -565,7 +577,7 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
   constexpr int KX = 8, KD = 2 * ((NU + 3) / 4);        // k-steps over the state / the stacked controls
   constexpr int nu = NU, nu4 = (NU + 3) / 4 * 4;
   const MlpDev<T> mlp = SH::template fold<T>(args.mlp);
-  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, p = ilqr_slot(args), lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
   const int nx = mlp.nx, n = nx + nu, no = SH::kStatic ? SH::no : args.obs_dim;
@@ -850,14 +862,14 @@ __global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const Il
 // models (65..128 states), the K-tiled step of linear_kernels.hpp on the 16 candidate rows.
 template <typename T, int NT, int W, int DYN = 0, typename SH = DynShape, bool WIDE = false>
 __global__ __launch_bounds__(64 * W) void ilqr_iter_kernel(const IlqrArgs<T> args) {
-  const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
+  const int mode = args.slot_mode ? args.slot_mode[ilqr_slot(args)] : args.mode;   // (queue: per slot)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
   // nothing resident: the kernel is launched once per iteration and runs only H steps, so filling
   // resident fragments does not pay (measured with a static shape: 0.74 ms resident vs 0.58 ms)
   using Net = TileNet<T, NT, 1, W, false, 2, SH, WIDE>;
   constexpr int M = 16, NTHR = 64 * W, TPS = NTHR / M;
-  const int tid = threadIdx.x, p = blockIdx.x;
+  const int tid = threadIdx.x, p = ilqr_slot(args);
   const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] {               // (per-slot models: mlp_tile.hpp)
     return model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0); });
   const TileLds L = SH::template fold_lds<T, M, W>(args.lds);
@@ -1144,6 +1156,33 @@ template <typename T> __device__ __forceinline__ bool ilqr_slot_started(const Il
   __syncthreads();                                     // (every thread has read the mode before it changes)
   if (tid == 0) args.slot_mode[p] = 1;
   return true;
+}
+
+// slot_of for the iteration being queued (one workgroup, after the refill / chain kernels): slots that have work --
+// solving, or loaded and about to roll out their guess -- first and in slot order, the idle ones behind them.
+template <typename T>
+__global__ __launch_bounds__(256) void ilqr_compact_kernel(const IlqrArgs<T> args, int B, int* __restrict__ slot_of) {
+  __shared__ int cnt[256];
+  __shared__ int total_s;
+  const int tid = threadIdx.x;
+  const int per = (B + 255) / 256, lo = tid * per < B ? tid * per : B, hi = lo + per < B ? lo + per : B;
+  auto has_work = [&](int p) { return args.active[p] != 0 || args.slot_mode[p] == 0; };
+  int c = 0;
+  for (int p = lo; p < hi; ++p) c += has_work(p) ? 1 : 0;
+  cnt[tid] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int v = cnt[i]; cnt[i] = run; run += v; }
+    total_s = run;
+  }
+  __syncthreads();
+  if (tid == 0) slot_of[B] = total_s;                   // (read by the refresh kernels: row groups past it have no live row)
+  int w = cnt[tid], d = total_s + (lo - cnt[tid]);      // next position among the slots with work / the idle ones
+  for (int p = lo; p < hi; ++p) {
+    if (has_work(p)) slot_of[w++] = p;
+    else slot_of[d++] = p;
+  }
 }
 
 template <typename T>

@@ -125,10 +125,11 @@ __host__ __device__ constexpr Ls4Lds make_ls4_lds(int nu, int k1p, int nxp, int 
 
 template <int NT, bool RES, typename SH = DynShape>
 __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<double> args) {
-  const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
+  const int slot = ilqr_slot(args);
+  const int mode = args.slot_mode ? args.slot_mode[slot] : args.mode;   // (queue: per slot)
   if (mode == 0 && blockIdx.y > 0) return;       // (side-by-side passes: a slot rolling out its guess has one)
   // second launch of a split line search (below): only problems the first launch left undecided
-  if (args.ls_split == 2 && args.ls_pass[blockIdx.x] == 0) return;
+  if (args.ls_split == 2 && args.ls_pass[slot] == 0) return;
   using T = double;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* lds = reinterpret_cast<T*>(smem_raw);
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_ls4_kernel(const IlqrArgs<dou
   static_assert(NGH % NB == 0 && D < NGH, "ring phase must repeat per layer");
   constexpr bool STREAM = !RES || SPR > 0;
   constexpr bool W0LDS = ls4_w0_lds(NT);
-  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, p = slot, lane = tid & 63;
   const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] {               // (per-slot models: mlp_tile.hpp)
     return model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0); });
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

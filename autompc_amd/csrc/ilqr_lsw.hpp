@@ -51,7 +51,8 @@ template <typename T> __device__ __forceinline__ void st_buf(T* base, unsigned v
 
 template <int NT, bool RES, typename SH, int RB>
 __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<double> args) {
-  const int mode = args.slot_mode ? args.slot_mode[blockIdx.x] : args.mode;   // (queue: per slot)
+  const int slot = ilqr_slot(args);
+  const int mode = args.slot_mode ? args.slot_mode[slot] : args.mode;   // (queue: per slot)
   using T = double;
   // (phase_time build: this wave's marks -- 0..7 one time step, 8 kernel entry, 9 / 10 around the time loop
   //  of pass 0, 11 objectives done)
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(64 * kLs4W) void ilqr_lsw_kernel(const IlqrArgs<dou
   static_assert(!RES || G < PPR, "the rolling ring needs a k-step behind the last streamed one");
   constexpr bool STREAM = !RES || SPR > 0;
   constexpr bool W0LDS = ls4_w0_lds(NT);
-  const int tid = threadIdx.x, p = blockIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, p = slot, lane = tid & 63;
   const MlpDev<T> mlp = plan_model<SH, T>(args.mlp, [&] {               // (per-slot models: mlp_tile.hpp)
     return model_delta_of(args.model_delta, args.model_delta ? args.slot_model[p] : 0); });
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

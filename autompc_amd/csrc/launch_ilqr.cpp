@@ -13,6 +13,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
 #endif
   ampc_handle* h = p->h;
   IlqrArgs<T> a = make_ilqr_args<T>(p, mode);
+  const int Bg = ilqr_grid_slots(p);        // (slots with work first: the grid ends where they end)
   hipEvent_t* e = mode == 1 ? p->ev_cur : nullptr;
   if (e) HIP_OK(hipEventRecord(e[0], h->stream));
 #ifndef AMPC_JIT_PLUGIN
@@ -21,7 +22,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
       const size_t wb = (size_t)make_wide_lds(h->nx, h->nu, h->obs_dim).total * sizeof(T);
 #define AMPC_WIDE_NU(NUV)                                                                          \
       case NUV: { auto rk = ilqr_riccati_wide_kernel<T, NUV>; HIP_OK(allow_lds(rk, wb));              \
-        hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), wb, h->stream, a); } break;
+        hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), wb, h->stream, a); } break;
       switch (h->nu) {
         AMPC_WIDE_NU(1) AMPC_WIDE_NU(2) AMPC_WIDE_NU(3) AMPC_WIDE_NU(4) AMPC_WIDE_NU(6) AMPC_WIDE_NU(8)
         default: return fail("internal: control dimension of a wide linear iLQR plan");
@@ -32,7 +33,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (e) HIP_OK(hipEventRecord(e[1], h->stream));
     auto k = ilqr_iter_kernel<T, 1, 8, 2>;
     HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * 8), p->lds_bytes, h->stream, a);
+    hipLaunchKernelGGL(k, dim3(Bg), dim3(64 * 8), p->lds_bytes, h->stream, a);
     HIP_OK(hipGetLastError());
     if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
@@ -47,7 +48,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     const bool mfma_sweep = p->use_mfma_sweep != 0;
 #define AMPC_RIC_NU(NUV, SHT)                                                                        \
     case NUV: { auto rk = ilqr_riccati_mfma_kernel<T, NUV, SHT>; HIP_OK(allow_lds(rk, mb));          \
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; break; }
+      hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), mb, h->stream, a); done = true; break; }
     bool done = false;
     // (the control dimensions the latency-optimised sweep is validated for; a shape-specialised
     //  build takes the same decision as the run-time-shape one, so both give identical results)
@@ -55,7 +56,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (mfma_sweep && h->nx <= 32 && nu_ok) {
       if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto rk = ilqr_riccati_mfma_kernel<T, SH::nu, SH>; HIP_OK(allow_lds(rk, mb));   \
-        hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), mb, h->stream, a); done = true; }
+        hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), mb, h->stream, a); done = true; }
         AMPC_STATIC_DISPATCH(p->static_shape, 0);    // (the sweep never evaluates the activation)
 #undef AMPC_SD_BODY
       } else {
@@ -72,7 +73,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     if (done) {
     } else if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto rk = ilqr_riccati_kernel<T, false, SH>; HIP_OK(allow_lds(rk, rb));   \
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a); }
+      hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), rb, h->stream, a); }
       AMPC_STATIC_DISPATCH(p->static_shape, 0);
 #undef AMPC_SD_BODY
     }
@@ -82,11 +83,11 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     else if (h->nx > 32) {
       auto rk = ilqr_riccati_kernel<T, true>;
       HIP_OK(allow_lds(rk, rb));
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+      hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), rb, h->stream, a);
     } else {
       auto rk = ilqr_riccati_kernel<T, false>;
       HIP_OK(allow_lds(rk, rb));
-      hipLaunchKernelGGL(rk, dim3(p->B), dim3(kRicThreads), rb, h->stream, a);
+      hipLaunchKernelGGL(rk, dim3(Bg), dim3(kRicThreads), rb, h->stream, a);
     }
 #endif
     HIP_OK(hipGetLastError());
@@ -96,7 +97,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   if (h->has_sindy) {
     auto k = ilqr_iter_kernel<T, 1, 4, 1>;
     HIP_OK(allow_lds(k, p->lds_bytes));
-    hipLaunchKernelGGL(k, dim3(p->B), dim3(256), p->lds_bytes, h->stream, a);
+    hipLaunchKernelGGL(k, dim3(Bg), dim3(256), p->lds_bytes, h->stream, a);
     HIP_OK(hipGetLastError());
     if (e) HIP_OK(hipEventRecord(e[2], h->stream));
     return 0;
@@ -172,11 +173,11 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
         return 0;
       };
       a.ls_split = split ? 1 : 0;
-      if (int rc = launch_ls(dim3(p->B, a.par_passes ? npass : 1), a)) return rc;
+      if (int rc = launch_ls(dim3(Bg, a.par_passes ? npass : 1), a)) return rc;
       if (split) {
         HIP_OK(hipGetLastError());
         a.ls_split = 2;
-        if (int rc = launch_ls(dim3(p->B, npass - 1), a)) return rc;
+        if (int rc = launch_ls(dim3(Bg, npass - 1), a)) return rc;
       }
       HIP_OK(hipGetLastError());
       if (e) HIP_OK(hipEventRecord(e[2], h->stream));
@@ -185,7 +186,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
   }
   if (p->static_shape >= 0) {
 #define AMPC_SD_BODY { auto k = ilqr_iter_kernel<T, NT, W, 0, SH>; HIP_OK(allow_lds(k, p->lds_bytes));   \
-      hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a); }
+      hipLaunchKernelGGL(k, dim3(Bg), dim3(64 * W), p->lds_bytes, h->stream, a); }
     AMPC_STATIC_DISPATCH(p->static_shape, h->act == 0);
 #undef AMPC_SD_BODY
   } else {
@@ -195,7 +196,7 @@ template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
     AMPC_DISPATCH(h, 1, {
       auto k = ilqr_iter_kernel<T, NT, W, 0, DynShape, WD>;
       HIP_OK(allow_lds(k, p->lds_bytes));
-      hipLaunchKernelGGL(k, dim3(p->B), dim3(64 * W), p->lds_bytes, h->stream, a);
+      hipLaunchKernelGGL(k, dim3(Bg), dim3(64 * W), p->lds_bytes, h->stream, a);
     });
 #endif
   }

@@ -84,11 +84,12 @@ template <typename T> int ilqr_refresh_jacobians(ampc_ilqr_plan* p) {
   // 16-row tiles, so that a tile's rows share one model
   const bool per_slot = p->queue_on && p->var_model;
   const int gpad = per_slot ? round_up(p->H, 16) : 0;
-  const int rows = p->B * (per_slot ? gpad : p->H);
+  const int rows = ilqr_grid_slots(p) * (per_slot ? gpad : p->H);
   const int n_pad = round_up(rows, 64);
   const RowMap rm{p->H, (long long)(p->H + 1) * nx, (long long)p->H * nu, (const int*)p->flags.p + 4 * p->B,
                   (p->queue_on && p->var_h) ? (const int*)p->slot_h.p : nullptr,
-                  gpad, per_slot ? (const int*)p->slot_model.p : nullptr, per_slot ? (const long long*)p->mlp_tab.p : nullptr};
+                  gpad, per_slot ? (const int*)p->slot_model.p : nullptr, per_slot ? (const long long*)p->mlp_tab.p : nullptr,
+                  p->B, (p->queue_on && p->compact_on) ? (const int*)p->slot_of.p : nullptr};
   if (per_slot) HIP_OK(p->dz.reserve((size_t)m.n_hidden * n_pad * m.hpad * sizeof(T)));
 #ifndef AMPC_JIT_PLUGIN
   if (h->has_lin) {               // a linear model's Jacobians are constant ([A | B], LinDev::jp): nothing to refresh

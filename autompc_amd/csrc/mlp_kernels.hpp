@@ -33,23 +33,33 @@ struct RowMap {
   int grp_pad;
   const int* grp_model;
   const long long* model_delta;
-  __device__ __forceinline__ bool plain() const { return mask == nullptr && glen == nullptr && grp_pad == 0; }
+  int n_groups;          // groups (slots) of the plan: perm has n_groups + 1 entries
+  const int* perm;       // group g of the row index space is slot perm[g] (iLQR queue with more slots than CUs: the
+                         // slots with work first, ilqr_compact_kernel -- tiles without a live row bunch at the end
+                         // of the grid instead of being interleaved with the live ones); nullptr: identity
+  // (perm[number of groups] = how many of them have work: a tile that starts past those has no live row)
+  __device__ __forceinline__ bool past_work(int first_row, int n_groups) const {
+    return perm != nullptr && first_row / gp() >= perm[n_groups];
+  }
+  __device__ __forceinline__ bool plain() const { return mask == nullptr && glen == nullptr && grp_pad == 0 && perm == nullptr; }
   __device__ __forceinline__ int gp() const { return grp_pad > 0 ? grp_pad : grp; }
-  __device__ __forceinline__ int group(int v) const { return v / gp(); }
+  __device__ __forceinline__ int slot(int g) const { return perm != nullptr ? perm[g] : g; }
+  __device__ __forceinline__ int group(int v) const { return slot(v / gp()); }      // the slot row v belongs to
   __device__ __forceinline__ int step(int v) const { return v % gp(); }
   __device__ __forceinline__ long long out_row(int v) const { return (long long)group(v) * grp + step(v); }
   __device__ __forceinline__ bool live(int v) const {
-    const int g = group(v), t = v - g * gp();
+    const int t = v % gp(), g = group(v);
     return t < grp && (mask == nullptr || mask[g] != 0) && (glen == nullptr || t < glen[g]);
   }
   // some row of [first, last] is live
   __device__ __forceinline__ bool any_live(int first, int last) const {
     const int G = gp();
-    for (int g = first / G; g <= last / G; ++g) {
+    for (int vg = first / G; vg <= last / G; ++vg) {
+      const int g = slot(vg);
       if (mask != nullptr && mask[g] == 0) continue;
       const int len = glen != nullptr ? (glen[g] < grp ? glen[g] : grp) : grp;
-      const int lo = first > g * G ? first : g * G;
-      const int hi = g * G + len - 1;
+      const int lo = first > vg * G ? first : vg * G;
+      const int hi = vg * G + len - 1;
       if (lo <= (hi < last ? hi : last)) return true;
     }
     return false;
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(64 * W) void mlp_forward_kernel(const MlpDev<T> mlp
   const int tid = threadIdx.x, nx = mlp.nx, nu = mlp.nu;
   T* xu = lds + L.xu;
   if (!rm.plain() && first < n) {          // (iLQR refresh) every row of this tile is masked out
-    if (!rm.any_live(first, first + M - 1 < n ? first + M - 1 : n - 1)) return;
+    if (rm.past_work(first, rm.n_groups) || !rm.any_live(first, first + M - 1 < n ? first + M - 1 : n - 1)) return;
   }
   Net net;
   net.init(mlp);
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(64 * W, (MT == 1 && W == 8) ? 6 : 1) void mlp_jacob
   const T* wout_plain = reinterpret_cast<const T*>(reinterpret_cast<const char*>(wout_plain_in) + mlp.delta);
   const size_t lstride = (size_t)n_pad * hpad;
   if (!rm.plain()) {                   // every row this tile touches is masked out: nothing to refresh
-    if (s0 >= n || !rm.any_live(s0, s0 + M - 1 < n ? s0 + M - 1 : n - 1)) return;
+    if (s0 >= n || rm.past_work(s0, rm.n_groups) || !rm.any_live(s0, s0 + M - 1 < n ? s0 + M - 1 : n - 1)) return;
   }
 
   // G_L[s][k] = W_out'[i][k] * d_L[s][k]

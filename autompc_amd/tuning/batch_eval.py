@@ -566,7 +566,7 @@ class IlqrCandidateEvaluator:
     on the batch it is in or on the rank that evaluates it."""
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0, device_resident=True,
-                 max_slots=256, max_threads=32, one_plan=True):
+                 max_slots=1024, max_threads=32, one_plan=True):
         """device_resident: episodes of known length run entirely on the device (ampc_ilqr_closed_loop_var;
         a user termination condition is asked on the host, one queue of solves per control step);
         max_slots: problems solved side by side (one workgroup each);

@@ -378,7 +378,9 @@ def secondary_workload(args, R, emit=True):
     system, task, model, spec = make_workload("c3", precision=args.precision, device=R.local_rank)
     nx, nu = spec["nx"], spec["nu"]
     world, rank = R.world, R.rank
-    B = args.batch if args.batch > 0 else (64 if args.workload == "c5" else 256)
+    # c4: --batch B = B slots with 4 B problems streamed through them (continuous batching); default: 1024 problems
+    # admitted at once (1024 slots, no drain -- round 5: the kernels of an iteration take the slots with work first)
+    B = args.batch if args.batch > 0 else (64 if args.workload == "c5" else 1024)
     mlp_macs = sum(a * b for a, b in zip([nx + nu] + spec["hidden"], spec["hidden"] + [nx]))
     extra = {}
     steps, warm = max(1, min(args.steps, 10)), max(1, min(args.warmup, 2))
@@ -392,18 +394,18 @@ def secondary_workload(args, R, emit=True):
         # batching (ampc_ilqr_solve_queue) -- a slot whose problem has converged takes the next one at
         # the following iteration boundary, on the device.  One step = P complete solves.
         Q, Rm, F = task.get_cost().get_cost_matrices()
-        P = 4 * B
+        P = 4 * B if args.batch > 0 else B
         rng = np.random.default_rng(rank)
         x0 = rng.uniform(-0.1, 0.1, size=(max(P, 4096), nx))
         stream = R.torch.cuda.current_stream().cuda_stream
 
-        def make(bounded):
+        def make(bounded, slots=0):
             hh = _lib.Handle(R.local_rank, args.precision, stream=stream)
             model.stage_into(hh)
             hh.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
             if bounded:
                 hh.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
-            return hh, _lib.IlqrPlan(hh, B, 50, system.dt, clip_to_bounds=bounded)
+            return hh, _lib.IlqrPlan(hh, slots or B, 50, system.dt, clip_to_bounds=bounded)
         h, plan = make(True)
         last = {}
 
@@ -413,7 +415,9 @@ def secondary_workload(args, R, emit=True):
                 last.setdefault("rows", []).append(plan.stats()["candidate_rows"])
                 last.setdefault("launched", []).append(plan.stats()["iterations"])
         label = ("c4: HalfCheetah MLP 2x256, iLQR horizon 50, controls clipped to +-0.25 (converging set): %d "
-                 "independent problems per step per GPU streamed through %d slots (continuous batching)" % (P, B))
+                 "independent problems per step per GPU " % P +
+                 ("streamed through %d slots (continuous batching)" % B if P > B else
+                  "admitted at once (%d slots; a slot is idle once its problem has converged)" % B))
         unit_per_step = P
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
         elapsed, n_pre = timed_loop(R, step, steps, warm, min(args.preheat, 0.3),
@@ -430,6 +434,23 @@ def secondary_workload(args, R, emit=True):
                 o = fn()
                 R.sync_all()
                 return o, R.max_over_ranks(time.perf_counter() - t0)
+            B0 = 256                       # one slot per CU: the configuration of rounds 3-4
+            if B != B0:
+                h0, plan0 = make(True, B0)
+                o, e = once(lambda: plan0.solve_queue(x0[:P], max_iter=50, gains=False, trajectories=False))
+                sub["slots_256"] = {"workload": "the same %d problems streamed through %d slots (rounds 3-4)" % (P, B0),
+                                    "value": world * P / e, "unit": "solves/s", "ms": 1e3 * e,
+                                    "iterations_launched": plan0.stats()["iterations"]}
+            else:
+                h0, plan0 = h, plan
+            if B < 4096 and not args.batch:
+                h4, plan4 = make(True, 4096)
+                o, e = once(lambda: plan4.solve_queue(x0[:4096], max_iter=50, gains=False, trajectories=False))
+                sub["all_at_once_4096"] = {"workload": "4096 problems admitted at once (4096 slots)",
+                                           "value": world * 4096 / e, "unit": "solves/s", "ms": 1e3 * e,
+                                           "iterations_launched": plan4.stats()["iterations"]}
+                plan4.close()
+                h4.close()
             # a long stream: the drain of the last (non-converging, 50-iteration) problems amortised
             o, e = once(lambda: plan.solve_queue(x0[:4096], max_iter=50, gains=False, trajectories=False))
             sub["stream_4096"] = {"workload": "the same set, 4096 problems through %d slots" % B,
@@ -469,17 +490,20 @@ def secondary_workload(args, R, emit=True):
             # its slowest problem) -- what round 3 measured
 
             def batches():
-                res = [plan.solve(x0[lo:lo + B], np.zeros((B, 50, nu)), max_iter=50) for lo in range(0, P, B)]
+                res = [plan0.solve(x0[lo:lo + B0], np.zeros((B0, 50, nu)), max_iter=50) for lo in range(0, P, B0)]
                 return {k: np.concatenate([r[k] for r in res]) for k in ("converged", "iters")}
             o, e = once(batches)
-            sub["lockstep_batches"] = {"workload": "the same %d problems as %d lock-step batches of %d" % (P, P // B, B),
+            sub["lockstep_batches"] = {"workload": "the same %d problems as %d lock-step batches of %d" % (P, P // B0, B0),
                                        "value": world * P / e, "unit": "solves/s", "ms": 1e3 * e,
                                        "converged_fraction": float(o["converged"].mean())}
+            if plan0 is not plan:
+                plan0.close()
+                h0.close()
             # the unbounded problems of rounds 1-3: none converges within the reference's 50 iterations
-            hu, pu = make(False)
-            o, e = once(lambda: pu.solve(x0[:B], np.zeros((B, 50, nu)), max_iter=50))
-            sub["capped_variant"] = {"workload": "%d UNBOUNDED problems (never converge: 50-iteration capped solves)" % B,
-                                     "value": world * B / e, "unit": "solves/s", "ms": 1e3 * e,
+            hu, pu = make(False, B0)
+            o, e = once(lambda: pu.solve(x0[:B0], np.zeros((B0, 50, nu)), max_iter=50))
+            sub["capped_variant"] = {"workload": "%d UNBOUNDED problems (never converge: 50-iteration capped solves)" % B0,
+                                     "value": world * B0 / e, "unit": "solves/s", "ms": 1e3 * e,
                                      "converged_fraction": float(o["converged"].mean()),
                                      "mean_iterations_per_solve": float(o["iters"].mean())}
             pu.close()

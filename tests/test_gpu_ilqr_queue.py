@@ -260,3 +260,37 @@ def test_evaluator_one_plan_equals_horizon_groups():
         got = IlqrCandidateEvaluator(system, task, m, **kw).evaluate(cands, return_trajectories=True)
         for a, b in zip(got, ref):
             np.testing.assert_array_equal(a, b, err_msg=str(kw))
+
+
+@pytest.mark.parametrize("case", [
+    # nx, nu, hidden, act, H, B, P, bounds, max_iter, horizons
+    (17, 6, [256, 256], "relu", 20, 300, 300, (-0.25, 0.25), 14, False),   # all admitted at once, twelve-row search
+    (5, 2, [64, 48], "tanh", 12, 280, 700, None, 20, True),                # refills + per-problem horizons
+])
+def test_more_slots_than_cus_take_the_slots_with_work_first(case):
+    """A plan with more slots than the GPU has CUs (round 5): every kernel of an iteration takes its slot from
+    the iteration's live-first order (ilqr_compact_kernel) and the grids shrink with the polled count of slots
+    that still have work -- each problem still gets bit for bit what a one-problem solve gives it."""
+    from autompc_amd import _lib
+    nx, nu, hidden, act, H, B, P, bounds, max_iter, var_h = case
+    C = 3
+    p, h, _ = _setup(nx, nu, hidden, act, C, seed=nx + H, bounds=bounds)
+    rng = np.random.default_rng(P)
+    x0 = rng.uniform(-0.2, 0.2, size=(P, nx))
+    ci = rng.integers(0, C, size=P).astype(np.int32)
+    hz = rng.integers(3, H + 1, size=P).astype(np.int32) if var_h else None
+    plan = _lib.IlqrPlan(h, B, H, 0.05, cost_index=np.zeros(B, dtype=np.int32), clip_to_bounds=bounds is not None)
+    got = plan.solve_queue(x0, None, ci, max_iter=max_iter, horizon=hz)
+    assert len(set(got["iters"].tolist())) > 3          # problems finish at different times: the live set thins out
+    for j in rng.choice(P, size=24, replace=False):
+        Hj = int(hz[j]) if var_h else H
+        one = _lib.IlqrPlan(h, 1, Hj, 0.05, cost_index=ci[j:j + 1], clip_to_bounds=bounds is not None)
+        ref = one.solve(x0[j], np.zeros((Hj, nu)), max_iter=max_iter)
+        one.close()
+        for k in ("converged", "iters", "status", "objective"):
+            np.testing.assert_array_equal(got[k][j], ref[k][0], err_msg="problem %d, %s" % (j, k))
+        np.testing.assert_array_equal(got["states"][j, :Hj + 1], ref["states"][0])
+        for k in ("ctrls", "Ks", "ks"):
+            np.testing.assert_array_equal(got[k][j, :Hj], ref[k][0], err_msg="problem %d, %s" % (j, k))
+    plan.close()
+    h.close()

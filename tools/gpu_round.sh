@@ -17,6 +17,7 @@ b c3_f64_batch8 --batch 8 --steps 50 --warmup 5 --no-cpu-baseline
 b arx_f64 --workload arx --cpu-seconds 10
 b c1_sindy_f64 --workload c1 --cpu-seconds 10
 b c4_ilqr_f64 --workload c4 --steps 5 --warmup 1
+b c4_ilqr_f64_b256 --workload c4 --batch 256 --steps 5 --warmup 1 --no-cpu-baseline
 b c4_ilqr_f64_b512 --workload c4 --batch 512 --steps 2 --warmup 1 --no-cpu-baseline
 b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 # launcher plumbing: `bench.py --gpus 2` starts its own two ranks; both mapped onto this box's one
@@ -40,7 +41,7 @@ timeout 120 python tools/validate_glibc_log.py > $OUT/glibc_log.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f64_b1 --steps 600 --warmup 20 > $OUT/profile_c3.log 2>&1
 bash tools/gpu_profile.sh $TAG c3_f32_b1 --precision f32 --steps 600 --warmup 20 > $OUT/profile_c3f32.log 2>&1
 bash tools/gpu_profile.sh $TAG c2_f64_b1 --workload c2 --steps 2000 --warmup 50 > $OUT/profile_c2.log 2>&1
-bash tools/gpu_profile.sh $TAG c4_f64_b256 --workload c4 --steps 2 --warmup 1 > $OUT/profile_c4.log 2>&1
+bash tools/gpu_profile.sh $TAG c4_f64_b256 --workload c4 --batch 256 --steps 2 --warmup 1 > $OUT/profile_c4.log 2>&1
 bash tools/gpu_profile.sh $TAG c5_f64_b64 --workload c5 --steps 1 --warmup 1 > $OUT/profile_c5.log 2>&1
 cat $OUT/pytest_gpu.log | tail -3; cat $OUT/smoke.log | tail -1
 python - <<PY
