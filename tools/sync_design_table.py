@@ -33,13 +33,13 @@ out.append("| c2 Pendulum MPPI 1024×30 (four-row kernel §4.1b; latency-bound) 
 out.append("| arx: MPPI 1024×30 on a 20-state ARX model (latency-bound) | f64 | %s | %.3f ms | %.1f | — |"%(th(ax['value']),ax['roofline']['kernel_ms'],ax['roofline']['achieved']))
 out.append("| c1 CartPole SINDy MPPI 256×20 (§4.5; latency-bound) | f64 | %s | %.3f ms | — | — |"%(th(c1['value']),c1['roofline']['kernel_ms']))
 k4=c4['roofline']
-def sub(rec, key):
+def subv(rec, key):
     return th(rec[key]['value']) if isinstance(rec.get(key), dict) else "—"
 
 
 out.append("| **c4** HalfCheetah iLQR H=50, converging set, %d problems %s | f64 | **%s** (the same problems streamed through 256 slots: %s; 4096 problems at once: %s; 4096 through %d slots: %s; lock-step batches of 256: %s) | %s %.3f ms per launch | %.1f (whole solve) | %.0f %% |"
            % (c4['problems_per_step'], "admitted at once (%d slots)" % c4['slots'] if c4['slots'] >= c4['problems_per_step'] else "through %d slots" % c4['slots'],
-              th(c4['value']), sub(c4, 'slots_256'), sub(c4, 'all_at_once_4096'), c4['slots'], sub(c4, 'stream_4096'), sub(c4, 'lockstep_batches'),
+              th(c4['value']), subv(c4, 'slots_256'), subv(c4, 'all_at_once_4096'), c4['slots'], subv(c4, 'stream_4096'), subv(c4, 'lockstep_batches'),
               k4['kernel'], k4['kernel_ms'], c4['algorithmic_tflops'], 100 * c4['algorithmic_tflops'] / 78.6))
 out.append("| c5 64 candidates × 200-row closed loop, scored on device | f64 | %s (MPPI solves) | rollout %.3f ms per control step | %.1f (whole closed loop) | %.1f %% |"%(th(c5['value']),c5['roofline']['kernel_ms'],c5['algorithmic_tflops'],100*c5['algorithmic_tflops']/78.6))
 ie=sub.get('ilqr_eval')
