@@ -2179,7 +2179,7 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   HIP_OK(hipMemsetAsync(p->states.p, 0, (size_t)B * (H + 1) * nx * e, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
   if (p->poll_host) { (void)hipHostFree(p->poll_host); p->poll_host = nullptr; }
-  const int npoll = 2 * B + 2;               // active[B], ls_need[B], the chains' two counters
+  const int npoll = 2 * B + 3;               // active[B], ls_need[B], the chains' two counters, slots with work
   HIP_OK(hipHostMalloc((void**)&p->poll_host, (size_t)2 * npoll * sizeof(int), hipHostMallocDefault));
   if (!p->poll_ev[0])
     for (int i = 0; i < 2; ++i) HIP_OK(hipEventCreateWithFlags(&p->poll_ev[i], hipEventDisableTiming));
@@ -2218,8 +2218,9 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
   long long it = 0;
   int batch = 0, pending = -1;
   bool done = false;
-  while (!done && it < bound) {
-    for (int k = 0; k < kPoll; ++k) {
+  int poll_now = kPoll;                      // (2 once every chain has been handed out: the grids follow the count of
+  while (!done && it < bound) {             //  slots whose chain is unfinished, compact_on)
+    for (int k = 0; k < poll_now; ++k) {
       IlqrArgs<T> a = make_ilqr_args<T>(p, 1);
       hipLaunchKernelGGL(ilqr_chain_pre_kernel<T>, dim3(B), dim3(64), 0, h->stream, a, q);
       HIP_OK(hipGetLastError());
@@ -2231,17 +2232,25 @@ static int ilqr_closed_loop_impl(ampc_ilqr_plan* p, ampc_handle* sur, int C, con
       if (rc == 0) rc = ilqr_refresh_jacobians<T>(p);
       if (rc) { (void)hipStreamSynchronize(h->stream); return rc; }
     }
-    it += kPoll;
+    it += poll_now;
     const int slot = batch & 1;
     int* ph = p->poll_host + (size_t)slot * npoll;
     HIP_OK(hipMemcpyAsync(ph, (const int*)p->flags.p + B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipMemcpyAsync(ph + B, (const int*)p->flags.p + 8 * B, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipMemcpyAsync(ph + 2 * B, p->q_ctl.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    if (p->compact_on)
+      HIP_OK(hipMemcpyAsync(ph + 2 * B + 2, (const int*)p->slot_of.p + B, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipEventRecord(p->poll_ev[slot], h->stream));
     if (pending >= 0) {
       const int* pp = p->poll_host + (size_t)(pending & 1) * npoll;
       HIP_OK(hipEventSynchronize(p->poll_ev[pending & 1]));
       p->ls_rb_now = ls_rb_from_poll(pp, pp + B, B);
+      // every chain handed out: the slots with work (an unfinished chain: solving, or its next control step just
+      // loaded -- counted by ilqr_compact_kernel) can only become fewer
+      if (p->compact_on && pp[2 * B] >= C) {
+        p->active_hint = std::min(B, std::max(pp[2 * B + 2], 1));
+        poll_now = 2;
+      }
       if (pp[2 * B + 1] >= C) done = true;
     }
     pending = batch++;
