@@ -597,8 +597,9 @@ class MppiPlan:
     def set_outputs(self, keep_eps_out=True):
         check(self.lib.ampc_mppi_plan_set_outputs(self._p, int(bool(keep_eps_out))))
 
-    def set_timing(self, enable=True):
-        check(self.lib.ampc_mppi_plan_set_timing(self._p, int(bool(enable))))
+    def set_timing(self, enable=True, every=1):
+        """Bracket the kernels of every `every`-th solve with HIP events (timing())."""
+        check(self.lib.ampc_mppi_plan_set_timing(self._p, max(1, int(every)) if enable else 0))
 
     def timing(self):
         r, u, n = c_double(), c_double(), c_int()
@@ -644,8 +645,10 @@ class IlqrPlan:
         except Exception:
             pass
 
-    def set_timing(self, enable=True):
-        check(self.lib.ampc_ilqr_plan_set_timing(self._p, int(bool(enable))))
+    def set_timing(self, enable=True, every=1):
+        """Bracket the kernels of an iteration with HIP events (timing()); every > 1: only every n-th iteration of a
+        queue (solve_queue)."""
+        check(self.lib.ampc_ilqr_plan_set_timing(self._p, max(1, int(every)) if enable else 0))
 
     def timing(self):
         ms = np.zeros(4)

@@ -1593,6 +1593,8 @@ extern "C" int ampc_mppi_plan_info(const ampc_mppi_plan* p, int* n_workgroups, i
 extern "C" int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable) {
   REQUIRE(p, "ampc_mppi_plan_set_timing: NULL plan");
   p->timing = enable != 0;
+  p->timing_stride = enable > 1 ? enable : 1;      // (enable = n > 1: every n-th solve is bracketed)
+  p->timing_count = 0;
   p->ev_used = 0;
   return 0;
 }
@@ -1725,6 +1727,7 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
 extern "C" int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable) {
   REQUIRE(p, "ampc_ilqr_plan_set_timing: NULL plan");
   p->timing = enable != 0;
+  p->timing_stride = enable > 1 ? enable : 1;      // (queue: enable = n > 1 brackets every n-th iteration)
   p->ev_used = 0;
   return 0;
 }
@@ -1996,7 +1999,7 @@ static int ilqr_solve_queue_impl(ampc_ilqr_plan* p, int P, const double* x0, con
       hipLaunchKernelGGL(ilqr_queue_refill_kernel<T>, dim3(B), dim3(256), 0, h->stream, a, q);
       HIP_OK(hipGetLastError());
       if (int rc = ilqr_compact<T>(p)) return rc;
-      if (p->timing) {
+      if (p->timing && (it + k) % p->timing_stride == 0) {
         if (p->ev_used + 5 > p->ev.size())
           for (int i = 0; i < 5; ++i) {
             hipEvent_t x;

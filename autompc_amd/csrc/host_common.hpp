@@ -354,6 +354,8 @@ struct ampc_mppi_plan {
   int lds_aseq = 0, lds_cost = 0;
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
   bool timing = false;
+  int timing_stride = 1;        // every n-th solve is bracketed by events (three event records cost ~11 us of a solve)
+  long long timing_count = 0;
   std::vector<hipEvent_t> ev;   // 3 per solve: before rollout, after rollout, after update
   size_t ev_used = 0;
 };
@@ -430,6 +432,7 @@ struct ampc_ilqr_plan {
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg):
   // events bracket the four launches of an iteration: sweep | line search | forward | Jacobians
   bool timing = false;
+  int timing_stride = 1;        // queue: every n-th iteration is bracketed (five event records cost ~15 us of an iteration)
   std::vector<hipEvent_t> ev;   // 5 per timed iteration
   size_t ev_used = 0;
   hipEvent_t* ev_cur = nullptr; // the running iteration's five events (null: not timed)

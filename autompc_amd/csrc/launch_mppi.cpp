@@ -17,7 +17,7 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
   ampc_handle* h = p->h;
   MppiArgs<T> a = make_args<T>(p);
   hipEvent_t* e = nullptr;
-  if (p->timing) {
+  if (p->timing && (p->timing_count++ % p->timing_stride) == 0) {
     if (p->ev_used + 3 > p->ev.size()) {
       for (int i = 0; i < 3; ++i) {
         hipEvent_t x;

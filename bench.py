@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
+EVENT_STRIDE = 8                             # kernel events around every 8th timed MPPI solve (roofline.kernel_ms)
 PROFILE_TAG = "r05"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
 
 
@@ -421,7 +422,7 @@ def secondary_workload(args, R, emit=True):
         unit_per_step = P
         metric, unit = "MPC solves/sec (iLQR, full compute_ilqr_default per solve)", "solves/s"
         elapsed, n_pre = timed_loop(R, step, steps, warm, min(args.preheat, 0.3),
-                                    before_timed=lambda: plan.set_timing(True))
+                                    before_timed=lambda: plan.set_timing(True))     # (every iteration: their work differs)
         kt = plan.timing()
         plan.set_timing(False)
         ob = last["out"]
@@ -597,7 +598,7 @@ def secondary_workload(args, R, emit=True):
                 roof = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                         "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                         "kernel": "mppi_rollout_kernel", "kernel_ms": kt["rollout_ms"],
-                        "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"],
+                        "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"], "event_stride": 1,
                         "algorithmic_flops_per_launch": flops,
                         "note": "one launch = one control step of all %d candidates of rank 0" % B}
     if rank == 0:
@@ -750,9 +751,10 @@ def main():
             if args.noise == "device":
                 plan.generate_eps(rank, i & 0xffffffff)
             plan.solve()
-        # HIP events (on the launch stream) only around the timed solves
+        # HIP events (on the launch stream) around the kernels of every EVENT_STRIDE-th timed solve: the three
+        # event records of a solve cost ~11 us on the stream (3.7 % of a c3 solve) -- instrumentation, not work
         elapsed, n_pre = timed_loop(R, step, steps, warmup, preheat_s,
-                                    before_timed=lambda: plan.set_timing(True))
+                                    before_timed=lambda: plan.set_timing(True, every=EVENT_STRIDE))
         kt = plan.timing()
         plan.set_timing(False)
         rates = [world * steps * batch / elapsed]
@@ -778,7 +780,7 @@ def main():
                              "traffic": None,
                              "kernel": "mppi_rollout4_kernel" if inf["samples_per_wg"] == 4 else "mppi_rollout_kernel",
                              "kernel_ms": k["rollout_ms"], "update_kernel_ms": k["update_ms"],
-                             "launches_timed": k["count"], "algorithmic_flops_per_launch": inf["flops"],
+                             "launches_timed": k["count"], "event_stride": EVENT_STRIDE, "algorithmic_flops_per_launch": inf["flops"],
                              "workgroups": inf["workgroups"], "samples_per_workgroup": inf["samples_per_wg"],
                              "note": "latency-bound: %d workgroups of %d samples, %d dependent steps"
                                      % (inf["workgroups"], inf["samples_per_wg"], sp["horizon"])}}
@@ -886,7 +888,7 @@ def main():
                          "traffic_source": traffic["source"] if traffic else None,
                          "kernel": "mppi_rollout4_kernel" if info["samples_per_wg"] == 4 else "mppi_rollout_kernel",
                          "kernel_ms": kt["rollout_ms"],
-                         "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"],
+                         "update_kernel_ms": kt["update_ms"], "launches_timed": kt["count"], "event_stride": EVENT_STRIDE,
                          "algorithmic_flops_per_launch": info["flops"],
                          "algorithmic_bytes_per_launch": info["bytes"],
                          "workgroups": info["workgroups"], "samples_per_workgroup": info["samples_per_wg"]},

@@ -270,7 +270,8 @@ int ampc_mppi_plan_set_outputs(ampc_mppi_plan* p, int keep_eps_out);
 /* Per-kernel timing for the roofline report: when enabled, every ampc_mppi_solve brackets the
  * rollout and update launches with HIP events on the handle's stream.  ampc_mppi_plan_timing
  * synchronises, returns the AVERAGE duration (ms) of each kernel over the solves since the last
- * call, and resets the counters. */
+ * call, and resets the counters.  enable = n > 1: only every n-th solve is bracketed (the three event records
+ * of a solve cost about 11 us on the stream: 3.7 % of a config-3 solve). */
 int ampc_mppi_plan_set_timing(ampc_mppi_plan* p, int enable);
 int ampc_mppi_plan_timing(ampc_mppi_plan* p, double* rollout_ms, double* update_ms, int* count);
 
@@ -350,7 +351,8 @@ int ampc_ilqr_plan_destroy(ampc_ilqr_plan* p);
  * synchronises and returns the AVERAGE duration (ms) per iteration of
  *   kernel_ms[0] backward sweep   [1] line search + acceptance   [2] forward pass (activation
  *   derivatives of the accepted trajectory)   [3] Jacobian chain
- * over the iterations since the last call, and their number; then resets the counters. */
+ * over the iterations since the last call, and their number; then resets the counters.
+ * enable = n > 1: a queue (ampc_ilqr_solve_queue) brackets only every n-th iteration. */
 int ampc_ilqr_plan_set_timing(ampc_ilqr_plan* p, int enable);
 int ampc_ilqr_plan_timing(ampc_ilqr_plan* p, double* kernel_ms, int* iterations);
 /* Work of the last ampc_ilqr_solve: iterations performed (the largest per-problem count; the
