@@ -38,6 +38,8 @@ SIGNATURES = {
     "ampc_precision": (c_int, [c_void_p]),
     "ampc_set_mlp": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(_dp),
                              POINTER(_dp), _dp, _dp, _dp, _dp]),
+    "ampc_set_mlp_dev": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(c_void_p),
+                                 POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p]),
     "ampc_jit_status": (c_int, [c_void_p, c_char_p, c_int]),
     "ampc_jit_wait": (c_int, [c_void_p]),
     "ampc_plan_kernel_kind": (c_int, [c_void_p, c_void_p]),
@@ -217,6 +219,22 @@ class Handle:
                                     wp, bp, dptr(norm[0]), dptr(norm[1]), dptr(norm[2]),
                                     dptr(norm[3])))
         self.nx, self.nu = nx, nu
+        self._sindy = False
+
+    def set_mlp_dev(self, nx, nu, hidden, weight_ptrs, bias_ptrs, activation, norm_ptrs):
+        """Stage an MLP whose float64 parameters already live in this device's memory (e.g. the tensors a
+        PyTorch-ROCm fit produced): `weight_ptrs[l]` / `bias_ptrs[l]` are device addresses of contiguous
+        [out_l][in_l] / [out_l] arrays, `norm_ptrs` those of xu_means, xu_std, dy_means, dy_std.  Folding
+        and packing run on the device (csrc/api_model.cpp); the caller's arrays are only read, and must
+        be complete (their producing stream synchronised) when this is called."""
+        hidden = np.array([int(x) for x in hidden], dtype=np.int32)
+        if len(weight_ptrs) != len(hidden) + 1 or len(bias_ptrs) != len(hidden) + 1 or len(norm_ptrs) != 4:
+            raise ValueError("one weight and one bias pointer per layer (hidden + output), four normaliser pointers")
+        wp = (c_void_p * len(weight_ptrs))(*[c_void_p(int(p)) for p in weight_ptrs])
+        bp = (c_void_p * len(bias_ptrs))(*[c_void_p(int(p)) for p in bias_ptrs])
+        check(self.lib.ampc_set_mlp_dev(self._h, int(nx), int(nu), len(hidden), iptr(hidden), ACTIVATIONS[activation],
+                                        wp, bp, *[c_void_p(int(p)) for p in norm_ptrs]))
+        self.nx, self.nu = int(nx), int(nu)
         self._sindy = False
 
     def jit_status(self):

@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 106; }   // 1.06: round 5 (ampc_ilqr_*_var); 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
+extern "C" int ampc_version(void) { return 107; }   // 1.07: round 6 (ampc_set_mlp_dev); 1.06: round 5 (ampc_ilqr_*_var); 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -31,7 +31,7 @@ extern "C" int ampc_device_count(void) {
 
 // Start (or find) the shape plugin of the staged model as soon as model and observation dimension
 // are both known; never blocks.
-static void jit_kick(ampc_handle* h) {
+void ampc_internal_jit_kick(ampc_handle* h) {
   if (!h->has_mlp || h->obs_dim < 1) return;
   if (h->precision == AMPC_F64) {
     if (static_shape_of<double>(h, h->md) < 0) (void)jit::get<double>(h);
@@ -57,7 +57,7 @@ extern "C" int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr
 
 extern "C" int ampc_jit_wait(ampc_handle* h) {
   REQUIRE(h, "ampc_jit_wait: NULL handle");
-  jit_kick(h);
+  ampc_internal_jit_kick(h);
   if (!jit::eligible(h)) return 0;
   const bool reg = h->precision == AMPC_F64 ? static_shape_of<double>(h, h->md) >= 0
                                             : static_shape_of<float>(h, h->mf) >= 0;
@@ -144,233 +144,7 @@ static int ls_rb_from_poll(const int* active, const int* need, int B) {
   return most >= 3 ? 3 : 1;
 }
 
-// ---------------------------------------------------------------------------------------------
-// B[k][n] supplied by a functor; N-split over W waves, NT tiles per wave.
-// own_first: wave w's stream starts at k-group w (8 k-steps per group) and wraps around -- the
-// order TileNet::run consumes a hidden layer in when TileNet::OWN holds.
-template <typename F>
-static void pack_nsplit(std::vector<double>& dst, int kpad, int hpad, int NT, int W, F B,
-                        bool own_first = false) {
-  const int KS = kpad / 4, G = 8, NG = KS / G;
-  dst.assign((size_t)kpad * hpad, 0.0);
-  for (int w = 0; w < W; ++w)
-    for (int pos = 0; pos < KS; ++pos)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int nt = 0; nt < NT; ++nt) {
-          const int ks = own_first ? ((pos / G + w) % NG) * G + pos % G : pos;
-          const int k = 4 * ks + (lane >> 4);
-          const int n = 16 * (NT * w + nt) + (lane & 15);
-          dst[(((size_t)w * KS + pos) * 64 + lane) * NT + nt] = B(k, n);
-        }
-}
-// mirrors TileNet::OWN (mlp_tile.hpp): own columns = one k-group, power-of-two group count
-static bool own_first_packing(int NT, int W) {
-  const int ng = (16 * NT * W / 4) / 8;
-  return 16 * NT == 32 && (ng & (ng - 1)) == 0;
-}
-// K-split over W waves, `tiles` 16-column tiles.
-template <typename F>
-static void pack_ksplit(std::vector<double>& dst, int hpad, int tiles, int W, F B) {
-  const int KS = hpad / 4, KSW = KS / W;
-  dst.assign((size_t)hpad * tiles * 16, 0.0);
-  for (int w = 0; w < W; ++w)
-    for (int ksl = 0; ksl < KSW; ++ksl)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int t = 0; t < tiles; ++t) {
-          const int k = 4 * (w * KSW + ksl) + (lane >> 4);
-          const int n = 16 * t + (lane & 15);
-          dst[(((size_t)w * KSW + ksl) * 64 + lane) * tiles + t] = B(k, n);
-        }
-}
-
-template <typename T> static int build_model(ampc_handle* h) {
-  const int L = h->n_hidden, nx = h->nx, nu = h->nu, kin = nx + nu;
-  const int hpad = h->hpad, NT = h->nt, W = h->nw, k1p = h->k1p, nxp = h->nxp;
-  auto width_in = [&](int l) { return l == 0 ? kin : h->hidden[l - 1]; };
-  auto width_out = [&](int l) { return l == L ? nx : h->hidden[l]; };
-  const double* xmean = h->norm.data();
-  const double* xstd = xmean + kin;
-  const double* dmean = xstd + kin;
-  const double* dstd = dmean + nx;
-  // Fold the affine normalisers into the first / last layer (double precision, see mlp_tile.hpp).
-  std::vector<std::vector<double>> Wf = h->W, bf = h->b;
-  {
-    const int out0 = width_out(0);
-    for (int n = 0; n < out0; ++n) {
-      double shift = 0.0;
-      for (int k = 0; k < kin; ++k) {
-        Wf[0][(size_t)n * kin + k] = h->W[0][(size_t)n * kin + k] / xstd[k];
-        shift += Wf[0][(size_t)n * kin + k] * xmean[k];
-      }
-      bf[0][n] = h->b[0][n] - shift;
-    }
-    const int inL = width_in(L);
-    for (int i = 0; i < nx; ++i) {
-      for (int k = 0; k < inL; ++k) Wf[L][(size_t)i * inL + k] *= dstd[i];
-      bf[L][i] = bf[L][i] * dstd[i] + dmean[i];
-    }
-  }
-  std::vector<std::vector<double>> parts;  // in upload order
-  std::vector<size_t> off;
-  auto push = [&](std::vector<double>&& v) { parts.emplace_back(std::move(v)); };
-  // forward weights w[0..L]
-  for (int l = 0; l <= L; ++l) {
-    const std::vector<double>& Wl = Wf[l];
-    const int in = width_in(l), out = width_out(l);
-    std::vector<double> pk;
-    auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
-    if (l < L) pack_nsplit(pk, l == 0 ? k1p : hpad, hpad, NT, W, Bt, l > 0 && own_first_packing(NT, W));
-    else pack_ksplit(pk, hpad, nxp / 16, W, Bt);
-    push(std::move(pk));
-  }
-  // tail fragments for the 4x4x4 output path (MlpDev::wt): f64, 16 < nx <= 20
-  const bool tail4 = sizeof(T) == 8 && nx > 16 && nx <= 20 && env_int("AMPC_TAIL4", 1) != 0;
-  {
-    const int KSW = hpad / 4 / W;
-    std::vector<double> wt((size_t)W * KSW * 64, 0.0);
-    if (tail4) {
-      const std::vector<double>& Wl = Wf[L];
-      const int in = width_in(L);
-      for (int w = 0; w < W; ++w)
-        for (int ksl = 0; ksl < KSW; ++ksl)
-          for (int lane = 0; lane < 64; ++lane) {
-            const int k = 4 * (w * KSW + ksl) + lane / 16, col = 16 + lane % 4;
-            wt[((size_t)w * KSW + ksl) * 64 + lane] = (col < nx && k < in) ? Wl[(size_t)col * in + k] : 0.0;
-          }
-    }
-    push(std::move(wt));
-  }
-  // biases b[0..L]
-  for (int l = 0; l <= L; ++l) {
-    std::vector<double> bb(l < L ? hpad : nxp, 0.0);
-    for (int i = 0; i < width_out(l); ++i) bb[i] = bf[l][i];
-    push(std::move(bb));
-  }
-  // Jacobian-chain weights wj[0..L-1]: B[k][n] = W_l[k][n]  (k = out index, n = in index)
-  const int ni = (kin + 15) / 16;
-  for (int l = 0; l < L; ++l) {
-    const std::vector<double>& Wl = Wf[l];
-    const int in = width_in(l), out = width_out(l);
-    std::vector<double> pk;
-    auto Bn = [&](int k, int n) { return (k < out && n < in) ? Wl[(size_t)k * in + n] : 0.0; };
-    if (l == 0) pack_ksplit(pk, hpad, ni, W, Bn);
-    else pack_nsplit(pk, hpad, hpad, NT, W, Bn);
-    push(std::move(pk));
-  }
-  // folded output weights in plain [nx][hpad]
-  {
-    std::vector<double> wp((size_t)nx * hpad, 0.0);
-    const int in = width_in(L);
-    for (int i = 0; i < nx; ++i)
-      for (int k = 0; k < in; ++k) wp[(size_t)i * hpad + k] = Wf[L][(size_t)i * in + k];
-    push(std::move(wp));
-  }
-  // four-wave packing of the forward weights (MlpDev::w4, ilqr_ls4.hpp): N-split layers as
-  // [wave][k-step][chunk][lane][cw] with cw = 2 values per lane for even NT4, else 1 -- every fragment
-  // load is then one fully coalesced 16- or 8-byte-per-lane access -- and a K-split output layer
-  {
-    const int NT4 = hpad / 64;
-    const int cw = NT4 % 2 == 0 ? 2 : 1, chunks = NT4 / cw;
-    for (int l = 0; l <= L; ++l) {
-      const std::vector<double>& Wl = Wf[l];
-      const int in = width_in(l), out = width_out(l);
-      std::vector<double> pk;
-      auto Bt = [&](int k, int n) { return (n < out && k < in) ? Wl[(size_t)n * in + k] : 0.0; };
-      if (l < L) {
-        const int KS = (l == 0 ? k1p : hpad) / 4;
-        pk.assign((size_t)KS * 4 * hpad, 0.0);
-        for (int w = 0; w < 4; ++w)
-          for (int pos = 0; pos < KS; ++pos)
-            for (int c = 0; c < chunks; ++c)
-              for (int lane = 0; lane < 64; ++lane)
-                for (int e = 0; e < cw; ++e) {
-                  const int nt = c * cw + e;
-                  pk[((((size_t)w * KS + pos) * chunks + c) * 64 + lane) * cw + e] =
-                      Bt(4 * pos + (lane >> 4), 16 * (NT4 * w + nt) + (lane & 15));
-                }
-      } else {
-        pack_ksplit(pk, hpad, nxp / 16, 4, Bt);
-      }
-      push(std::move(pk));
-    }
-  }
-  size_t total = 0;
-  for (auto& v : parts) {
-    off.push_back(total);
-    total += (v.size() + 3) / 4 * 4;  // keep every array 16/32-byte aligned
-  }
-  std::vector<double> flat(total, 0.0);
-  for (size_t i = 0; i < parts.size(); ++i)
-    std::memcpy(flat.data() + off[i], parts[i].data(), parts[i].size() * sizeof(double));
-  HIP_OK(h->model_buf.reserve(total * sizeof(T)));
-  HIP_OK(upload_converted<T>(h->model_buf.p, flat.data(), total, h->stream));
-  HIP_OK(hipStreamSynchronize(h->stream));
-  MlpDev<T>& m = model_of<T>(h);
-  std::memset(&m, 0, sizeof(m));
-  m.nx = nx; m.nu = nu; m.kin = kin; m.k1p = k1p; m.n_hidden = L; m.hpad = hpad; m.nxp = nxp;
-  m.act = h->act;
-  const T* base = (const T*)h->model_buf.p;
-  m.wbase = base;
-  size_t idx = 0;
-  for (int l = 0; l <= L; ++l) m.w[l] = base + off[idx++];
-  m.wt = base + off[idx++];
-  m.tail4 = tail4 ? 1 : 0;
-  for (int l = 0; l <= L; ++l) m.b[l] = base + off[idx++];
-  for (int l = 0; l < L; ++l) m.wj[l] = base + off[idx++];
-  h->wout_plain = (const void*)(base + off[idx++]);
-  for (int l = 0; l <= L; ++l) m.w4[l] = base + off[idx++];
-  return 0;
-}
-
-extern "C" int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
-                            int activation, const double* const* weights,
-                            const double* const* biases, const double* xu_mean,
-                            const double* xu_std, const double* dy_mean, const double* dy_std) {
-  REQUIRE(h, "ampc_set_mlp: NULL handle");
-  REQUIRE(nx >= 1 && nx <= 64, "ampc_set_mlp: state dim must be in 1..64");
-  REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_mlp: ctrl dim must be in 1..16");
-  REQUIRE(n_hidden >= 1 && n_hidden <= kMaxHidden, "ampc_set_mlp: 1..4 hidden layers");
-  REQUIRE(activation >= 0 && activation <= 4, "ampc_set_mlp: unknown activation");
-  REQUIRE(weights && biases && xu_mean && xu_std && dy_mean && dy_std && hidden_sizes,
-          "ampc_set_mlp: NULL argument");
-  HIP_OK(hipSetDevice(h->device));
-  int hmax = 0;
-  for (int l = 0; l < n_hidden; ++l) {
-    REQUIRE(hidden_sizes[l] >= 1 && hidden_sizes[l] <= 256, "ampc_set_mlp: hidden size 1..256");
-    hmax = hidden_sizes[l] > hmax ? hidden_sizes[l] : hmax;
-  }
-  (void)hmax;   // (more than 32 states: the WIDE tile, three or four output column tiles, any hidden width)
-  h->nx = nx; h->nu = nu; h->n_hidden = n_hidden; h->act = activation;
-  for (int l = 0; l < kMaxHidden; ++l) h->hidden[l] = l < n_hidden ? hidden_sizes[l] : 0;
-  // Workgroup shape: 8 waves (two per SIMD) whenever the padded width allows whole 16-column
-  // tiles per wave, else 4 waves.  (W, NT) in {(4,1), (8,1), (4,3), (8,2)} for hpad 64..256.
-  h->hpad = round_up(hmax, 64);
-  h->nw = h->hpad % 128 == 0 ? 8 : 4;
-  h->nt = h->hpad / (16 * h->nw);
-  h->k1p = round_up(nx + nu, 8);
-  h->nxp = round_up(nx, 16);
-  h->W.assign(n_hidden + 1, {});
-  h->b.assign(n_hidden + 1, {});
-  for (int l = 0; l <= n_hidden; ++l) {
-    const int in = l == 0 ? nx + nu : hidden_sizes[l - 1];
-    const int out = l == n_hidden ? nx : hidden_sizes[l];
-    h->W[l].assign(weights[l], weights[l] + (size_t)in * out);
-    h->b[l].assign(biases[l], biases[l] + out);
-  }
-  const int kin = nx + nu;
-  h->norm.resize(2 * kin + 2 * nx);
-  std::memcpy(h->norm.data(), xu_mean, kin * 8);
-  std::memcpy(h->norm.data() + kin, xu_std, kin * 8);
-  std::memcpy(h->norm.data() + 2 * kin, dy_mean, nx * 8);
-  std::memcpy(h->norm.data() + 2 * kin + nx, dy_std, nx * 8);
-  int rc = h->precision == AMPC_F64 ? build_model<double>(h) : build_model<float>(h);
-  if (rc) return rc;
-  h->has_mlp = true;
-  h->has_sindy = false;
-  h->has_lin = false;
-  jit_kick(h);            // (needs obs_dim: if the cost is set later, ampc_set_quad_costs starts it)
-  return 0;
-}
+// (weight packing, ampc_set_mlp and ampc_set_mlp_dev: api_model.cpp)
 
 // Wide linear model (65 .. 256 states; AMPC_LINEAR_WIDE = 1: any size): [A | B] packed in MFMA
 // fragment order for linear_kernels.hpp, plus a plain copy.
@@ -474,7 +248,7 @@ extern "C" int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_d
         if (i != j && R[((size_t)c * nu + i) * nu + j] != 0.0) diag = false;
   }
   h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
-  jit_kick(h);
+  ampc_internal_jit_kick(h);
   return 0;
 }
 

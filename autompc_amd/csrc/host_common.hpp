@@ -3,6 +3,7 @@
 // dispatch and the heavy launchers' declarations.
 //
 //   api.cpp                       the C ABI (include/autompc_hip.h), host logic, the small kernels
+//   api_model.cpp                 MLP staging: weight packing, ampc_set_mlp, ampc_set_mlp_dev
 //   launch_mlp.cpp   -DAMPC_T=..  MLP forward / Jacobian launchers         } one unit per precision:
 //   launch_mppi.cpp  -DAMPC_T=..  MPPI rollout / update launcher           } each holds the explicit
 //   launch_ilqr.cpp  -DAMPC_T=..  iLQR sweep / line-search launcher        } instantiation for AMPC_T
@@ -155,6 +156,9 @@ struct ampc_handle {
   // scratch for the batched model calls -----------------------------------------------------------
   DevBuf s_states, s_ctrls, s_out, s_dz, s_jx, s_ju;
 };
+
+// Start (or find) the shape plugin of the staged model (api.cpp; never blocks).
+void ampc_internal_jit_kick(ampc_handle* h);
 
 template <typename T> inline MlpDev<T>& model_of(ampc_handle* h);
 template <> inline MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }

@@ -47,16 +47,17 @@ class MLP(Model):
         # numpy stream; real weights arrive through train() or set_parameters().
         rng = np.random.default_rng(seed)
         dims = [nx + nu] + sizes + [nx]
-        self.weights, self.biases = [], []
+        self._handle = None
+        self._dev_params = None             # (weights, biases, normalisers) as device tensors after a fit
+        self._weights, self._biases = [], []
         for fan_in, fan_out in zip(dims[:-1], dims[1:]):
             bound = 1.0 / np.sqrt(fan_in)
-            self.weights.append(rng.uniform(-bound, bound, size=(fan_out, fan_in)))
-            self.biases.append(rng.uniform(-bound, bound, size=(fan_out,)))
+            self._weights.append(rng.uniform(-bound, bound, size=(fan_out, fan_in)))
+            self._biases.append(rng.uniform(-bound, bound, size=(fan_out,)))
         self.xu_means = np.zeros(nx + nu)
         self.xu_std = np.ones(nx + nu)
         self.dy_means = np.zeros(nx)
         self.dy_std = np.ones(nx)
-        self._handle = None
 
     # -- reference Model surface (mlp.py:167-175) ---------------------------------
     def traj_to_state(self, traj):
@@ -71,9 +72,25 @@ class MLP(Model):
 
     # -- device staging -----------------------------------------------------------
     def stage_into(self, handle):
-        """Pack and upload the current weights + normalisers into a device handle."""
+        """Pack the current weights + normalisers into a device handle: from device memory when a fit left
+        them on the handle's GPU (ampc_set_mlp_dev: folded and packed by two kernels, no host copy), else
+        from the numpy arrays."""
+        dp = self._dev_params
+        if dp is not None and dp["w"][0].is_cuda and dp["w"][0].device.index == handle.device \
+                and self._normalisers_are_the_fit():
+            import torch
+            torch.cuda.current_stream(dp["w"][0].device).synchronize()     # the fit's kernels have finished
+            handle.set_mlp_dev(self.system.obs_dim, self.system.ctrl_dim, self.hidden_sizes,
+                               [w.data_ptr() for w in dp["w"]], [b.data_ptr() for b in dp["b"]], self.nonlintype,
+                               [v.data_ptr() for v in dp["norm_dev"]])
+            return
         handle.set_mlp(self.system.obs_dim, self.system.ctrl_dim, self.weights, self.biases,
                        self.nonlintype, self.xu_means, self.xu_std, self.dy_means, self.dy_std)
+
+    def _normalisers_are_the_fit(self):
+        """The device copy stands for the model only while the normalisers are the ones the fit computed."""
+        return all(np.array_equal(a, b) for a, b in zip(self._dev_params["norm_np"],
+                                                        (self.xu_means, self.xu_std, self.dy_means, self.dy_std)))
 
     def _dev(self):
         if self._handle is None:
@@ -87,8 +104,10 @@ class MLP(Model):
         self._handle = None
 
     def __getstate__(self):
+        self._fetch()
         state = self.__dict__.copy()
         state["_handle"] = None          # device handles do not pickle / deepcopy
+        state["_dev_params"] = None      # (the copy carries the numpy parameters)
         return state
 
     # -- inference (HIP) ------------------------------------------------------------
@@ -137,7 +156,7 @@ class MLP(Model):
             if old.shape != new.shape:
                 raise ValueError("net_state layer shape %r does not match model %r"
                                  % (new.shape, old.shape))
-        self.weights, self.biases = ws, bs
+        self._weights, self._biases, self._dev_params = ws, bs, None
         self.xu_means = np.array(params["xu_means"], dtype=np.float64)
         self.xu_std = np.array(params["xu_std"], dtype=np.float64)
         self.dy_means = np.array(params["dy_means"], dtype=np.float64)
@@ -146,39 +165,50 @@ class MLP(Model):
 
     # -- training (PyTorch, outside the hot path; mlp.py:177-217) ------------------------
     def train(self, trajs, silent=False, seed=100):
-        import torch
-        n_iter, n_batch, lr = self._train_data
-        X = np.concatenate([t.obs[:-1, :] for t in trajs])
-        dY = np.concatenate([t.obs[1:, :] - t.obs[:-1, :] for t in trajs])
-        U = np.concatenate([t.ctrls[:-1, :] for t in trajs])
-        XU = np.concatenate([X, U], axis=1)
-        self.xu_means, self.xu_std = XU.mean(axis=0), XU.std(axis=0)
-        self.dy_means, self.dy_std = dY.mean(axis=0), dY.std(axis=0)
-        feed = torch.from_numpy((XU - self.xu_means) / self.xu_std)
-        target = torch.from_numpy((dY - self.dy_means) / self.dy_std)
-        torch.manual_seed(seed)
-        dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
-        act = {"relu": torch.nn.ReLU, "tanh": torch.nn.Tanh, "sigmoid": torch.nn.Sigmoid,
-               "selu": torch.nn.SELU}[self.nonlintype]
-        layers, dims = [], [XU.shape[1]] + self.hidden_sizes
-        for a, b in zip(dims[:-1], dims[1:]):
-            layers += [torch.nn.Linear(a, b), act()]
-        layers.append(torch.nn.Linear(dims[-1], dY.shape[1]))
-        net = torch.nn.Sequential(*layers).double().to(dev)
-        opt = torch.optim.Adam(net.parameters(), lr=lr)
-        loss_fn = torch.nn.SmoothL1Loss()
-        n = feed.shape[0]
-        for _ in range(n_iter):
-            perm = torch.randperm(n)
-            for s in range(0, n, n_batch):
-                idx = perm[s:s + n_batch]
-                opt.zero_grad()
-                loss = loss_fn(net(feed[idx].to(dev)), target[idx].to(dev))
-                loss.backward()
-                opt.step()
-        lin = [m for m in net if isinstance(m, torch.nn.Linear)]
-        self.weights = [self._to_numpy(m.weight) for m in lin]
-        self.biases = [self._to_numpy(m.bias) for m in lin]
+        """The reference's fit -- normalisers from the data, then n_train_iters epochs of Adam on SmoothL1 over
+        shuffled mini-batches, with the reference's initial weights (torch.manual_seed(self.seed) before the
+        layers are built) and mini-batch order (torch.manual_seed(seed) + DataLoader(shuffle=True)) -- run by
+        sysid/mlp_fit.py on the GPU when there is one (HIP-graph-captured steps), else on the CPU.  The
+        fitted parameters stay on the device and are staged from there (ampc_set_mlp_dev)."""
+        from .mlp_fit import fit_mlps
+        fit_mlps([self], trajs, train_seed=seed)
+
+    def _adopt_fit(self, ws, bs, norms, norms_dev):
+        """Take over fitted parameters: float64 torch tensors `ws`, `bs` (any device) plus the data's normalisers
+        as numpy arrays and as tensors on the same device."""
+        self._invalidate()
+        norms = [np.array(v, dtype=np.float64) for v in norms]
+        self.xu_means, self.xu_std, self.dy_means, self.dy_std = [v.copy() for v in norms]
+        self._dev_params = {"w": list(ws), "b": list(bs), "norm_dev": list(norms_dev), "norm_np": norms}
+        self._weights = self._biases = None       # fetched when somebody asks (get_parameters, pickling)
+
+    # weights / biases: numpy [out][in] / [out] per layer.  After a fit they live in device memory and are
+    # downloaded on first access; assigning them drops the device copy.
+    def _fetch(self):
+        if self._weights is None:
+            self._weights = [self._to_numpy(w) for w in self._dev_params["w"]]
+            self._biases = [self._to_numpy(b) for b in self._dev_params["b"]]
+
+    @property
+    def weights(self):
+        self._fetch()
+        return self._weights
+
+    @weights.setter
+    def weights(self, value):
+        self._fetch()
+        self._weights, self._dev_params = list(value), None
+        self._invalidate()
+
+    @property
+    def biases(self):
+        self._fetch()
+        return self._biases
+
+    @biases.setter
+    def biases(self, value):
+        self._fetch()
+        self._biases, self._dev_params = list(value), None
         self._invalidate()
 
 

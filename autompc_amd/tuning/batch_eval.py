@@ -88,12 +88,15 @@ def model_handle(m, device, precision, opened):
 
 def _by_model_shape(candidates, default):
     """Candidate indices grouped by the shape of the model they carry (first appearance order), or None
-    when all share one shape."""
+    when every candidate's model has the shape of `default` (the evaluator's own model, which candidates
+    without a "model" entry run on): one plan on the evaluator's handle serves them all."""
     groups = {}
     for i, c in enumerate(candidates):
         m = c.get("model") if isinstance(c, dict) else None
         groups.setdefault(model_shape_key(default if m is None else m), []).append(i)
-    return None if len(groups) <= 1 else list(groups.values())
+    if len(groups) == 1 and next(iter(groups)) == model_shape_key(default):
+        return None
+    return list(groups.values())
 
 
 def global_ids(index_offset, n):
@@ -224,6 +227,7 @@ def default_episode_controls(task):
 
 class CandidateEvaluator:
     """Evaluates MPPI + QuadCost candidates for one (system, task, model, surrogate) on one GPU."""
+    accepts_global_ids = True          # evaluate(index_offset=<array of global indices>) is understood
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0,
                  tile_rows=32, horizon_cap=30, term_check_every=8):
@@ -305,9 +309,9 @@ class CandidateEvaluator:
             # Candidates that carry controller models of DIFFERENT shapes (pipeline.py:138-145: a model per
             # configuration): one plan per shape, evaluated in turn; same-shape models share a plan
             # (ampc_mppi_plan_set_models).  A candidate's randomness is keyed by its global index either way.
-            if eps_all is not None or act_init is not None:
-                raise ValueError("recorded noise / warm starts are laid out for ONE plan: evaluate the candidates of "
-                                 "each model shape separately")
+            if eps_all is not None or act_init is not None or timing is not None:
+                raise ValueError("recorded noise / warm starts / kernel timing are laid out for ONE plan: evaluate "
+                                 "the candidates of each model shape separately")
             return self._evaluate_shape_groups(shape_groups, candidates, ids, dict(
                 n_steps=n_steps, seed=seed, init_obs=init_obs, return_trajectories=return_trajectories))
         opened = []                       # device objects, closed on every exit path
@@ -322,11 +326,13 @@ class CandidateEvaluator:
         import copy
         B = len(candidates)
         scores, trajs, lengths = np.empty(B), [None] * B, np.zeros(B, dtype=np.int64)
+        # every candidate's model is made explicit first: a candidate WITHOUT a "model" entry runs on the
+        # evaluator's own model, whatever the first candidate of its shape group carries
+        candidates = [dict(c, model=c.get("model") if c.get("model") is not None else self.model) for c in candidates]
         for idx in groups:
             sub = copy.copy(self)
-            sub.model = candidates[idx[0]].get("model") or self.model
-            if sub.surrogate is self.model and self.surrogate is self.model:
-                sub.surrogate = self.model               # (the simulation model stays the evaluator's)
+            sub.model = candidates[idx[0]]["model"]       # the group's plan handle is staged with one of ITS models
+            # (sub.surrogate stays the evaluator's simulation model: copy.copy kept the reference)
             out = sub.evaluate([candidates[i] for i in idx], index_offset=ids[idx], **kw)
             if kw["return_trajectories"]:
                 sc, ob, ct = out
@@ -341,6 +347,9 @@ class CandidateEvaluator:
         if not kw["return_trajectories"]:
             return scores
         L = max(t[0].shape[0] for t in trajs)
+        if len({t[0].shape[1:] for t in trajs}) != 1:
+            raise ValueError("return_trajectories: the shape groups record states of different widths; evaluate "
+                             "them separately")
         obs = np.full((B, L) + trajs[0][0].shape[1:], np.nan)
         ctl = np.full((B, L) + trajs[0][1].shape[1:], np.nan)
         for i, (o, c) in enumerate(trajs):
@@ -564,6 +573,8 @@ class IlqrCandidateEvaluator:
     followed by one batched surrogate step.  Either way everything is deterministic and every solve
     is bit-identical to a one-problem solve of its own horizon: a candidate's score does not depend
     on the batch it is in or on the rank that evaluates it."""
+
+    accepts_global_ids = True
 
     def __init__(self, system, task, model, surrogate=None, precision="f64", device=0, device_resident=True,
                  max_slots=1024, max_threads=32, one_plan=True):

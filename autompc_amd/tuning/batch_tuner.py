@@ -18,12 +18,14 @@ honoured on both paths (CandidateEvaluator.evaluate).
 Scores that are not finite (a diverged rollout) count as ``inf``, as ``eval_cfg`` does for a
 controller that raises ``LinAlgError`` (:236-239).
 """
+import time
 from collections import namedtuple
 
 import numpy as np
 
 from .batch_eval import (IlqrCandidateEvaluator, evaluate_sharded, global_ids, random_candidates,
                          random_ilqr_candidates)
+from .configs import (DictConfiguration, candidates_from_configs, config_from_candidate, sample_mlp_config)
 
 # same fields, same order as the reference's namedtuple (pipeline_tuner.py:19-21)
 PipelineTuneResult = namedtuple("PipelineTuneResult", [
@@ -36,11 +38,26 @@ class BatchPipelineTuner:
     required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
 
     def __init__(self, system, evaluator, batch_size=64, sampler=None, truedyn_noise="device",
-                 eval_kwargs=None, keep_trajs=False, balance=True, models=None):
+                 eval_kwargs=None, keep_trajs=False, balance=None, models=None, model_factory=None,
+                 trajs=None, as_configs=False):
         """truedyn_noise: the noise mode of the controllers scored against the true dynamics
         (MPPI(noise=...): "device" Philox, or "numpy" / "numpy_device" = the reference's global
         legacy stream).  eval_kwargs: extra keyword arguments for every ``evaluator.evaluate`` call
-        (e.g. a recorded noise stream to replay)."""
+        (e.g. a recorded noise stream to replay).
+
+        model_factory + trajs: the model axis as the reference runs it -- ``eval_cfg`` calls
+        ``pipeline(cfg, task, trajs)``, which instantiates AND TRAINS the configuration's model
+        (pipeline.py:138-145 -> ModelFactory.__call__, sysid/model.py:24-48).  Candidates then carry a
+        ``model_cfg`` (the `_model:` sub-configuration; the default sampler draws it from MLPFactory's
+        ranges); before a shard is evaluated its models are built with ``model_factory(cfg, trajs,
+        skip_train_model=True)`` and fitted together by ``sysid.mlp_fit.fit_mlps`` (lockstep PyTorch-ROCm fit,
+        HIP-graph captured; each model exactly as its own ``train(trajs)``), their parameters staged from
+        device memory (ampc_set_mlp_dev).  Fits are cached by configuration; every rank fits only the models
+        of its own shard.  ``fit_seconds`` / ``eval_seconds`` accumulate what the two phases took.
+
+        as_configs: report ``cfgs`` / ``inc_cfg`` as pipeline configurations with the reference's key names
+        (`_ctrlr:horizon`, `_cost:<obs>_Q`, `_model:lr`, ...; tuning/configs.py) instead of candidate dicts;
+        candidates that came from configurations (``run(..., configs=...)``) are always reported as those."""
         self.system, self.evaluator = system, evaluator
         self.truedyn_noise = truedyn_noise
         self.eval_kwargs = dict(eval_kwargs or {})
@@ -50,7 +67,10 @@ class BatchPipelineTuner:
         self.keep_trajs = bool(keep_trajs)
         # balance: the shards of a batch are balanced by work (num_path x horizon; evaluate_sharded's
         # weights="auto") instead of being contiguous; scores are the same either way
-        self.balance = bool(balance)
+        # (None: balanced when the evaluator declares that it takes an ARRAY of global indices as
+        # index_offset -- the in-tree evaluators do; an evaluator written against the documented integer
+        # interface gets contiguous shards)
+        self.balance = bool(getattr(evaluator, "accepts_global_ids", False)) if balance is None else bool(balance)
         # models: the model axis of the search -- the reference's pipeline configuration space joins
         # `_model:`, `_ctrlr:` and `_cost:` sub-spaces (pipeline.py:90-105) and eval_cfg builds (trains) the
         # model of every configuration (pipeline.py:138-145).  Here the candidate models are given
@@ -58,6 +78,13 @@ class BatchPipelineTuner:
         # sampler draws each candidate's "model" among them, the evaluators run candidates with
         # different models in one batch (ampc_*_plan_set_models).  Custom samplers may set c["model"] too.
         self.models = list(models) if models else None
+        self.model_factory, self.trajs = model_factory, trajs
+        if model_factory is not None and trajs is None:
+            raise ValueError("model_factory needs the training trajectories (trajs=...)")
+        self.as_configs = bool(as_configs)
+        self._fitted = {}                      # model configuration -> fitted model
+        self.fit_seconds = self.eval_seconds = 0.0
+        self.models_fitted = 0
         self.batch_size = int(batch_size)
         if self.batch_size < 1:
             raise ValueError("batch_size must be >= 1")
@@ -76,7 +103,46 @@ class BatchPipelineTuner:
         if self.models:
             for c, k in zip(cands, rng.integers(len(self.models), size=n)):
                 c["model"], c["model_index"] = self.models[int(k)], int(k)
+        elif self.model_factory is not None:
+            draw_cfg = getattr(self.model_factory, "sample_configuration", None)
+            for c in cands:
+                c["model_cfg"] = dict(draw_cfg(rng)) if draw_cfg else sample_mlp_config(rng)
         return cands
+
+    # -- the model axis: fit what a shard asks for (pipeline.py:138-145) ---------------------------------
+    @staticmethod
+    def _cfg_key(cfg):
+        return tuple(sorted((str(k), repr(v)) for k, v in cfg.items()))
+
+    def fit_models(self, candidates):
+        """Give every candidate that carries a ``model_cfg`` (and no ``model`` yet) its trained model."""
+        import time
+        want = [c for c in candidates if isinstance(c, dict) and c.get("model") is None and c.get("model_cfg")]
+        if not want:
+            return
+        if self.model_factory is None:
+            raise ValueError("candidates carry a model configuration (`_model:` keys) but the tuner has no "
+                             "model_factory / trajs to build and fit them with")
+        t0 = time.perf_counter()
+        fresh = {}
+        for c in want:
+            key = self._cfg_key(c["model_cfg"])
+            if key not in self._fitted and key not in fresh:
+                fresh[key] = self.model_factory(DictConfiguration(c["model_cfg"]), self.trajs, skip_train_model=True)
+        if fresh:
+            from ..sysid.mlp import MLP
+            from ..sysid.mlp_fit import fit_mlps
+            mlps = [m for m in fresh.values() if isinstance(m, MLP)]
+            if mlps:
+                fit_mlps(mlps, self.trajs)
+            for m in fresh.values():
+                if not isinstance(m, MLP):
+                    m.train(self.trajs, silent=True)
+            self._fitted.update(fresh)
+            self.models_fitted += len(fresh)
+        for c in want:
+            c["model"] = self._fitted[self._cfg_key(c["model_cfg"])]
+        self.fit_seconds += time.perf_counter() - t0
 
     # -- ask / tell ---------------------------------------------------------------------------
     def ask(self, n, rng):
@@ -99,6 +165,8 @@ class BatchPipelineTuner:
         for i, (cfg, s) in enumerate(zip(candidates, scores)):
             s = float(s) if np.isfinite(s) else float("inf")
             td = None if truedyn_scores is None else float(truedyn_scores[i])
+            if isinstance(cfg, dict) and (self.as_configs or cfg.get("cfg") is not None):
+                cfg = config_from_candidate(self.system, cfg)
             if s < self._inc_cost or self._inc_cfg is None:
                 self._inc_cost, self._inc_cfg, self._inc_truedyn = s, cfg, td
             self.cfgs.append(cfg)
@@ -157,8 +225,11 @@ class BatchPipelineTuner:
             kept = {k: v for part in parts for k, v in part.items()}
         return [kept[i] for i in range(n)]
 
-    def run(self, n_iters, rng, seed=0, truedyn=None):
-        """Evaluate `n_iters` candidates in batches of `batch_size`.  Every rank must call this
+    def run(self, n_iters, rng, seed=0, truedyn=None, configs=None):
+        """Evaluate `n_iters` candidates in batches of `batch_size`.  configs: pipeline configurations
+        (ConfigSpace ``Configuration`` objects or mappings with the reference's `_model:` / `_ctrlr:` /
+        `_cost:` keys, e.g. ``cs.sample_configuration(512)`` or SMAC's initial design) to evaluate INSTEAD of
+        sampling -- the first `n_iters` of them, in order; they come back as ``cfgs`` / ``inc_cfg``.  Every rank must call this
         with an identically seeded `rng` (proposals are drawn redundantly on every rank so that
         no broadcast is needed); each rank evaluates its contiguous shard of every batch and the
         scores are all-gathered.  With `truedyn`, every candidate is also scored against the true
@@ -166,13 +237,26 @@ class BatchPipelineTuner:
         done = 0
         while done < n_iters:
             n = min(self.batch_size, n_iters - done)
-            batch = self.ask(n, rng)
+            if configs is not None:
+                if len(configs) < done + n:
+                    raise ValueError("%d configurations given, %d evaluations asked" % (len(configs), n_iters))
+                batch = candidates_from_configs(self.system, configs[done:done + n])
+            else:
+                batch = self.ask(n, rng)
             # randomness keyed by (seed, global evaluation index): scores do not depend on the
             # world size or on the batch size
             kept = {}
 
             def local(shard, lo, d=done):
                 # (lo: the shard's first index in the batch, or -- balanced shards -- all of its indices)
+                self.fit_models(shard)
+                t0 = time.perf_counter()
+                try:
+                    return evaluate(shard, lo, d)
+                finally:
+                    self.eval_seconds += time.perf_counter() - t0
+
+            def evaluate(shard, lo, d):
                 if not self.keep_trajs:
                     return self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo, **self.eval_kwargs)
                 sc, obs, ctl = self.evaluator.evaluate(shard, seed=seed, index_offset=d + lo,

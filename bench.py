@@ -657,6 +657,77 @@ def ilqr_eval_record(args, R, n_cand=64, n_rows=50):
             "scores_finite": int(np.isfinite(scores).sum())}
 
 
+def model_axis_record(args, R, n_cand=64, n_models=8, n_rows=200, n_traj=40, traj_rows=201, epochs=50,
+                      seq_epochs=2):
+    """The tuner's MODEL axis: eval_cfg fits a model per configuration (pipeline.py:138-145 ->
+    MLP.train, sysid/mlp.py:177-217: Adam, SmoothL1, 50 epochs of 64-row mini-batches) before it simulates.
+    `n_models` distinct 2x256 configurations (own seeds / learning rates) fitted on one trajectory set
+    (`n_traj` surrogate rollouts under random controls), then `n_cand` MPPI candidates spread over them, one
+    eval_cfg episode each.  fit_s = the lockstep PyTorch-ROCm fit of all models (HIP-graph captured, capture
+    time included); sequential_fit_s = the same models one after the other with nn.Linear + torch.optim.Adam on
+    the GPU, extrapolated from `seq_epochs` epochs of one model; stage_s = ampc_set_mlp_dev for all models;
+    eval_s = the batched closed-loop evaluation."""
+    import torch
+    from autompc_amd import MLP, zeros
+    from autompc_amd.synthetic import make_workload
+    from autompc_amd.sysid import mlp_fit
+    from autompc_amd.tuning import CandidateEvaluator, random_candidates
+    system, task, model, spec = make_workload("c3", precision="f64", device=R.local_rank)
+    task.set_num_steps(n_rows)
+    rng = np.random.default_rng(0)
+    nx, nu = system.obs_dim, system.ctrl_dim
+    X = rng.uniform(-0.1, 0.1, size=(n_traj, nx))
+    trajs = [zeros(system, traj_rows) for _ in range(n_traj)]
+    for t in range(traj_rows):                       # the surrogate under random bounded controls
+        U = rng.uniform(-1.0, 1.0, size=(n_traj, nu))
+        for k in range(n_traj):
+            trajs[k].obs[t], trajs[k].ctrls[t] = X[k], U[k]
+        X = model.pred_batch(X, U)
+    models = [MLP(system, n_hidden_layers=2, hidden_size=256, nonlintype="relu", n_train_iters=epochs, n_batch=64,
+                  lr=1e-3 * (1 + 0.25 * k), seed=k, device=R.local_rank) for k in range(n_models)]
+    XU, dY, xm, xs, dm, ds = mlp_fit.training_arrays(trajs)
+    feed, target = [torch.from_numpy(v).cuda(R.local_rank) for v in mlp_fit.normalised(XU, dY, xm, xs, dm, ds)]
+    dims = [nx + nu, 256, 256, nx]
+    dev = "cuda:%d" % R.local_rank
+    mlp_fit.fit_reference_style(dims, "relu", feed[:256], target[:256], 1, 64, 1e-3, 0, device=dev)   # library warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mlp_fit.fit_reference_style(dims, "relu", feed, target, seq_epochs, 64, 1e-3, 0, device=dev)
+    torch.cuda.synchronize()
+    seq_one = (time.perf_counter() - t0) * epochs / seq_epochs
+    info = mlp_fit.fit_mlps(models, trajs, device=dev)
+    t0 = time.perf_counter()
+    for m in models:
+        m._dev()
+    stage_s = time.perf_counter() - t0
+    staged_from_device = all(m._weights is None for m in models)
+    # held-out one-step error of the fitted models against the surrogate that generated the data
+    S, U = rng.uniform(-0.3, 0.3, size=(512, nx)), rng.uniform(-1.0, 1.0, size=(512, nu))
+    truth = model.pred_batch(S, U)
+    rel = [float(np.linalg.norm(m.pred_batch(S, U) - truth) / np.linalg.norm(truth - S)) for m in models]
+    cands = random_candidates(system, n_cand, seed=0)
+    for i, c in enumerate(cands):
+        c["model"] = models[i % n_models]
+    ev = CandidateEvaluator(system, task, model, device=R.local_rank)
+    ev.evaluate(cands[:8], seed=1)
+    R.sync_all()
+    t0 = time.perf_counter()
+    scores = ev.evaluate(cands, seed=1)
+    eval_s = time.perf_counter() - t0
+    steps = info["steps"]
+    return {"workload": "%d MPPI candidates over %d distinct 2x256 MLP configurations fitted on %d rows (%d epochs x %d "
+                        "mini-batches of 64 = %d optimiser steps each), then one eval_cfg episode per candidate (%d "
+                        "control steps)" % (n_cand, n_models, feed.shape[0], epochs, -(-feed.shape[0] // 64), steps, n_rows - 1),
+            "fit_s": info["fit_s"], "stage_s": stage_s, "eval_s": eval_s, "fit_over_eval": info["fit_s"] / eval_s,
+            "sequential_fit_s": seq_one * n_models, "lockstep_speedup": seq_one * n_models / info["fit_s"],
+            "optimiser_steps_per_s": steps / info["fit_s"], "us_per_lockstep_step": 1e6 * info["fit_s"] / steps,
+            "models_per_s": n_models / info["fit_s"], "staged_from_device_memory": staged_from_device,
+            "heldout_rel_err_of_delta": {"min": min(rel), "max": max(rel)},
+            "scores_finite": int(np.isfinite(scores).sum()),
+            "note": "the fit is a chain of %d DEPENDENT optimiser steps on 64 rows (the reference's batch size): "
+                    "its floor is steps x the per-step kernel chain, whatever the number of models" % steps}
+
+
 def c5_sharded_record(args, R, per_gpu=64, probes=4):
     """north_star's multi-GPU path inside the default (c3) bench line of an N > 1 run: BASELINE
     config 5's candidate sharding -- per_gpu * world candidates, shards balanced by num_path x horizon, randomness keyed
@@ -929,6 +1000,7 @@ def main():
                 recs[wl] = {k: v for k, v in r.items()
                             if k not in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "preheat_steps")}
             recs["ilqr_eval"] = ilqr_eval_record(args, R)
+            recs["model_axis"] = model_axis_record(args, R)
             recs["dropin"] = dropin_record()
             out["sub_records"] = recs
         if not args.no_cpu_baseline and world == 1:

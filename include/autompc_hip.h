@@ -39,7 +39,7 @@ enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 const char* ampc_last_error(void);
 int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs;
                            * 106: + ampc_ilqr_solve_queue_var, ampc_ilqr_closed_loop_var, ampc_set_indicator_costs,
-                           *      ampc_mppi_plan_set_models, ampc_ilqr_plan_set_models */
+                           *      ampc_mppi_plan_set_models, ampc_ilqr_plan_set_models; 107: + ampc_set_mlp_dev */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -62,6 +62,19 @@ int ampc_set_mlp(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden
                  int activation, const double* const* weights, const double* const* biases,
                  const double* xu_mean, const double* xu_std, const double* dy_mean,
                  const double* dy_std);
+
+/* The same model from DEVICE memory: every pointer (the two pointer arrays themselves are host arrays) is a
+ * float64 array in the memory of the handle's device, laid out as above -- what a PyTorch-ROCm fit of the
+ * network leaves behind (mlp.py:177-217: the reference trains on its torch device and predicts there,
+ * mlp.py:229-236; its weights never visit numpy).  The normalisers are folded and the MFMA fragment
+ * packings written by two kernels on the handle's stream (csrc/api_model.cpp), bit for bit what
+ * ampc_set_mlp produces from the same numbers; no host copy of the parameters is made.  The arrays are
+ * only read and may be released when the call returns; work that produces them must be complete
+ * (synchronise the producing stream) before the call. */
+int ampc_set_mlp_dev(ampc_handle* h, int nx, int nu, int n_hidden, const int* hidden_sizes,
+                     int activation, const double* const* weights_dev, const double* const* biases_dev,
+                     const double* xu_mean_dev, const double* xu_std_dev, const double* dy_mean_dev,
+                     const double* dy_std_dev);
 
 /* ---- kernels specialised for the staged model's shape -------------------------------------------
  * The reference's MLP configuration space is 1-4 hidden layers of 16-256 units (mlp.py:113-122).

@@ -1202,7 +1202,45 @@ def gen_ilqr_arx4():
          clip_bounds=np.array([-0.15, 0.2]), **out)
 
 
-GENERATORS = {"ilqr_arx4": gen_ilqr_arx4, "evalcfg_twomodels": gen_evalcfg_twomodels, "mppi_indicator": gen_mppi_indicator, "linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
+# --------------------------------------------------------------------------- MLP fitting
+MLPFIT_CASES = [
+    # tag, nx, nu, hidden, activation, init seed, lr, epochs, batch, (n_traj, rows)
+    ("p_tanh", 3, 2, [32, 24], "tanh", 7, 3e-3, 4, 64, (3, 51)),          # 150 rows: 2 full batches + 22
+    ("hc_relu3", 17, 6, [48, 32, 16], "relu", 11, 1e-3, 3, 64, (4, 49)),   # 192 rows: no ragged batch
+    ("p_selu1", 2, 1, [40], "selu", 100, 1e-2, 5, 32, (2, 41)),
+]
+
+
+def gen_mlpfit():
+    """The reference's own MLP(...).train(trajs) on its torch CPU path (mlp.py:137-165, 177-217): the net as
+    constructed (torch.manual_seed(seed) + nn.Linear defaults), the normalisers and the net after training
+    (Adam, SmoothL1, DataLoader(shuffle=True)), plus its predictions on fresh points."""
+    for tag, nx, nu, hidden, act, seed, lr, n_iter, n_batch, (n_traj, rows) in MLPFIT_CASES:
+        system = make_system(nx, nu)
+        rng = np.random.default_rng(seed + 3000)
+        trajs = []
+        for _ in range(n_traj):
+            t = ampc.zeros(system, rows)
+            t.obs[:] = 0.1 * rng.normal(size=(rows, nx)).cumsum(axis=0)
+            t.ctrls[:] = rng.normal(size=(rows, nu))
+            trajs.append(t)
+        kw = {"hidden_size_%d" % (i + 1): h for i, h in enumerate(hidden)}
+        model = quiet(MLP, system, n_hidden_layers=len(hidden), nonlintype=act, n_train_iters=n_iter,
+                      n_batch=n_batch, lr=lr, seed=seed, use_cuda=False, **kw)
+        init = [p.detach().clone().numpy() for p in model.net.parameters()]     # w0, b0, w1, b1, ...
+        quiet(model.train, trajs)
+        final = [p.detach().clone().numpy() for p in model.net.parameters()]
+        states, ctrls = rng.normal(size=(16, nx)), rng.normal(size=(16, nu))
+        out = {"init_%d" % i: v for i, v in enumerate(init)}
+        out.update({"final_%d" % i: v for i, v in enumerate(final)})
+        save("mlpfit_" + tag, nx=nx, nu=nu, hidden=np.array(hidden), activation=act, seed=seed, lr=lr,
+             n_train_iters=n_iter, n_batch=n_batch, obs=np.stack([t.obs for t in trajs]),
+             ctrls=np.stack([t.ctrls for t in trajs]), xu_means=model.xu_means, xu_std=model.xu_std,
+             dy_means=model.dy_means, dy_std=model.dy_std, states=states, ctrls_q=ctrls,
+             pred=model.pred_batch(states, ctrls), torch_version=torch.__version__, **out)
+
+
+GENERATORS = {"mlpfit": gen_mlpfit, "ilqr_arx4": gen_ilqr_arx4, "evalcfg_twomodels": gen_evalcfg_twomodels, "mppi_indicator": gen_mppi_indicator, "linear_wide": gen_linear_wide, "sindy": gen_sindy, "linear": gen_linear, "mlp": gen_mlp, "cost": gen_cost, "mppi": gen_mppi, "ilqr": gen_ilqr,
               "closed_loop": gen_closed_loop, "evalcfg": gen_evalcfg, "cost_terms": gen_cost_terms, "sumcost": gen_sumcost, "linear_wide2": gen_linear_wide2, "evalcfg_koopman": gen_evalcfg_koopman}
 
 if __name__ == "__main__":

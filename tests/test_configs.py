@@ -1,0 +1,166 @@
+"""Pipeline configurations <-> evaluator candidates (tuning/configs.py), and the tuner's model axis
+(``BatchPipelineTuner(model_factory=..., trajs=...)``: a model built and FITTED per configuration, as
+``eval_cfg`` does through ``pipeline(cfg, task, trajs)``, pipeline.py:138-145).  CPU: host logic; the
+evaluator is a stand-in that reads the candidate's fitted model."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from autompc_amd import MLP, zeros
+from autompc_amd.sysid.mlp import MLPFactory
+from autompc_amd.tuning import (BatchPipelineTuner, DictConfiguration, candidate_from_config,
+                                candidates_from_configs, config_from_candidate, random_candidates,
+                                random_ilqr_candidates, sample_pipeline_configs)
+from tests.helpers import make_system
+
+
+class _Configuration:
+    """What the evaluators may rely on of ConfigSpace's Configuration: get_dictionary()."""
+
+    def __init__(self, d):
+        self._d = dict(d)
+
+    def get_dictionary(self):
+        return dict(self._d)
+
+
+def test_512_sampled_configurations_round_trip_with_the_references_key_names():
+    system = make_system(4, 2)
+    cfgs = sample_pipeline_configs(system, 512, np.random.default_rng(0), model_axis=True)
+    keys = set(cfgs[0])
+    assert {"_ctrlr:horizon", "_ctrlr:sigma", "_ctrlr:lmda", "_ctrlr:num_path", "_cost:x0_Q", "_cost:x3_F",
+            "_cost:u1_R", "_model:nonlintype", "_model:n_hidden_layers", "_model:hidden_size_1", "_model:lr"} <= keys
+    cands = candidates_from_configs(system, [_Configuration(c) for c in cfgs])
+    for cfg, c in zip(cfgs, cands):
+        assert 5 <= c["horizon"] <= 30 and 100 <= c["num_path"] <= 1000 and 1e-4 <= c["sigma"] <= 2.0
+        assert c["Q"].shape == (4,) and c["R"].shape == (2,) and np.all(c["Q"] >= 1e-3) and np.all(c["F"] <= 1e4)
+        assert c["Q"][2] == cfg["_cost:x2_Q"] and c["R"][1] == cfg["_cost:u1_R"]
+        depth = int(c["model_cfg"]["n_hidden_layers"])
+        assert isinstance(c["model_cfg"]["n_hidden_layers"], str)           # the reference's categorical holds strings
+        assert sorted(k for k in c["model_cfg"] if k.startswith("hidden_size")) == ["hidden_size_%d" % (i + 1) for i in range(depth)]
+        # the candidate -> configuration direction, without the ride-along object
+        back = config_from_candidate(system, {k: v for k, v in c.items() if k != "cfg"})
+        assert back.get_dictionary() == dict(cfg)
+    assert config_from_candidate(system, cands[3]) is cands[3]["cfg"]
+
+
+def test_absent_gains_are_zero_and_ilqr_configurations_have_no_mppi_keys():
+    system = make_system(3, 1)
+    c = candidate_from_config(system, {"_ctrlr:horizon": 12, "_cost:x0_Q": 2.0, "_cost:u0_R": 0.5})
+    assert "num_path" not in c and c["horizon"] == 12
+    np.testing.assert_array_equal(c["Q"], [2.0, 0.0, 0.0])                 # quad_cost_factory.py:76-79
+    np.testing.assert_array_equal(c["F"], [0.0, 0.0, 0.0])
+    with pytest.raises(KeyError):
+        candidate_from_config(system, {"_ctrlr:horizon": 12, "_ctrlr:sigma": 1.0})
+    with pytest.raises(KeyError):
+        candidate_from_config(system, {"_cost:x0_Q": 1.0})
+    for cand in random_candidates(system, 5, seed=1) + random_ilqr_candidates(system, 5, seed=1):
+        again = candidate_from_config(system, config_from_candidate(system, cand))
+        for k in cand:
+            np.testing.assert_array_equal(again[k], cand[k])
+    with pytest.raises(ValueError):
+        config_from_candidate(system, dict(horizon=5, Q=np.ones((3, 3)), R=np.ones(1), F=np.ones(3)))
+
+
+class _ModelReadingEvaluator:
+    """score = a statistic of the candidate's controller model (so a wrong / untrained model shows)."""
+
+    def __init__(self, default):
+        self.model, self.calls = default, []
+
+    def evaluate(self, candidates, seed=0, index_offset=0):
+        self.calls.append(index_offset)
+        return np.array([float(sum(np.abs(w).sum() for w in (c.get("model") or self.model).weights))
+                         + 1e-3 * c["horizon"] for c in candidates])
+
+
+def _trajs(system, n=3, rows=40, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        t = zeros(system, rows)
+        t.obs[:] = 0.1 * rng.normal(size=(rows, system.obs_dim)).cumsum(axis=0)
+        t.ctrls[:] = rng.normal(size=(rows, system.ctrl_dim))
+        out.append(t)
+    return out
+
+
+def test_tuner_runs_given_configurations_and_reports_them_back():
+    system = make_system(3, 2)
+    cfgs = [_Configuration(c) for c in sample_pipeline_configs(system, 40, np.random.default_rng(1))]
+    ev = _ModelReadingEvaluator(MLP(system, n_hidden_layers=1, hidden_size=16))
+    tuner = BatchPipelineTuner(system, ev, batch_size=16)
+    assert tuner.balance is False              # a plain evaluator gets the documented integer index_offset
+    best, res = tuner.run(40, np.random.default_rng(0), configs=cfgs)
+    assert ev.calls == [0, 16, 32]
+    assert all(a is b for a, b in zip(res.cfgs, cfgs)) and best is cfgs[int(np.argmin(res.costs))]
+    assert "_ctrlr:horizon" in best.get_dictionary()
+    with pytest.raises(ValueError):
+        tuner.run(41, np.random.default_rng(0), configs=cfgs)
+    # sampled candidates reported as configurations on request
+    t2 = BatchPipelineTuner(system, ev, batch_size=8, as_configs=True)
+    best2, res2 = t2.run(8, np.random.default_rng(0))
+    assert isinstance(best2, DictConfiguration) and set(best2) >= {"_ctrlr:num_path", "_cost:x1_F", "_cost:u0_R"}
+
+
+def test_model_axis_fits_a_model_per_configuration_in_lockstep_groups_and_caches_them():
+    system = make_system(3, 2)
+    trajs = _trajs(system)
+    cfgs = sample_pipeline_configs(system, 24, np.random.default_rng(2), model_axis=True)
+    for c in cfgs[12:]:                         # the second half repeats the first half's models
+        for k in [k for k in c if k.startswith("_model:")]:
+            del c[k]
+    for a, b in zip(cfgs[:12], cfgs[12:]):
+        b.update({k: v for k, v in a.items() if k.startswith("_model:")})
+    default = MLP(system, n_hidden_layers=1, hidden_size=16)
+    ev = _ModelReadingEvaluator(default)
+    factory = MLPFactory(system, n_train_iters=1, n_batch=32)
+    tuner = BatchPipelineTuner(system, ev, batch_size=12, model_factory=factory, trajs=trajs)
+    best, res = tuner.run(24, np.random.default_rng(0), configs=cfgs)
+    assert tuner.models_fitted == 12 and tuner.fit_seconds > 0.0 and tuner.eval_seconds > 0.0
+    # every score came from THE configuration's model, fitted as MLP(...).train(trajs) fits it
+    for cfg, cost in list(zip(cfgs, res.costs))[::5]:
+        c = candidate_from_config(system, cfg)
+        m = factory(DictConfiguration(c["model_cfg"]), trajs)
+        assert m.hidden_sizes == [int(c["model_cfg"]["hidden_size_%d" % (i + 1)]) for i in range(len(m.hidden_sizes))]
+        want = float(sum(np.abs(w).sum() for w in m.weights)) + 1e-3 * c["horizon"]
+        assert abs(cost - want) < 1e-9 * want
+    assert "_model:lr" in best.get_dictionary()
+    # the default sampler draws the model sub-configuration itself
+    t2 = BatchPipelineTuner(system, ev, batch_size=6, model_factory=factory, trajs=trajs, as_configs=True)
+    best2, res2 = t2.run(6, np.random.default_rng(3))
+    assert t2.models_fitted == 6 and "_model:nonlintype" in best2
+    with pytest.raises(ValueError):
+        BatchPipelineTuner(system, ev, model_factory=factory)
+    with pytest.raises(ValueError):
+        BatchPipelineTuner(system, ev).run(4, np.random.default_rng(0), configs=cfgs[:4])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/autompc"), reason="needs the reference tree: build container only")
+def test_configurations_mean_to_the_references_factories_what_they_mean_here():
+    """The reference's REAL QuadCostFactory / MLPFactory (ConfigSpace stubbed as in gen_golden.py) called the way
+    Pipeline.__call__ calls them (pipeline.py:138-166) on the sub-configurations of sampled configurations:
+    the cost it builds has the candidate's Q / R / F, the model it builds has the candidate's layer sizes."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import gen_golden as gg
+    from autompc.costs import QuadCost, QuadCostFactory
+    from autompc.sysid.mlp import MLPFactory as RefMLPFactory
+    from autompc.tasks import Task
+    from autompc_amd.tuning.configs import subspace
+    system = gg.make_system(4, 2)
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(4), np.eye(2), goal=np.array([0.1, 0.0, -0.2, 0.0])))
+    for cfg in sample_pipeline_configs(make_system(4, 2), 6, np.random.default_rng(5), model_axis=True):
+        cand = candidate_from_config(make_system(4, 2), cfg)
+        cost = QuadCostFactory(system)(subspace(cfg, "_cost"), task, [])
+        Q, R, F = cost.get_cost_matrices()
+        np.testing.assert_array_equal(Q, np.diag(cand["Q"]))
+        np.testing.assert_array_equal(R, np.diag(cand["R"]))
+        np.testing.assert_array_equal(F, np.diag(cand["F"]))
+        model = gg.quiet(RefMLPFactory(system, use_cuda=False), DictConfiguration(cand["model_cfg"]), [],
+                         skip_train_model=True)
+        ours = MLPFactory(make_system(4, 2))(DictConfiguration(cand["model_cfg"]), [], skip_train_model=True)
+        ref_sizes = [m.out_features for m in model.net.layers.values()]
+        assert ref_sizes == ours.hidden_sizes
