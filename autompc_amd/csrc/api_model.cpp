@@ -345,9 +345,11 @@ struct FoldArgs {
 };
 
 // Middle layers and raw biases: plain copies.  First layer: one thread per output row n, the same
-// left-to-right sum as fold_host (no fused multiply-add: the host code is not contracted either).
-// Last layer: one thread per entry.
+// left-to-right sum as fold_host.  Last layer: one thread per entry.  No fused multiply-add anywhere: the host
+// code (x86-64 baseline) has none, and HIP's __dmul_rn / __dadd_rn are plain operators that the compiler
+// would contract -- the pragma is what keeps every product and sum separately rounded.
 __global__ void fold_model_kernel(FoldArgs a, double* __restrict__ F) {
+#pragma clang fp contract(off)
   const FoldLayout& f = a.f;
   const int L = f.L, kin = f.nx + f.nu;
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
@@ -361,18 +363,21 @@ __global__ void fold_model_kernel(FoldArgs a, double* __restrict__ F) {
     for (int k = 0; k < kin; ++k) {
       const double w = a.W[0][n * kin + k] / a.xstd[k];
       F[f.w_off[0] + n * kin + k] = w;
-      shift = __dadd_rn(shift, __dmul_rn(w, a.xmean[k]));
+      const double prod = w * a.xmean[k];
+      shift = shift + prod;
     }
-    F[f.b_off[0] + n] = __dsub_rn(a.b[0][n], shift);
+    F[f.b_off[0] + n] = a.b[0][n] - shift;
   }
   const int inL = f.in[L];
   // (L >= 1: the first and the last layer are different layers, each written by one loop only)
   for (size_t i = tid; i < (size_t)f.nx * inL; i += nthreads) {
     const size_t row = i / inL;
-    F[f.w_off[L] + i] = __dmul_rn(a.W[L][i], a.dstd[row]);
+    F[f.w_off[L] + i] = a.W[L][i] * a.dstd[row];
   }
-  for (size_t i = tid; i < (size_t)f.nx; i += nthreads)
-    F[f.b_off[L] + i] = __dadd_rn(__dmul_rn(a.b[L][i], a.dstd[i]), a.dmean[i]);
+  for (size_t i = tid; i < (size_t)f.nx; i += nthreads) {
+    const double scaled = a.b[L][i] * a.dstd[i];
+    F[f.b_off[L] + i] = scaled + a.dmean[i];
+  }
 }
 
 template <typename T>

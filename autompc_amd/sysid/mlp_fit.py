@@ -10,11 +10,12 @@ runs at device speed.
 Training stays PyTorch; what this module adds is the SHAPE of the torch program:
 
 * ``fit_mlps`` trains K models **in lockstep**: parameters stacked ``[K, out, in]``, one ``baddbmm`` per
-  layer for all K, hand-written backward pass, one Adam update over ONE flat buffer holding every
-  parameter of every model (per-model learning rates as a per-element vector).  Models of one depth and
-  activation but different widths are zero-padded to the group's widest layer (a mask keeps the padding
-  at zero).  A step is ~35 small kernels whatever K is -- the loop is launch-bound, so K models cost
-  about what one costs.
+  layer for all K, a backward pass written out with the kernels autograd itself runs
+  (``smooth_l1_loss_backward``, ``threshold_backward`` / ``tanh_backward`` / ...), and ONE fused Adam kernel
+  over ONE flat buffer holding every parameter of every model (per-model learning rates applied as a
+  per-element vector).  Models of one depth and activation but different widths are zero-padded to the
+  group's widest layer (a mask keeps the padding at zero).  A step is ~22 small kernels whatever K is, so K
+  models cost about what one costs.
 * on a GPU the steps are captured into **HIP graphs** (``torch.cuda.CUDAGraph``: a chunk of up to 64
   optimiser steps per graph, the mini-batches of a chunk gathered by one indexing kernel into a static
   buffer), which removes the per-kernel launch cost that dominates a 64-row step.
@@ -103,18 +104,6 @@ def epoch_order(gen, n):
 def _act(name):
     import torch
     return {"relu": torch.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid, "selu": torch.selu}[name]
-
-
-def _act_prime(name, z, a):
-    """d act / d z from the pre-activation z and the activation a = act(z)."""
-    import torch
-    if name == "relu":
-        return (z > 0).to(z.dtype)
-    if name == "tanh":
-        return 1.0 - a * a
-    if name == "sigmoid":
-        return a * (1.0 - a)
-    return torch.where(z > 0, torch.full_like(z, _SELU_SCALE), a + _SELU_SCALE * _SELU_ALPHA)
 
 
 # -- one model, the reference's own program ----------------------------------------------------------------
@@ -217,15 +206,20 @@ class LockstepFit:
         self.W, self.B = views(self.flat)
         self.gW, self.gB = views(self.grad)
         self.steps_done = 0
-        self._bc = None                    # (1 - beta1^t, sqrt(1 - beta2^t)) table, one row per step
-        self._t = torch.zeros(1, dtype=torch.int64, device=dev)     # steps taken, on the device (graphs read it)
+        self.dirn = torch.zeros_like(self.flat)                     # Adam's direction at lr = 1
+        self._t = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken, on the device (the fused kernel reads it)
+        self._k = torch.tensor(float(K), dtype=f64, device=dev)
         self._graphs = {}
         self.kernel_s = 0.0
 
     # .. one optimiser step on mini-batches x [K, nb, in], y [K, nb, out] ....................................
     def _step(self, x, y):
+        """Forward, backward and update with the kernels autograd would run for the reference's program -- one
+        launch each: smooth_l1_loss_backward, <activation>_backward, the fused Adam kernel -- on the stacked
+        tensors."""
         torch = self.torch
         act, nl = self.act, self.nl
+        aten = torch.ops.aten
         f = _act(act)
         a, z = [x], []
         for l in range(nl - 1):
@@ -233,31 +227,32 @@ class LockstepFit:
             z.append(zl)
             a.append(f(zl))
         out = torch.baddbmm(self.B[nl - 1], a[-1], self.W[nl - 1].transpose(1, 2))
-        d = out - y
-        # SmoothL1Loss (beta = 1, mean over the batch's nb * out entries): gradient d where |d| < 1, else sign(d)
-        g = torch.clamp(d, -1.0, 1.0) * (1.0 / (d.shape[1] * d.shape[2]))
+        # SmoothL1Loss(beta = 1), mean over EACH model's nb * out entries: the op averages over all K models'
+        # entries, the incoming gradient K undoes that (for K = 1 this is the reference's own backward kernel)
+        g = aten.smooth_l1_loss_backward(self._k, out, y, 1, 1.0)
         for l in range(nl - 1, -1, -1):
             torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])
             torch.sum(g, dim=1, keepdim=True, out=self.gB[l])
             if l > 0:
-                g = torch.bmm(g, self.W[l]) * _act_prime(act, z[l - 1], a[l])
+                g = torch.bmm(g, self.W[l])
+                if act == "relu":
+                    g = aten.threshold_backward(g, z[l - 1], 0.0)
+                elif act == "tanh":
+                    g = aten.tanh_backward(g, a[l])
+                elif act == "sigmoid":
+                    g = aten.sigmoid_backward(g, a[l])
+                else:
+                    g = aten.elu_backward(g, _SELU_ALPHA, _SELU_SCALE, 1.0, False, z[l - 1])
         if self.padded:
             self.grad.mul_(self.mask)
-        # Adam, torch.optim.Adam's arithmetic (single-tensor form) over the flat buffer
-        bc = self._bc.index_select(0, self._t)                     # [1, 2]: this step's bias corrections
+        # Adam over the flat buffer in ONE kernel (torch's fused implementation, the step count on the device):
+        # run with lr = 1 on a zeroed direction buffer, so that every model's own learning rate can scale its
+        # part of the direction afterwards (one lr per fused call is all the kernel takes)
+        self.dirn.zero_()
         self._t.add_(1)
-        self.m.lerp_(self.grad, 1.0 - _BETA1)
-        self.v.mul_(_BETA2).addcmul_(self.grad, self.grad, value=1.0 - _BETA2)
-        denom = (self.v.sqrt() / bc[0, 1]).add_(_EPS)
-        self.flat.addcmul_(self.m / denom, self.lr_flat / bc[0, 0], value=-1.0)
-
-    def _ensure_tables(self, total_steps):
-        torch = self.torch
-        have = 0 if self._bc is None else self._bc.shape[0]
-        if have >= total_steps + 1:
-            return
-        rows = [(1.0 - _BETA1 ** t, (1.0 - _BETA2 ** t) ** 0.5) for t in range(1, total_steps + 2)]
-        self._bc = torch.tensor(rows, dtype=torch.float64, device=self.device)
+        torch._fused_adam_([self.dirn], [self.grad], [self.m], [self.v], [], [self._t], lr=1.0, beta1=_BETA1,
+                           beta2=_BETA2, weight_decay=0.0, eps=_EPS, amsgrad=False, maximize=False)
+        self.flat.addcmul_(self.dirn, self.lr_flat)
 
     # .. a chunk of `steps` consecutive optimiser steps on rows idx [K, steps * nb] .............................
     def _run_chunk(self, idx, steps, nb):
@@ -302,7 +297,6 @@ class LockstepFit:
         n, nb, K = self.n, self.n_batch, self.K
         n_full, rag = divmod(n, nb)
         per_epoch = n_full + (1 if rag else 0)
-        self._ensure_tables(self.steps_done + int(n_iter) * per_epoch)
         n_chunks = max(1, -(-n_full // CHUNK))
         t0 = time.perf_counter()
         for _ in range(int(n_iter)):

@@ -400,12 +400,12 @@ def secondary_workload(args, R, emit=True):
         x0 = rng.uniform(-0.1, 0.1, size=(max(P, 4096), nx))
         stream = R.torch.cuda.current_stream().cuda_stream
 
-        def make(bounded, slots=0):
+        def make(bounded, slots=0, bound=0.25):
             hh = _lib.Handle(R.local_rank, args.precision, stream=stream)
             model.stage_into(hh)
             hh.set_quad_costs(Q, Rm, F, task.get_cost().get_goal())
             if bounded:
-                hh.set_ctrl_bounds(np.full(nu, -0.25), np.full(nu, 0.25))
+                hh.set_ctrl_bounds(np.full(nu, -bound), np.full(nu, bound))
             return hh, _lib.IlqrPlan(hh, slots or B, 50, system.dt, clip_to_bounds=bounded)
         h, plan = make(True)
         last = {}
@@ -505,6 +505,30 @@ def secondary_workload(args, R, emit=True):
             if plan0 is not plan:
                 plan0.close()
                 h0.close()
+            # SURVEY 8(d)'s protocol for config 4: "iLQR H=50 on C3's model, unbounded and bounded (+-1) variants,
+            # solves/s AND iterations/solve" -- the same P problems through the same queue, next to the +-0.25
+            # converging set of the headline.  slot-iterations/s = solves/s x iterations/solve is the rate that
+            # does not depend on how soon a problem set converges.  with_outputs: Ks / ks / states / ctrls of
+            # every problem downloaded as well (the headline step leaves them on the device).
+            proto = {}
+            for tag, bounded, bound in (("unbounded", False, 0.0), ("bounded_1.0", True, 1.0)):
+                hp, pp = make(bounded, B, bound)
+                o, e = once(lambda: pp.solve_queue(x0[:P], max_iter=50, gains=False, trajectories=False))
+                its = float(o["iters"].mean())
+                proto[tag] = {"workload": "%d problems, %s" % (P, "controls clipped to +-%g" % bound if bounded else "no control bounds"),
+                              "value": world * P / e, "unit": "solves/s", "ms": 1e3 * e,
+                              "mean_iterations_per_solve": its, "converged_fraction": float(o["converged"].mean()),
+                              "slot_iterations_per_s": world * P * its / e}
+                pp.close()
+                hp.close()
+            o, e = once(lambda: plan.solve_queue(x0[:P], max_iter=50, gains=True, trajectories=True))
+            its = float(o["iters"].mean())
+            proto["bounded_0.25_with_outputs"] = {
+                "workload": "the headline set (+-0.25) with states / ctrls / Ks / ks of all %d problems downloaded "
+                            "(%.1f MB)" % (P, P * 8 * (51 * nx + 50 * nu + 50 * nu * nx + 50 * nu) / 1e6),
+                "value": world * P / e, "unit": "solves/s", "ms": 1e3 * e, "mean_iterations_per_solve": its,
+                "slot_iterations_per_s": world * P * its / e}
+            sub["protocol_variants"] = proto
             # the unbounded problems of rounds 1-3: none converges within the reference's 50 iterations
             hu, pu = make(False, B0)
             o, e = once(lambda: pu.solve(x0[:B0], np.zeros((B0, 50, nu)), max_iter=50))
@@ -529,6 +553,10 @@ def secondary_workload(args, R, emit=True):
             extra["slots"] = B
             extra["mean_iterations_per_solve"] = it
             extra["converged_fraction"] = float(ob["converged"].mean())
+            extra["slot_iterations_per_s"] = world * steps * P * it / elapsed
+            extra["outputs_left_on_device"] = ("the timed step downloads objective / converged / iterations per problem; "
+                                               "states, ctrls, Ks, ks stay on the device (protocol_variants."
+                                               "bounded_0.25_with_outputs downloads them too)")
             extra["iteration_cap"] = 50
             extra["iterations_launched_per_step"] = float(np.mean(last["launched"]))
             extra["ideal_iterations_per_step"] = P * (it + 1) / B
