@@ -85,6 +85,7 @@ SIGNATURES = {
     "ampc_ilqr_plan_create": (c_int, [c_void_p, c_int, c_int, c_double, _ip, c_int,
                                       POINTER(c_void_p)]),
     "ampc_ilqr_plan_destroy": (c_int, [c_void_p]),
+    "ampc_ilqr_plan_set_constants": (c_int, [c_void_p, c_double, c_int, c_double, c_double]),
     "ampc_ilqr_plan_set_terminal_goal": (c_int, [c_void_p, c_int]),
     "ampc_ilqr_plan_set_timing": (c_int, [c_void_p, c_int]),
     "ampc_ilqr_plan_timing": (c_int, [c_void_p, _dp, _ip]),
@@ -662,6 +663,11 @@ class IlqrPlan:
             self.close()
         except Exception:
             pass
+
+    def set_constants(self, u_threshold=1e-3, ls_max_iter=10, ls_discount=0.2, ls_cost_threshold=0.3):
+        """compute_ilqr_default's keyword constants (ilqr.py:100-101) for the solves that follow."""
+        check(self.lib.ampc_ilqr_plan_set_constants(self._p, float(u_threshold), int(ls_max_iter), float(ls_discount),
+                                                    float(ls_cost_threshold)))
 
     def set_timing(self, enable=True, every=1):
         """Bracket the kernels of an iteration with HIP events (timing()); every > 1: only every n-th iteration of a

@@ -120,9 +120,15 @@ class IterativeLQR(Controller):
 
     def compute_ilqr_default(self, state, uguess, u_threshold=1e-3, max_iter=50, ls_max_iter=10,
                              ls_discount=0.2, ls_cost_threshold=0.3, silent=False):
-        if (u_threshold, ls_max_iter, ls_discount, ls_cost_threshold) != (1e-3, 10, 0.2, 0.3):
-            raise NotImplementedError("the HIP solve is built for the reference's constants")
-        out = self._device().solve(np.asarray(state)[None, :], np.asarray(uguess)[None], max_iter)
+        consts = (float(u_threshold), int(ls_max_iter), float(ls_discount), float(ls_cost_threshold))
+        plan = self._device()
+        if consts != getattr(plan, "_consts", (1e-3, 10, 0.2, 0.3)):
+            # the reference takes them per call (ilqr.py:100-101): they are kernel arguments of the plan
+            if not 1 <= consts[1] <= 16:
+                raise ValueError("ls_max_iter must be in 1..16 (the step sizes are the rows of one MFMA tile)")
+            plan.set_constants(*consts)
+            plan._consts = consts
+        out = plan.solve(np.asarray(state)[None, :], np.asarray(uguess)[None], max_iter)
         if out["status"][0] == 1:
             raise np.linalg.LinAlgError("Singular matrix")
         self.last_iters = int(out["iters"][0])

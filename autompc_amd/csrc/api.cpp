@@ -22,7 +22,7 @@ extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
 extern "C" const char* ampc_last_error(void) { return g_err.c_str(); }
-extern "C" int ampc_version(void) { return 107; }   // 1.07: round 6 (ampc_set_mlp_dev); 1.06: round 5 (ampc_ilqr_*_var); 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
+extern "C" int ampc_version(void) { return 107; }   // 1.07: round 6 (ampc_set_mlp_dev, ampc_ilqr_plan_set_constants); 1.06: round 5 (ampc_ilqr_*_var); 1.04: round 3 (ampc_set_sindy monomial pair list; ampc_mppi_run_legacy)
 extern "C" int ampc_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1187,6 +1187,13 @@ extern "C" int ampc_mppi_plan_set_geometry(ampc_mppi_plan* p, int tile_rows, int
   const uint64_t seed = p->eps_seed, stream = p->eps_stream;
   p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
   if (int rc = p->h->precision == AMPC_F64 ? plan_build<double>(p) : plan_build<float>(p)) return rc;
+  if (!p->models.empty()) {
+    // a model table was set before: the rebuilt plan must still be on the shape-specialised kernels (the only
+    // ones that take the per-problem model offset) -- refuse here rather than roll out on one model silently
+    if (int rc = p->h->precision == AMPC_F64 ? mppi_require_static<double>(p, "ampc_mppi_plan_set_geometry")
+                                             : mppi_require_static<float>(p, "ampc_mppi_plan_set_geometry")) return rc;
+    if (int rc = build_tile_order(p)) return rc;
+  }
   return redraw ? ampc_mppi_generate_eps(p, seed, stream) : 0;
 }
 
@@ -1495,6 +1502,24 @@ extern "C" int ampc_ilqr_plan_create(ampc_handle* h, int B, int horizon, double 
   int rc = h->precision == AMPC_F64 ? ilqr_plan_build<double>(p) : ilqr_plan_build<float>(p);
   if (rc) { ampc_ilqr_plan_destroy(p); return rc; }
   *out = p;
+  return 0;
+}
+
+extern "C" int ampc_ilqr_plan_set_constants(ampc_ilqr_plan* p, double u_threshold, int ls_max_iter, double ls_discount,
+                                            double ls_cost_threshold) {
+  REQUIRE(p, "ampc_ilqr_plan_set_constants: NULL plan");
+  REQUIRE(ls_max_iter >= 1 && ls_max_iter <= kIlqrMaxLs, "ampc_ilqr_plan_set_constants: 1..16 line-search step sizes");
+  REQUIRE(u_threshold >= 0.0 && ls_discount > 0.0, "ampc_ilqr_plan_set_constants: u_threshold >= 0 and ls_discount > 0");
+  ampc_handle* h = p->h;
+  HIP_OK(hipSetDevice(h->device));
+  HIP_OK(hipStreamSynchronize(h->stream));            // the candidate buffers below may be re-allocated
+  p->u_threshold = u_threshold;
+  p->ls_discount = ls_discount;
+  p->ls_cost_threshold = ls_cost_threshold;
+  p->ls_n = ls_max_iter;
+  const size_t e = h->esz();
+  HIP_OK(p->ls_states.reserve((size_t)p->B * p->ls_n * (p->H + 1) * h->nx * e));
+  HIP_OK(p->ls_ctrls.reserve((size_t)p->B * p->ls_n * p->H * h->nu * e));
   return 0;
 }
 

@@ -9,6 +9,9 @@
 
 template <typename T> int ilqr_launch_iter(ampc_ilqr_plan* p, int mode) {
 #ifndef AMPC_JIT_PLUGIN
+  if (p->var_model && p->static_shape < 0 && !p->jit)
+    return fail("iLQR plan: per-slot controller models need the shape-specialised kernels (the run-time-shape kernels "
+                "take one model per plan); call ampc_ilqr_plan_set_models on a plan of a registered / compiled shape");
   if (p->jit) return jit_result(p->jit, p->jit->ilqr_iter(p, mode));
 #endif
   ampc_handle* h = p->h;

@@ -11,7 +11,16 @@ template <typename T> int mppi_solve_impl(ampc_mppi_plan* p) {
 #ifndef AMPC_JIT_PLUGIN
   // indicator cost terms (set on the handle, possibly after the plan was built) live in the run-time-shape
   // kernels only (mppi_kernels.hpp): same tiles, same LDS map, same arithmetic
+  // (a plan that holds a table of controller models -- ampc_mppi_plan_set_models -- runs the shape-specialised
+  //  kernels only: the run-time-shape kernels do not take the per-problem model offset and would roll every
+  //  problem out on the plan handle's model without saying so)
+  if (!p->models.empty() && p->h->n_ind > 0)
+    return fail("ampc_mppi_solve: the plan holds a table of controller models and its handle has indicator cost terms; "
+                "indicator terms run on the run-time-shape kernels, which take one model per plan");
   if ((p->static_shape >= 0 || p->jit) && p->h->n_ind > 0) { p->static_shape = -1; p->jit = nullptr; }
+  if (!p->models.empty() && p->static_shape < 0 && !p->jit)
+    return fail("ampc_mppi_solve: the plan holds a table of controller models but is no longer on the shape-specialised "
+                "kernels (its geometry was rebuilt?): call ampc_mppi_plan_set_models again after ampc_mppi_plan_set_geometry");
   if (p->jit) return jit_result(p->jit, p->jit->mppi_solve(p));     // same function, compiled for the shape
 #endif
   ampc_handle* h = p->h;

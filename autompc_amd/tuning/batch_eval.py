@@ -705,7 +705,8 @@ class IlqrCandidateEvaluator:
             items = list(plans.values())
             if len(items) > 1:
                 from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=min(len(items), self.max_threads)) as pool:
+                from .hostpin import thread_cap
+                with ThreadPoolExecutor(max_workers=thread_cap(min(len(items), self.max_threads))) as pool:
                     results = list(pool.map(run_group, items))
             else:
                 results = [run_group(items[0])]

@@ -321,7 +321,13 @@ class Ranks:
             raise SystemExit("bench.py: rank %d needs GPU %d but only %d device(s) are visible "
                              "(--gpus %d)" % (self.rank, self.local_rank, torch.cuda.device_count(), args.gpus))
         torch.cuda.set_device(self.local_rank)
+        self.pinned = None
         if self.world > 1:
+            # this rank's host threads next to its GPU: the CPUs of the GPU's NUMA node, divided among the ranks
+            # that share the node; pools capped at the share (autompc_amd/tuning/hostpin.py; AMPC_PIN=0 disables)
+            from autompc_amd.tuning.hostpin import pin_rank
+            self.pinned = pin_rank(int(os.environ.get("LOCAL_RANK", "0")),
+                                   int(os.environ.get("LOCAL_WORLD_SIZE", str(self.world))))
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))

@@ -39,7 +39,7 @@ enum { AMPC_TERM_REFERENCE = 0, AMPC_TERM_PER_PARTICLE = 1 };
 const char* ampc_last_error(void);
 int ampc_version(void);   /* 100 * major + minor; 104: + ampc_mppi_run_legacy; 105: + ampc_set_affine_quad_costs;
                            * 106: + ampc_ilqr_solve_queue_var, ampc_ilqr_closed_loop_var, ampc_set_indicator_costs,
-                           *      ampc_mppi_plan_set_models, ampc_ilqr_plan_set_models; 107: + ampc_set_mlp_dev */
+                           *      ampc_mppi_plan_set_models, ampc_ilqr_plan_set_models; 107: + ampc_set_mlp_dev, ampc_ilqr_plan_set_constants */
 int ampc_device_count(void);
 
 /* ---- handle ------------------------------------------------------------------------------ */
@@ -382,6 +382,12 @@ int ampc_ilqr_plan_stats(ampc_ilqr_plan* p, long long* iterations, long long* ca
  * (cost.py:195, 208-211).  use_goal != 0: (F + F') (x_N - goal), the derivative of the terminal
  * cost actually charged; what QuadCost(strict_reference=False) asks for. */
 int ampc_ilqr_plan_set_terminal_goal(ampc_ilqr_plan* p, int use_goal);
+/* The constants compute_ilqr_default takes as arguments (ilqr.py:100-101; defaults u_threshold 1e-3,
+ * ls_max_iter 10, ls_discount 0.2, ls_cost_threshold 0.3 -- what a new plan holds): convergence / early-exit
+ * norm, number of step sizes alpha_j = ls_discount^j (1..16: they are the rows of one MFMA tile), and the
+ * acceptance ratio.  max_iter is an argument of every solve.  Applies to the solves that follow. */
+int ampc_ilqr_plan_set_constants(ampc_ilqr_plan* p, double u_threshold, int ls_max_iter, double ls_discount,
+                                 double ls_cost_threshold);
 int ampc_ilqr_solve(ampc_ilqr_plan* p, const double* x0, const double* uguess, int max_iter,
                     double* states, double* ctrls, double* Ks, double* ks, int* converged,
                     int* iters, int* status, double* objective);

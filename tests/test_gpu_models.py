@@ -169,3 +169,70 @@ def test_batch_tuner_searches_over_models():
         h0.set_ctrl_bounds(-np.ones(1), np.ones(1))
         plan = _lib.MppiPlan(h0, [64], [5], [1.0], [1.0])
         plan.set_models([h1], [0])
+
+
+def test_candidates_with_and_without_a_model_run_on_their_own_models():
+    """a candidate WITHOUT a "model" entry runs on the evaluator's model -- also when other candidates of
+    the batch carry models of the same or of another shape, and when every candidate that carries one has a shape
+    the evaluator's model does not have."""
+    from autompc_amd import QuadCost, Task
+    from autompc_amd.tuning import CandidateEvaluator, random_candidates
+    system, models = _hc_models(3, hidden=(64, 64), nx=4, nu=1)
+    _, other = _hc_models(2, hidden=(64, 48), nx=4, nu=1)
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(4), 0.01 * np.eye(1), np.eye(4)))
+    task.set_ctrl_bounds(-np.ones(1), np.ones(1))
+    task.set_init_obs(np.array([0.1, -0.1, 0.05, 0.0]))
+    task.set_num_steps(6)
+    ev = CandidateEvaluator(system, task, models[0])
+    cands = random_candidates(system, 6, seed=3)
+    for c in cands:
+        c["Q"], c["R"], c["F"], c["num_path"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25, 128
+    alone = {}
+    for i, c in enumerate(cands):                         # every candidate alone on each model it will meet
+        for tag, m in (("default", None), ("same", models[1]), ("other", other[0])):
+            alone[i, tag] = ev.evaluate([dict(c, **({} if m is None else {"model": m}))], seed=5, index_offset=i)[0]
+    mixes = [["same", "default", "same", "default", "default", "same"],          # one shape: explicit + default
+             ["other", "default", "same", "other", "default", "other"],          # two shapes, the first group's
+             ["other", "other", "other", "other", "other", "other"]]             # first candidate is NOT the default
+    for mix in mixes:
+        batch = [dict(c, **({} if t == "default" else {"model": models[1] if t == "same" else other[0]}))
+                 for c, t in zip(cands, mix)]
+        got = ev.evaluate(batch, seed=5)
+        for i, t in enumerate(mix):
+            assert got[i] == alone[i, t], (mix, i)
+
+
+def test_a_model_table_never_meets_the_run_time_shape_kernels_silently():
+    """the run-time-shape kernels take one model per plan.  A plan with a model table refuses indicator
+    cost terms (they live in those kernels), and a geometry rebuild keeps the table on the specialised kernels."""
+    from autompc_amd import _lib
+    system, models = _hc_models(2, hidden=(64, 64), nx=4, nu=1)
+    hs = [_lib.Handle(0, "f64") for _ in range(2)]
+    for h, m in zip(hs, models):
+        m.stage_into(h)
+    h0 = hs[0]
+    h0.set_quad_costs(np.eye(4), 0.01 * np.eye(1), np.eye(4), np.zeros(4))
+    h0.set_ctrl_bounds(-np.ones(1), np.ones(1))
+    plan = _lib.MppiPlan(h0, [64, 64], [8, 8], [1.0, 1.0], [1.0, 1.0])
+    plan.set_geometry(32, 30)
+    plan.set_models(hs, [0, 1])
+    x0 = np.tile([0.1, -0.1, 0.05, 0.0], (2, 1))
+    act = np.zeros((2, 8, 1))
+    plan.upload(x0, act, None)
+    plan.generate_eps(1, 0)
+    plan.solve()
+    a1 = plan.download(act_seq=True, u=False)[0].reshape(2, 8).copy()
+    plan.set_geometry(16, 30)                         # rebuild with the table in place: still per-problem models
+    plan.upload(x0, act, None)
+    plan.generate_eps(1, 0)
+    plan.solve()
+    a2 = plan.download(act_seq=True, u=False)[0].reshape(2, 8)
+    assert rel_err(a2, a1) < 1e-9 and not np.array_equal(a1[0], a1[1])
+    from autompc_amd.costs.terms import THRESHOLD
+    thr = (np.array([THRESHOLD], dtype=np.int32), np.concatenate([np.zeros(4), [0.0, 4.0, 0.5]]))   # goal | obs range | threshold
+    h0.set_indicator_costs(thr)
+    with pytest.raises(_lib.AmpcError, match="table of controller models"):
+        plan.solve()
+    h0.set_indicator_costs(None)
+    plan.solve()
