@@ -5,6 +5,7 @@
 #include "host_common.hpp"
 #include "legacy_rng_kernels.hpp"      // (non-template kernels: this translation unit only)
 #include <link.h>                      // dl_iterate_phdr: the C library's log() tables (host_log_mode)
+#include <atomic>
 #include <mutex>
 #include "jit_host.hpp"                // shape plugins compiled at run time
 
@@ -145,6 +146,9 @@ static int ls_rb_from_poll(const int* active, const int* need, int B) {
 }
 
 // (weight packing, ampc_set_mlp and ampc_set_mlp_dev: api_model.cpp)
+
+// Anything that rewrites a plan's noise buffer (or rebuilds the plan) drops a pre-drawn next call (mppi_run_impl).
+static inline void legacy_predraw_drop(ampc_mppi_plan* p) { p->lg_pre = false; p->u_in_pin = false; }
 
 // Wide linear model (65 .. 256 states; AMPC_LINEAR_WIDE = 1: any size): [A | B] packed in MFMA
 // fragment order for linear_kernels.hpp, plus a plain copy.
@@ -572,6 +576,7 @@ template <typename T> static int plan_build(ampc_mppi_plan* p) {
     HIP_OK(p->act[i].reserve((size_t)p->sum_hnu * sizeof(T)));
     HIP_OK(hipMemset(p->act[i].p, 0, (size_t)p->sum_hnu * sizeof(T)));
   }
+  legacy_predraw_drop(p);
   HIP_OK(p->eps.reserve((size_t)p->sum_nhnu * sizeof(T)));
   HIP_OK(hipMemset(p->eps.p, 0, (size_t)p->sum_nhnu * sizeof(T)));
   HIP_OK(p->eps_out.reserve((size_t)p->sum_nhnu * sizeof(T)));
@@ -649,6 +654,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
+  if (p->pin_flag) (void)hipHostFree(p->pin_flag);
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
@@ -756,6 +762,7 @@ static int mppi_upload_impl(ampc_mppi_plan* p, const double* x0, const double* a
   if (x0) HIP_OK(upload_converted<T>(p->x0.p, x0, (size_t)p->B * h->nx, h->stream));
   if (act_seq) HIP_OK(upload_converted<T>(p->act[p->cur].p, act_seq, (size_t)p->sum_hnu, h->stream));
   if (eps) {
+    legacy_predraw_drop(p);
     HIP_OK(upload_converted<T>(p->eps.p, eps, (size_t)p->sum_nhnu, h->stream));
     p->eps_inline = false;
     p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
@@ -775,6 +782,7 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
   const int nu = h->nu;
+  p->lg_pre = false;               // (a pre-drawn numpy-stream call is overwritten)
   // The four-row rollout (small problems: a solve is a few tens of microseconds, a launch is five)
   // forms this noise in its own prologue -- the same values, element by element -- so nothing is
   // launched here; the buffer keeps whatever it held (AMPC_INLINE_NOISE = 0: always generate it).
@@ -1150,6 +1158,7 @@ template <typename T>
 static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
                               uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out) {
   LegacyDraw d;
+  legacy_predraw_drop(p);           // (a pre-drawn next call of ampc_mppi_run_legacy: drawn again here, same values)
   if (int rc = legacy_enqueue<T>(p, key, pos, has_gauss, cached, &d)) return rc;
   if (int rc = legacy_speculate(p, d)) return rc;
   HIP_OK(hipStreamSynchronize(p->h->stream));
@@ -1235,6 +1244,7 @@ extern "C" int ampc_mppi_plan_set_noise_ids(ampc_mppi_plan* p, const uint32_t* i
 extern "C" int ampc_mppi_solve(ampc_mppi_plan* p) {
   REQUIRE(p, "ampc_mppi_solve: NULL plan");
   HIP_OK(hipSetDevice(p->h->device));
+  p->u_in_pin = false;
   return p->h->precision == AMPC_F64 ? mppi_solve_impl<double>(p) : mppi_solve_impl<float>(p);
 }
 
@@ -1252,7 +1262,12 @@ static int mppi_download_impl(ampc_mppi_plan* p, double* act_seq, double* u, dou
     p->costs_final = true;
   }
   if (act_seq) HIP_OK(download_converted<T>(act_seq, p->act[p->cur].p, (size_t)p->sum_hnu, h->stream));
-  if (u) HIP_OK(download_converted<T>(u, p->u_out.p, (size_t)p->B * h->nu, h->stream));
+  if (u && p->u_in_pin) {          // the last solve was a one-call control step: its controls went to host memory
+    HIP_OK(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < (size_t)p->B * h->nu; ++i) u[i] = (double)((const T*)p->pin_u)[i];
+  } else if (u) {
+    HIP_OK(download_converted<T>(u, p->u_out.p, (size_t)p->B * h->nu, h->stream));
+  }
   if (costs) HIP_OK(download_converted<T>(costs, p->costs.p, (size_t)p->sum_n, h->stream));
   if (eps_out) HIP_OK(download_converted<T>(eps_out, p->eps_out.p, (size_t)p->sum_nhnu, h->stream));
   HIP_OK(hipStreamSynchronize(h->stream));
@@ -1277,35 +1292,112 @@ struct LegacyState {          // numpy's legacy generator state, in and out (amp
   uint32_t* key_out; int* pos_out; int* has_gauss_out; double* cached_out;
 };
 
+static inline void draw_pack(const LegacyDraw& d, long long* o) {
+  o[0] = d.trivial ? 1 : 0; o[1] = d.pos; o[2] = d.shift; o[3] = d.n; o[4] = d.n_pairs; o[5] = d.n_att;
+}
+static inline LegacyDraw draw_unpack(const long long* o) {
+  LegacyDraw d;
+  d.trivial = o[0] != 0; d.pos = (int)o[1]; d.shift = (int)o[2]; d.n = o[3]; d.n_pairs = o[4]; d.n_att = o[5];
+  return d;
+}
+
+// One control step in one call (MPPI.run, mppi.py:154-168).  The host's part of it is kept off the stream:
+//   * x0 is written into host memory the rollout reads directly (mapped), no copy packet;
+//   * the update writes u into mapped host memory and raises a per-problem sequence word behind it
+//     (MppiArgs::done_flag); the host polls that word -- no copy packet, no hipStreamSynchronize;
+//   * numpy-stream mode: the NEXT call's normals are drawn behind this call's update from the generator state
+//     this call returns; a next call presenting exactly that state (nobody drew from numpy's generator in
+//     between) launches only the rollout (+ update) -- otherwise it draws as before, results identical.
+// AMPC_RUN_MAPPED=0 / AMPC_LEGACY_PREDRAW=0 restore the copy / in-call-draw behaviour (same results).
 template <typename T>
 static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
                          uint64_t seed, uint64_t stream, double* u, const LegacyState* lg = nullptr) {
   ampc_handle* h = p->h;
   const size_t nx0 = (size_t)p->B * h->nx, nuo = (size_t)p->B * h->nu;
   if (!p->pin_x0) {
-    HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocDefault));
-    HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocDefault));
+    HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc((void**)&p->pin_flag, (size_t)p->B * sizeof(unsigned long long), hipHostMallocMapped));
+    HIP_OK(hipHostGetDevicePointer(&p->pin_x0_dev, p->pin_x0, 0));
+    HIP_OK(hipHostGetDevicePointer(&p->pin_u_dev, p->pin_u, 0));
+    HIP_OK(hipHostGetDevicePointer((void**)&p->pin_flag_dev, p->pin_flag, 0));
+    std::memset(p->pin_flag, 0, (size_t)p->B * sizeof(unsigned long long));
   }
+  const bool mapped = env_int("AMPC_RUN_MAPPED", 1) != 0;
   LegacyDraw draw;
-  if (lg)
-    if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw)) return rc;
+  bool pre_hit = false;
+  if (lg) {
+    if (p->lg_pre) {
+      pre_hit = p->lg_pre_pos == lg->pos && p->lg_pre_has_gauss == lg->has_gauss &&
+                (lg->has_gauss == 0 || std::memcmp(&p->lg_pre_cached, &lg->cached, sizeof(double)) == 0) &&
+                std::memcmp(p->lg_pre_key.data(), lg->key, kMtN * sizeof(uint32_t)) == 0;
+      p->lg_pre = false;
+      if (pre_hit) draw = draw_unpack(p->lg_pre_draw);
+    }
+    if (!pre_hit)
+      if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw)) return rc;
+  } else {
+    legacy_predraw_drop(p);
+  }
   T* px = (T*)p->pin_x0;
   for (size_t i = 0; i < nx0; ++i) px[i] = (T)x0[i];
-  HIP_OK(hipMemcpyAsync(p->x0.p, px, nx0 * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  if (!mapped) HIP_OK(hipMemcpyAsync(p->x0.p, px, nx0 * sizeof(T), hipMemcpyHostToDevice, h->stream));
   if (act_seq) HIP_OK(upload_converted<T>(p->act[p->cur].p, act_seq, (size_t)p->sum_hnu, h->stream));
   if (noise == 1)
     if (int rc = mppi_generate_impl<T>(p, seed, stream)) return rc;
-  if (int rc = mppi_solve_impl<T>(p)) return rc;
-  HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  const unsigned long long seq = ++p->run_seq;
+  p->host_io = mapped;
+  const int rc_solve = mppi_solve_impl<T>(p);
+  p->host_io = false;
+  if (rc_solve) return rc_solve;
+  if (!mapped) HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
   // (the solve is on its way: the next call's raw stream goes to the side stream behind it)
-  if (lg)
+  if (lg && !pre_hit)
     if (int rc = legacy_speculate(p, draw)) return rc;
-  HIP_OK(hipStreamSynchronize(h->stream));
+  if (mapped) {
+    // poll the problems' completion words; every so often ask the stream whether it has stopped (an error, or --
+    // never expected -- a finished stream whose words did not arrive)
+    volatile const unsigned long long* f = p->pin_flag;
+    for (unsigned spins = 1;; ++spins) {
+      bool all = true;
+      for (int b = 0; b < p->B; ++b) all = all && f[b] == seq;
+      if (all) break;
+      if ((spins & 0xfffu) == 0) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) {
+          bool now = true;
+          for (int b = 0; b < p->B; ++b) now = now && f[b] == seq;
+          REQUIRE(now, "ampc_mppi_run: the stream finished but the solve's completion word did not arrive");
+          break;
+        }
+        if (q != hipErrorNotReady) return fail(std::string("ampc_mppi_run: ") + hipGetErrorString(q));
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    HIP_OK(hipStreamSynchronize(h->stream));
+  }
   if (lg)
     if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
       return rc;
   const T* pu = (const T*)p->pin_u;
   for (size_t i = 0; i < nuo; ++i) u[i] = (double)pu[i];
+  p->u_in_pin = mapped;
+  // (only once calls follow each other on the generator -- this call took its words from the run-ahead or from a
+  //  pre-drawn buffer: a caller who draws from numpy's generator between calls never pays for a wasted draw)
+  if (lg && !draw.trivial && (pre_hit || p->lg_hits > 0) && env_int("AMPC_LEGACY_PREDRAW", 1) != 0) {
+    // the next call's draw, from the state just handed back, behind this call's update on the same stream
+    LegacyDraw nd;
+    if (int rc = legacy_enqueue<T>(p, lg->key_out, *lg->pos_out, *lg->has_gauss_out, *lg->cached_out, &nd)) return rc;
+    if (!nd.trivial) {
+      if (int rc = legacy_speculate(p, nd)) return rc;
+      p->lg_pre_key.assign(lg->key_out, lg->key_out + kMtN);
+      p->lg_pre_pos = *lg->pos_out; p->lg_pre_has_gauss = *lg->has_gauss_out; p->lg_pre_cached = *lg->cached_out;
+      draw_pack(nd, p->lg_pre_draw);
+      p->lg_pre = true;
+    }
+  }
   return 0;
 }
 
@@ -2195,6 +2287,7 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
                             double* scores = nullptr) {
   ampc_handle* h = p->h;
   const int nx = h->nx, nu = h->nu, B = p->B, T1 = n_steps + 1;
+  legacy_predraw_drop(p);
   // With a state lift (Koopman controller model) the simulation model's state is carried separately:
   // simulate() advances simstate = sim_model.pred(simstate, u) and hands the controller only the
   // observation simstate[:obs_dim], from which update_state re-lifts (simulation.py:52-58,

@@ -315,6 +315,22 @@ struct ampc_mppi_plan {
   uint64_t step_offset = 0;   // ampc_mppi_plan_set_step_offset: index of the next closed loop's first control step
   void* pin_x0 = nullptr;     // ampc_mppi_run: pinned staging of x0 in / controls out (compute precision)
   void* pin_u = nullptr;
+  // ... mapped into the device's address space: the rollout reads x0 and the update writes u straight from / to
+  // host memory, followed by a per-problem sequence word the host polls (MppiArgs::done_flag)
+  void* pin_x0_dev = nullptr;
+  void* pin_u_dev = nullptr;
+  unsigned long long* pin_flag = nullptr;       // [B]
+  unsigned long long* pin_flag_dev = nullptr;
+  unsigned long long run_seq = 0;
+  bool host_io = false;       // the launch being assembled is such a one-call control step (make_args)
+  bool u_in_pin = false;      // the last solve was one: its controls are in pin_u, not in u_out (ampc_mppi_download)
+  // numpy-stream mode: the NEXT call's normals are drawn right behind this call's update, from the generator
+  // state this call hands back (lg_pre_*); a next call that presents exactly that state finds its noise in place
+  bool lg_pre = false;
+  int lg_pre_pos = 0, lg_pre_has_gauss = 0;
+  double lg_pre_cached = 0.0;
+  std::vector<uint32_t> lg_pre_key;
+  long long lg_pre_draw[6] = {0, 0, 0, 0, 0, 0};   // the LegacyDraw of the pre-drawn call (api.cpp)
   int static_shape = -1;  // >= 0: id of the registered shape whose specialised kernel runs (shapes.hpp)
   const JitPlugin* jit = nullptr;   // the shape's kernels live in a run-time compiled plugin (id 0 there)
   int static_lv = 0;      // which LDS map variant (StaticShape LV) the plan's tile uses
@@ -404,6 +420,14 @@ template <typename T> static MppiArgs<T> make_args(ampc_mppi_plan* p) {
   a.costs = (T*)p->costs.p;
   a.term_last = (T*)p->term_last.p;
   a.u_out = (T*)p->u_out.p;
+  a.done_flag = nullptr;
+  a.done_seq = 0;
+  if (p->host_io) {           // one-call control step: x0 / u / completion word in mapped host memory
+    a.x0 = (const T*)p->pin_x0_dev;
+    a.u_out = (T*)p->pin_u_dev;
+    a.done_flag = p->pin_flag_dev;
+    a.done_seq = p->run_seq;
+  }
   return a;
 }
 

@@ -81,7 +81,23 @@ template <typename T> struct MppiArgs {
                                 // tiles of one model are dealt to ONE XCD (workgroups go round-robin over the eight
                                 // XCDs, each with its own 4 MB L2): an XCD then streams one or two models' weights
                                 // from its L2 instead of all of them
+  // One-call control steps (ampc_mppi_run[_legacy]): x0 and u_out then point into host memory mapped into the
+  // device's address space, and problem p's first action is followed by done_seq in done_flag[p] (host memory as
+  // well, system-scope release) -- the host polls that word instead of waiting for copy packets and a stream
+  // synchronisation.  nullptr everywhere else.
+  unsigned long long* done_flag;
+  unsigned long long done_seq;
 };
+
+// First action of problem p, control j (lanes j < nu of ONE wave call this together, mppi.py:166).
+template <typename T>
+__device__ __forceinline__ void publish_u(const MppiArgs<T>& args, int p, int nu, int j, T value) {
+  args.u_out[p * nu + j] = value;
+  if (args.done_flag) {
+    __threadfence_system();            // the wave's stores to host memory are through before the flag goes up
+    if (j == 0) __hip_atomic_store(args.done_flag + p, args.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 template <typename T> __device__ __forceinline__ T block_min(T v, T* scratch);
 template <typename T> __device__ __forceinline__ T block_sum(T v, T* scratch);
@@ -166,7 +182,7 @@ __device__ __forceinline__ void finish_update_if_last(const MppiArgs<T>& args, c
       const int ts = (t + 1 < H) ? t + 1 : H - 1;
       const T a_new = args.act_in[pr.a_off + ts * nu + j] + tot / ssum;
       args.act_out[pr.a_off + ee] = a_new;
-      if (t == 0) args.u_out[p * nu + j] = a_new * args.bounds[2 * nu + j];
+      if (t == 0) publish_u(args, p, nu, j, a_new * args.bounds[2 * nu + j]);
     }
   }
 }
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(kWG) void mppi_combine_kernel(const MppiArgs<T> arg
     const int ts = (t + 1 < H) ? t + 1 : H - 1;
     const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s / ssum;
     args.act_out[pr.a_off + t * nu + tid] = a_new;
-    if (t == 0) args.u_out[p * nu + tid] = a_new * args.bounds[2 * nu + tid];
+    if (t == 0) publish_u(args, p, nu, tid, a_new * args.bounds[2 * nu + tid]);
   }
 }
 
@@ -593,7 +609,7 @@ __global__ __launch_bounds__(kWG) void mppi_update_kernel(const MppiArgs<T> args
     const int ts = (t + 1 < pr.H) ? t + 1 : pr.H - 1;
     const T a_new = args.act_in[pr.a_off + ts * nu + tid] + s / ssum;
     args.act_out[pr.a_off + t * nu + tid] = a_new;
-    if (t == 0) args.u_out[p * nu + tid] = a_new * args.bounds[2 * nu + tid];
+    if (t == 0) publish_u(args, p, nu, tid, a_new * args.bounds[2 * nu + tid]);
   }
 }
 

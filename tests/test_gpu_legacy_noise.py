@@ -366,3 +366,55 @@ def test_concurrent_draws_of_several_plans_continue_their_own_streams():
         plan.close()
         h.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("shape", [(2, 1, [64, 64], 1024, 30), (17, 6, [256, 256], 512, 12)])
+def test_hot_call_is_the_same_with_mapped_io_and_pre_drawn_noise(shape, monkeypatch):
+    """MPPI.run() in the parity-graded numpy-stream mode (ampc_mppi_run_legacy): x0 / u through mapped host memory
+    with a polled completion word, and the NEXT call's normals drawn behind this call's update from the generator
+    state it returns (round 6).  Twelve consecutive control steps -- with somebody else drawing from numpy's
+    generator before steps 4 and 9, which must invalidate the pre-drawn noise -- give bit-identical controls,
+    states of the global generator and warm starts in all four combinations of the two switches, and equal the
+    step-by-step path (upload / legacy_normal / solve / download: return_details=True)."""
+    if not _exact():
+        pytest.skip("the host's log() is not one of the two glibc builds the library reproduces")
+    from autompc_amd import MLP, MPPI, QuadCost, Task
+    nx, nu, hidden, N, H = shape
+    system = make_system(nx, nu)
+    p = omlp.random_params(nx, nu, hidden, "relu", seed=5)
+
+    def controller():
+        m = MLP(system, n_hidden_layers=2, nonlintype="relu", hidden_size_1=hidden[0], hidden_size_2=hidden[1])
+        m.weights, m.biases = [w.copy() for w in p["weights"]], [b.copy() for b in p["biases"]]
+        m.xu_means, m.xu_std, m.dy_means, m.dy_std = p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"]
+        task = Task(system)
+        task.set_cost(QuadCost(system, np.eye(nx), 0.01 * np.eye(nu), np.eye(nx)))
+        task.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+        return MPPI(system, task, m, horizon=H, num_path=N, sigma=0.5, lmda=1.0, noise="numpy_device")
+
+    def episode(details=False):
+        np.random.seed(99)
+        ctl = controller()
+        x = np.random.default_rng(0).uniform(-0.1, 0.1, size=nx)
+        state = np.concatenate([x, np.zeros(nu)])
+        us, gens = [], []
+        for step in range(12):
+            if step in (4, 9):
+                np.random.normal(size=5 + step)
+            u, state = ctl.run(state, x, return_details=details)
+            x = ctl.model.pred(x, u)
+            us.append(u)
+            gens.append(np.random.get_state()[1:4])
+        return np.array(us), gens
+    runs = {}
+    for mapped in ("1", "0"):
+        for pre in ("1", "0"):
+            monkeypatch.setenv("AMPC_RUN_MAPPED", mapped)
+            monkeypatch.setenv("AMPC_LEGACY_PREDRAW", pre)
+            runs[mapped, pre] = episode()
+    ref_u, ref_g = episode(details=True)
+    for key, (us, gens) in runs.items():
+        np.testing.assert_array_equal(us, ref_u, err_msg=str(key))
+        for a, b in zip(gens, ref_g):
+            np.testing.assert_array_equal(a[0], b[0])
+            assert a[1:] == b[1:]

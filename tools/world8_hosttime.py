@@ -86,10 +86,13 @@ if __name__ == "__main__":
         outside = np.array([d["outside_s"] for d in res])
         if base is None:
             base = dict(cpu=cpu.mean(), wall=wall.mean())
-        print("world %d %-8s wall/rank %.3f s (x%.2f of 1 rank; the GPU is shared)   host CPU/rank mean %.3f s max %.3f s "
-              "(x%.2f of 1 rank)   outside the evaluator %.4f s   CPUs/rank %s"
+        print("world %d %-8s wall/rank %.3f s (x%.2f of 1 rank; the GPU is shared)   host CPU/rank mean %.3f s max %.3f s   "
+              "cores busy per rank %.2f   outside the evaluator (max over ranks) %.4f s   CPUs/rank %s"
               % (w, "pinned" if pin and w > 1 else "unpinned", wall.mean(), wall.mean() / base["wall"], cpu.mean(),
-                 cpu.max(), cpu.mean() / base["cpu"], outside.max(), res[0]["cpus"]))
-    print("reading: a rank's host CPU seconds stay at the one-rank figure while wall time grows with the shared GPU -> the "
-          "host side of a rank does not depend on the world size; 8 x (host CPU per rank / wall per rank on its own GPU) "
-          "cores is what an 8-GPU node needs.")
+                 cpu.max(), cpu.mean() / wall.mean(), outside.max(), res[0]["cpus"]))
+    print("reading: wall time per rank grows with W because W ranks share ONE GPU here.  What a rank asks of the host is "
+          "'cores busy per rank' = CPU seconds / wall seconds: the calling thread polls inside the C ABI for the whole "
+          "episode (hipStreamSynchronize spins) plus the HIP runtime's helper thread -- if that figure is the same at "
+          "W = 1, 2 and 8, a rank's host side does not depend on the world size and an 8-GPU node needs 8 x that many "
+          "cores (it has hundreds).  'outside the evaluator' is everything that is not the device episode: sharding, the "
+          "gloo all-gather, Python.")
