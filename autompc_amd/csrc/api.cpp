@@ -655,6 +655,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->pin_flag) (void)hipHostFree(p->pin_flag);
+  if (p->lg_pre_done) (void)hipEventDestroy(p->lg_pre_done);
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
@@ -1324,18 +1325,27 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
     std::memset(p->pin_flag, 0, (size_t)p->B * sizeof(unsigned long long));
   }
   const bool mapped = env_int("AMPC_RUN_MAPPED", 1) != 0;
+  const bool predraw = lg && env_int("AMPC_LEGACY_PREDRAW", 1) != 0;
   LegacyDraw draw;
-  bool pre_hit = false;
+  bool pre_hit = false, finished = false;
   if (lg) {
     if (p->lg_pre) {
       pre_hit = p->lg_pre_pos == lg->pos && p->lg_pre_has_gauss == lg->has_gauss &&
                 (lg->has_gauss == 0 || std::memcmp(&p->lg_pre_cached, &lg->cached, sizeof(double)) == 0) &&
                 std::memcmp(p->lg_pre_key.data(), lg->key, kMtN * sizeof(uint32_t)) == 0;
       p->lg_pre = false;
-      if (pre_hit) draw = draw_unpack(p->lg_pre_draw);
     }
-    if (!pre_hit)
+    if (pre_hit) {
+      // this call's normals were drawn behind the previous call's update: what the draw left for the host is (or
+      // will in a moment be) in pinned memory -- the generator state to hand back is known BEFORE the solve
+      draw = draw_unpack(p->lg_pre_draw);
+      HIP_OK(hipEventSynchronize(p->lg_pre_done));
+      if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
+        return rc;
+      finished = true;
+    } else {
       if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw)) return rc;
+    }
   } else {
     legacy_predraw_drop(p);
   }
@@ -1351,9 +1361,28 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
   p->host_io = false;
   if (rc_solve) return rc_solve;
   if (!mapped) HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+  // The NEXT call's draw, from the generator state this call hands back, behind this call's update on the same
+  // stream -- only once calls follow each other on the generator (this call took its words from the run-ahead or
+  // from a pre-drawn buffer): a caller who draws from numpy's generator between calls never pays for a wasted draw.
+  auto enqueue_next = [&]() -> int {
+    if (!predraw || draw.trivial || !(pre_hit || p->lg_hits > 0)) return 0;
+    LegacyDraw nd;
+    if (int rc = legacy_enqueue<T>(p, lg->key_out, *lg->pos_out, *lg->has_gauss_out, *lg->cached_out, &nd)) return rc;
+    if (nd.trivial) return 0;
+    if (!p->lg_pre_done) HIP_OK(hipEventCreateWithFlags(&p->lg_pre_done, hipEventDisableTiming));
+    HIP_OK(hipEventRecord(p->lg_pre_done, h->stream));
+    if (int rc = legacy_speculate(p, nd)) return rc;
+    p->lg_pre_key.assign(lg->key_out, lg->key_out + kMtN);
+    p->lg_pre_pos = *lg->pos_out; p->lg_pre_has_gauss = *lg->has_gauss_out; p->lg_pre_cached = *lg->cached_out;
+    draw_pack(nd, p->lg_pre_draw);
+    p->lg_pre = true;
+    return 0;
+  };
   // (the solve is on its way: the next call's raw stream goes to the side stream behind it)
   if (lg && !pre_hit)
     if (int rc = legacy_speculate(p, draw)) return rc;
+  if (finished)                       // ... and so does the next call's draw, while the host would only be waiting
+    if (int rc = enqueue_next()) return rc;
   if (mapped) {
     // poll the problems' completion words; every so often ask the stream whether it has stopped (an error, or --
     // never expected -- a finished stream whose words did not arrive)
@@ -1378,26 +1407,14 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
   } else {
     HIP_OK(hipStreamSynchronize(h->stream));
   }
-  if (lg)
+  if (lg && !finished) {
     if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
       return rc;
+    if (int rc = enqueue_next()) return rc;
+  }
   const T* pu = (const T*)p->pin_u;
   for (size_t i = 0; i < nuo; ++i) u[i] = (double)pu[i];
   p->u_in_pin = mapped;
-  // (only once calls follow each other on the generator -- this call took its words from the run-ahead or from a
-  //  pre-drawn buffer: a caller who draws from numpy's generator between calls never pays for a wasted draw)
-  if (lg && !draw.trivial && (pre_hit || p->lg_hits > 0) && env_int("AMPC_LEGACY_PREDRAW", 1) != 0) {
-    // the next call's draw, from the state just handed back, behind this call's update on the same stream
-    LegacyDraw nd;
-    if (int rc = legacy_enqueue<T>(p, lg->key_out, *lg->pos_out, *lg->has_gauss_out, *lg->cached_out, &nd)) return rc;
-    if (!nd.trivial) {
-      if (int rc = legacy_speculate(p, nd)) return rc;
-      p->lg_pre_key.assign(lg->key_out, lg->key_out + kMtN);
-      p->lg_pre_pos = *lg->pos_out; p->lg_pre_has_gauss = *lg->has_gauss_out; p->lg_pre_cached = *lg->cached_out;
-      draw_pack(nd, p->lg_pre_draw);
-      p->lg_pre = true;
-    }
-  }
   return 0;
 }
 

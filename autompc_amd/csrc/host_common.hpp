@@ -327,6 +327,7 @@ struct ampc_mppi_plan {
   // numpy-stream mode: the NEXT call's normals are drawn right behind this call's update, from the generator
   // state this call hands back (lg_pre_*); a next call that presents exactly that state finds its noise in place
   bool lg_pre = false;
+  hipEvent_t lg_pre_done = nullptr;   // the pre-drawn call's draw kernel has finished
   int lg_pre_pos = 0, lg_pre_has_gauss = 0;
   double lg_pre_cached = 0.0;
   std::vector<uint32_t> lg_pre_key;
