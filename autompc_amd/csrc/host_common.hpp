@@ -230,8 +230,27 @@ static hipError_t download_converted(double* dst, const void* src, size_t n, hip
 // ---------------------------------------------------------------------------------------------
 template <typename K> static hipError_t allow_lds(K kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  // (the attribute sticks to the function: asked again only when a larger amount is needed -- a hot control
+  //  step launches the same kernel with the same size thousands of times a second)
+  static thread_local const void* last_fn[4] = {nullptr, nullptr, nullptr, nullptr};
+  static thread_local size_t last_bytes[4] = {0, 0, 0, 0};
+  static thread_local int last_dev[4] = {-1, -1, -1, -1};
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int slot = -1;
+  for (int i = 0; i < 4; ++i)
+    if (last_fn[i] == fn && last_dev[i] == dev) { slot = i; break; }
+  if (slot >= 0 && last_bytes[slot] >= bytes) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return e;
+  if (slot < 0) {
+    static thread_local int next = 0;
+    slot = next;
+    next = (next + 1) % 4;
+  }
+  last_fn[slot] = fn; last_bytes[slot] = bytes; last_dev[slot] = dev;
+  return hipSuccess;
 }
 
 // (W, NT) is one of (4,1) (8,1) (4,3) (8,2); MT is 1, 2 or 4.  The body sees W, NT, MT and WD
