@@ -1,5 +1,6 @@
-// api_model.cpp -- staging an MLP into a handle: ampc_set_mlp (host arrays) and ampc_set_mlp_dev (device
-// arrays, e.g. the parameters a PyTorch-ROCm fit has just produced).
+// api_model.cpp -- what a handle holds: the model (ampc_set_mlp from host arrays, ampc_set_mlp_dev from device
+// arrays, e.g. the parameters a PyTorch-ROCm fit has just produced; ampc_set_linear; ampc_set_sindy), cost blocks,
+// indicator terms, control bounds -- and the batched model calls (ampc_mlp_pred_*, ampc_sindy_pred_*).
 //
 // The packed model buffer (layouts: mlp_tile.hpp, MlpDev) is a pure GATHER of the folded weights: which
 // folded entry lands in which packed slot depends on the model's SHAPE only.  build_pack_map() writes
@@ -7,6 +8,9 @@
 // on the host, the device path applies it in one kernel after folding the normalisers on the device
 // with the host's arithmetic (no contraction, same summation order), so both give the same bytes.
 #include "host_common.hpp"
+
+extern template int pred_impl<double>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
+extern template int pred_impl<float>(ampc_handle*, const double*, const double*, double*, double*, double*, int);
 
 #include <map>
 #include <memory>
@@ -436,4 +440,403 @@ extern "C" int ampc_set_mlp_dev(ampc_handle* h, int nx, int nu, int n_hidden, co
   if (rc) return rc;
   model_staged(h);
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// linear models, cost blocks, bounds, batched prediction
+// ---------------------------------------------------------------------------------------------
+// Wide linear model (65 .. 256 states; AMPC_LINEAR_WIDE = 1: any size): [A | B] packed in MFMA
+// fragment order for linear_kernels.hpp, plus a plain copy.
+constexpr int kLinMaxNx = 256;
+static int set_linear_wide(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
+  HIP_OK(hipSetDevice(h->device));
+  const int k = nx + nu, nxp = round_up(nx, 16), kp = round_up(k, 4), ntile = nxp / 16, ksn = kp / 4;
+  const int ldj = round_up(k, 16), plain_sz = round_up(nx * k, 4);
+  std::vector<double> buf((size_t)ntile * ksn * 64 + (size_t)plain_sz + (size_t)nxp * ldj, 0.0);
+  auto Mat = [&](int row, int col) -> double {
+    if (row >= nx || col >= k) return 0.0;
+    return col < nx ? A[(size_t)row * nx + col] : B[(size_t)row * nu + (col - nx)];
+  };
+  for (int nt = 0; nt < ntile; ++nt)
+    for (int ks = 0; ks < ksn; ++ks)
+      for (int l = 0; l < 64; ++l)
+        buf[((size_t)nt * ksn + ks) * 64 + l] = Mat(16 * nt + (l & 15), 4 * ks + (l >> 4));
+  double* plain = buf.data() + (size_t)ntile * ksn * 64;
+  for (int r = 0; r < nx; ++r)
+    for (int c = 0; c < k; ++c) plain[(size_t)r * k + c] = Mat(r, c);
+  double* jp = plain + plain_sz;                         // [nxp][ldj], zero padded: the wide iLQR sweep's J
+  for (int r = 0; r < nx; ++r)
+    for (int c = 0; c < k; ++c) jp[(size_t)r * ldj + c] = Mat(r, c);
+  HIP_OK(h->lin_buf.reserve(buf.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->lin_buf.p, buf.data(), buf.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  if (nx != h->nx || nu != h->nu) { h->n_costs = 0; h->obs_dim = 0; h->has_bounds = false; h->n_ind = 0; }   // other dimensions
+  h->nx = nx; h->nu = nu; h->l_nxp = nxp; h->l_kp = kp;
+  h->n_hidden = 0; h->act = 4; h->hpad = 0;
+  std::memset(&h->md, 0, sizeof(h->md));
+  std::memset(&h->mf, 0, sizeof(h->mf));
+  h->md.nx = h->mf.nx = nx; h->md.nu = h->mf.nu = nu; h->md.kin = h->mf.kin = nx + nu;
+  h->has_lin = true; h->has_mlp = false; h->has_sindy = false;
+  return 0;
+}
+
+// x' = A x + B u, staged as the one-hidden-layer identity-activation network
+//   x' = x + I * ([A - I | B] [x; u])
+// so that every kernel written for the MLP (rollout, Jacobians, iLQR, closed loop) serves the
+// linear models too.  Multiplying by the identity output layer is exact; A - I rounds once.
+extern "C" int ampc_set_linear(ampc_handle* h, int nx, int nu, const double* A, const double* B) {
+  REQUIRE(h && A && B, "ampc_set_linear: NULL argument");
+  REQUIRE(nx >= 1 && nx <= kLinMaxNx, "ampc_set_linear: state dim must be in 1..256");
+  REQUIRE(nu >= 1 && nu <= kMaxNu, "ampc_set_linear: ctrl dim must be in 1..16");
+  if (nx > 64 || env_int("AMPC_LINEAR_WIDE", 0) != 0) return set_linear_wide(h, nx, nu, A, B);
+  const int kin = nx + nu;
+  std::vector<double> w0((size_t)nx * kin), w1((size_t)nx * nx, 0.0), b0(nx, 0.0);
+  for (int i = 0; i < nx; ++i) {
+    for (int j = 0; j < nx; ++j) w0[(size_t)i * kin + j] = A[(size_t)i * nx + j] - (i == j ? 1.0 : 0.0);
+    for (int j = 0; j < nu; ++j) w0[(size_t)i * kin + nx + j] = B[(size_t)i * nu + j];
+    w1[(size_t)i * nx + i] = 1.0;
+  }
+  std::vector<double> zeros(kin, 0.0), ones(kin, 1.0);
+  const double* ws[2] = {w0.data(), w1.data()};
+  const double* bs[2] = {b0.data(), b0.data()};
+  const int hidden = nx;
+  return ampc_set_mlp(h, nx, nu, 1, &hidden, 4, ws, bs, zeros.data(), ones.data(), zeros.data(),
+                      ones.data());
+}
+
+extern "C" int ampc_set_affine_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                                          const double* R, const double* F, const double* goal,
+                                          const double* lin, const double* lin_term, const double* consts) {
+  REQUIRE(h && Q && R && F && goal, "ampc_set_affine_quad_costs: NULL argument");
+  REQUIRE(h->has_model(), "ampc_set_affine_quad_costs: set the model first");
+  REQUIRE(n_costs >= 1, "ampc_set_affine_quad_costs: n_costs < 1");
+  REQUIRE(obs_dim >= 1 && obs_dim <= h->nx, "ampc_set_affine_quad_costs: obs_dim must be <= state dim");
+  HIP_OK(hipSetDevice(h->device));
+  const int no = obs_dim, nu = h->nu;
+  const int stride = cost_block_stride(no, nu);
+  std::vector<double> flat((size_t)n_costs * stride, 0.0);
+  bool affine = false;
+  for (int c = 0; c < n_costs; ++c) {
+    double* d = flat.data() + (size_t)c * stride;
+    std::memcpy(d, Q + (size_t)c * no * no, no * no * 8);
+    std::memcpy(d + no * no, R + (size_t)c * nu * nu, nu * nu * 8);
+    std::memcpy(d + no * no + nu * nu, F + (size_t)c * no * no, no * no * 8);
+    std::memcpy(d + cost_off_goal(no, nu), goal + (size_t)c * no, no * 8);
+    if (lin) std::memcpy(d + cost_off_lin(no, nu), lin + (size_t)c * no, no * 8);
+    if (lin_term) std::memcpy(d + cost_off_lint(no, nu), lin_term + (size_t)c * no, no * 8);
+    if (consts) std::memcpy(d + cost_off_c(no, nu), consts + (size_t)c * 2, 2 * 8);
+    for (int i = cost_off_lin(no, nu); i < cost_off_c(no, nu) + 2; ++i) affine = affine || d[i] != 0.0;
+  }
+  HIP_OK(h->cost_buf.reserve(flat.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->cost_buf.p, flat.data(), flat.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->n_costs = n_costs;
+  if (h->obs_dim != obs_dim) h->n_ind = 0;      // (the indicator table is laid out for the old observation)
+  h->obs_dim = obs_dim;
+  h->cost_stride = stride;
+  h->cost_affine = affine ? 1 : 0;
+  bool diag = true;
+  for (int c = 0; c < n_costs && diag; ++c) {
+    for (int i = 0; i < no && diag; ++i)
+      for (int j = 0; j < no; ++j)
+        if (i != j && (Q[((size_t)c * no + i) * no + j] != 0.0 || F[((size_t)c * no + i) * no + j] != 0.0)) diag = false;
+    for (int i = 0; i < nu && diag; ++i)
+      for (int j = 0; j < nu; ++j)
+        if (i != j && R[((size_t)c * nu + i) * nu + j] != 0.0) diag = false;
+  }
+  h->cost_diag = (diag && env_int("AMPC_DENSE_COST", 0) == 0) ? 1 : 0;
+  ampc_internal_jit_kick(h);
+  return 0;
+}
+
+extern "C" int ampc_set_quad_costs(ampc_handle* h, int n_costs, int obs_dim, const double* Q,
+                                   const double* R, const double* F, const double* goal) {
+  REQUIRE(h && Q && R && F && goal, "ampc_set_quad_costs: NULL argument");
+  return ampc_set_affine_quad_costs(h, n_costs, obs_dim, Q, R, F, goal, nullptr, nullptr, nullptr);
+}
+
+// Indicator terms of the MPPI stage cost (mlp_tile.hpp: indicator_rows): threshold / box terms of the
+// controller's cost, added to every cost block's stage cost of x_0 .. x_{H-1}
+extern "C" int ampc_set_indicator_costs(ampc_handle* h, int n_terms, const int* kinds, const double* params) {
+  REQUIRE(h, "ampc_set_indicator_costs: NULL handle");
+  REQUIRE(n_terms >= 0 && n_terms <= kMaxInd, "ampc_set_indicator_costs: at most 8 indicator terms");
+  if (n_terms == 0) { h->n_ind = 0; return 0; }
+  REQUIRE(kinds && params, "ampc_set_indicator_costs: NULL argument");
+  REQUIRE(h->n_costs > 0 && h->obs_dim > 0,
+          "ampc_set_indicator_costs: set the quadratic part first (ampc_set_quad_costs; zeros for a cost without one)");
+  HIP_OK(hipSetDevice(h->device));
+  const int no = h->obs_dim, st = ind_stride(no);
+  std::vector<double> tab((size_t)n_terms * st, 0.0);
+  const double* par = params;
+  for (int k = 0; k < n_terms; ++k) {
+    double* t = tab.data() + (size_t)k * st;
+    if (kinds[k] == SCORE_THRESHOLD) {            // goal[no] lo hi threshold  (as ampc_score_trajectories)
+      const int lo = std::max(0, (int)par[no]), hi = std::min(no, (int)par[no + 1]);
+      t[0] = 1.0;
+      for (int i = 0; i < no; ++i) {
+        t[2 + i] = par[i];
+        t[2 + no + i] = (i >= lo && i < hi) ? par[no + 2] : INFINITY;
+      }
+      par += no + 3;
+    } else if (kinds[k] == SCORE_BOX) {           // lower[no] upper[no]
+      t[0] = 2.0;
+      for (int i = 0; i < no; ++i) { t[2 + i] = par[i]; t[2 + no + i] = par[no + i]; }
+      par += 2 * no;
+    } else {
+      return fail("ampc_set_indicator_costs: kinds must be 1 (threshold) or 2 (box)");
+    }
+  }
+  HIP_OK(h->ind_buf.reserve(tab.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->ind_buf.p, tab.data(), tab.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->ind_buf.p, tab.data(), tab.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->n_ind = n_terms;
+  return 0;
+}
+
+extern "C" int ampc_set_ctrl_bounds(ampc_handle* h, const double* lo, const double* hi) {
+  REQUIRE(h && lo && hi, "ampc_set_ctrl_bounds: NULL argument");
+  REQUIRE(h->has_model(), "ampc_set_ctrl_bounds: set the model first");
+  HIP_OK(hipSetDevice(h->device));
+  const int nu = h->nu;
+  h->lo.assign(lo, lo + nu);
+  h->hi.assign(hi, hi + nu);
+  // MPPI works in units of umax (ctrl_scale = umax, mppi.py:100-102): store lo/scale, hi/scale, scale.
+  std::vector<double> flat(3 * nu);
+  for (int j = 0; j < nu; ++j) {
+    flat[j] = lo[j] / hi[j];
+    flat[nu + j] = hi[j] / hi[j];
+    flat[2 * nu + j] = hi[j];
+  }
+  HIP_OK(h->bounds_buf.reserve(flat.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->bounds_buf.p, flat.data(), flat.size(), h->stream));
+  std::vector<double> raw(2 * nu);
+  for (int j = 0; j < nu; ++j) { raw[j] = lo[j]; raw[nu + j] = hi[j]; }
+  HIP_OK(h->ubounds_buf.reserve(raw.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->ubounds_buf.p, raw.data(), raw.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->ubounds_buf.p, raw.data(), raw.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->has_bounds = true;
+  return 0;
+}
+
+// Model.pred_batch / pred_diff_batch of a wide linear model (linear_kernels.hpp)
+template <typename T>
+static int lin_pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out, double* jx,
+                         double* ju, int n) {
+  const int nx = h->nx, nu = h->nu;
+  const LinDev<T> m = lin_of<T>(h);
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const size_t lb = (size_t)16 * lin_xs(m.kp, (int)sizeof(T)) * sizeof(T);
+  HIP_OK(allow_lds(linear_forward_kernel<T>, lb));
+  hipLaunchKernelGGL(linear_forward_kernel<T>, dim3((n + 15) / 16), dim3(64 * kLinW), lb, h->stream, m,
+                     (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
+  HIP_OK(hipGetLastError());
+  if (jx) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    hipLaunchKernelGGL(linear_jacobian_kernel<T>, dim3(1024), dim3(256), 0, h->stream, m, (T*)h->s_jx.p,
+                       (T*)h->s_ju.p, n);
+    HIP_OK(hipGetLastError());
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
+extern "C" int ampc_mlp_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                   double* out, int n) {
+  REQUIRE(h && states && ctrls && out, "ampc_mlp_pred_batch: NULL argument");
+  if (h->has_sindy) return ampc_sindy_pred_batch(h, states, ctrls, out, n);
+  if (h->has_lin) {
+    if (n <= 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    return h->precision == AMPC_F64 ? lin_pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                    : lin_pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+  }
+  REQUIRE(h->has_mlp, "ampc_mlp_pred_batch: no model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                  : pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+}
+
+extern "C" int ampc_mlp_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                        double* out, double* jx, double* ju, int n) {
+  REQUIRE(h && states && ctrls && out && jx && ju, "ampc_mlp_pred_diff_batch: NULL argument");
+  if (h->has_sindy) return ampc_sindy_pred_diff_batch(h, states, ctrls, out, jx, ju, n);
+  if (h->has_lin) {
+    if (n <= 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    return h->precision == AMPC_F64 ? lin_pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                    : lin_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
+  }
+  REQUIRE(h->has_mlp, "ampc_mlp_pred_diff_batch: no model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                  : pred_impl<float>(h, states, ctrls, out, jx, ju, n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SINDy feature-library model
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int sindy_pred_impl(ampc_handle* h, const double* states, const double* ctrls, double* out,
+                           double* jx, double* ju, int n) {
+  const int nx = h->nx, nu = h->nu;
+  const SindyDev<T> m = sindy_of<T>(h);
+  HIP_OK(h->s_states.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(h->s_ctrls.reserve((size_t)n * nu * sizeof(T)));
+  HIP_OK(h->s_out.reserve((size_t)n * nx * sizeof(T)));
+  HIP_OK(upload_converted<T>(h->s_states.p, states, (size_t)n * nx, h->stream));
+  HIP_OK(upload_converted<T>(h->s_ctrls.p, ctrls, (size_t)n * nu, h->stream));
+  const size_t lb = (size_t)(2 * nx + nu + h->s_ntab) * 64 * sizeof(T) + sindy_stage_bytes<T>(h);
+  HIP_OK(allow_lds(sindy_forward_kernel<T>, lb));
+  hipLaunchKernelGGL(sindy_forward_kernel<T>, dim3((n + 63) / 64), dim3(64), lb, h->stream, m,
+                     (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_out.p, n);
+  if (jx) {
+    HIP_OK(h->s_jx.reserve((size_t)n * nx * nx * sizeof(T)));
+    HIP_OK(h->s_ju.reserve((size_t)n * nx * nu * sizeof(T)));
+    hipLaunchKernelGGL(sindy_jacobian_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, h->stream, m,
+                       (const T*)h->s_states.p, (const T*)h->s_ctrls.p, (T*)h->s_jx.p, (T*)h->s_ju.p, n,
+                       RowMap{n, 0, 0, nullptr});
+  }
+  HIP_OK(hipGetLastError());
+  if (jx) {
+    HIP_OK(download_converted<T>(jx, h->s_jx.p, (size_t)n * nx * nx, h->stream));
+    HIP_OK(download_converted<T>(ju, h->s_ju.p, (size_t)n * nx * nu, h->stream));
+  }
+  HIP_OK(download_converted<T>(out, h->s_out.p, (size_t)n * nx, h->stream));
+  return 0;
+}
+
+extern "C" int ampc_set_sindy(ampc_handle* h, int nx, int nu, int n_feat, const int* kind,
+                              const int* arg0, const int* arg1, const double* param,
+                              const double* xi, int continuous, double dt, int strict_reference,
+                              int n_pairs, const int* pair_var, const int* pair_exp) {
+  REQUIRE(h && kind && arg0 && arg1 && param && xi, "ampc_set_sindy: NULL argument");
+  REQUIRE(nx >= 1 && nx <= 64 && nu >= 1 && nu <= kMaxNu, "ampc_set_sindy: nx in 1..64, nu in 1..16");
+  REQUIRE(n_feat >= 1 && n_feat <= 4096, "ampc_set_sindy: n_feat in 1..4096");
+  REQUIRE(n_pairs >= 0 && n_pairs <= 10 * 4096 && (n_pairs == 0 || (pair_var && pair_exp)),
+          "ampc_set_sindy: bad monomial pair list");
+  for (int j = 0; j < n_pairs; ++j)
+    REQUIRE(pair_var[j] >= 0 && pair_var[j] < nx + nu && pair_exp[j] >= 1 && pair_exp[j] <= 64,
+            "ampc_set_sindy: monomial pair needs a variable index and an exponent in 1..64");
+  for (int k = 0; k < n_feat; ++k) {
+    if (kind[k] == SF_MONO) {
+      REQUIRE(arg1[k] >= 1 && arg1[k] <= 10 && arg0[k] >= 0 && arg0[k] + arg1[k] <= n_pairs,
+              "ampc_set_sindy: monomial feature needs 1..10 pairs inside the pair list");
+      continue;
+    }
+    REQUIRE(kind[k] >= 0 && kind[k] <= 5 && arg0[k] >= 0 && arg0[k] < nx + nu && arg1[k] >= 0 &&
+                arg1[k] < nx + nu, "ampc_set_sindy: bad feature descriptor");
+  }
+  HIP_OK(hipSetDevice(h->device));
+  // product form (SindyDev): distinct trig arguments and powers, two factor indices per feature
+  std::vector<int> tvar, pvar, fx(n_feat, 0), fy(n_feat, 0), tslot(n_feat, -1);
+  std::vector<double> tpar, ppar;
+  for (int k = 0; k < n_feat; ++k) {
+    if (kind[k] >= 1 && kind[k] <= 4) {
+      const int var = kind[k] <= 2 ? arg0[k] : arg1[k];   // sin/cos(p v_a) vs v_a sin/cos(p v_b)
+      int slot = -1;
+      for (size_t j = 0; j < tvar.size(); ++j)
+        if (tvar[j] == var && tpar[j] == param[k]) { slot = (int)j; break; }
+      if (slot < 0) { slot = (int)tvar.size(); tvar.push_back(var); tpar.push_back(param[k]); }
+      tslot[k] = slot;
+    } else if (kind[k] == 5) {
+      int slot = -1;
+      for (size_t j = 0; j < pvar.size(); ++j)
+        if (pvar[j] == arg0[k] && ppar[j] == param[k]) { slot = (int)j; break; }
+      if (slot < 0) { slot = (int)pvar.size(); pvar.push_back(arg0[k]); ppar.push_back(param[k]); }
+      tslot[k] = slot;
+    }
+  }
+  std::vector<int> moff, mcnt;                                // one table entry per monomial feature
+  for (int k = 0; k < n_feat; ++k)
+    if (kind[k] == SF_MONO) { tslot[k] = (int)moff.size(); moff.push_back(arg0[k]); mcnt.push_back(arg1[k]); }
+  int n_trig = (int)tvar.size(), n_pow = (int)pvar.size(), n_mon = (int)moff.size();
+  int n_tab = 2 * n_trig + n_pow + n_mon + 1;
+  if (n_tab > kSindyMaxTab) n_trig = n_pow = n_mon = n_tab = 0;      // direct evaluation instead
+  if (n_tab > 0) {
+    const int one = n_tab - 1;
+    for (int k = 0; k < n_feat; ++k) {
+      switch (kind[k]) {
+        case 0: fx[k] = arg0[k]; fy[k] = one; break;
+        case 1: fx[k] = -(2 * tslot[k]) - 1; fy[k] = one; break;
+        case 2: fx[k] = -(2 * tslot[k] + 1) - 1; fy[k] = one; break;
+        case 3: fx[k] = arg0[k]; fy[k] = 2 * tslot[k]; break;
+        case 4: fx[k] = arg0[k]; fy[k] = 2 * tslot[k] + 1; break;
+        case SF_MONO: fx[k] = -(2 * n_trig + n_pow + tslot[k]) - 1; fy[k] = one; break;
+        default: fx[k] = -(2 * n_trig + tslot[k]) - 1; fy[k] = one; break;
+      }
+    }
+  }
+  std::vector<int> ints(9 * (size_t)n_feat + 2 * (size_t)n_pairs + 2, 0);
+  std::memcpy(ints.data(), kind, n_feat * sizeof(int));
+  std::memcpy(ints.data() + n_feat, arg0, n_feat * sizeof(int));
+  std::memcpy(ints.data() + 2 * n_feat, arg1, n_feat * sizeof(int));
+  std::memcpy(ints.data() + 3 * n_feat, fx.data(), n_feat * sizeof(int));
+  std::memcpy(ints.data() + 4 * n_feat, fy.data(), n_feat * sizeof(int));
+  if (n_trig > 0) std::memcpy(ints.data() + 5 * n_feat, tvar.data(), n_trig * sizeof(int));
+  if (n_pow > 0) std::memcpy(ints.data() + 6 * n_feat, pvar.data(), n_pow * sizeof(int));
+  if (n_mon > 0) {
+    std::memcpy(ints.data() + 7 * n_feat, moff.data(), n_mon * sizeof(int));
+    std::memcpy(ints.data() + 8 * n_feat, mcnt.data(), n_mon * sizeof(int));
+  }
+  for (int j = 0; j < n_pairs; ++j) {
+    ints[9 * (size_t)n_feat + 2 * j] = pair_var[j];
+    ints[9 * (size_t)n_feat + 2 * j + 1] = pair_exp[j];
+  }
+  HIP_OK(h->sindy_int.reserve(ints.size() * sizeof(int)));
+  HIP_OK(hipMemcpy(h->sindy_int.p, ints.data(), ints.size() * sizeof(int), hipMemcpyHostToDevice));
+  std::vector<double> flt((size_t)n_feat * (nx + 3), 0.0);
+  std::memcpy(flt.data(), param, n_feat * 8);
+  std::memcpy(flt.data() + n_feat, xi, (size_t)n_feat * nx * 8);
+  if (n_trig > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 1), tpar.data(), n_trig * 8);
+  if (n_pow > 0) std::memcpy(flt.data() + (size_t)n_feat * (nx + 2), ppar.data(), n_pow * 8);
+  h->s_ntrig = n_trig; h->s_npow = n_pow; h->s_ntab = n_tab;
+  h->s_nmon = n_mon; h->s_npool = n_pairs;
+  HIP_OK(h->sindy_flt.reserve(flt.size() * h->esz()));
+  if (h->precision == AMPC_F64) HIP_OK(upload_converted<double>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
+  else HIP_OK(upload_converted<float>(h->sindy_flt.p, flt.data(), flt.size(), h->stream));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  h->nx = nx; h->nu = nu; h->s_nfeat = n_feat; h->s_continuous = continuous ? 1 : 0;
+  h->s_dt = dt; h->s_strict = strict_reference ? 1 : 0;
+  std::memset(&h->md, 0, sizeof(h->md));
+  std::memset(&h->mf, 0, sizeof(h->mf));
+  h->md.nx = h->mf.nx = nx; h->md.nu = h->mf.nu = nu; h->md.kin = h->mf.kin = nx + nu;
+  h->n_hidden = 0;
+  h->has_sindy = true;
+  h->has_mlp = false;
+  h->has_lin = false;
+  return 0;
+}
+
+extern "C" int ampc_sindy_pred_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                     double* out, int n) {
+  REQUIRE(h && states && ctrls && out, "ampc_sindy_pred_batch: NULL argument");
+  REQUIRE(h->has_sindy, "ampc_sindy_pred_batch: no SINDy model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? sindy_pred_impl<double>(h, states, ctrls, out, nullptr, nullptr, n)
+                                  : sindy_pred_impl<float>(h, states, ctrls, out, nullptr, nullptr, n);
+}
+
+extern "C" int ampc_sindy_pred_diff_batch(ampc_handle* h, const double* states, const double* ctrls,
+                                          double* out, double* jx, double* ju, int n) {
+  REQUIRE(h && states && ctrls && out && jx && ju, "ampc_sindy_pred_diff_batch: NULL argument");
+  REQUIRE(h->has_sindy, "ampc_sindy_pred_diff_batch: no SINDy model set");
+  if (n <= 0) return 0;
+  HIP_OK(hipSetDevice(h->device));
+  return h->precision == AMPC_F64 ? sindy_pred_impl<double>(h, states, ctrls, out, jx, ju, n)
+                                  : sindy_pred_impl<float>(h, states, ctrls, out, jx, ju, n);
 }

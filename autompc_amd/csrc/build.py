@@ -1,7 +1,7 @@
 """Build libautompc_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-Eight translation units compiled in parallel and linked into one shared library: api.cpp (the C
-ABI and host logic), api_model.cpp (MLP staging) plus launch_{mlp,mppi,ilqr}.cpp once per precision (-DAMPC_T=double|float).
+Ten translation units compiled in parallel and linked into one shared library: api.cpp + api_{model,mppi,ilqr}.cpp (the C ABI
+and host logic by family) plus launch_{mlp,mppi,ilqr}.cpp once per precision (-DAMPC_T=double|float).
 """
 import concurrent.futures
 import os
@@ -20,7 +20,8 @@ def _headers():
     """Every header a translation unit may include: all of csrc/*.hpp and the public C header."""
     return sorted(glob.glob(os.path.join(HERE, "*.hpp"))) + [os.path.join(ROOT, "include", "autompc_hip.h")]
 # (object name, source file, extra flags)
-UNITS = [("api", "api.cpp", []), ("api_model", "api_model.cpp", [])] + [
+UNITS = [("api", "api.cpp", []), ("api_model", "api_model.cpp", []), ("api_mppi", "api_mppi.cpp", []),
+         ("api_ilqr", "api_ilqr.cpp", [])] + [
     ("%s_%s" % (fam, t), "launch_%s.cpp" % fam, ["-DAMPC_T=%s" % t] + (["-DAMPC_T_IS_F64=1"] if t == "double" else []))
     for fam in ("mlp", "mppi", "ilqr") for t in ("double", "float")]
 SOURCES = sorted({u[1] for u in UNITS})

@@ -160,9 +160,57 @@ struct ampc_handle {
 // Start (or find) the shape plugin of the staged model (api.cpp; never blocks).
 void ampc_internal_jit_kick(ampc_handle* h);
 
+// Plans hold references on their handles (api.cpp).
+void handle_release(ampc_handle* h);
+
 template <typename T> inline MlpDev<T>& model_of(ampc_handle* h);
 template <> inline MlpDev<double>& model_of<double>(ampc_handle* h) { return h->md; }
 template <> inline MlpDev<float>& model_of<float>(ampc_handle* h) { return h->mf; }
+
+// ---- several controller models of one shape in a plan (ampc_*_plan_set_models) ----------------------------
+inline int check_same_shape(const ampc_handle* h, const ampc_handle* m, const char* who) {
+  const std::string w(who);
+  REQUIRE(m != nullptr, w + ": NULL model handle");
+  REQUIRE(m->has_mlp && h->has_mlp, w + ": per-problem models are MLP models");
+  REQUIRE(m->device == h->device && m->precision == h->precision, w + ": models must share the plan's device and precision");
+  bool same = m->nx == h->nx && m->nu == h->nu && m->n_hidden == h->n_hidden && m->act == h->act &&
+              m->hpad == h->hpad && m->nw == h->nw && m->nt == h->nt;
+  for (int l = 0; l < kMaxHidden; ++l) same = same && m->hidden[l] == h->hidden[l];
+  REQUIRE(same, w + ": every model must have the shape (dimensions, hidden layers, activation) of the plan's model");
+  return 0;
+}
+
+// device table of the models' buffer offsets (mlp_tile.hpp: shift_model); takes a reference on every handle
+template <typename T>
+inline int build_model_table(ampc_handle* h, int n, ampc_handle* const* ms, DevBuf* tab, std::vector<ampc_handle*>* keep) {
+  std::vector<long long> host(n);
+  const MlpDev<T>& m0 = model_of<T>(h);
+  for (int i = 0; i < n; ++i) {
+    const MlpDev<T>& mi = model_of<T>(ms[i]);
+    host[i] = (long long)((const char*)mi.wbase - (const char*)m0.wbase);
+    // same shape => same packing: every array sits at the same offset of its model's buffer
+    bool same = true;
+    for (int l = 0; l <= h->n_hidden; ++l)
+      same = same && (mi.w[l] - mi.wbase) == (m0.w[l] - m0.wbase) && (mi.b[l] - mi.wbase) == (m0.b[l] - m0.wbase) &&
+             (mi.w4[l] - mi.wbase) == (m0.w4[l] - m0.wbase);
+    REQUIRE(same && ((const T*)ms[i]->wout_plain - mi.wbase) == ((const T*)h->wout_plain - m0.wbase),
+            "internal: models of one shape are packed differently");
+  }
+  HIP_OK(tab->reserve(host.size() * sizeof(long long)));
+  HIP_OK(hipStreamSynchronize(h->stream));
+  HIP_OK(hipMemcpy(tab->p, host.data(), host.size() * sizeof(long long), hipMemcpyHostToDevice));
+  for (ampc_handle* old : *keep) handle_release(old);
+  keep->assign(ms, ms + n);
+  for (ampc_handle* mh : *keep) mh->refs++;
+  return 0;
+}
+
+
+static const char* const kNeedStatic =
+    ": several controller models in one plan run on the kernels specialised for the model's shape; they are "
+    "not available for this plan (AMPC_STATIC=0 / AMPC_JIT=0, no hipcc for the run-time build of an unregistered "
+    "shape, a tile geometry without a specialised instantiation, or a cost with indicator terms)";
+
 
 // LDS bytes the kernels need on top of their own regions for the staged feature program
 template <typename T> static size_t sindy_stage_bytes(const ampc_handle* h) {
