@@ -1,12 +1,12 @@
 #!/bin/bash
 # One GPU-box session for the record: parity tests, smoke, every bench line, rocprofv3 summaries.
-# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r05
+# Usage (from repo root, via gpurun):  bash tools/gpu_round.sh r06
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $OUT/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q -rs -p no:cacheprovider 2>&1 | tail -25 > $OUT/pytest_gpu.log      # (-rs: skip reasons in the log)
 timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1
 b() { name=$1; shift; timeout 900 python bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err; }
 b c3_f64 
@@ -25,6 +25,10 @@ b c5_candidates_f64 --workload c5 --steps 2 --warmup 1
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_2rank_plumbing.json 2> $OUT/bench_2rank_plumbing.err
 AMPC_BENCH_FORCE_DEVICE=0 AMPC_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --workload c5 --batch 8 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_2rank_c5_plumbing.json 2> $OUT/bench_2rank_c5_plumbing.err
 timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
+timeout 300 python tools/dropin_breakdown.py > $OUT/dropin_breakdown.log 2>&1
+timeout 600 python tools/model_axis_rate.py > $OUT/model_axis_rate.log 2>&1
+timeout 900 python tools/world8_hosttime.py 8 64 200 > $OUT/world8_hosttime.log 2>&1
+timeout 600 bash tools/c4_trace_iterations.sh 1024 1024 > $OUT/c4_iterations.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
 timeout 500 bash tools/dropin_kernels.sh $TAG > /dev/null 2>&1
 timeout 600 python tools/jit_rate.py > $OUT/jit_rate.log 2>&1
