@@ -209,9 +209,6 @@ class LockstepFit:
         self.dirn = torch.zeros_like(self.flat)                     # Adam's direction at lr = 1
         self._t = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken, on the device (the fused kernel reads it)
         self._k = torch.tensor(float(K), dtype=f64, device=dev)
-        import os
-        self._side = (torch.cuda.Stream(device=dev) if self.use_graphs and os.environ.get("AMPC_FIT_FORK", "1") != "0"
-                      else None)
         self._graphs = {}
         self.kernel_s = 0.0
 
@@ -233,22 +230,9 @@ class LockstepFit:
         # SmoothL1Loss(beta = 1), mean over EACH model's nb * out entries: the op averages over all K models'
         # entries, the incoming gradient K undoes that (for K = 1 this is the reference's own backward kernel)
         g = aten.smooth_l1_loss_backward(self._k, out, y, 1, 1.0)
-        # The parameter gradients of a layer (one bmm, one sum) hang off the chain that carries the error to the
-        # layer below: in a captured graph they are issued on a second stream -- a parallel branch of the graph,
-        # joined again ahead of the update -- so the chain of a step is forward, error back-propagation, update.
-        fork = self._side is not None and torch.cuda.is_current_stream_capturing()
-        main = torch.cuda.current_stream(self.device) if fork else None
-        keep = []                               # (errors read by the side branch stay allocated until the join)
         for l in range(nl - 1, -1, -1):
-            if fork:
-                keep.append(g)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])
-                    torch.sum(g, dim=1, keepdim=True, out=self.gB[l])
-            else:
-                torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])
-                torch.sum(g, dim=1, keepdim=True, out=self.gB[l])
+            torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])
+            torch.sum(g, dim=1, keepdim=True, out=self.gB[l])
             if l > 0:
                 g = torch.bmm(g, self.W[l])
                 if act == "relu":
@@ -259,8 +243,6 @@ class LockstepFit:
                     g = aten.sigmoid_backward(g, a[l])
                 else:
                     g = aten.elu_backward(g, _SELU_ALPHA, _SELU_SCALE, 1.0, False, z[l - 1])
-        if fork:
-            main.wait_stream(self._side)
         if self.padded:
             self.grad.mul_(self.mask)
         # Adam over the flat buffer in ONE kernel (torch's fused implementation, the step count on the device):
