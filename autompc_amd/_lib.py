@@ -59,6 +59,7 @@ SIGNATURES = {
     "ampc_mppi_plan_destroy": (c_int, [c_void_p]),
     "ampc_mppi_upload": (c_int, [c_void_p, _dp, _dp, _dp]),
     "ampc_mppi_generate_eps": (c_int, [c_void_p, c_uint64, c_uint64]),
+    "ampc_mppi_plan_legacy_redraws": (c_int, [c_void_p, POINTER(ctypes.c_longlong)]),
     "ampc_mppi_plan_set_noise_ids": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ampc_set_mt_jump_table": (c_int, [POINTER(c_uint32), c_int, c_int]),
     "ampc_legacy_log_mode": (c_int, []),
@@ -540,6 +541,12 @@ class MppiPlan:
         check(self.lib.ampc_mppi_run(self._p, dptr(x0), dptr(act_seq), 0 if philox is None else 1,
                                      int(seed), int(stream), dptr(u)))
         return u
+
+    def legacy_redraws(self):
+        """Draws repeated because a bounded wait inside the draw kernel expired (ampc_mppi_plan_legacy_redraws)."""
+        n = ctypes.c_longlong()
+        check(self.lib.ampc_mppi_plan_legacy_redraws(self._p, ctypes.byref(n)))
+        return int(n.value)
 
     def run_legacy_inplace(self, x0, act_seq, ls):
         """run() with the reference's own noise: numpy's legacy draw from the global generator

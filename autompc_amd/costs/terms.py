@@ -37,9 +37,13 @@ def cost_terms(cost, obs_dim, ctrl_dim):
         if _is_threshold(c):
             lo, hi = _threshold_range(c)
             lo, hi = max(lo, 0), min(hi, obs_dim)      # numpy slicing clamps the same way
+            if hi <= lo:
+                # the reference's eval_obs_cost takes norm(., inf) of an EMPTY slice there: numpy raises
+                raise ValueError("ThresholdCost with an empty obs_range %r: zero-size array to reduction operation "
+                                 "maximum which has no identity" % (tuple(_threshold_range(c)),))
             goal = np.asarray(c._goal, dtype=np.float64).reshape(obs_dim)
             kinds.append(THRESHOLD)
-            params.append(np.concatenate([goal, [lo, max(hi, lo), float(c._threshold)]]))
+            params.append(np.concatenate([goal, [lo, hi, float(c._threshold)]]))
         elif _is_box(c):
             lim = np.asarray(c._limits, dtype=np.float64).reshape(obs_dim, 2)
             kinds.append(BOX)

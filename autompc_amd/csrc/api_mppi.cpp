@@ -589,9 +589,13 @@ static int legacy_blocks_for(int start_pos, long long n_att) {
 // paid once per several calls.  A call whose generator state is not the one the previous call left
 // (someone else drew from numpy's generator in between) generates its own words on the main
 // stream and the run-ahead starts again from there.
+// What legacy_finish returns when a look-back wait of the draw kernel expired (the results are not to be used: draw
+// again -- the generator state the caller passed in has not been touched).
+constexpr int kLegacyExpired = 2;
+
 template <typename T>
 static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
-                          LegacyDraw* d) {
+                          LegacyDraw* d, bool retry = false) {
   p->eps_inline = false;          // (this draw fills the plan's noise buffer)
   p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
   ampc_handle* h = p->h;
@@ -681,7 +685,9 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
   hipLaunchKernelGGL(draw, dim3(std::min(n_wg, kPolarMaxWgs)), dim3(256), 0, h->stream, u, (int)n_att,
                      (unsigned long long*)p->lg_cnt.p, p->lg_epoch & 0xffffffu, n, shift, cached,
                      (const MppiProblem<T>*)p->probs.p, (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, stream, pos,
-                     (long long*)p->lg_pin_dev, (const double*)p->lg_logtab.p, n_wg);
+                     (long long*)p->lg_pin_dev, (const double*)p->lg_logtab.p, n_wg,
+                     // (a second attempt always waits the full bound; AMPC_POLAR_SPIN_LIMIT is the tests' hook)
+                     retry ? kPolarSpinLimit : std::max(1, env_int("AMPC_POLAR_SPIN_LIMIT", kPolarSpinLimit)));
   HIP_OK(hipGetLastError());
   return 0;
 }
@@ -723,7 +729,10 @@ static int legacy_finish(ampc_mppi_plan* p, const LegacyDraw& d, const uint32_t*
   const long long* gl = (const long long*)p->lg_pin;
   const long long fin[2] = {gl[0], gl[1]};
   const int total = (int)gl[2];
-  REQUIRE(gl[kLegacyStatusSlot] == 0, "legacy normal: the draw kernel gave up waiting for a workgroup's pair count");
+  if (gl[kLegacyStatusSlot] != 0) {
+    g_err = "legacy normal: the draw kernel gave up waiting for a workgroup's pair count";
+    return kLegacyExpired;
+  }
   REQUIRE(total >= d.n_pairs && fin[0] >= 0, "legacy normal: not enough accepted pairs in the generated stream");
   // generator state after the last consumed word
   const long long idx = (long long)d.pos + 4 * (fin[0] + 1);
@@ -749,12 +758,22 @@ static int legacy_finish(ampc_mppi_plan* p, const LegacyDraw& d, const uint32_t*
 template <typename T>
 static int legacy_normal_impl(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
                               uint32_t* key_out, int* pos_out, int* has_gauss_out, double* cached_out) {
-  LegacyDraw d;
   legacy_predraw_drop(p);           // (a pre-drawn next call of ampc_mppi_run_legacy: drawn again here, same values)
-  if (int rc = legacy_enqueue<T>(p, key, pos, has_gauss, cached, &d)) return rc;
-  if (int rc = legacy_speculate(p, d)) return rc;
-  HIP_OK(hipStreamSynchronize(p->h->stream));
-  return legacy_finish(p, d, key, key_out, pos_out, has_gauss_out, cached_out);
+  for (int attempt = 0;; ++attempt) {
+    LegacyDraw d;
+    if (int rc = legacy_enqueue<T>(p, key, pos, has_gauss, cached, &d, attempt > 0)) return rc;
+    if (int rc = legacy_speculate(p, d)) return rc;
+    HIP_OK(hipStreamSynchronize(p->h->stream));
+    const int rc = legacy_finish(p, d, key, key_out, pos_out, has_gauss_out, cached_out);
+    if (rc != kLegacyExpired || attempt > 0) return rc == kLegacyExpired ? -1 : rc;
+    ++p->lg_redraws;                // (a look-back wait expired under contention: the same draw once more)
+  }
+}
+
+extern "C" int ampc_mppi_plan_legacy_redraws(const ampc_mppi_plan* p, long long* count) {
+  REQUIRE(p && count, "ampc_mppi_plan_legacy_redraws: NULL argument");
+  *count = p->lg_redraws;
+  return 0;
 }
 
 extern "C" int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
@@ -903,7 +922,8 @@ static inline LegacyDraw draw_unpack(const long long* o) {
 // AMPC_RUN_MAPPED=0 / AMPC_LEGACY_PREDRAW=0 restore the copy / in-call-draw behaviour (same results).
 template <typename T>
 static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
-                         uint64_t seed, uint64_t stream, double* u, const LegacyState* lg = nullptr) {
+                         uint64_t seed, uint64_t stream, double* u, const LegacyState* lg = nullptr,
+                         bool redo = false) {
   ampc_handle* h = p->h;
   const size_t nx0 = (size_t)p->B * h->nx, nuo = (size_t)p->B * h->nu;
   if (!p->pin_x0) {
@@ -931,12 +951,13 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
       // will in a moment be) in pinned memory -- the generator state to hand back is known BEFORE the solve
       draw = draw_unpack(p->lg_pre_draw);
       HIP_OK(hipEventSynchronize(p->lg_pre_done));
-      if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
-        return rc;
-      finished = true;
-    } else {
-      if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw)) return rc;
+      const int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out);
+      if (rc == kLegacyExpired) { pre_hit = false; ++p->lg_redraws; }       // the pre-drawn noise is void: draw in this call
+      else if (rc) return rc;
+      else finished = true;
     }
+    if (!pre_hit)
+      if (int rc = legacy_enqueue<T>(p, lg->key, lg->pos, lg->has_gauss, lg->cached, &draw, redo)) return rc;
   } else {
     legacy_predraw_drop(p);
   }
@@ -999,9 +1020,16 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
     HIP_OK(hipStreamSynchronize(h->stream));
   }
   if (lg && !finished) {
-    if (int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out))
-      return rc;
-    if (int rc = enqueue_next()) return rc;
+    const int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out);
+    if (rc == kLegacyExpired && !redo) {
+      // a look-back wait of this call's draw expired (contention): the solve ran on void noise.  The generator state
+      // is still the caller's and the solve read act[cur ^ 1 now] without modifying it: the whole step once more.
+      ++p->lg_redraws;
+      p->cur ^= 1;
+      return mppi_run_impl<T>(p, x0, nullptr, noise, seed, stream, u, lg, true);
+    }
+    if (rc) return rc == kLegacyExpired ? -1 : rc;
+    if (int rc2 = enqueue_next()) return rc2;
   }
   const T* pu = (const T*)p->pin_u;
   for (size_t i = 0; i < nuo; ++i) u[i] = (double)pu[i];

@@ -432,6 +432,7 @@ struct ampc_mppi_plan {
   bool lg_next = false;           // lg_stream[1 - lg_cur] holds (or is receiving) the continuation
   int lg_next_from = 0;           //   of lg_stream[lg_cur] from this block on
   int lg_hits = 0;                // consecutive calls served from the run-ahead
+  long long lg_redraws = 0;       // draws repeated because a look-back wait of the draw kernel expired (ampc_mppi_plan_info)
   int lds_eps = -1, lds_red = 0;   // fused softmin update (tile partials) when the noise fits LDS
   bool keep_eps_out = true;        // materialise the clipped noise in HBM (download / non-fused)
   int cur = 0;          // act[cur] is the input of the next solve

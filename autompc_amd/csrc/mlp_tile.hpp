@@ -1120,12 +1120,18 @@ __device__ __forceinline__ T affine_rows(const T* __restrict__ lin, const T* __r
 //   kind 1  threshold: a = goal, b_i = threshold inside the term's observation range, +inf outside;
 //                      violated where  x_i - a_i > b_i  or  a_i - x_i > b_i   (|x - g|_inf > threshold)
 //   kind 2  box:       a = lower, b = upper limits;  violated where  x_i < a_i  or  x_i > b_i
-// A NaN observation violates nothing, as in the reference (its comparisons are false).
+// NaN observations, as in the reference: a box term compares entry by entry (a NaN entry violates nothing, the other
+// entries still count, thresh_cost.py:73-77); a threshold term is `norm(diff, inf) > thr` (thresh_cost.py:27-32) --
+// numpy's maximum is NaN as soon as ONE in-range entry is, and NaN > thr is false: the term is not charged at all.
 constexpr int kMaxInd = 8;
 __host__ __device__ constexpr int ind_stride(int no) { return 2 * no + 2; }
 template <typename T> __device__ __forceinline__ bool ind_entry(int kind, T x, T a, T b) {
   if (kind == 1) { const T d = x - a; return d > b || -d > b; }
   return x < a || x > b;
+}
+// a NaN entry inside a threshold term's range (b = the threshold there, +inf outside) voids the term
+template <typename T> __device__ __forceinline__ bool ind_void(int kind, T x, T b) {
+  return kind == 1 && x != x && b < T(INFINITY);
 }
 // The rows of a sample split over `tps` consecutive lanes of a wave (tps a power of two <= 64; lane r of the
 // group checks entries r, r + tps, ...; v[i * vs] = entry i): number of violated terms, on the group's lane
@@ -1139,11 +1145,17 @@ __device__ __forceinline__ T indicator_rows(const T* __restrict__ tab, int n_ind
   for (int k = 0; k < n_ind; ++k) {
     const T* tk = tab + (size_t)k * ind_stride(no);
     const int kind = (int)tk[0];
-    bool viol = false;
-    for (int i = r; i < no; i += tps) viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
-    const unsigned long long bal = __ballot(viol);
-    const unsigned long long grp = tps >= 64 ? bal : (bal >> (lane & ~(tps - 1))) & ((1ull << tps) - 1ull);
-    if (r == 0 && grp != 0ull) acc += T(1);
+    bool viol = false, nan_in = false;
+    for (int i = r; i < no; i += tps) {
+      viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
+      nan_in = nan_in || ind_void<T>(kind, v[i * vs], tk[2 + no + i]);
+    }
+    const unsigned long long bal = __ballot(viol), nal = __ballot(nan_in);
+    const int sh = lane & ~(tps - 1);
+    const unsigned long long msk = tps >= 64 ? ~0ull : (1ull << tps) - 1ull;
+    const unsigned long long grp = tps >= 64 ? bal : (bal >> sh) & msk;
+    const unsigned long long gna = tps >= 64 ? nal : (nal >> sh) & msk;
+    if (r == 0 && grp != 0ull && gna == 0ull) acc += T(1);
   }
   return acc;
 }
@@ -1154,9 +1166,12 @@ __device__ __forceinline__ T indicator_all(const T* __restrict__ tab, int n_ind,
   for (int k = 0; k < n_ind; ++k) {
     const T* tk = tab + (size_t)k * ind_stride(no);
     const int kind = (int)tk[0];
-    bool viol = false;
-    for (int i = 0; i < no; ++i) viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
-    if (viol) acc += T(1);
+    bool viol = false, nan_in = false;
+    for (int i = 0; i < no; ++i) {
+      viol = viol || ind_entry<T>(kind, v[i * vs], tk[2 + i], tk[2 + no + i]);
+      nan_in = nan_in || ind_void<T>(kind, v[i * vs], tk[2 + no + i]);
+    }
+    if (viol && !nan_in) acc += T(1);
   }
   return acc;
 }

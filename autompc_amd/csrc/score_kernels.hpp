@@ -54,12 +54,13 @@ __device__ inline T score_stage(int kind, const T* __restrict__ par, const T* __
   if (kind == SCORE_THRESHOLD) {
     const int lo = (int)par[no], hi = (int)par[no + 1];
     const T thr = par[no + 2];
-    bool out = false;
+    bool out = false, nan_in = false;       // (norm(diff, inf) is NaN as soon as one in-range entry is: not charged)
     for (int i = lo; i < hi; ++i) {
       const T d = x[i] - par[i];
       out = out || (d > thr) || (-d > thr);
+      nan_in = nan_in || d != d;
     }
-    return out ? T(1) : T(0);
+    return (out && !nan_in) ? T(1) : T(0);
   }
   bool out = false;
   for (int i = 0; i < no; ++i) out = out || (x[i] < par[i]) || (x[i] > par[no + i]);

@@ -508,11 +508,14 @@ __global__ __launch_bounds__(64) void mppi_rollout_sindy_fp_kernel(const MppiArg
       for (int k = 0; k < args.n_ind; ++k) {
         const T* tk = args.ind_tab + (size_t)k * ind_stride(no);
         const int kind = (int)tk[0];
-        bool viol = false;
+        bool viol = false, nan_in = false;
 #pragma unroll
         for (int i = 0; i < NR; ++i)
-          if (i < no) viol = viol || ind_entry<T>(kind, xreg[i], tk[2 + i], tk[2 + no + i]);
-        if (viol) c += T(1);
+          if (i < no) {
+            viol = viol || ind_entry<T>(kind, xreg[i], tk[2 + i], tk[2 + no + i]);
+            nan_in = nan_in || ind_void<T>(kind, xreg[i], tk[2 + no + i]);
+          }
+        if (viol && !nan_in) c += T(1);
       }
     }
     // ---- table entries of this lane (the first one from hoisted operands)

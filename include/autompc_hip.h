@@ -229,6 +229,11 @@ int ampc_legacy_log_mode(void);
 int ampc_mppi_legacy_normal(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss,
                             double cached, uint32_t* key_out, int* pos_out, int* has_gauss_out,
                             double* cached_out);
+/* How many draws of this plan were repeated because a wait inside the draw kernel expired (its workgroups look
+ * back at their predecessors' pair counts with a bounded wait; under heavy contention from other streams or
+ * processes a wait can run out).  A repeated draw starts from the same generator state and gives the same values;
+ * the count is diagnostic.  AMPC_POLAR_SPIN_LIMIT in the environment shortens the first attempt's bound (tests). */
+int ampc_mppi_plan_legacy_redraws(const ampc_mppi_plan* p, long long* count);
 /* Jump polynomials of MT19937 (autompc_amd/data/mt19937_jump.npz, computed by tools/mt_jump.py):
  * polys[n_polys][624] = bits of t^(s * jump_blocks * 624) mod phi for s = 1 .. n_polys.  With a
  * table installed (process-wide) ampc_mppi_legacy_normal generates the raw stream block-parallel

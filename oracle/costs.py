@@ -153,7 +153,7 @@ class ThresholdCostOracle(_IndicatorOracle):
 
     def violated(self, obs):
         gap = np.abs(obs[self.lo:self.hi] - self.goal[self.lo:self.hi])
-        return bool(gap.size) and bool(np.max(gap) > self.thr)
+        return bool(np.max(gap) > self.thr)      # (numpy: NaN if any entry is NaN -> False; ValueError on an empty range)
 
 
 class BoxCostOracle(_IndicatorOracle):

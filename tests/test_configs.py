@@ -13,7 +13,7 @@ from autompc_amd.sysid.mlp import MLPFactory
 from autompc_amd.tuning import (BatchPipelineTuner, DictConfiguration, candidate_from_config,
                                 candidates_from_configs, config_from_candidate, random_candidates,
                                 random_ilqr_candidates, sample_pipeline_configs)
-from tests.helpers import make_system
+from helpers import make_system
 
 
 class _Configuration:

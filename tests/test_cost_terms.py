@@ -120,3 +120,60 @@ def test_reference_style_cost_objects_flatten_too():
     np.testing.assert_array_equal(params, p2)
     for b in range(g["obs"].shape[0]):
         assert score_terms(kinds, params, g["obs"][b], g["ctrls"][b]) == g["score_sum_tb"][b]
+
+
+def _nan_rows():
+    """Rows with NaN entries: inside / outside the threshold term's range, next to violating and harmless entries."""
+    g = golden("cost_terms")
+    lo, hi = [int(v) for v in g["thr_range"]]
+    base = g["goal"].copy()
+    rows = []
+    for nan_at, bump_at in ((lo, lo + 1), (lo, None), (hi if hi < 5 else 0, lo), (hi if hi < 5 else 0, None)):
+        x = base.copy()
+        if bump_at is not None:
+            x[bump_at] += 10.0 * float(g["thr"])            # a violating entry
+        x[nan_at] = np.nan
+        rows.append(x)
+    return g, np.array(rows)
+
+
+def test_nan_observations_are_charged_as_the_reference_charges_them():
+    """ADVICE r5.  ThresholdCost is norm(diff, inf) > thr (thresh_cost.py:27-32): one NaN inside the range makes the
+    norm NaN and the term is NOT charged, whatever the other entries do; a NaN outside the range is invisible.
+    BoxThresholdCost compares entry by entry (:73-77): a NaN entry violates nothing, the others still count.
+    An empty obs_range raises in the reference (maximum of an empty slice): cost_terms refuses it."""
+    g, rows = _nan_rows()
+    system, costs = _costs(g)
+    lo, hi = [int(v) for v in g["thr_range"]]
+    for x in rows:
+        in_range_nan = bool(np.isnan(x[lo:hi]).any())
+        finite = np.nan_to_num(x, nan=float(g["goal"][0]))
+        viol = bool(np.max(np.abs(finite[lo:hi] - g["goal"][lo:hi])) > float(g["thr"]))
+        want = 0.0 if in_range_nan else float(viol)
+        with np.errstate(invalid="ignore"):
+            assert costs["thresh"].eval_obs_cost(x) == want
+            kinds, params = cost_terms(costs["thresh"], 5, 3)
+            assert score_terms(kinds, params, x[None, :], np.zeros((1, 3))) == want
+            lim = g["limits"]
+            box_want = float(bool((x < lim[:, 0]).any() or (x > lim[:, 1]).any()))
+            assert costs["box"].eval_obs_cost(x) == box_want
+    with pytest.raises(ValueError, match="empty obs_range"):
+        cost_terms(ThresholdCost(system, g["goal"], [2, 2], 0.5), 5, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_device_scores_of_nan_rows(precision):
+    from autompc_amd import _lib
+    g, rows = _nan_rows()
+    _, costs = _costs(g)
+    obs = np.repeat(rows[:, None, :], 3, axis=1)               # [B, T, no]: three identical rows each
+    ctl = np.zeros((rows.shape[0], 3, 3))
+    h = _lib.Handle(0, precision)
+    for name in ("thresh", "box", "sum_tb"):
+        terms = cost_terms(costs[name], 5, 3)
+        got = h.score_trajectories(terms, obs, ctl)
+        with np.errstate(invalid="ignore"):
+            want = np.array([score_terms(terms[0], terms[1], o, c) for o, c in zip(obs, ctl)])
+        np.testing.assert_array_equal(got, want)
+    h.close()

@@ -418,3 +418,42 @@ def test_hot_call_is_the_same_with_mapped_io_and_pre_drawn_noise(shape, monkeypa
         for a, b in zip(gens, ref_g):
             np.testing.assert_array_equal(a[0], b[0])
             assert a[1:] == b[1:]
+
+
+def test_an_expired_look_back_wait_is_drawn_again(monkeypatch):
+    """the draw kernel's workgroups wait (bounded) for their predecessors' pair counts; with the bound
+    forced to ONE poll the first attempt of a many-workgroup draw gives up -- the library draws again from the
+    untouched generator state with the full bound: numpy's values and generator state, bit for bit, through the
+    stand-alone draw and through the one-call control step (whose solve is repeated with the good noise)."""
+    if not _exact():
+        pytest.skip("the host's log() is not one of the two glibc builds the library reproduces")
+    N, H, nu, sigma = 4096, 30, 6, 0.0049
+    monkeypatch.setenv("AMPC_POLAR_SPIN_LIMIT", "1")
+    h, plan = _plan(N, H, sigma, nx=2, nu=nu)
+    np.random.seed(5)
+    for _ in range(3):
+        st0 = np.random.get_state()
+        ref = np.random.normal(scale=np.sqrt(sigma), size=(N, H, nu))
+        st_ref = np.random.get_state()
+        np.random.set_state(st0)
+        st_dev, e = _device_draw(plan)
+        np.testing.assert_array_equal(e.reshape(H, N, nu).transpose(1, 0, 2), ref)
+        np.testing.assert_array_equal(st_dev[1], st_ref[1])
+        assert st_dev[2:4] == st_ref[2:4]
+        np.random.set_state(st_dev)
+    assert plan.legacy_redraws() >= 1
+    # the hot call: same controls as with the full bound
+    from autompc_amd import _npstate
+    ls = _npstate.get()
+    if ls is not None:
+        x0, outs = np.zeros((1, 2)), {}
+        for limit in ("1", str(1 << 22)):
+            monkeypatch.setenv("AMPC_POLAR_SPIN_LIMIT", limit)
+            np.random.seed(11)
+            plan.upload(x0=x0, act_seq=np.zeros(plan.sum_hnu))
+            outs[limit] = [plan.run_legacy_inplace(x0, None, _npstate.get()).copy() for _ in range(4)]
+            outs[limit].append(np.random.get_state()[1].copy())
+        for a, b in zip(outs["1"], outs[str(1 << 22)]):
+            np.testing.assert_array_equal(a, b)
+    plan.close()
+    h.close()

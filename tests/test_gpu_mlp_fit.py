@@ -10,9 +10,9 @@ from autompc_amd import MLP, _lib, zeros
 from autompc_amd.sysid import mlp_fit as F
 from autompc_amd.sysid.mlp import MLPFactory
 from oracle import mlp as omlp
-from tests.conftest import golden
-from tests.helpers import make_system
-from tests.test_mlp_fit import _case, _interleave
+from conftest import golden
+from helpers import make_system
+from test_mlp_fit import _case, _interleave
 
 pytestmark = pytest.mark.gpu
 

@@ -17,8 +17,8 @@ import torch
 from autompc_amd import MLP, zeros
 from autompc_amd.sysid import mlp_fit as F
 from oracle import mlp as omlp
-from tests.conftest import golden
-from tests.helpers import make_system
+from conftest import golden
+from helpers import make_system
 
 CASES = ["p_tanh", "hc_relu3", "p_selu1"]
 TOL = 1e-10

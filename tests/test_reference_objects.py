@@ -126,3 +126,33 @@ def test_reference_task_and_trajectory_through_the_plugins():
     obs, ctrls = rng.normal(size=(3, 6, 3)), rng.normal(size=(3, 6, 1))
     want = [cost(_ref_traj(system, obs[b], ctrls[b])) for b in range(3)]
     np.testing.assert_allclose(score_trajectories(cost, obs, ctrls), want, rtol=1e-11)
+
+
+def test_reference_threshold_costs_on_nan_rows_and_empty_ranges():
+    """What the REFERENCE's ThresholdCost / BoxThresholdCost do with NaN observations and an empty obs_range
+    (thresh_cost.py:27-32, 73-77) is what the host classes, the flattened terms and the oracle do."""
+    from autompc_amd.costs import ThresholdCost as OurThreshold
+    from helpers import make_system
+    system = gg.make_system(5, 3)
+    goal = np.array([0.1, -0.2, 0.3, 0.0, 0.5])
+    thr = ThresholdCost(system, goal, [1, 4], 0.4)
+    box = BoxThresholdCost(system, np.array([[-1.0, 1.0], [-np.inf, 0.5], [-0.5, np.inf], [-1, 1], [-np.inf, np.inf]]))
+    kinds, params = cost_terms(thr + box, 5, 3)
+    rows = []
+    for nan_at, bump_at in ((1, 2), (2, None), (0, 3), (4, None), (3, 0)):
+        x = goal.copy()
+        if bump_at is not None:
+            x[bump_at] += 5.0
+        x[nan_at] = np.nan
+        rows.append(x)
+    with np.errstate(invalid="ignore"):
+        for x in rows:
+            want = thr.eval_obs_cost(x) + box.eval_obs_cost(x)
+            assert score_terms(kinds, params, x[None, :], np.zeros((1, 3))) == want
+    empty = ThresholdCost(system, goal, [2, 2], 0.4)
+    with pytest.raises(ValueError):
+        empty.eval_obs_cost(goal)                                   # numpy: maximum of an empty slice
+    with pytest.raises(ValueError):
+        cost_terms(empty, 5, 3)
+    with pytest.raises(ValueError):
+        cost_terms(OurThreshold(make_system(5, 3), goal, [2, 2], 0.4), 5, 3)
