@@ -344,6 +344,16 @@ static int choose_mt(const ampc_handle* h, const MlpDev<T>& m, long long total_r
     if (bytes > kLdsLimit) break;
     if (forced == mt) return mt;
     if (mt == 4 && h->nt == 3 && sizeof(T) == 8) break;   // 12 f64 accumulator tiles per wave spill
+    if (h->hpad == 256) {
+      // 256-wide networks, measured on 2 / 4 / 8 config-3 solves per launch (round 6, profiles/r06_tile_height.log):
+      //   f32: 16-row tiles at every size (0.79-0.80 of the f32 peak against 0.77 / 0.73 at 32 / 64 rows) -- the
+      //        16-row kernel holds 116 VGPRs, so TWO workgroups share a CU and one tile's serial chain (layer 0,
+      //        output reduction, state update, barriers) runs behind the other's MFMAs;
+      //   f64: 32-row tiles once they give a workgroup per CU (0.84 against 0.82 at 16 rows and 0.80 at 64).
+      if (sizeof(T) == 4) { if (mt == 1) best = 1; }
+      else if (mt == 1 || (mt == 2 && total_rows / 32 >= h->n_cus)) best = mt;
+      continue;
+    }
     if (mt == 1 || total_rows / (16 * mt) >= 512) best = mt;
   }
   return best;

@@ -823,7 +823,7 @@ def main():
 
     from autompc_amd import _lib
     from autompc_amd.synthetic import make_workload
-    batch = args.batch if args.batch > 0 else 1
+    batch = batch_default = args.batch if args.batch > 0 else 1
 
     def build_plan(precision, nb, workload=None):
         system, task, model, spec = make_workload(workload or args.workload, precision=precision,
@@ -841,10 +841,12 @@ def main():
         plan = _lib.MppiPlan(h, [N] * nb, [H] * nb, [1.0] * nb, [1.0] * nb)
         return h, plan, task, spec
 
-    def timed_run(precision, steps, warmup, preheat_s, workload=None, windows=1):
+    def timed_run(precision, steps, warmup, preheat_s, workload=None, windows=1, nb=None):
         """pre-heat + W untimed + K timed solves, bracketed by barrier + synchronize; max over ranks.
         windows > 1: the timed window is repeated (same plan, noise stream running on); the first
-        window is the one returned as `elapsed`, all of them in `rates`."""
+        window is the one returned as `elapsed`, all of them in `rates`.  nb: solves per launch (default:
+        --batch)."""
+        batch = nb if nb else batch_default
         h, plan, task, spec = build_plan(precision, batch, workload)
         nx, nu, N, H = spec["nx"], spec["nu"], spec["num_path"], spec["horizon"]
         rng = np.random.default_rng(1000 + rank)
@@ -1021,6 +1023,19 @@ def main():
                                     "kernel_ms": k32["rollout_ms"], "achieved_tflops": a32,
                                     "frac_of_f32_mfma_peak": a32 / PEAK_TFLOPS["f32"],
                                     "vs_f64_solve": f32_vs_f64_parity()}
+            # eight independent solves per launch -- what a tuner's batch looks like: enough tiles for two 16-row
+            # f32 workgroups per CU (one's serial chain behind the other's MFMAs) / one 32-row f64 workgroup per CU
+            for prec, key in (("f32", "f32_fast_mode"), ("f64", "batch8_f64")):
+                sb = max(1, args.steps // 8)
+                e8, k8, i8, _, _ = timed_run(prec, sb, max(1, args.warmup // 4), 0.2, nb=8)
+                a8 = i8["flops"] / (k8["rollout_ms"] * 1e-3) / 1e12
+                rec8 = {"workload": "8 independent config-3 solves per launch (%d-row tiles)" % i8["samples_per_wg"],
+                        "value": world * sb * 8 / e8, "unit": "solves/s", "kernel_ms": k8["rollout_ms"],
+                        "achieved_tflops": a8, "frac_of_mfma_peak": a8 / PEAK_TFLOPS[prec]}
+                if prec == "f32":
+                    out["f32_fast_mode"]["batch8"] = rec8
+                else:
+                    out[key] = rec8
         if default_line:
             # the other BASELINE configurations and the user-visible call rates, measured inside the
             # same driver-timed process; full records: --workload c2 / c4 / c5
