@@ -209,6 +209,10 @@ class LockstepFit:
         self.dirn = torch.zeros_like(self.flat)                     # Adam's direction at lr = 1
         self._t = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken, on the device (the fused kernel reads it)
         self._k = torch.tensor(float(K), dtype=f64, device=dev)
+        piece = max(1024, -(-total // 64))
+        self._dirn_v, self._grad_v = list(torch.split(self.dirn, piece)), list(torch.split(self.grad, piece))
+        self._m_v, self._v_v = list(torch.split(self.m, piece)), list(torch.split(self.v, piece))
+        self._t_v = [self._t] * len(self._dirn_v)
         self._graphs = {}
         self.kernel_s = 0.0
 
@@ -250,7 +254,9 @@ class LockstepFit:
         # part of the direction afterwards (one lr per fused call is all the kernel takes)
         self.dirn.zero_()
         self._t.add_(1)
-        torch._fused_adam_([self.dirn], [self.grad], [self.m], [self.v], [], [self._t], lr=1.0, beta1=_BETA1,
+        # (handed over as ~64 slices: the multi-tensor kernel gives every tensor chunk ONE workgroup -- the whole flat
+        #  buffer as one tensor is ten 65536-element chunks on ten workgroups, 58 us; sliced, a few microseconds)
+        torch._fused_adam_(self._dirn_v, self._grad_v, self._m_v, self._v_v, [], self._t_v, lr=1.0, beta1=_BETA1,
                            beta2=_BETA2, weight_decay=0.0, eps=_EPS, amsgrad=False, maximize=False)
         self.flat.addcmul_(self.dirn, self.lr_flat)
 
