@@ -9,13 +9,14 @@ runs at device speed.
 
 Training stays PyTorch; what this module adds is the SHAPE of the torch program:
 
-* ``fit_mlps`` trains K models **in lockstep**: parameters stacked ``[K, out, in]``, one ``baddbmm`` per
-  layer for all K, a backward pass written out with the kernels autograd itself runs
-  (``smooth_l1_loss_backward``, ``threshold_backward`` / ``tanh_backward`` / ...), and ONE fused Adam kernel
-  over ONE flat buffer holding every parameter of every model (per-model learning rates applied as a
-  per-element vector).  Models of one depth and activation but different widths are zero-padded to the
-  group's widest layer (a mask keeps the padding at zero).  A step is ~22 small kernels whatever K is, so K
-  models cost about what one costs.
+* ``fit_mlps`` trains K models **in lockstep**: parameters stacked ``[K, out, in + 1]`` (the bias is the weight
+  of a constant-1 input column), one ``bmm`` per layer for all K, a backward pass written out with the kernels
+  autograd itself runs (``smooth_l1_loss_backward``, ``threshold_backward`` / ``tanh_backward`` / ...) -- one
+  ``bmm`` per layer yields the gradients of weights and bias together --, and torch's fused Adam kernel over ONE
+  flat buffer holding every parameter of every model (per-model learning rates applied as a per-element
+  vector).  Models of one depth and activation but different widths are zero-padded to the group's widest layer
+  (a mask keeps the padding at zero).  A step is 18 small kernels whatever K is, so K models cost about what one
+  costs.
 * on a GPU the steps are captured into **HIP graphs** (``torch.cuda.CUDAGraph``: a chunk of up to 64
   optimiser steps per graph, the mini-batches of a chunk gathered by one indexing kernel into a static
   buffer), which removes the per-kernel launch cost that dominates a 64-row step.
@@ -139,7 +140,11 @@ def fit_reference_style(dims, act, feed, target, n_iter, n_batch, lr, init_seed,
 
 # -- K models in lockstep ----------------------------------------------------------------------------------
 class LockstepFit:
-    """K MLPs of one depth and one activation over one data set; see the module docstring."""
+    """K MLPs of one depth and one activation over one data set; see the module docstring.
+
+    The bias of a layer is the weight of a constant-1 input column: parameters are stacked `[K, out, in + 1]`,
+    activations carry a last column of ones (written once into static buffers), so a layer is ONE `bmm` forward and
+    ONE `bmm` for the gradients of weights and bias together (no bias broadcast, no bias-gradient reduction)."""
 
     def __init__(self, dims_list, act, lrs, init_seeds, feed, target, n_batch, train_seeds=None, device=None,
                  use_graphs=None):
@@ -162,15 +167,15 @@ class LockstepFit:
         self.use_graphs = self.on_gpu if use_graphs is None else bool(use_graphs and self.on_gpu)
         self.n_batch = int(n_batch)
         dev, f64 = self.device, torch.float64
-        self.feed, self.target = feed.to(dev, f64).contiguous(), target.to(dev, f64).contiguous()
+        feed = feed.to(dev, f64)
+        self.feed = torch.cat([feed, torch.ones(feed.shape[0], 1, dtype=f64, device=dev)], dim=1).contiguous()
+        self.target = target.to(dev, f64).contiguous()
         self.n = int(self.feed.shape[0])
         train_seeds = [100] * K if train_seeds is None else list(train_seeds)
         self.gens = [seeded_generator(s) for s in train_seeds]
-        # ONE flat buffer for all parameters: per layer the stacked weights [K, out, in], then the stacked
-        # biases [K, 1, out]; gradients, both Adam moments, the learning rates and the padding mask alike
-        sizes = []
-        for l in range(self.nl):
-            sizes += [K * self.dmax[l + 1] * self.dmax[l], K * self.dmax[l + 1]]
+        # ONE flat buffer for all parameters: per layer the stacked [K, out, in + 1] (last column: the bias);
+        # gradients, both Adam moments, the learning rates and the padding mask alike
+        sizes = [K * self.dmax[l + 1] * (self.dmax[l] + 1) for l in range(self.nl)]
         total = sum(sizes)
         self.flat = torch.zeros(total, dtype=f64, device=dev)
         self.grad = torch.zeros_like(self.flat)
@@ -180,31 +185,26 @@ class LockstepFit:
         host_lr = torch.zeros(total, dtype=f64)
 
         def views(buf):
-            out_w, out_b, o = [], [], 0
+            out, o = [], 0
             for l in range(self.nl):
-                nw, nb = K * self.dmax[l + 1] * self.dmax[l], K * self.dmax[l + 1]
-                out_w.append(buf[o:o + nw].view(K, self.dmax[l + 1], self.dmax[l]))
-                out_b.append(buf[o + nw:o + nw + nb].view(K, 1, self.dmax[l + 1]))
-                o += nw + nb
-            return out_w, out_b
-        hw, hb = views(host_flat)
-        mw, mb = views(host_mask)
-        lw, lb = views(host_lr)
+                n = sizes[l]
+                out.append(buf[o:o + n].view(K, self.dmax[l + 1], self.dmax[l] + 1))
+                o += n
+            return out
+        hw, mw, lw = views(host_flat), views(host_mask), views(host_lr)
         for k, (d, seed, lr) in enumerate(zip(self.dims_list, init_seeds, lrs)):
             ws, bs = initial_parameters(seed, d)
             for l in range(self.nl):
                 hw[l][k, :d[l + 1], :d[l]] = ws[l]
-                hb[l][k, 0, :d[l + 1]] = bs[l]
+                hw[l][k, :d[l + 1], self.dmax[l]] = bs[l]
                 mw[l][k, :d[l + 1], :d[l]] = 1.0
-                mb[l][k, 0, :d[l + 1]] = 1.0
+                mw[l][k, :d[l + 1], self.dmax[l]] = 1.0
                 lw[l][k] = float(lr)
-                lb[l][k] = float(lr)
         self.flat.copy_(host_flat)
         self.padded = bool((host_mask == 0).any())
         self.mask = host_mask.to(dev) if self.padded else None
         self.lr_flat = host_lr.to(dev)
-        self.W, self.B = views(self.flat)
-        self.gW, self.gB = views(self.grad)
+        self.W, self.gW = views(self.flat), views(self.grad)
         self.steps_done = 0
         self.dirn = torch.zeros_like(self.flat)                     # Adam's direction at lr = 1
         self._t = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken, on the device (the fused kernel reads it)
@@ -213,10 +213,19 @@ class LockstepFit:
         self._dirn_v, self._grad_v = list(torch.split(self.dirn, piece)), list(torch.split(self.grad, piece))
         self._m_v, self._v_v = list(torch.split(self.m, piece)), list(torch.split(self.v, piece))
         self._t_v = [self._t] * len(self._dirn_v)
+        self._acts = {}                    # mini-batch rows -> the hidden layers' activation buffers (ones column set)
         self._graphs = {}
         self.kernel_s = 0.0
 
-    # .. one optimiser step on mini-batches x [K, nb, in], y [K, nb, out] ....................................
+    def _act_buffers(self, nb):
+        """Static activation buffers [K, nb, width + 1] of the hidden layers, last column = 1 (the bias input)."""
+        if nb not in self._acts:
+            torch = self.torch
+            self._acts[nb] = [torch.ones(self.K, nb, self.dmax[l + 1] + 1, dtype=torch.float64, device=self.device)
+                              for l in range(self.nl - 1)]
+        return self._acts[nb]
+
+    # .. one optimiser step on mini-batches x [K, nb, in + 1] (ones column included), y [K, nb, out] .................
     def _step(self, x, y):
         """Forward, backward and update with the kernels autograd would run for the reference's program -- one
         launch each: smooth_l1_loss_backward, <activation>_backward, the fused Adam kernel -- on the stacked
@@ -224,38 +233,47 @@ class LockstepFit:
         torch = self.torch
         act, nl = self.act, self.nl
         aten = torch.ops.aten
-        f = _act(act)
+        bufs = self._act_buffers(x.shape[1])
         a, z = [x], []
         for l in range(nl - 1):
-            zl = torch.baddbmm(self.B[l], a[-1], self.W[l].transpose(1, 2))
+            zl = torch.bmm(a[-1], self.W[l].transpose(1, 2))
+            h = bufs[l][:, :, :self.dmax[l + 1]]                 # (the ones column stays)
+            if act == "relu":
+                torch.clamp_min(zl, 0.0, out=h)
+            elif act == "tanh":
+                torch.tanh(zl, out=h)
+            elif act == "sigmoid":
+                torch.sigmoid(zl, out=h)
+            else:
+                aten.elu.out(zl, _SELU_ALPHA, _SELU_SCALE, 1.0, out=h)
             z.append(zl)
-            a.append(f(zl))
-        out = torch.baddbmm(self.B[nl - 1], a[-1], self.W[nl - 1].transpose(1, 2))
+            a.append(bufs[l])
+        out = torch.bmm(a[-1], self.W[nl - 1].transpose(1, 2))
         # SmoothL1Loss(beta = 1), mean over EACH model's nb * out entries: the op averages over all K models'
         # entries, the incoming gradient K undoes that (for K = 1 this is the reference's own backward kernel)
         g = aten.smooth_l1_loss_backward(self._k, out, y, 1, 1.0)
         for l in range(nl - 1, -1, -1):
-            torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])
-            torch.sum(g, dim=1, keepdim=True, out=self.gB[l])
+            torch.bmm(g.transpose(1, 2), a[l], out=self.gW[l])   # weights' and (last column) bias' gradients
             if l > 0:
-                g = torch.bmm(g, self.W[l])
+                g = torch.bmm(g, self.W[l])[:, :, :self.dmax[l]]
+                h = a[l][:, :, :self.dmax[l]]
                 if act == "relu":
                     g = aten.threshold_backward(g, z[l - 1], 0.0)
                 elif act == "tanh":
-                    g = aten.tanh_backward(g, a[l])
+                    g = aten.tanh_backward(g, h)
                 elif act == "sigmoid":
-                    g = aten.sigmoid_backward(g, a[l])
+                    g = aten.sigmoid_backward(g, h)
                 else:
                     g = aten.elu_backward(g, _SELU_ALPHA, _SELU_SCALE, 1.0, False, z[l - 1])
         if self.padded:
             self.grad.mul_(self.mask)
-        # Adam over the flat buffer in ONE kernel (torch's fused implementation, the step count on the device):
-        # run with lr = 1 on a zeroed direction buffer, so that every model's own learning rate can scale its
-        # part of the direction afterwards (one lr per fused call is all the kernel takes)
+        # Adam over the flat buffer (torch's fused implementation, the step count on the device): run with lr = 1 on
+        # a zeroed direction buffer, so that every model's own learning rate can scale its part of the direction
+        # afterwards (one lr per fused call is all the kernel takes).  Handed over as ~64 slices: the multi-tensor
+        # kernel gives every tensor chunk ONE workgroup -- the whole buffer as one tensor is ten 65536-element chunks
+        # on ten workgroups, 58 us; sliced, 2 x 15.
         self.dirn.zero_()
         self._t.add_(1)
-        # (handed over as ~64 slices: the multi-tensor kernel gives every tensor chunk ONE workgroup -- the whole flat
-        #  buffer as one tensor is ten 65536-element chunks on ten workgroups, 58 us; sliced, a few microseconds)
         torch._fused_adam_(self._dirn_v, self._grad_v, self._m_v, self._v_v, [], self._t_v, lr=1.0, beta1=_BETA1,
                            beta2=_BETA2, weight_decay=0.0, eps=_EPS, amsgrad=False, maximize=False)
         self.flat.addcmul_(self.dirn, self.lr_flat)
@@ -264,6 +282,7 @@ class LockstepFit:
     def _run_chunk(self, idx, steps, nb):
         torch = self.torch
         K = self.K
+        self._act_buffers(nb)                                  # (allocated outside any capture)
         if not self.use_graphs:
             x = self.feed[idx].view(K, steps, nb, -1)
             y = self.target[idx].view(K, steps, nb, -1)
@@ -324,7 +343,7 @@ class LockstepFit:
         """Model k's weights [out][in] and biases [out]: contiguous float64 tensors on the fit's device."""
         d = self.dims_list[k]
         ws = [self.W[l][k, :d[l + 1], :d[l]].contiguous() for l in range(self.nl)]
-        bs = [self.B[l][k, 0, :d[l + 1]].contiguous() for l in range(self.nl)]
+        bs = [self.W[l][k, :d[l + 1], self.dmax[l]].contiguous() for l in range(self.nl)]
         return ws, bs
 
 
