@@ -207,12 +207,16 @@ class LockstepFit:
         self.W, self.gW = views(self.flat), views(self.grad)
         self.steps_done = 0
         self.dirn = torch.zeros_like(self.flat)                     # Adam's direction at lr = 1
-        self._t = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken, on the device (the fused kernel reads it)
+        # Adam's step count as the fused kernel wants it, on the device: entry j of a small table = the count at the
+        # j-th step of the running chunk, written by ONE launch per chunk (not one increment per step)
+        self._count = 0
+        self._ar = torch.arange(1, CHUNK + 2, dtype=torch.float32, device=dev)
+        self._tt = torch.zeros(CHUNK + 1, dtype=torch.float32, device=dev)
         self._k = torch.tensor(float(K), dtype=f64, device=dev)
         piece = max(1024, -(-total // 64))
         self._dirn_v, self._grad_v = list(torch.split(self.dirn, piece)), list(torch.split(self.grad, piece))
         self._m_v, self._v_v = list(torch.split(self.m, piece)), list(torch.split(self.v, piece))
-        self._t_v = [self._t] * len(self._dirn_v)
+        self._t_v = [[self._tt[j]] * len(self._dirn_v) for j in range(CHUNK + 1)]
         self._acts = {}                    # mini-batch rows -> the hidden layers' activation buffers (ones column set)
         self._graphs = {}
         self.kernel_s = 0.0
@@ -226,8 +230,8 @@ class LockstepFit:
         return self._acts[nb]
 
     # .. one optimiser step on mini-batches x [K, nb, in + 1] (ones column included), y [K, nb, out] .................
-    def _step(self, x, y):
-        """Forward, backward and update with the kernels autograd would run for the reference's program -- one
+    def _step(self, x, y, j):
+        """The j-th step of the running chunk.  Forward, backward and update with the kernels autograd would run for the reference's program -- one
         launch each: smooth_l1_loss_backward, <activation>_backward, the fused Adam kernel -- on the stacked
         tensors."""
         torch = self.torch
@@ -273,8 +277,7 @@ class LockstepFit:
         # kernel gives every tensor chunk ONE workgroup -- the whole buffer as one tensor is ten 65536-element chunks
         # on ten workgroups, 58 us; sliced, 2 x 15.
         self.dirn.zero_()
-        self._t.add_(1)
-        torch._fused_adam_(self._dirn_v, self._grad_v, self._m_v, self._v_v, [], self._t_v, lr=1.0, beta1=_BETA1,
+        torch._fused_adam_(self._dirn_v, self._grad_v, self._m_v, self._v_v, [], self._t_v[j], lr=1.0, beta1=_BETA1,
                            beta2=_BETA2, weight_decay=0.0, eps=_EPS, amsgrad=False, maximize=False)
         self.flat.addcmul_(self.dirn, self.lr_flat)
 
@@ -284,37 +287,42 @@ class LockstepFit:
         K = self.K
         self._act_buffers(nb)                                  # (allocated outside any capture)
         if not self.use_graphs:
+            torch.add(self._ar, float(self._count), out=self._tt)
             x = self.feed[idx].view(K, steps, nb, -1)
             y = self.target[idx].view(K, steps, nb, -1)
             for j in range(steps):
-                self._step(x[:, j], y[:, j])
+                self._step(x[:, j], y[:, j], j)
+            self._count += steps
             return
         key = (steps, nb)
         if key not in self._graphs:
             sidx = torch.zeros(K, steps * nb, dtype=torch.int64, device=self.device)
-            snap = (self.flat.clone(), self.m.clone(), self.v.clone(), self._t.clone())
+            snap = (self.flat.clone(), self.m.clone(), self.v.clone())
+            torch.add(self._ar, float(self._count), out=self._tt)
 
             def body():
                 x = self.feed[sidx].view(K, steps, nb, -1)
                 y = self.target[sidx].view(K, steps, nb, -1)
                 for j in range(steps):
-                    self._step(x[:, j], y[:, j])
+                    self._step(x[:, j], y[:, j], j)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                      # warm-up outside the capture (library workspaces)
                 x = self.feed[sidx[:, :nb]].view(K, 1, nb, -1)
                 y = self.target[sidx[:, :nb]].view(K, 1, nb, -1)
-                self._step(x[:, 0], y[:, 0])
+                self._step(x[:, 0], y[:, 0], 0)
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 body()
             # warm-up and capture ran (resp. recorded) real updates: restore the state they touched
-            self.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2]); self._t.copy_(snap[3])
+            self.flat.copy_(snap[0]); self.m.copy_(snap[1]); self.v.copy_(snap[2])
             self._graphs[key] = (graph, sidx)
         graph, sidx = self._graphs[key]
         sidx.copy_(idx)
+        torch.add(self._ar, float(self._count), out=self._tt)
         graph.replay()
+        self._count += steps
 
     def run(self, n_iter):
         """`n_iter` more epochs."""
