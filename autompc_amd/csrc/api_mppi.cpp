@@ -20,8 +20,12 @@ extern template int mppi_solve_impl<float>(ampc_mppi_plan*);
 extern template int ilqr_launch_iter<double>(ampc_ilqr_plan*, int);
 extern template int ilqr_launch_iter<float>(ampc_ilqr_plan*, int);
 
-// Anything that rewrites a plan's noise buffer (or rebuilds the plan) drops a pre-drawn next call (mppi_run_impl).
-static inline void legacy_predraw_drop(ampc_mppi_plan* p) { p->lg_pre = false; p->u_in_pin = false; }
+// Anything that rewrites a plan's noise buffer (or rebuilds the plan) drops a pre-drawn next call (mppi_run_impl);
+// a draw that is still running is waited for (it writes buffers the caller is about to reuse).
+static inline void legacy_predraw_drop(ampc_mppi_plan* p) {
+  p->lg_pre = false; p->u_in_pin = false;
+  if (p->lg_pre_inflight) { (void)hipEventSynchronize(p->lg_pre_done); p->lg_pre_inflight = false; }
+}
 
 // Workgroup -> tile order of a plan whose problems run on several models: workgroups are dealt round-robin
 // to the eight XCDs (blockIdx % 8), each with its own 4 MB L2, and the rollout streams its model's weights
@@ -287,7 +291,9 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->pin_flag) (void)hipHostFree(p->pin_flag);
+  if (p->lg_draw) { (void)hipStreamSynchronize(p->lg_draw); (void)hipStreamDestroy(p->lg_draw); }
   if (p->lg_pre_done) (void)hipEventDestroy(p->lg_pre_done);
+  p->eps_pre.release();
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
@@ -374,7 +380,7 @@ extern "C" int ampc_mppi_upload(ampc_mppi_plan* p, const double* x0, const doubl
 template <typename T> static int mppi_generate_impl(ampc_mppi_plan* p, uint64_t seed, uint64_t stream) {
   ampc_handle* h = p->h;
   const int nu = h->nu;
-  p->lg_pre = false;               // (a pre-drawn numpy-stream call is overwritten)
+  if (p->lg_pre || p->lg_pre_inflight) legacy_predraw_drop(p);     // (a pre-drawn numpy-stream call is void)
   // The four-row rollout (small problems: a solve is a few tens of microseconds, a launch is five)
   // forms this noise in its own prologue -- the same values, element by element -- so nothing is
   // launched here; the buffer keeps whatever it held (AMPC_INLINE_NOISE = 0: always generate it).
@@ -592,17 +598,37 @@ static int legacy_blocks_for(int start_pos, long long n_att) {
 // What legacy_finish returns when a look-back wait of the draw kernel expired (the results are not to be used: draw
 // again -- the generator state the caller passed in has not been touched).
 constexpr int kLegacyExpired = 2;
+// ... and legacy_enqueue for a pre-draw it cannot serve from the run-ahead (nothing was launched).
+constexpr int kLegacySkip = 3;
 
+// A pre-drawn next call (mppi_run_impl) may still be running on its own stream: it writes the second noise buffer,
+// the look-back words and the pinned results.  Anything else that is about to touch those waits for it first.
+static int legacy_predraw_wait(ampc_mppi_plan* p) {
+  if (p->lg_pre_inflight) {
+    HIP_OK(hipEventSynchronize(p->lg_pre_done));
+    p->lg_pre_inflight = false;
+  }
+  return 0;
+}
+
+// pre = true: the draw of the NEXT control step, made while the current solve runs -- on a stream of its own
+// (p->lg_draw), into the plan's second noise buffer (p->eps_pre), and only if its words are already in the
+// run-ahead buffer (kLegacySkip otherwise).  The draw kernel's workgroups (4 waves, 115 VGPRs) fit next to a
+// rollout workgroup on every CU (8 waves of 172 VGPRs), so the scan runs inside the rollout's shadow.
 template <typename T>
 static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int has_gauss, double cached,
-                          LegacyDraw* d, bool retry = false) {
-  p->eps_inline = false;          // (this draw fills the plan's noise buffer)
-  p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
+                          LegacyDraw* d, bool retry = false, bool pre = false) {
   ampc_handle* h = p->h;
+  if (!pre) {
+    if (int rc = legacy_predraw_wait(p)) return rc;
+    p->eps_inline = false;          // (this draw fills the plan's noise buffer)
+    p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
+  }
   const long long n = p->sum_nhnu;
   const int shift = has_gauss ? 1 : 0;
   const long long n_pairs = (n - shift + 1) / 2;
   d->pos = pos; d->shift = shift; d->n = n; d->n_pairs = n_pairs;
+  if (n_pairs == 0 && pre) return kLegacySkip;
   if (n_pairs == 0) {          // the single value asked for is the cached one
     HIP_OK(p->lg_scale.reserve(sizeof(double)));
     const double sc = std::sqrt(p->sigma[0]);
@@ -628,10 +654,26 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
     for (hipEvent_t& e : p->lg_evs) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&p->lg_drawn, hipEventDisableTiming));
   }
+  if (pre) {
+    // served from the run-ahead or not at all (the same test as below, without its side effects on a miss)
+    bool ok = p->lg_spec && p->lg_spec_pos == pos && std::memcmp(p->lg_spec_key.data(), key, kMtN * sizeof(uint32_t)) == 0;
+    if (ok) {
+      const bool sw = p->lg_next && p->lg_blk0 >= p->lg_next_from;
+      const int cur = sw ? 1 - p->lg_cur : p->lg_cur, blk0 = sw ? p->lg_blk0 - p->lg_next_from : p->lg_blk0;
+      ok = p->lg_blocks[cur] - blk0 >= nblocks;
+    }
+    if (!ok) return kLegacySkip;
+    if (!p->lg_draw) {
+      HIP_OK(hipStreamCreateWithFlags(&p->lg_draw, hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&p->lg_pre_done, hipEventDisableTiming));
+    }
+    HIP_OK(p->eps_pre.reserve((size_t)p->sum_nhnu * sizeof(T)));
+  }
+  const hipStream_t st = pre ? p->lg_draw : h->stream;
   // look-back words of the draw kernel: cleared when (re)allocated and when the 24-bit epoch wraps
   if ((size_t)n_wg * sizeof(unsigned long long) > p->lg_cnt.bytes || (++p->lg_epoch & 0xffffffu) == 0) {
     HIP_OK(p->lg_cnt.reserve((size_t)n_wg * sizeof(unsigned long long)));
-    HIP_OK(hipMemsetAsync(p->lg_cnt.p, 0, p->lg_cnt.bytes, h->stream));
+    HIP_OK(hipMemsetAsync(p->lg_cnt.p, 0, p->lg_cnt.bytes, st));
     p->lg_epoch = 1;
   }
   if (!p->lg_pin) {
@@ -656,9 +698,10 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
   }
   if (hit && p->lg_blocks[p->lg_cur] - p->lg_blk0 < nblocks) hit = false;    // (buffer too short)
   if (hit) {
-    HIP_OK(hipStreamWaitEvent(h->stream, p->lg_evs[p->lg_cur], 0));
+    HIP_OK(hipStreamWaitEvent(st, p->lg_evs[p->lg_cur], 0));
     ++p->lg_hits;
   } else {
+    REQUIRE(!pre, "internal: a pre-draw missed the run-ahead after the check");
     HIP_OK(hipStreamSynchronize(p->lg_side));         // (a stale run-ahead may still be running)
     p->lg_cur = 0; p->lg_blk0 = 0; p->lg_next = false; p->lg_hits = 0;
     HIP_OK(p->lg_key[0].reserve(kMtN * sizeof(uint32_t)));
@@ -677,14 +720,15 @@ static int legacy_enqueue(ampc_mppi_plan* p, const uint32_t* key, int pos, int h
   const int logv = host_log_mode();
   if (logv && p->lg_logtab.bytes == 0) {
     HIP_OK(p->lg_logtab.reserve(sizeof(g_log_table)));
-    HIP_OK(hipMemcpyAsync(p->lg_logtab.p, g_log_table, sizeof(g_log_table), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipMemcpyAsync(p->lg_logtab.p, g_log_table, sizeof(g_log_table), hipMemcpyHostToDevice, st));
   }
   // ONE launch: attempts, the scan of the accept flags, the normals, and what the host needs afterwards (last
   // attempt, cached value, pair count, the stream block the generator ends in) straight into pinned memory
   auto draw = logv == 1 ? polar_draw_kernel<T, 1> : logv == 2 ? polar_draw_kernel<T, 2> : polar_draw_kernel<T, 0>;
-  hipLaunchKernelGGL(draw, dim3(std::min(n_wg, kPolarMaxWgs)), dim3(256), 0, h->stream, u, (int)n_att,
+  hipLaunchKernelGGL(draw, dim3(std::min(n_wg, kPolarMaxWgs)), dim3(256), 0, st, u, (int)n_att,
                      (unsigned long long*)p->lg_cnt.p, p->lg_epoch & 0xffffffu, n, shift, cached,
-                     (const MppiProblem<T>*)p->probs.p, (const double*)p->lg_scale.p, p->B, (T*)p->eps.p, stream, pos,
+                     (const MppiProblem<T>*)p->probs.p, (const double*)p->lg_scale.p, p->B,
+                     (T*)(pre ? p->eps_pre.p : p->eps.p), stream, pos,
                      (long long*)p->lg_pin_dev, (const double*)p->lg_logtab.p, n_wg,
                      // (a second attempt always waits the full bound; AMPC_POLAR_SPIN_LIMIT is the tests' hook)
                      retry ? kPolarSpinLimit : std::max(1, env_int("AMPC_POLAR_SPIN_LIMIT", kPolarSpinLimit)));
@@ -916,9 +960,10 @@ static inline LegacyDraw draw_unpack(const long long* o) {
 //   * x0 is written into host memory the rollout reads directly (mapped), no copy packet;
 //   * the update writes u into mapped host memory and raises a per-problem sequence word behind it
 //     (MppiArgs::done_flag); the host polls that word -- no copy packet, no hipStreamSynchronize;
-//   * numpy-stream mode: the NEXT call's normals are drawn behind this call's update from the generator state
-//     this call returns; a next call presenting exactly that state (nobody drew from numpy's generator in
-//     between) launches only the rollout (+ update) -- otherwise it draws as before, results identical.
+//   * numpy-stream mode: the NEXT call's normals are drawn from the generator state this call returns -- known
+//     before the solve on a pre-drawn call -- on a second stream into a second noise buffer, inside the running
+//     rollout's shadow; a next call presenting exactly that state (nobody drew from numpy's generator in between)
+//     swaps the buffers and launches only the rollout (+ update) -- otherwise it draws as before, results identical.
 // AMPC_RUN_MAPPED=0 / AMPC_LEGACY_PREDRAW=0 restore the copy / in-call-draw behaviour (same results).
 template <typename T>
 static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_seq, int noise,
@@ -950,9 +995,11 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
       // this call's normals were drawn behind the previous call's update: what the draw left for the host is (or
       // will in a moment be) in pinned memory -- the generator state to hand back is known BEFORE the solve
       draw = draw_unpack(p->lg_pre_draw);
-      HIP_OK(hipEventSynchronize(p->lg_pre_done));
+      if (int rcw = legacy_predraw_wait(p)) return rcw;
+      std::swap(p->eps, p->eps_pre);         // the pre-drawn buffer is this call's noise
+      p->eps_inline = false; p->eps_from_generator = false; p->ahead_valid = false; p->ahead_on = false;
       const int rc = legacy_finish(p, draw, lg->key, lg->key_out, lg->pos_out, lg->has_gauss_out, lg->cached_out);
-      if (rc == kLegacyExpired) { pre_hit = false; ++p->lg_redraws; }       // the pre-drawn noise is void: draw in this call
+      if (rc == kLegacyExpired) { pre_hit = false; ++p->lg_redraws; std::swap(p->eps, p->eps_pre); }   // void: draw in this call
       else if (rc) return rc;
       else finished = true;
     }
@@ -973,16 +1020,18 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
   p->host_io = false;
   if (rc_solve) return rc_solve;
   if (!mapped) HIP_OK(hipMemcpyAsync(p->pin_u, p->u_out.p, nuo * sizeof(T), hipMemcpyDeviceToHost, h->stream));
-  // The NEXT call's draw, from the generator state this call hands back, behind this call's update on the same
-  // stream -- only once calls follow each other on the generator (this call took its words from the run-ahead or
-  // from a pre-drawn buffer): a caller who draws from numpy's generator between calls never pays for a wasted draw.
+  // The NEXT call's draw, from the generator state this call hands back: on its own stream, into the second noise
+  // buffer, NEXT TO the solve that has just been launched (legacy_enqueue, pre) -- only once calls follow each other
+  // on the generator (this call took its words from the run-ahead or from a pre-drawn buffer): a caller who draws
+  // from numpy's generator between calls never pays for a wasted draw.
   auto enqueue_next = [&]() -> int {
     if (!predraw || draw.trivial || !(pre_hit || p->lg_hits > 0)) return 0;
     LegacyDraw nd;
-    if (int rc = legacy_enqueue<T>(p, lg->key_out, *lg->pos_out, *lg->has_gauss_out, *lg->cached_out, &nd)) return rc;
-    if (nd.trivial) return 0;
-    if (!p->lg_pre_done) HIP_OK(hipEventCreateWithFlags(&p->lg_pre_done, hipEventDisableTiming));
-    HIP_OK(hipEventRecord(p->lg_pre_done, h->stream));
+    const int rce = legacy_enqueue<T>(p, lg->key_out, *lg->pos_out, *lg->has_gauss_out, *lg->cached_out, &nd, false, true);
+    if (rce == kLegacySkip) return 0;          // (its words are not in the run-ahead yet: the next call draws itself)
+    if (rce) return rce;
+    HIP_OK(hipEventRecord(p->lg_pre_done, p->lg_draw));
+    p->lg_pre_inflight = true;
     if (int rc = legacy_speculate(p, nd)) return rc;
     p->lg_pre_key.assign(lg->key_out, lg->key_out + kMtN);
     p->lg_pre_pos = *lg->pos_out; p->lg_pre_has_gauss = *lg->has_gauss_out; p->lg_pre_cached = *lg->cached_out;

@@ -405,6 +405,9 @@ struct ampc_mppi_plan {
   // state this call hands back (lg_pre_*); a next call that presents exactly that state finds its noise in place
   bool lg_pre = false;
   hipEvent_t lg_pre_done = nullptr;   // the pre-drawn call's draw kernel has finished
+  hipStream_t lg_draw = nullptr;      // ... it runs on this stream, next to the current solve, into eps_pre
+  DevBuf eps_pre;                     // (swapped with eps when the next call presents the predicted generator state)
+  bool lg_pre_inflight = false;       // a pre-draw has been enqueued and not been waited for yet
   int lg_pre_pos = 0, lg_pre_has_gauss = 0;
   double lg_pre_cached = 0.0;
   std::vector<uint32_t> lg_pre_key;
