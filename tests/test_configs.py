@@ -164,3 +164,49 @@ def test_configurations_mean_to_the_references_factories_what_they_mean_here():
         ours = MLPFactory(make_system(4, 2))(DictConfiguration(cand["model_cfg"]), [], skip_train_model=True)
         ref_sizes = [m.out_features for m in model.net.layers.values()]
         assert ref_sizes == ours.hidden_sizes
+
+
+def _axis_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    system = make_system(3, 2)
+    trajs = _trajs(system)
+    cfgs = sample_pipeline_configs(system, 10, np.random.default_rng(7), model_axis=True)
+    ev = _ModelReadingEvaluator(MLP(system, n_hidden_layers=1, hidden_size=16))
+    ev.accepts_global_ids = True                         # (it ignores index_offset: balanced shards are fine)
+    tuner = BatchPipelineTuner(system, ev, batch_size=10, model_factory=MLPFactory(system, n_train_iters=1, n_batch=32),
+                               trajs=trajs)
+    best, res = tuner.run(10, np.random.default_rng(0), configs=cfgs)
+    q.put((rank, list(res.costs), tuner.models_fitted, cfgs.index(best)))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_fit_only_their_own_shards_models_and_agree_on_the_scores():
+    """The model axis under torch.distributed (gloo, world 2): every rank builds and fits the models of ITS shard
+    only (pipeline.py:138-145 runs inside the sharded evaluation), the all-gathered scores are the single-process
+    scores."""
+    import torch.multiprocessing as mp
+    from test_sharded_eval import _free_port
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_axis_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (c, n, b) for r, c, n, b in (q.get(timeout=300) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    system = make_system(3, 2)
+    trajs = _trajs(system)
+    cfgs = sample_pipeline_configs(system, 10, np.random.default_rng(7), model_axis=True)
+    ev = _ModelReadingEvaluator(MLP(system, n_hidden_layers=1, hidden_size=16))
+    single = BatchPipelineTuner(system, ev, batch_size=10, model_factory=MLPFactory(system, n_train_iters=1, n_batch=32),
+                                trajs=trajs)
+    best, res = single.run(10, np.random.default_rng(0), configs=cfgs)
+    assert single.models_fitted == 10
+    for r in range(2):
+        np.testing.assert_allclose(got[r][0], res.costs, rtol=1e-12)
+        assert got[r][2] == cfgs.index(best)
+    assert got[0][1] + got[1][1] == 10 and 3 <= got[0][1] <= 7       # each rank fitted its shard's models only

@@ -31,3 +31,36 @@ def test_view_tracks_numpy_and_writes_are_numpys_state():
         ls.has_gauss.value, ls.gauss.value = st[3], st[4]
     np.testing.assert_array_equal(np.random.normal(size=9), ref)
     assert ls.current()
+
+
+def test_recognition_reports_what_it_found_and_never_raises():
+    """the direct view relies on numpy's private RandomState layout.  On every numpy this
+    suite runs under, `get()` either proves the layout on a private instance and on the global one, or returns
+    None (MPPI then goes through get_state / set_state: tests/test_gpu_legacy_noise.py forces that route on the
+    device) -- it must never raise, and a recognised layout must survive seeding and draws.  The numpy version is
+    part of the assertion message so a bump that loses the fast path shows in the log instead of skipping silently."""
+    ls = _npstate.get()
+    assert ls is None or ls.current(), "numpy %s: a stale view was handed out" % np.__version__
+    if ls is None:
+        import warnings
+        warnings.warn("numpy %s: RandomState layout not recognised -- MPPI(noise='numpy') uses get_state()/set_state() "
+                      "(slower per call, same results)" % np.__version__)
+
+
+def test_a_layout_that_does_not_match_is_refused_not_trusted(monkeypatch):
+    """What happens on a numpy whose RandomState keeps its Gaussian cache elsewhere: the scan of the PRIVATE probe
+    instance finds nothing, nothing is ever written through raw addresses of the global generator, `get()` warns
+    once and returns None from then on -- and the global stream is untouched by the attempt."""
+    import ctypes
+    monkeypatch.setattr(_npstate, "_state", None)
+    monkeypatch.setattr(_npstate, "_failed", False)
+    monkeypatch.setattr(ctypes, "string_at", lambda addr, size: bytes(size))      # a layout with no cache in sight
+    np.random.seed(5)
+    np.random.normal(size=3)                                  # (a value sits in the cache)
+    before = np.random.get_state()
+    with pytest.warns(RuntimeWarning, match="in-place access"):
+        assert _npstate.get() is None
+    assert _npstate.get() is None                             # sticky: no second probe, no second warning
+    after = np.random.get_state()
+    np.testing.assert_array_equal(before[1], after[1])
+    assert before[2:] == after[2:]
