@@ -287,14 +287,16 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
                     &p->lg_key[0], &p->lg_key[1], &p->lg_stream[0], &p->lg_stream[1], &p->lg_cnt,
                     &p->lg_scale, &p->lg_xraw, &p->lg_poly[0], &p->lg_poly[1], &p->lg_poly[2], &p->lg_poly[3],
                     &p->lg_win, &p->lg_logtab};
+  // (a pre-drawn next call / the raw-stream run-ahead may still be running on their own streams: they write the
+  //  pinned results and the buffers freed below)
+  if (p->lg_draw) { (void)hipStreamSynchronize(p->lg_draw); (void)hipStreamDestroy(p->lg_draw); }
+  if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
+  if (p->lg_pre_done) (void)hipEventDestroy(p->lg_pre_done);
+  p->eps_pre.release();
   if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
   if (p->pin_flag) (void)hipHostFree(p->pin_flag);
-  if (p->lg_draw) { (void)hipStreamSynchronize(p->lg_draw); (void)hipStreamDestroy(p->lg_draw); }
-  if (p->lg_pre_done) (void)hipEventDestroy(p->lg_pre_done);
-  p->eps_pre.release();
-  if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   for (hipEvent_t e : p->lg_evs) if (e) (void)hipEventDestroy(e);
   if (p->lg_drawn) (void)hipEventDestroy(p->lg_drawn);
   for (DevBuf* b : bufs) b->release();
