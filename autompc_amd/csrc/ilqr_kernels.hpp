@@ -568,7 +568,7 @@ __device__ __forceinline__ int lu_solve_lane(const T (&A0)[NU][NU], T (&x)[NU]) 
 }
 
 template <typename T, int NU, typename SH = DynShape>
-__global__ __launch_bounds__(kRicThreads) void ilqr_riccati_mfma_kernel(const IlqrArgs<T> args) {
+__global__ __launch_bounds__(kRicThreads) AMPC_PROBE_RIC_OCC void ilqr_riccati_mfma_kernel(const IlqrArgs<T> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* Wr = reinterpret_cast<T*>(smem_raw);
   using acc_t = typename Acc<T>::type;

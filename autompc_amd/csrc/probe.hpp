@@ -22,6 +22,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// ric_occ: the backward sweep compiled for FOUR waves per SIMD (<= 128 VGPRs: two sweep workgroups per CU) instead of
+//          two -- an attribute, so it cannot be an `if constexpr` constant like the others
+#ifdef AMPC_X_RIC_OCC
+#define AMPC_PROBE_RIC_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define AMPC_PROBE_RIC_OCC
+#endif
+
 namespace ampc {
 
 #define AMPC_PROBE_FLAG(name, macro) static constexpr bool name = macro
