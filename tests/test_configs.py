@@ -89,16 +89,17 @@ def _trajs(system, n=3, rows=40, seed=0):
 
 def test_tuner_runs_given_configurations_and_reports_them_back():
     system = make_system(3, 2)
-    cfgs = [_Configuration(c) for c in sample_pipeline_configs(system, 40, np.random.default_rng(1))]
+    cfgs = [_Configuration(c) for c in sample_pipeline_configs(system, 512, np.random.default_rng(1))]
     ev = _ModelReadingEvaluator(MLP(system, n_hidden_layers=1, hidden_size=16))
-    tuner = BatchPipelineTuner(system, ev, batch_size=16)
+    tuner = BatchPipelineTuner(system, ev, batch_size=64)
     assert tuner.balance is False              # a plain evaluator gets the documented integer index_offset
-    best, res = tuner.run(40, np.random.default_rng(0), configs=cfgs)
-    assert ev.calls == [0, 16, 32]
+    best, res = tuner.run(512, np.random.default_rng(0), configs=cfgs)      # BASELINE config 5's 512 pipelines
+    assert ev.calls == list(range(0, 512, 64))
     assert all(a is b for a, b in zip(res.cfgs, cfgs)) and best is cfgs[int(np.argmin(res.costs))]
-    assert "_ctrlr:horizon" in best.get_dictionary()
+    assert {"_ctrlr:horizon", "_ctrlr:num_path", "_cost:x0_Q", "_cost:u1_R"} <= set(best.get_dictionary())
+    assert res.inc_cfgs[-1] is best and len(res.costs) == 512
     with pytest.raises(ValueError):
-        tuner.run(41, np.random.default_rng(0), configs=cfgs)
+        tuner.run(513, np.random.default_rng(0), configs=cfgs)
     # sampled candidates reported as configurations on request
     t2 = BatchPipelineTuner(system, ev, batch_size=8, as_configs=True)
     best2, res2 = t2.run(8, np.random.default_rng(0))
