@@ -329,11 +329,24 @@ class CandidateEvaluator:
         # every candidate's model is made explicit first: a candidate WITHOUT a "model" entry runs on the
         # evaluator's own model, whatever the first candidate of its shape group carries
         candidates = [dict(c, model=c.get("model") if c.get("model") is not None else self.model) for c in candidates]
-        for idx in groups:
+
+        def run_group(idx):
             sub = copy.copy(self)
             sub.model = candidates[idx[0]]["model"]       # the group's plan handle is staged with one of ITS models
             # (sub.surrogate stays the evaluator's simulation model: copy.copy kept the reference)
-            out = sub.evaluate([candidates[i] for i in idx], index_offset=ids[idx], **kw)
+            return idx, sub, sub.evaluate([candidates[i] for i in idx], index_offset=ids[idx], **kw)
+        # The groups are independent plans on handles (streams) of their own; most of a small group's time is host
+        # work (staging the model, building the plan, freeing both), so they run side by side on a few host threads
+        # -- the library calls release the GIL.  Results do not depend on the order (nothing is shared).
+        from .hostpin import thread_cap
+        workers = thread_cap(min(len(groups), int(getattr(self, "group_threads", 8))))
+        if workers > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                results = list(pool.map(run_group, groups))
+        else:
+            results = [run_group(idx) for idx in groups]
+        for idx, sub, out in results:
             if kw["return_trajectories"]:
                 sc, ob, ct = out
                 for k, i in enumerate(idx):
