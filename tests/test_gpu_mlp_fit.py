@@ -10,7 +10,6 @@ from autompc_amd import MLP, _lib, zeros
 from autompc_amd.sysid import mlp_fit as F
 from autompc_amd.sysid.mlp import MLPFactory
 from oracle import mlp as omlp
-from conftest import golden
 from helpers import make_system
 from test_mlp_fit import _case, _interleave
 
