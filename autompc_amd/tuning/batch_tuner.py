@@ -35,7 +35,11 @@ PipelineTuneResult = namedtuple("PipelineTuneResult", [
 
 class BatchPipelineTuner:
     """``evaluator.evaluate(candidates, seed=..., index_offset=...) -> scores`` is the only thing
-    required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it)."""
+    required of the evaluator (autompc_amd.tuning.CandidateEvaluator provides it).  ``index_offset`` is the
+    global evaluation index of the shard's first candidate -- an ``int`` -- unless the evaluator sets the class
+    attribute ``accepts_global_ids = True`` (both in-tree evaluators do): shards are then balanced by work and
+    ``index_offset`` may be the ARRAY of the shard's global indices (``tuning.batch_eval.global_ids`` turns either
+    form into indices).  ``balance=True`` / ``False`` overrides the choice."""
 
     def __init__(self, system, evaluator, batch_size=64, sampler=None, truedyn_noise="device",
                  eval_kwargs=None, keep_trajs=False, balance=None, models=None, model_factory=None,
