@@ -293,6 +293,7 @@ extern "C" int ampc_mppi_plan_destroy(ampc_mppi_plan* p) {
   if (p->lg_side) { (void)hipStreamSynchronize(p->lg_side); (void)hipStreamDestroy(p->lg_side); }
   if (p->lg_pre_done) (void)hipEventDestroy(p->lg_pre_done);
   p->eps_pre.release();
+  p->cl_obs.release(); p->cl_ctl.release(); p->cl_next.release(); p->cl_sim.release();
   if (p->lg_pin) (void)hipHostFree(p->lg_pin);
   if (p->pin_x0) (void)hipHostFree(p->pin_x0);
   if (p->pin_u) (void)hipHostFree(p->pin_u);
@@ -1278,7 +1279,9 @@ static int closed_loop_impl(ampc_mppi_plan* p, ampc_handle* sur, const double* i
   // koopman.py:166-168).  snx = width of the carried state = width of the recorded rows.
   const bool lift = p->lift_n > 0;
   const int snx = lift ? sur->nx : nx;
-  ScopedBuf d_obs, d_ctl, d_next, d_sim;
+  // (scratch of the loop, kept by the plan: an evaluator that runs an episode in segments -- a user termination
+  //  condition -- calls this every few control steps, and every hipFree synchronises the whole device)
+  DevBuf &d_obs = p->cl_obs, &d_ctl = p->cl_ctl, &d_next = p->cl_next, &d_sim = p->cl_sim;
   HIP_OK(d_obs.reserve((size_t)B * T1 * snx * sizeof(T)));
   HIP_OK(d_ctl.reserve((size_t)B * T1 * nu * sizeof(T)));
   HIP_OK(d_next.reserve((size_t)B * snx * sizeof(T)));

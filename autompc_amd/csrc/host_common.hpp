@@ -407,6 +407,7 @@ struct ampc_mppi_plan {
   hipEvent_t lg_pre_done = nullptr;   // the pre-drawn call's draw kernel has finished
   hipStream_t lg_draw = nullptr;      // ... it runs on this stream, next to the current solve, into eps_pre
   DevBuf eps_pre;                     // (swapped with eps when the next call presents the predicted generator state)
+  DevBuf cl_obs, cl_ctl, cl_next, cl_sim;   // scratch of the device-resident closed loop (trajectory rows, next states)
   bool lg_pre_inflight = false;       // a pre-draw has been enqueued and not been waited for yet
   int lg_pre_pos = 0, lg_pre_has_gauss = 0;
   double lg_pre_cached = 0.0;
