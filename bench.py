@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}   # MI355X dense MFMA peaks for the arithmetic type used
 EVENT_STRIDE = 8                             # kernel events around every 8th timed MPPI solve (roofline.kernel_ms)
-PROFILE_TAG = "r05"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
+PROFILE_TAG = "r06"                          # profiles/<tag>_hbm_traffic.json feeds roofline.traffic
 
 
 def parse():
