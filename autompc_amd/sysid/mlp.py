@@ -13,7 +13,9 @@ reference's ``state_dict`` keys ``layers.layer{i}.weight|bias`` /
 analytic chain  W_out prod_l diag(act'(z_l)) W_l  rather than the reference's
 autograd over an nx-fold repeated batch (mlp.py:288-295).  Training (mlp.py:177-217,
 Adam + SmoothL1 on normalised deltas) stays in PyTorch -- it is outside the MPC
-inner loop -- and only produces the weights that are then staged on the device.
+inner loop: sysid/mlp_fit.py runs the reference's loop (its initial weights, its
+mini-batch order) on PyTorch-ROCm, for one model or for K models in lockstep, and the
+fitted tensors are staged from device memory (ampc_set_mlp_dev).
 """
 import numpy as np
 
