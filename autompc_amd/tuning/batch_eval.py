@@ -99,6 +99,18 @@ def _by_model_shape(candidates, default):
     return list(groups.values())
 
 
+def _close_or_defer(evaluator, opened):
+    """Close an evaluation's device objects (handles, plans) -- or, inside a model-shape group running next to
+    other groups, hand them to the caller: freeing device memory synchronises the WHOLE device, so a group that
+    finishes would stall the groups still running; the caller closes everything once all groups are done."""
+    later = getattr(evaluator, "_close_later", None)
+    if later is not None:
+        later.extend(reversed(opened))
+        return
+    for obj in reversed(opened):
+        obj.close()
+
+
 def global_ids(index_offset, n):
     """Global indices of a shard's n candidates: index_offset is the first one's (a contiguous shard) or
     the array of all of them (a balanced shard, evaluate_sharded(..., weights=...))."""
@@ -319,8 +331,7 @@ class CandidateEvaluator:
             return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
                                   return_trajectories, ids, opened, timing)
         finally:
-            for obj in reversed(opened):
-                obj.close()
+            _close_or_defer(self, opened)
 
     def _evaluate_shape_groups(self, groups, candidates, ids, kw):
         import copy
@@ -330,8 +341,11 @@ class CandidateEvaluator:
         # evaluator's own model, whatever the first candidate of its shape group carries
         candidates = [dict(c, model=c.get("model") if c.get("model") is not None else self.model) for c in candidates]
 
+        later = []                        # (list.extend is atomic under the GIL)
+
         def run_group(idx):
             sub = copy.copy(self)
+            sub._close_later = later
             sub.model = candidates[idx[0]]["model"]       # the group's plan handle is staged with one of ITS models
             # (sub.surrogate stays the evaluator's simulation model: copy.copy kept the reference)
             return idx, sub, sub.evaluate([candidates[i] for i in idx], index_offset=ids[idx], **kw)
@@ -340,12 +354,16 @@ class CandidateEvaluator:
         # -- the library calls release the GIL.  Results do not depend on the order (nothing is shared).
         from .hostpin import thread_cap
         workers = thread_cap(min(len(groups), int(getattr(self, "group_threads", 8))))
-        if workers > 1:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                results = list(pool.map(run_group, groups))
-        else:
-            results = [run_group(idx) for idx in groups]
+        try:
+            if workers > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    results = list(pool.map(run_group, groups))
+            else:
+                results = [run_group(idx) for idx in groups]
+        finally:
+            for obj in later:
+                obj.close()
         for idx, sub, out in results:
             if kw["return_trajectories"]:
                 sc, ob, ct = out
@@ -640,8 +658,7 @@ class IlqrCandidateEvaluator:
         try:
             return self._evaluate(candidates, n_steps, init_obs, return_trajectories, int(max_iter), opened)
         finally:
-            for obj in reversed(opened):
-                obj.close()
+            _close_or_defer(self, opened)
 
     def _evaluate(self, candidates, n_steps, init_obs, return_trajectories, max_iter, opened):
         from ..trajectory import Trajectory
