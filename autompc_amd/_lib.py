@@ -41,6 +41,7 @@ SIGNATURES = {
     "ampc_set_mlp_dev": (c_int, [c_void_p, c_int, c_int, c_int, _ip, c_int, POINTER(c_void_p),
                                  POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_void_p]),
     "ampc_jit_status": (c_int, [c_void_p, c_char_p, c_int]),
+    "ampc_handle_set_jit": (c_int, [c_void_p, c_int]),
     "ampc_jit_wait": (c_int, [c_void_p]),
     "ampc_plan_kernel_kind": (c_int, [c_void_p, c_void_p]),
     "ampc_set_linear": (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
@@ -166,7 +167,9 @@ def _shutdown():
 class Handle:
     """One device context: model + cost blocks + bounds on one MI355X / one stream."""
 
-    def __init__(self, device=0, precision="f64", stream=None):
+    def __init__(self, device=0, precision="f64", stream=None, jit=True):
+        """jit=False: never start (or wait for) the run-time build of shape-specialised kernels for what this
+        handle holds (ampc_handle_set_jit) -- models that live for one evaluation."""
         lib = load()
         if lib.ampc_device_count() <= 0:
             raise AmpcError("no HIP device visible: the MI355X path cannot run here "
@@ -178,6 +181,8 @@ class Handle:
         check(lib.ampc_create(int(device), self.precision, c_void_p(stream) if stream else None,
                               ctypes.byref(self._h)))
         self.device = int(device)
+        if not jit:
+            check(lib.ampc_handle_set_jit(self._h, 0))
         self.nx = self.nu = None
         self._plans = weakref.WeakSet()      # plans hold raw pointers into this handle
         _live_handles.add(self)

@@ -58,6 +58,12 @@ extern "C" int ampc_plan_kernel_kind(const ampc_mppi_plan* mppi, const ampc_ilqr
   return sid < 0 ? 0 : (j ? 2 : 1);
 }
 
+extern "C" int ampc_handle_set_jit(ampc_handle* h, int build) {
+  REQUIRE(h, "ampc_handle_set_jit: NULL handle");
+  h->jit_build = build != 0;
+  return 0;
+}
+
 extern "C" int ampc_jit_wait(ampc_handle* h) {
   REQUIRE(h, "ampc_jit_wait: NULL handle");
   ampc_internal_jit_kick(h);

@@ -121,6 +121,9 @@ struct ampc_handle {
   // actually freed when ampc_destroy has been called AND the last plan is gone.
   int refs = 0;
   bool dead = false;
+  // ampc_handle_set_jit: may this handle START (and wait for) the run-time build of kernels specialised for its
+  // model's shape?  A plugin that is already loaded or cached on disk is used either way.
+  bool jit_build = true;
 
   // model (host copy, double) ---------------------------------------------------------------
   bool has_mlp = false;

@@ -300,11 +300,12 @@ template <typename T> inline const JitPlugin* get(const ampc_handle* h, bool blo
       if (e.state == 0) {
         e.so = cache_dir() + "/shape_" + key + "_" + source_hash() + "_" + compiler_id() + ".so";
         if (exists(e.so)) load(e, h, sizeof(T));
-        else start_build<T>(e, h, key);
+        else if (h->jit_build) start_build<T>(e, h, key);
+        else { table().erase(key); return nullptr; }     // (ampc_handle_set_jit(h, 0): uses, never builds)
       }
       poll(e, h, sizeof(T));
       reap_all();
-      if (e.state != 1 || !block) return e.state == 2 ? &e.plug : nullptr;
+      if (e.state != 1 || !block || !h->jit_build) return e.state == 2 ? &e.plug : nullptr;
     }
     usleep(20000);
   }

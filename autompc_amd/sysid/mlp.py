@@ -44,6 +44,9 @@ class MLP(Model):
         self.precision = precision
         self.device = device
         self._train_data = (n_train_iters, n_batch, lr)
+        # jit_kernels: may handles that hold this model start the run-time build of kernels specialised for its
+        # shape (3-7 s in the background, cached)?  A tuner sets False on models it fits for ONE evaluation.
+        self.jit_kernels = True
         nx, nu = system.obs_dim, system.ctrl_dim
         # torch.nn.Linear default initialisation (U(-1/sqrt(in), 1/sqrt(in))) from a seeded
         # numpy stream; real weights arrive through train() or set_parameters().
@@ -96,7 +99,7 @@ class MLP(Model):
 
     def _dev(self):
         if self._handle is None:
-            self._handle = _lib.Handle(self.device, self.precision)
+            self._handle = _lib.Handle(self.device, self.precision, jit=getattr(self, "jit_kernels", True))
             self.stage_into(self._handle)
         return self._handle
 

@@ -80,7 +80,7 @@ def model_handle(m, device, precision, opened):
         raise TypeError("a candidate's model must be device-stageable (autompc_amd.sysid.MLP)")
     if hasattr(m, "_dev") and getattr(m, "device", None) == device and getattr(m, "precision", None) == precision:
         return m._dev()
-    hm = _lib.Handle(device, precision)
+    hm = _lib.Handle(device, precision, jit=getattr(m, "jit_kernels", True))
     opened.append(hm)
     m.stage_into(hm)
     return hm
@@ -97,6 +97,21 @@ def _by_model_shape(candidates, default):
     if len(groups) == 1 and next(iter(groups)) == model_shape_key(default):
         return None
     return list(groups.values())
+
+
+def _by_model(candidates, default):
+    """Candidate indices grouped by the model OBJECT they carry (first appearance order)."""
+    groups = {}
+    for i, c in enumerate(candidates):
+        m = c.get("model") if isinstance(c, dict) else None
+        groups.setdefault(id(default if m is None else m), []).append(i)
+    return list(groups.values())
+
+
+def _needs_specialised_kernels(err):
+    """The library's refusal of a model TABLE on a plan that runs the run-time-shape kernels (several models of one
+    unregistered shape whose plugin is not built -- and, for one-evaluation models, never will be)."""
+    return "several controller models in one plan" in str(err)
 
 
 def _close_or_defer(evaluator, opened):
@@ -330,6 +345,17 @@ class CandidateEvaluator:
         try:
             return self._evaluate(candidates, n_steps, seed, init_obs, eps_all, act_init,
                                   return_trajectories, ids, opened, timing)
+        except _lib.AmpcError as e:
+            # several models of ONE shape share a plan through a model table, which needs the kernels specialised
+            # for the shape; where those are not to be had (a shape that is not registered, on handles that do not
+            # build plugins -- jit_kernels = False: models fitted for this one evaluation) every model gets a plan
+            # of its own on the run-time-shape kernels.  Same scores: a candidate's randomness follows its index.
+            by_model = _by_model(candidates, self.model)
+            if not _needs_specialised_kernels(e) or len(by_model) < 2 or eps_all is not None or act_init is not None \
+                    or timing is not None:
+                raise
+            return self._evaluate_shape_groups(by_model, candidates, ids, dict(
+                n_steps=n_steps, seed=seed, init_obs=init_obs, return_trajectories=return_trajectories))
         finally:
             _close_or_defer(self, opened)
 
@@ -391,7 +417,7 @@ class CandidateEvaluator:
     def _stage(self, candidates, opened):
         nu, no = self.system.ctrl_dim, self.system.obs_dim
         B = len(candidates)
-        h = _lib.Handle(self.device, self.precision)
+        h = _lib.Handle(self.device, self.precision, jit=getattr(self.model, "jit_kernels", True))
         opened.append(h)
         self.model.stage_into(h)
         # controller models the candidates carry (same shape as the evaluator's: evaluate() groups by shape):
@@ -657,6 +683,13 @@ class IlqrCandidateEvaluator:
         opened = []
         try:
             return self._evaluate(candidates, n_steps, init_obs, return_trajectories, int(max_iter), opened)
+        except _lib.AmpcError as e:           # (as CandidateEvaluator.evaluate: a plan per model where no table can be had)
+            by_model = _by_model(candidates, self.model)
+            if not _needs_specialised_kernels(e) or len(by_model) < 2:
+                raise
+            return CandidateEvaluator._evaluate_shape_groups(
+                self, by_model, candidates, global_ids(index_offset, B),
+                dict(n_steps=n_steps, init_obs=init_obs, return_trajectories=return_trajectories, max_iter=max_iter))
         finally:
             _close_or_defer(self, opened)
 
@@ -690,7 +723,7 @@ class IlqrCandidateEvaluator:
                 raise ValueError("candidates that carry their own model need the one-plan evaluator (one_plan=True)")
             model_handles = [model_handle(m, self.device, self.precision, opened) for m in models]
         for H, idx in groups.items():
-            h = _lib.Handle(self.device, self.precision)
+            h = _lib.Handle(self.device, self.precision, jit=getattr(self.model, "jit_kernels", True))
             opened.append(h)
             self.model.stage_into(h)
             blocks, term_goal = candidate_cost_blocks([candidates[i] for i in idx], self.goal, no, nu)

@@ -133,6 +133,10 @@ class BatchPipelineTuner:
             key = self._cfg_key(c["model_cfg"])
             if key not in self._fitted and key not in fresh:
                 fresh[key] = self.model_factory(DictConfiguration(c["model_cfg"]), self.trajs, skip_train_model=True)
+                # a model per configuration lives for its candidates' evaluation: no 5 s kernel build for it
+                # (a plugin already cached for its shape is still used; the incumbent's controller, built by
+                #  Pipeline.__call__ afterwards, is a new model object with the default)
+                fresh[key].jit_kernels = False
         if fresh:
             from ..sysid.mlp import MLP
             from ..sysid.mlp_fit import fit_mlps

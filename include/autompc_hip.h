@@ -90,6 +90,10 @@ int ampc_set_mlp_dev(ampc_handle* h, int nx, int nu, int n_hidden, const int* hi
  *                    2 ready, -1 failed; msg (optional) receives the plugin path or the build log's path
  *   ampc_jit_wait    block until the handle's shape is ready (returns 0) or failed (< 0)            */
 int ampc_jit_status(ampc_handle* h, char* msg, int msg_len);
+/* build = 0: this handle never STARTS (nor waits for) a run-time build -- for models that live for one evaluation
+ * (a tuner fits a model per configuration, pipeline.py:138-145: a 5 s build for 40 ms of use); a plugin that is
+ * already loaded or cached is still used.  Default 1.  Call before the model is staged. */
+int ampc_handle_set_jit(ampc_handle* h, int build);
 int ampc_jit_wait(ampc_handle* h);
 /* Which kernels a plan launches (pass one plan, NULL for the other): 0 run-time-shape, 1 a shape
  * registered at build time, 2 a shape plugin compiled at run time, 3 the run-time-shape four-row rollout kernel

@@ -236,3 +236,46 @@ def test_a_model_table_never_meets_the_run_time_shape_kernels_silently():
         plan.solve()
     h0.set_indicator_costs(None)
     plan.solve()
+
+
+def test_one_evaluation_models_never_build_kernels_and_share_no_table(monkeypatch, tmp_path):
+    """Models a tuner fits for ONE evaluation (jit_kernels = False; BatchPipelineTuner.fit_models sets it): handles
+    that hold them never start -- or wait for -- the run-time build of shape-specialised kernels
+    (ampc_handle_set_jit), and two such models that share an unregistered shape, which cannot share a plan through a
+    model table, get a plan each on the run-time-shape kernels.  Scores are those of each candidate alone."""
+    import time
+    from autompc_amd import QuadCost, Task, _lib
+    from autompc_amd.tuning import CandidateEvaluator, IlqrCandidateEvaluator, random_candidates, random_ilqr_candidates
+    monkeypatch.setenv("AMPC_JIT_CACHE", str(tmp_path))          # an empty cache: nothing to find
+    system, models = _hc_models(3, hidden=(80, 48), nx=5, nu=2)           # (not a registered shape)
+    for m in models[1:]:
+        m.jit_kernels = False
+    task = Task(system)
+    task.set_cost(QuadCost(system, np.eye(5), 0.01 * np.eye(2), np.eye(5)))
+    task.set_ctrl_bounds(-np.ones(2), np.ones(2))
+    task.set_init_obs(np.array([0.1, -0.1, 0.05, 0.0, 0.02]))
+    task.set_num_steps(6)
+    h = _lib.Handle(0, "f64", jit=False)
+    models[1].stage_into(h)
+    h.set_quad_costs(np.eye(5), 0.01 * np.eye(2), np.eye(5), np.zeros(5))
+    assert h.jit_status()[0] == 0 and not list(tmp_path.iterdir())        # no build was started
+    h.close()
+    cands = random_candidates(system, 4, seed=2)
+    for c in cands:
+        c["Q"], c["R"], c["F"], c["num_path"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25, 128
+    batch = [dict(c, model=models[1 + i % 2]) for i, c in enumerate(cands)]
+    ev = CandidateEvaluator(system, task, models[1])
+    t0 = time.perf_counter()
+    got = ev.evaluate(batch, seed=3)
+    assert time.perf_counter() - t0 < 3.0                                # (a build takes 3-7 s: none was waited for)
+    for i, c in enumerate(batch):
+        np.testing.assert_array_equal(ev.evaluate([c], seed=3, index_offset=i), got[i:i + 1])
+    ic = random_ilqr_candidates(system, 4, seed=2)
+    for c in ic:
+        c["Q"], c["R"], c["F"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25
+    ibatch = [dict(c, model=models[1 + i % 2]) for i, c in enumerate(ic)]
+    iev = IlqrCandidateEvaluator(system, task, models[1])
+    igot = iev.evaluate(ibatch)
+    for i, c in enumerate(ibatch):
+        np.testing.assert_array_equal(iev.evaluate([c], index_offset=i), igot[i:i + 1])
+    assert not list(tmp_path.glob("*.so"))
