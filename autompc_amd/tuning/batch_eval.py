@@ -351,7 +351,8 @@ class CandidateEvaluator:
             # build plugins -- jit_kernels = False: models fitted for this one evaluation) every model gets a plan
             # of its own on the run-time-shape kernels.  Same scores: a candidate's randomness follows its index.
             by_model = _by_model(candidates, self.model)
-            if not _needs_specialised_kernels(e) or len(by_model) < 2 or eps_all is not None or act_init is not None \
+            own_only = len(by_model) == 1 and (candidates[0].get("model") is None or candidates[0]["model"] is self.model)
+            if not _needs_specialised_kernels(e) or own_only or eps_all is not None or act_init is not None \
                     or timing is not None:
                 raise
             return self._evaluate_shape_groups(by_model, candidates, ids, dict(
@@ -685,7 +686,8 @@ class IlqrCandidateEvaluator:
             return self._evaluate(candidates, n_steps, init_obs, return_trajectories, int(max_iter), opened)
         except _lib.AmpcError as e:           # (as CandidateEvaluator.evaluate: a plan per model where no table can be had)
             by_model = _by_model(candidates, self.model)
-            if not _needs_specialised_kernels(e) or len(by_model) < 2:
+            own_only = len(by_model) == 1 and (candidates[0].get("model") is None or candidates[0]["model"] is self.model)
+            if not _needs_specialised_kernels(e) or own_only:
                 raise
             return CandidateEvaluator._evaluate_shape_groups(
                 self, by_model, candidates, global_ids(index_offset, B),
