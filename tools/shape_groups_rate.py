@@ -20,21 +20,22 @@ for c in cands:
     c["Q"], c["R"], c["F"] = c["Q"] ** 0.25, c["R"] ** 0.25, c["F"] ** 0.25
 
 
-def shaped(n_shapes):
+def shaped(n_shapes, jit):
     ms = []
     for k in range(n_shapes):
         cfg = sample_mlp_config(rng)
         cfg.pop("lr")
         m = MLP(system, seed=k, **cfg)
         m.dy_std = np.full(system.obs_dim, 0.05)
+        m.jit_kernels = jit          # False: what BatchPipelineTuner sets on the models it fits for one evaluation
         ms.append(m)
     return ms
 
 
 ev = CandidateEvaluator(system, task, model)
 ev.evaluate(cands[:4], seed=1)
-for n_shapes in (1, 16, 64):
-    ms = shaped(n_shapes)
+for n_shapes, jit in ((1, True), (16, True), (64, True), (16, False), (64, False)):
+    ms = shaped(n_shapes, jit)
     batch = [dict(c, model=ms[i % n_shapes]) for i, c in enumerate(cands)]
     t0 = time.perf_counter()
     s = ev.evaluate(batch, seed=1)
@@ -42,5 +43,6 @@ for n_shapes in (1, 16, 64):
     s2 = ev.evaluate(batch, seed=1)
     t2 = time.perf_counter()
     assert np.array_equal(s, s2)
-    print("%2d model shapes in a batch of 64 candidates x 49 control steps: first evaluation %.2f s, again %.2f s (finite %d)"
-          % (n_shapes, t1 - t0, t2 - t1, int(np.isfinite(s).sum())))
+    print("%2d model shapes (%s) in a batch of 64 candidates x 49 control steps: first evaluation %.2f s, again %.2f s "
+          "(finite %d)" % (n_shapes, "kernel builds started in the background" if jit else "one-evaluation models: no builds",
+                           t1 - t0, t2 - t1, int(np.isfinite(s).sum())))
