@@ -28,6 +28,8 @@ timeout 300 python tools/dropin_rate.py > $OUT/dropin_rate.log 2>&1
 timeout 300 python tools/dropin_breakdown.py > $OUT/dropin_breakdown.log 2>&1
 timeout 600 python tools/model_axis_rate.py > $OUT/model_axis_rate.log 2>&1
 timeout 900 python tools/world8_hosttime.py 8 64 200 > $OUT/world8_hosttime.log 2>&1
+timeout 300 python tools/shape_groups_rate.py > $OUT/shape_groups_rate.log 2>&1
+timeout 300 bash tools/fit_kernels.sh $TAG > /dev/null 2>&1
 timeout 600 bash tools/c4_trace_iterations.sh 1024 1024 > $OUT/c4_iterations.log 2>&1
 timeout 300 python tools/dropin_ilqr.py > $OUT/dropin_ilqr.log 2>&1
 timeout 500 bash tools/dropin_kernels.sh $TAG > /dev/null 2>&1
