@@ -455,3 +455,46 @@ def test_kernel_events_can_be_taken_on_every_nth_solve():
         if a is not None:
             np.testing.assert_array_equal(a, b)
     h.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 1, [64, 64], [256, 100, 333], [12, 30, 7]), (17, 6, [256, 256], [512, 160], [10, 25])])
+def test_one_call_step_with_several_problems_equals_upload_solve_download(shape, monkeypatch):
+    """ampc_mppi_run on a plan of several problems (own N, H): x0 is read from mapped host memory, every problem's
+    control is written there followed by ITS completion word (MppiArgs::done_flag), the host polls all of them.
+    Controls and warm starts equal the step-by-step path (upload, generate_eps, solve, download) bit for bit, with
+    and without mapped I/O, over consecutive steps; ampc_mppi_download after a one-call step returns its controls."""
+    from autompc_amd import _lib
+    nx, nu, hidden, Ns, Hs = shape
+    p = omlp.random_params(nx, nu, hidden, "relu", seed=8)
+    h = _lib.Handle(0, "f64")
+    h.set_mlp(nx, nu, p["weights"], p["biases"], "relu", p["xu_means"], p["xu_std"], p["dy_means"], p["dy_std"])
+    h.set_quad_costs(np.eye(nx), 0.01 * np.eye(nu), np.eye(nx), np.zeros(nx))
+    h.set_ctrl_bounds(-np.ones(nu), np.ones(nu))
+    B = len(Ns)
+    rng = np.random.default_rng(4)
+    x0s = rng.uniform(-0.2, 0.2, size=(3, B, nx))
+    act0 = rng.normal(scale=0.3, size=sum(Hs) * nu)
+    outs = {}
+    for mode in ("steps", "1", "0"):
+        plan = _lib.MppiPlan(h, Ns, Hs, [0.6] * B, [0.8] * B)
+        res = []
+        for k in range(3):
+            if mode == "steps":
+                plan.upload(x0=x0s[k], act_seq=act0 if k == 0 else None)
+                plan.generate_eps(5, k)
+                plan.solve()
+                a, u, _, _ = plan.download()
+            else:
+                monkeypatch.setenv("AMPC_RUN_MAPPED", mode)
+                u = plan.run(x0s[k], act0 if k == 0 else None, philox=(5, k))
+                a, u2, _, _ = plan.download()
+                np.testing.assert_array_equal(u2, u)
+            res.append((u.copy(), a.copy()))
+        outs[mode] = res
+        plan.close()
+    for mode in ("1", "0"):
+        for (u, a), (ur, ar) in zip(outs[mode], outs["steps"]):
+            np.testing.assert_array_equal(u, ur)
+            np.testing.assert_array_equal(a, ar)
+    assert not np.array_equal(outs["1"][0][0][0], outs["1"][0][0][1])
+    h.close()
