@@ -975,9 +975,9 @@ static int mppi_run_impl(ampc_mppi_plan* p, const double* x0, const double* act_
   ampc_handle* h = p->h;
   const size_t nx0 = (size_t)p->B * h->nx, nuo = (size_t)p->B * h->nu;
   if (!p->pin_x0) {
-    HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocMapped));
-    HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocMapped));
-    HIP_OK(hipHostMalloc((void**)&p->pin_flag, (size_t)p->B * sizeof(unsigned long long), hipHostMallocMapped));
+    HIP_OK(hipHostMalloc(&p->pin_x0, nx0 * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc(&p->pin_u, nuo * sizeof(T), hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_OK(hipHostMalloc((void**)&p->pin_flag, (size_t)p->B * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_OK(hipHostGetDevicePointer(&p->pin_x0_dev, p->pin_x0, 0));
     HIP_OK(hipHostGetDevicePointer(&p->pin_u_dev, p->pin_u, 0));
     HIP_OK(hipHostGetDevicePointer((void**)&p->pin_flag_dev, p->pin_flag, 0));
